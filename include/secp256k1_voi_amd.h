@@ -1,0 +1,123 @@
+/*
+ * secp256k1_voi_amd.h — C-ABI of the MI355X (gfx950) batch engine for the verify /
+ * scalar-multiplication path of Yawning/secp256k1-voi.
+ *
+ * The reference is a pure-Go library with no FFI of its own; its
+ * boundary is the exported Go API.  This header is what a cgo shim that keeps the
+ * reference's Point / Scalar / secec.Verify surface binds to (INTEGRATION.md shows the
+ * shim).  Every entry point names the reference symbol it serves (file:line relative to
+ * the reference tree).
+ *
+ * Conventions (identical to the reference's canonical encodings):
+ *   - scalars and field elements: 32-byte big-endian (Scalar.Bytes scalar.go:148,
+ *     Element.Bytes field.go:151);
+ *   - points, where a full point crosses the boundary: fixed 65-byte records, either
+ *     0x04‖X‖Y (Point.UncompressedBytes, point_s11n.go:66) or 0x00 followed by 64 zero
+ *     bytes for the identity (the reference's 1-byte identity encoding, padded);
+ *   - public keys of the verify path: 64-byte X‖Y (the 65-byte SEC1 form minus the 0x04
+ *     prefix, i.e. PublicKey.Bytes()[1:], secec.go:80-85);
+ *   - per-item results are data (0/1 bytes), never errors — like Verify returning false
+ *     (ecdsa.go:186-188).  The int return value reports infrastructure errors only.
+ *   - all buffers are caller-owned; nothing is retained after a call returns.
+ *   - a context is bound to one GPU; calls on one context are serialised by the caller
+ *     (one context per goroutine/thread, like distinct receivers in the reference).
+ *
+ * There is no CPU fallback: every function fails with S2K_ERR_NO_DEVICE / S2K_ERR_HIP
+ * when the GPU is not usable.
+ */
+#ifndef SECP256K1_VOI_AMD_H
+#define SECP256K1_VOI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct s2k_ctx s2k_ctx;
+
+enum {
+  S2K_OK = 0,
+  S2K_ERR_NO_DEVICE = -1, /* no usable gfx950 device */
+  S2K_ERR_HIP = -2,       /* a HIP runtime call failed; see s2k_last_error */
+  S2K_ERR_ARG = -3,       /* null pointer / bad length / length mismatch (the reference panics: point_mul_multi.go:27) */
+  S2K_ERR_NOMEM = -4
+};
+
+/* flags for the ECDSA entry points */
+#define S2K_ECDSA_REJECT_MALLEABLE 1u /* ECDSAOptions.RejectMalleable: reject s > n/2 (ecdsa.go:212) */
+
+#define S2K_POINT_RECORD 65
+#define S2K_SCALAR_SIZE 32 /* ScalarSize, scalar.go:17 */
+#define S2K_COORD_SIZE 32  /* CoordSize, point_s11n.go:27-44 */
+
+/* ---- context --------------------------------------------------------------------- */
+/* Selects the device, builds the resident generator tables (the device analogue of the
+ * package-init unpack of generatorHugeAffineTable, point_mul_table.go:75-100). */
+int s2k_ctx_create(int device_index, s2k_ctx **out);
+void s2k_ctx_destroy(s2k_ctx *ctx);
+const char *s2k_last_error(const s2k_ctx *ctx);
+const char *s2k_version(void);
+
+/* ---- hot path: batch ECDSA verification ------------------------------------------- */
+/* For each i < n: secec.PublicKey.VerifyRaw(digest, r, s) (ecdsa.go:234 -> verify :392)
+ * after ParseCompactSignature's range checks (s11n.go:129-144) and NewPublicKey's point
+ * validation (secec.go:188-216, point_s11n.go:178-209), all done on the device:
+ *   valid[i] = 1 iff r,s in [1,n), (flags&REJECT_MALLEABLE => s <= n/2), (X,Y) canonical
+ *              and on the curve, R = u1*G + u2*Q != identity and x(R) mod n == r,
+ *   with e = digest32 reduced mod n (hashToScalar, ecdsa.go:477-486; the caller passes
+ *   the leftmost 32 bytes of its digest).
+ * Host-pointer form: copies in, runs, copies out. */
+int s2k_ecdsa_verify_batch(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy /* n*64 */,
+                           const uint8_t *digest32 /* n*32 */, const uint8_t *r /* n*32 */,
+                           const uint8_t *s /* n*32 */, uint32_t flags, uint8_t *valid /* n */);
+/* Device-pointer form: all pointers are device memory (16-byte aligned); enqueues on
+ * `hip_stream` (a hipStream_t, NULL = default stream) and returns without synchronising. */
+int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, const void *d_digest32,
+                                  const void *d_r, const void *d_s, uint32_t flags, void *d_valid,
+                                  void *hip_stream);
+/* Bytes of device workspace the context holds for batches of up to n signatures. */
+size_t s2k_ecdsa_workspace_bytes(size_t n);
+
+/* ---- group operations (batched; host pointers) ------------------------------------- */
+/* out[i] = k[i]*G — Point.ScalarBaseMult (point_mul_table.go:168) / scalarBaseMultVartime (:197) */
+int s2k_scalar_base_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k /* n*32 */, uint8_t *out /* n*65 */);
+/* out[i] = k[i]*P[i] — Point.ScalarMult (point_mul_glv.go:257) / scalarMultVartimeGLV (:203) */
+int s2k_scalar_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k, const uint8_t *points /* n*65 */, uint8_t *out);
+/* out[i] = u1[i]*G + u2[i]*P[i] — Point.DoubleScalarMultBasepointVartime (point_mul_glv.go:307) */
+int s2k_double_scalar_mult_basepoint_batch(s2k_ctx *ctx, size_t n, const uint8_t *u1, const uint8_t *u2,
+                                           const uint8_t *points, uint8_t *out);
+/* out[i] = a[i] + b[i] — Point.Add (point.go:62); out[i] = 2*a[i] — Point.Double (point.go:71) */
+int s2k_point_add_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
+int s2k_point_double_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, uint8_t *out);
+/* SEC1 decode of n fixed-size encodings (enc_len = 33: SetCompressedBytes point_s11n.go:140;
+ * enc_len = 65: SetUncompressedBytes :178).  ok[i] = 1 and out[i] = point on success,
+ * ok[i] = 0 and out[i] = zeros otherwise. */
+int s2k_point_decode_batch(s2k_ctx *ctx, size_t n, size_t enc_len, const uint8_t *enc, uint8_t *out, uint8_t *ok);
+
+/* ---- field / scalar element operations (batched; host pointers) -------------------- */
+/* Element / Scalar methods, for API parity and for the parity tests of the device
+ * arithmetic.  Inputs are reduced first (SetBytes semantics, field.go:115, scalar.go:123). */
+enum {
+  S2K_OP_MUL = 0, /* Multiply (field.go:82, scalar.go:84) */
+  S2K_OP_SQR = 1, /* Square */
+  S2K_OP_ADD = 2, /* Add */
+  S2K_OP_SUB = 3, /* Subtract */
+  S2K_OP_NEG = 4, /* Negate */
+  S2K_OP_INV = 5, /* Invert (field_invert.go:11, scalar_invert.go:11); 0 -> 0 */
+  S2K_OP_SQRT = 6 /* Fp only: Sqrt (field_sqrt_ratio.go:14); flag[i] = root exists */
+};
+int s2k_fp_op_batch(s2k_ctx *ctx, int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *flag);
+int s2k_fn_op_batch(s2k_ctx *ctx, int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *flag);
+/* GLV split (point_mul_glv.go:59): k == k1 + k2*lambda (mod n), both canonical */
+int s2k_fn_split_glv_batch(s2k_ctx *ctx, size_t n, const uint8_t *k, uint8_t *k1, uint8_t *k2);
+
+/* ---- introspection used by the tests ------------------------------------------------ */
+/* Copies generator-table entry T_i[d] (X‖Y big-endian) to out64.  Layout: DESIGN.md §3. */
+int s2k_debug_gtable_entry(s2k_ctx *ctx, unsigned i, unsigned d, uint8_t *out64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,233 @@
+"""secp256k1_voi_amd — MI355X (gfx950) batch engine for the verify / scalar-mult path of
+Yawning/secp256k1-voi.
+
+This module is the thin Python binding of the C-ABI in include/secp256k1_voi_amd.h
+(ctypes; no torch types cross the boundary).  All compute happens in the HIP library
+``libsecp256k1_voi_amd.so`` built from csrc/; there is NO CPU fallback: importing works
+everywhere, but creating an :class:`Engine` raises if the library or a GPU is missing.
+
+Encodings are the reference's canonical ones: 32-byte big-endian scalars / coordinates,
+65-byte point records (0x04‖X‖Y, or 65 zero bytes for the identity).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsecp256k1_voi_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+REJECT_MALLEABLE = 1
+
+OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
+
+IDENTITY = bytes(65)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "secp256k1_voi_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+           os.path.join(CSRC, "engine.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the engine.  Raises EngineError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u32, ci = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    lib.s2k_ctx_create.argtypes = [ci, C.POINTER(vp)]
+    lib.s2k_ctx_destroy.argtypes = [vp]
+    lib.s2k_ctx_destroy.restype = None
+    lib.s2k_last_error.argtypes = [vp]
+    lib.s2k_last_error.restype = C.c_char_p
+    lib.s2k_version.restype = C.c_char_p
+    lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
+    lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
+    lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
+    lib.s2k_ecdsa_workspace_bytes.restype = sz
+    lib.s2k_scalar_base_mult_batch.argtypes = [vp, sz, vp, vp]
+    lib.s2k_scalar_mult_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.s2k_double_scalar_mult_basepoint_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.s2k_point_add_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.s2k_point_double_batch.argtypes = [vp, sz, vp, vp]
+    lib.s2k_point_decode_batch.argtypes = [vp, sz, sz, vp, vp, vp]
+    lib.s2k_fp_op_batch.argtypes = [vp, ci, sz, vp, vp, vp, vp]
+    lib.s2k_fn_op_batch.argtypes = [vp, ci, sz, vp, vp, vp, vp]
+    lib.s2k_fn_split_glv_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.s2k_debug_gtable_entry.argtypes = [vp, C.c_uint, C.c_uint, vp]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
+    "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
+    "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
+    "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
+    "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry",
+]
+
+
+def _arr(x, width, n=None):
+    """bytes / list of bytes / ndarray -> contiguous uint8 array of shape (n, width)."""
+    if isinstance(x, (list, tuple)):
+        x = b"".join(x)
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(x), dtype=np.uint8)
+    else:
+        a = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1)
+    if a.size % width:
+        raise ValueError(f"buffer length {a.size} is not a multiple of {width}")
+    a = a.reshape(-1, width)
+    if n is not None and a.shape[0] != n:
+        # the reference panics on length mismatch (point_mul_multi.go:27-29)
+        raise ValueError(f"length mismatch: expected {n} items, got {a.shape[0]}")
+    return np.ascontiguousarray(a)
+
+
+class Engine:
+    """One context bound to one GPU (s2k_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.s2k_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"s2k_ctx_create failed ({rc}): {self._lib.s2k_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s2k_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(f"engine call failed ({rc}): {self._lib.s2k_last_error(self._h).decode()}")
+
+    # ---- hot path -------------------------------------------------------------------
+    def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
+        """valid bits (uint8 0/1) for n (pubkey, digest, r, s) tuples; host buffers."""
+        r = _arr(r, 32)
+        n = r.shape[0]
+        pub_xy, digest32, s = _arr(pub_xy, 64, n), _arr(digest32, 32, n), _arr(s, 32, n)
+        out = np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.s2k_ecdsa_verify_batch(self._h, n, pub_xy.ctypes.data, digest32.ctypes.data,
+                                                     r.ctypes.data, s.ctypes.data,
+                                                     REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data))
+        return out
+
+    def ecdsa_verify_batch_device(self, n, d_pub_xy, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):
+        """Device-pointer form: integer device addresses, enqueued on `stream` (a hipStream_t value)."""
+        self._check(self._lib.s2k_ecdsa_verify_batch_device(self._h, int(n), d_pub_xy, d_digest32, d_r, d_s,
+                                                            int(flags), d_valid, stream))
+
+    def workspace_bytes(self, n):
+        return self._lib.s2k_ecdsa_workspace_bytes(int(n))
+
+    # ---- group ----------------------------------------------------------------------
+    def _points_out(self, n):
+        return np.zeros((n, 65), dtype=np.uint8)
+
+    def scalar_base_mult_batch(self, k):
+        k = _arr(k, 32)
+        out = self._points_out(k.shape[0])
+        self._check(self._lib.s2k_scalar_base_mult_batch(self._h, k.shape[0], k.ctypes.data, out.ctypes.data))
+        return out
+
+    def scalar_mult_batch(self, k, points):
+        k = _arr(k, 32)
+        n = k.shape[0]
+        points = _arr(points, 65, n)
+        out = self._points_out(n)
+        self._check(self._lib.s2k_scalar_mult_batch(self._h, n, k.ctypes.data, points.ctypes.data, out.ctypes.data))
+        return out
+
+    def double_scalar_mult_basepoint_batch(self, u1, u2, points):
+        u1 = _arr(u1, 32)
+        n = u1.shape[0]
+        u2, points = _arr(u2, 32, n), _arr(points, 65, n)
+        out = self._points_out(n)
+        self._check(self._lib.s2k_double_scalar_mult_basepoint_batch(self._h, n, u1.ctypes.data, u2.ctypes.data,
+                                                                     points.ctypes.data, out.ctypes.data))
+        return out
+
+    def point_add_batch(self, a, b):
+        a = _arr(a, 65)
+        n = a.shape[0]
+        b = _arr(b, 65, n)
+        out = self._points_out(n)
+        self._check(self._lib.s2k_point_add_batch(self._h, n, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        return out
+
+    def point_double_batch(self, a):
+        a = _arr(a, 65)
+        out = self._points_out(a.shape[0])
+        self._check(self._lib.s2k_point_double_batch(self._h, a.shape[0], a.ctypes.data, out.ctypes.data))
+        return out
+
+    def point_decode_batch(self, enc, enc_len):
+        enc = _arr(enc, enc_len)
+        n = enc.shape[0]
+        out, ok = self._points_out(n), np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.s2k_point_decode_batch(self._h, n, enc_len, enc.ctypes.data, out.ctypes.data, ok.ctypes.data))
+        return out, ok
+
+    # ---- field / scalar -------------------------------------------------------------
+    def _field(self, fn, op, a, b):
+        a = _arr(a, 32)
+        n = a.shape[0]
+        bb = _arr(b, 32, n) if b is not None else None
+        out, flag = np.zeros((n, 32), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        self._check(fn(self._h, op, n, a.ctypes.data, bb.ctypes.data if bb is not None else None, out.ctypes.data,
+                       flag.ctypes.data))
+        return out, flag
+
+    def fp_op_batch(self, op, a, b=None):
+        return self._field(self._lib.s2k_fp_op_batch, op, a, b)
+
+    def fn_op_batch(self, op, a, b=None):
+        return self._field(self._lib.s2k_fn_op_batch, op, a, b)
+
+    def fn_split_glv_batch(self, k):
+        k = _arr(k, 32)
+        n = k.shape[0]
+        k1, k2 = np.zeros((n, 32), dtype=np.uint8), np.zeros((n, 32), dtype=np.uint8)
+        self._check(self._lib.s2k_fn_split_glv_batch(self._h, n, k.ctypes.data, k1.ctypes.data, k2.ctypes.data))
+        return k1, k2
+
+    def gtable_entry(self, i, d) -> bytes:
+        out = np.zeros(64, dtype=np.uint8)
+        self._check(self._lib.s2k_debug_gtable_entry(self._h, i, d, out.ctypes.data))
+        return out.tobytes()

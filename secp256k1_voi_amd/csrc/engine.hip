@@ -1,0 +1,744 @@
+// engine.hip — gfx950 kernels and the C-ABI of include/secp256k1_voi_amd.h.
+//
+// One lane per signature / per point; every lane of a wave runs the same instruction
+// stream (complete formulas, fixed windows), so there is no divergence on secret- or
+// data-dependent branches and no idle lanes.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/secp256k1_voi_amd.h"
+#include "fe.h"
+#include "point.h"
+#include "sc.h"
+
+using namespace s2k;
+
+// ---------------------------------------------------------------------------------------
+// Generator tables (resident in HBM, 64 MiB):  GT_WINDOWS tables of 2^16 affine points,
+//   T_0[d] = (d - sum_{i>=1} 2^(16 i)) * G          (d + K0, K0 = that constant mod n)
+//   T_i[d] = (d + 1) * 2^(16 i) * G,  i = 1..15
+// so that  u*G = sum_i T_i[(u >> 16 i) & 0xffff]  with 16 mixed additions, no doublings, no
+// zero-digit special case (no entry is the identity) and no final correction.
+// The reference's scalarBaseMultVartime (point_mul_table.go:197-211) is the same idea with
+// 8-bit windows, sized for a CPU cache (510 KiB); with 288 GB of HBM and a 256 MiB
+// Infinity Cache the 16-bit version halves the additions.
+// Entry layout: 16 x u32 = X limbs (little-endian words) then Y limbs, 64-byte aligned.
+// ---------------------------------------------------------------------------------------
+constexpr int GT_WINDOWS = 16;
+constexpr int GT_BITS = 16;
+constexpr size_t GT_ENTRIES = (size_t)GT_WINDOWS << GT_BITS;
+__device__ static const uint32_t GT_K0[8] = {0xd0354141u, 0xbfd15e8bu, 0xaf47a03au, 0xbaaddce5u,
+                                             0xfffefffdu, 0xfffefffeu, 0xfffefffeu, 0xfffefffeu};
+
+S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit) {
+  const uint4* p = reinterpret_cast<const uint4*>(gt + ((size_t)((window << GT_BITS) | digit) << 4));
+  uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+  apt r;
+  r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
+  r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
+  r.y.v[0] = c.x; r.y.v[1] = c.y; r.y.v[2] = c.z; r.y.v[3] = c.w;
+  r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
+  return r;
+}
+
+// k*P by MSB-first double-and-add with complete formulas (any 256-bit k, any P).
+// Used to build the tables and by the generic point entry points; not on the hot path.
+S2K_DEV pt pt_mul_generic(const uint32_t k_in[8], const apt& p) {
+  uint32_t k[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = k_in[i];
+  pt acc = pt_identity();
+#pragma unroll 1
+  for (int bit = 0; bit < 256; ++bit) {
+    acc = pt_double_complete(acc);
+    bool b = (k[7] >> 31) != 0;
+    pt sum = pt_add_mixed(acc, p);
+    acc = pt_select(b, acc, sum);
+#pragma unroll
+    for (int i = 7; i > 0; --i) k[i] = (k[i] << 1) | (k[i - 1] >> 31);
+    k[0] <<= 1;
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt) {
+  uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  uint32_t window = id >> GT_BITS, digit = id & 0xffffu;
+  uint32_t k[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = 0;
+  if (window == 0) {
+    unsigned c = 0;
+    k[0] = __builtin_addc(GT_K0[0], digit, c, &c);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) k[i] = __builtin_addc(GT_K0[i], 0u, c, &c);
+  } else {
+    // (digit + 1) << (16 * window): a 17-bit value at a 16-bit aligned offset
+    uint32_t v = digit + 1;
+    uint32_t limb = window >> 1;
+    uint32_t lo = (window & 1) ? (v << 16) : v;
+    uint32_t hi = (window & 1) ? (v >> 16) : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) k[i] = (i == limb) ? lo : ((i == limb + 1) ? hi : 0u);
+    if (window == GT_WINDOWS - 1 && digit == 0xffffu) {
+      // (0xffff + 1) << 240 = 2^256 does not fit: use 2^256 mod n
+#pragma unroll
+      for (int i = 0; i < 8; ++i) k[i] = SC_ONE_M[i];
+    }
+  }
+  apt g;
+  g.x = fe_from_limbs(FE_GX);
+  g.y = fe_from_limbs(FE_GY);
+  pt r = pt_mul_generic(k, g);
+  apt a;
+  pt_to_affine(a, r);
+  uint4* o = reinterpret_cast<uint4*>(gt + ((size_t)id << 4));
+  o[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
+  o[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
+  o[2] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]);
+  o[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
+}
+
+// u*G for a plain scalar u (any 256-bit value): 16 table additions
+S2K_DEV pt pt_base_mul(const uint32_t* __restrict__ gt, const uint32_t u_in[8]) {
+  uint32_t u[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u[i] = u_in[i];
+  pt acc = pt_from_affine(gt_load(gt, 0, u[0] & 0xffffu));
+#pragma unroll 1
+  for (uint32_t w = 1; w < GT_WINDOWS; ++w) {
+    // shift right by 16
+#pragma unroll
+    for (int i = 0; i < 7; ++i) u[i] = (u[i] >> 16) | (u[i + 1] << 16);
+    u[7] >>= 16;
+    acc = pt_add_mixed(acc, gt_load(gt, w, u[0] & 0xffffu));
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// k*Q for a per-lane point: GLV split (point_mul_glv.go:203-254), then one fixed-window
+// ladder over both 128-bit halves with signed odd digits:
+//   k' = k | 1 = sum_{i=0..32} d_i 16^i,  d_i = 2*((k' >> (4i+1)) & 15) - 15 for i < 32, d_32 = 1
+// every digit is odd and non-zero, so the per-lane table holds only the 8 odd multiples
+// {1,3,..,15}*Q (the reference keeps 15 multiples and skips zero digits,
+// point_mul_table.go:30-49) and every lane adds at every window.  The "+1" for even k is
+// removed by one more complete addition of -+Q (or of the identity).
+// beta*Q entries are derived on lookup by one multiplication (mulBeta, :191-200).
+// Table storage: global scratch, word-major [entry*24 + coord*8 + limb][lane] so that a
+// wave's access to one word of one entry is one contiguous 256-byte segment.
+// ---------------------------------------------------------------------------------------
+constexpr int QT_ENTRIES = 8;
+constexpr int QT_WORDS = QT_ENTRIES * 24;
+
+S2K_DEV void qt_store(uint32_t* __restrict__ qt, size_t stride, size_t lane, int entry, const pt& p) {
+  uint32_t* base = qt + ((size_t)entry * 24) * stride + lane;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) base[(size_t)l * stride] = p.x.v[l];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) base[(size_t)(8 + l) * stride] = p.y.v[l];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) base[(size_t)(16 + l) * stride] = p.z.v[l];
+}
+S2K_DEV pt qt_load(const uint32_t* __restrict__ qt, size_t stride, size_t lane, uint32_t entry) {
+  const uint32_t* base = qt + ((size_t)entry * 24) * stride + lane;
+  pt p;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) p.x.v[l] = base[(size_t)l * stride];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) p.y.v[l] = base[(size_t)(8 + l) * stride];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) p.z.v[l] = base[(size_t)(16 + l) * stride];
+  return p;
+}
+
+// top window first: returns (k' >> 125) & 15 ... by keeping k' left-aligned in 5 limbs
+struct digit_stream {
+  uint32_t w[5];   // k' << 31, so that bits (4i+1 .. 4i+4) of window 31 are the top nibble
+};
+S2K_DEV digit_stream ds_init(const sc& k_odd) {
+  // k' < 2^129 occupies limbs 0..4 (limb 4 <= 1).  Window 31 is bits 125..128.
+  // Left-align: shift so that bit 128 becomes bit 159 (top of limb 4): shift left by 31.
+  digit_stream d;
+  d.w[4] = (k_odd.v[4] << 31) | (k_odd.v[3] >> 1);
+  d.w[3] = (k_odd.v[3] << 31) | (k_odd.v[2] >> 1);
+  d.w[2] = (k_odd.v[2] << 31) | (k_odd.v[1] >> 1);
+  d.w[1] = (k_odd.v[1] << 31) | (k_odd.v[0] >> 1);
+  d.w[0] = (k_odd.v[0] << 31);
+  return d;
+}
+S2K_DEV uint32_t ds_next(digit_stream& d) {
+  uint32_t nib = d.w[4] >> 28;
+  d.w[4] = (d.w[4] << 4) | (d.w[3] >> 28);
+  d.w[3] = (d.w[3] << 4) | (d.w[2] >> 28);
+  d.w[2] = (d.w[2] << 4) | (d.w[1] >> 28);
+  d.w[1] = (d.w[1] << 4) | (d.w[0] >> 28);
+  d.w[0] <<= 4;
+  return nib;
+}
+
+S2K_DEV pt pt_mul_glv(const sc& k, const apt& q, uint32_t* __restrict__ qt, size_t stride, size_t lane) {
+  sc k1, k2;
+  bool neg1, neg2;
+  sc_split_glv(k, k1, neg1, k2, neg2);
+  bool even1 = (k1.v[0] & 1u) == 0, even2 = (k2.v[0] & 1u) == 0;
+  k1.v[0] |= 1u;
+  k2.v[0] |= 1u;
+
+  // table of odd multiples: T[j] = (2j+1) Q
+  pt q1 = pt_from_affine(q);
+  pt q2 = pt_double_complete(q1);
+  {
+    pt cur = q1;
+    qt_store(qt, stride, lane, 0, cur);
+#pragma unroll 1
+    for (int j = 1; j < QT_ENTRIES; ++j) {
+      cur = pt_add_complete(cur, q2);
+      qt_store(qt, stride, lane, j, cur);
+    }
+  }
+  fe beta = fe_from_limbs(FE_BETA);
+
+  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+  // top digits are +1: acc = s1*Q + s2*beta*Q
+  pt acc = pt_cond_neg(q1, neg1);
+  {
+    pt qb = q1;
+    qb.x = fe_mul(qb.x, beta);
+    acc = pt_add_complete(acc, pt_cond_neg(qb, neg2));
+  }
+#pragma unroll 1
+  for (int i = 31; i >= 0; --i) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) acc = pt_double_complete(acc);
+    uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      uint32_t w = t ? w2 : w1;
+      bool neg = (t ? neg2 : neg1) != (w < 8u);
+      uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+      pt a = qt_load(qt, stride, lane, entry);
+      if (t) a.x = fe_mul(a.x, beta);
+      acc = pt_add_complete(acc, pt_cond_neg(a, neg));
+    }
+  }
+  // remove the +1 of even halves: acc -= s*Q  <=>  add (-s)*Q
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    pt a = q1;
+    if (t) a.x = fe_mul(a.x, beta);
+    a = pt_cond_neg(a, !(t ? neg2 : neg1));
+    bool even = t ? even2 : even1;
+    acc = pt_add_complete(acc, pt_select(even, pt_identity(), a));
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// ECDSA verification kernel, "complete" variant (every step exception-free).
+// secec/ecdsa.go:392-470 per lane.
+// ---------------------------------------------------------------------------------------
+__device__ static const uint32_t FE_P_MINUS_N[8] = {0x2fc9baeeu, 0x402da172u, 0x50b75fc4u, 0x45512319u,
+                                                    0x00000001u, 0, 0, 0};
+
+__global__ void __launch_bounds__(256)
+k_ecdsa_verify(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
+               const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
+               uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  sc r, s;
+  uint32_t e_raw[8];
+  apt q;
+  load_be32(r.v, rsig + idx * 32);
+  load_be32(s.v, ssig + idx * 32);
+  load_be32(e_raw, dig + idx * 32);
+  load_be32(q.x.v, pub + idx * 64);
+  load_be32(q.y.v, pub + idx * 64 + 32);
+
+  // ParseCompactSignature range checks (s11n.go:129-144) + verify step 1 (ecdsa.go:400)
+  bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
+  if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);   // ecdsa.go:212
+  // NewPublicKey: canonical coordinates on the curve (point_s11n.go:187-201)
+  ok = ok && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v) && apt_on_curve(q);
+
+  sc e = sc_reduce_once(e_raw);                    // hashToScalar (ecdsa.go:477-486)
+  sc s_inv_m = sc_mont_inv(sc_to_mont(s));         // s^-1 * R
+  sc u1 = sc_montmul(e, s_inv_m);                  // e / s   (plain)
+  sc u2 = sc_montmul(r, s_inv_m);                  // r / s
+
+  pt rg = pt_base_mul(gt, u1.v);
+  pt rq = pt_mul_glv(u2, q, qt, stride, idx);
+  pt R = pt_add_complete(rg, rq);                  // point_mul_glv.go:316
+
+  ok = ok && !pt_is_identity(R);                   // ecdsa.go:450
+  // x(R) mod n == r  <=>  X == r*Z  or  (r + n < p and X == (r + n)*Z)   (ecdsa.go:459-465)
+  fe rf;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rf.v[i] = r.v[i];
+  bool match = fe_eq(R.x, fe_mul(rf, R.z));
+  if (u256_lt(r.v, FE_P_MINUS_N)) {
+    fe r2;
+    u256_add(r2.v, r.v, SC_N);
+    match = match || fe_eq(R.x, fe_mul(r2, R.z));
+  }
+  out[idx] = (ok && match) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Element-wise kernels behind the Point / Scalar / Element entry points
+// ---------------------------------------------------------------------------------------
+S2K_DEV void load_be32_unaligned(uint32_t out[8], const uint8_t* p) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint8_t* q = p + (7 - i) * 4;
+    out[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+}
+S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint8_t* q = p + (7 - i) * 4;
+    q[0] = (uint8_t)(in[i] >> 24); q[1] = (uint8_t)(in[i] >> 16); q[2] = (uint8_t)(in[i] >> 8); q[3] = (uint8_t)in[i];
+  }
+}
+// 65-byte record -> projective point.  Returns false (and the identity) for malformed records.
+S2K_DEV bool point_record_load(pt& p, const uint8_t* rec) {
+  p = pt_identity();
+  if (rec[0] == 0x00) return true;
+  if (rec[0] != 0x04) return false;
+  apt a;
+  load_be32_unaligned(a.x.v, rec + 1);
+  load_be32_unaligned(a.y.v, rec + 33);
+  if (!fe_is_canonical_raw(a.x.v) || !fe_is_canonical_raw(a.y.v) || !apt_on_curve(a)) return false;
+  p = pt_from_affine(a);
+  return true;
+}
+S2K_DEV void point_record_store(uint8_t* rec, const pt& p) {
+  apt a;
+  bool finite = pt_to_affine(a, p);
+  if (!finite) {
+    for (int i = 0; i < 65; ++i) rec[i] = 0;
+    return;
+  }
+  rec[0] = 0x04;
+  store_be32_unaligned(rec + 1, a.x.v);
+  store_be32_unaligned(rec + 33, a.y.v);
+}
+
+enum { PK_BASE_MUL = 0, PK_MUL = 1, PK_DOUBLE_MUL = 2, PK_ADD = 3, PK_DOUBLE = 4 };
+
+__global__ void __launch_bounds__(256)
+k_point_op(int op, uint32_t n, const uint8_t* __restrict__ k1, const uint8_t* __restrict__ k2,
+           const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, uint8_t* __restrict__ out,
+           const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  pt res = pt_identity();
+  if (op == PK_BASE_MUL) {
+    uint32_t raw[8];
+    load_be32(raw, k1 + idx * 32);
+    sc k = sc_reduce_once(raw);
+    res = pt_base_mul(gt, k.v);
+  } else if (op == PK_MUL || op == PK_DOUBLE_MUL) {
+    uint32_t raw[8];
+    pt p;
+    point_record_load(p, pa + idx * 65);
+    bool p_inf = pt_is_identity(p);
+    apt a;
+    a.x = p.x;
+    a.y = p.y;                    // Z = 1 for finite records
+    if (p_inf) {                   // keep the arithmetic on the curve; result is masked below
+      a.x = fe_from_limbs(FE_GX);
+      a.y = fe_from_limbs(FE_GY);
+    }
+    load_be32(raw, (op == PK_MUL ? k1 : k2) + idx * 32);
+    sc k = sc_reduce_once(raw);
+    pt rq = pt_mul_glv(k, a, qt, stride, idx);
+    rq = pt_select(p_inf, rq, pt_identity());
+    if (op == PK_DOUBLE_MUL) {
+      load_be32(raw, k1 + idx * 32);
+      sc u1 = sc_reduce_once(raw);
+      res = pt_add_complete(pt_base_mul(gt, u1.v), rq);
+    } else {
+      res = rq;
+    }
+  } else if (op == PK_ADD) {
+    pt a, b;
+    point_record_load(a, pa + idx * 65);
+    point_record_load(b, pb + idx * 65);
+    res = pt_add_complete(a, b);
+  } else if (op == PK_DOUBLE) {
+    pt a;
+    point_record_load(a, pa + idx * 65);
+    res = pt_double_complete(a);
+  }
+  point_record_store(out + idx * 65, res);
+}
+
+__global__ void __launch_bounds__(256)
+k_point_decode(uint32_t n, uint32_t enc_len, const uint8_t* __restrict__ enc, uint8_t* __restrict__ out,
+               uint8_t* __restrict__ okv) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const uint8_t* e = enc + idx * enc_len;
+  uint8_t* o = out + idx * 65;
+  bool ok = false;
+  apt a;
+  a.x = fe_zero();
+  a.y = fe_zero();
+  if (enc_len == 33) {
+    // SetCompressedBytes (point_s11n.go:140-172)
+    uint8_t tag = e[0];
+    load_be32_unaligned(a.x.v, e + 1);
+    ok = (tag == 0x02 || tag == 0x03) && fe_is_canonical_raw(a.x.v);
+    fe y;
+    bool has = fe_sqrt(y, fe_curve_rhs(a.x));
+    ok = ok && has;
+    y = fe_normalize(y);
+    bool flip = ((y.v[0] & 1u) != (uint32_t)(tag & 1));
+    a.y = fe_normalize(fe_select(flip, y, fe_neg(y)));
+  } else {
+    // SetUncompressedBytes (point_s11n.go:178-209)
+    load_be32_unaligned(a.x.v, e + 1);
+    load_be32_unaligned(a.y.v, e + 33);
+    ok = e[0] == 0x04 && fe_is_canonical_raw(a.x.v) && fe_is_canonical_raw(a.y.v) && apt_on_curve(a);
+  }
+  okv[idx] = ok ? 1 : 0;
+  if (ok) {
+    o[0] = 0x04;
+    store_be32_unaligned(o + 1, a.x.v);
+    store_be32_unaligned(o + 33, a.y.v);
+  } else {
+    for (int i = 0; i < 65; ++i) o[i] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fp_op(int op, uint32_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+        uint8_t* __restrict__ out, uint8_t* __restrict__ flag) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  fe x, y = fe_zero(), r;
+  load_be32(x.v, a + idx * 32);
+  if (b) load_be32(y.v, b + idx * 32);
+  uint8_t f = 1;
+  switch (op) {
+    case S2K_OP_MUL: r = fe_mul(x, y); break;
+    case S2K_OP_SQR: r = fe_sqr(x); break;
+    case S2K_OP_ADD: r = fe_add(x, y); break;
+    case S2K_OP_SUB: r = fe_sub(x, y); break;
+    case S2K_OP_NEG: r = fe_neg(x); break;
+    case S2K_OP_INV: r = fe_inv(x); break;
+    default: f = fe_sqrt(r, x) ? 1 : 0; break;
+  }
+  r = fe_normalize(r);
+  store_be32(out + idx * 32, r.v);
+  if (flag) flag[idx] = f;
+}
+
+__global__ void __launch_bounds__(256)
+k_fn_op(int op, uint32_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+        uint8_t* __restrict__ out, uint8_t* __restrict__ out2) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  uint32_t raw[8];
+  load_be32(raw, a + idx * 32);
+  sc x = sc_reduce_once(raw), y = sc_zero(), r = sc_zero();
+  if (b) {
+    load_be32(raw, b + idx * 32);
+    y = sc_reduce_once(raw);
+  }
+  switch (op) {
+    case S2K_OP_MUL: r = sc_montmul(x, sc_to_mont(y)); break;
+    case S2K_OP_SQR: r = sc_montmul(x, sc_to_mont(x)); break;
+    case S2K_OP_ADD: r = sc_add(x, y); break;
+    case S2K_OP_SUB: r = sc_add(x, sc_neg(y)); break;
+    case S2K_OP_NEG: r = sc_neg(x); break;
+    case S2K_OP_INV: {
+      sc one;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) one.v[i] = i == 0 ? 1u : 0u;
+      r = sc_montmul(sc_mont_inv(sc_to_mont(x)), one);
+      break;
+    }
+    default: {   // GLV split, un-normalised (k1, k2 canonical mod n)
+      sc k1, k2;
+      bool n1, n2;
+      sc_split_glv(x, k1, n1, k2, n2);
+      r = n1 ? sc_neg(k1) : k1;
+      sc r2 = n2 ? sc_neg(k2) : k2;
+      store_be32(out2 + idx * 32, r2.v);
+      break;
+    }
+  }
+  store_be32(out + idx * 32, r.v);
+}
+
+__global__ void k_gtable_entry(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit, uint8_t* out64) {
+  apt a = gt_load(gt, window, digit);
+  store_be32(out64, a.x.v);
+  store_be32(out64 + 32, a.y.v);
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct s2k_ctx {
+  int device = -1;
+  uint32_t* gtable = nullptr;
+  void* ws = nullptr;           // workspace: per-lane Q tables
+  size_t ws_bytes = 0;
+  char err[512] = {0};
+};
+
+static thread_local char g_err[512];
+
+static int fail(s2k_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", buf);
+  snprintf(g_err, sizeof g_err, "%s", buf);
+  return code;
+}
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(ctx, S2K_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+static inline size_t lane_stride(size_t n) { return (n + 63) & ~(size_t)63; }
+
+extern "C" {
+
+const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
+const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+size_t s2k_ecdsa_workspace_bytes(size_t n) { return lane_stride(n) * QT_WORDS * sizeof(uint32_t); }
+
+static int ensure_ws(s2k_ctx* ctx, size_t n) {
+  size_t need = s2k_ecdsa_workspace_bytes(n);
+  if (need <= ctx->ws_bytes) return S2K_OK;
+  if (ctx->ws) {
+    HIP_TRY(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->ws, need));
+  ctx->ws_bytes = need;
+  return S2K_OK;
+}
+
+int s2k_ctx_create(int device_index, s2k_ctx** out) {
+  if (!out) return fail(nullptr, S2K_ERR_ARG, "s2k_ctx_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(nullptr, S2K_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+  if (device_index < 0 || device_index >= count)
+    return fail(nullptr, S2K_ERR_ARG, "device index %d out of range (0..%d)", device_index, count - 1);
+  s2k_ctx* ctx = new (std::nothrow) s2k_ctx();
+  if (!ctx) return fail(nullptr, S2K_ERR_NOMEM, "out of host memory");
+  ctx->device = device_index;
+  hipError_t e = hipSetDevice(device_index);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->gtable, GT_ENTRIES * 64);
+  if (e == hipSuccess) {
+    k_gen_gtable<<<(unsigned)(GT_ENTRIES / 256), 256>>>(ctx->gtable);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    int rc = fail(nullptr, S2K_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+    if (ctx->gtable) (void)hipFree(ctx->gtable);
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return S2K_OK;
+}
+
+void s2k_ctx_destroy(s2k_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->gtable) (void)hipFree(ctx->gtable);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  delete ctx;
+}
+
+int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const void* d_dig, const void* d_r,
+                                  const void* d_s, uint32_t flags, void* d_valid, void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!d_pub || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_ws(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)hip_stream;
+  k_ecdsa_verify<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
+                                                (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
+                                                ctx->gtable, (uint32_t*)ctx->ws, lane_stride(n));
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+// small RAII helper for the host-pointer entry points
+struct dev_buf {
+  void* p = nullptr;
+  ~dev_buf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  hipError_t upload(const void* src, size_t bytes) {
+    hipError_t e = alloc(bytes);
+    if (e != hipSuccess || !bytes) return e;
+    return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+  }
+};
+
+int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                           const uint8_t* s, uint32_t flags, uint8_t* valid) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf dp, dd, dr, ds, dv;
+  HIP_TRY(ctx, dp.upload(pub, n * 64));
+  HIP_TRY(ctx, dd.upload(dig, n * 32));
+  HIP_TRY(ctx, dr.upload(r, n * 32));
+  HIP_TRY(ctx, ds.upload(s, n * 32));
+  HIP_TRY(ctx, dv.alloc(n));
+  int rc = s2k_ecdsa_verify_batch_device(ctx, n, dp.p, dd.p, dr.p, ds.p, flags, dv.p, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(valid, dv.p, n, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+static int point_op(s2k_ctx* ctx, int op, size_t n, const uint8_t* k1, const uint8_t* k2, const uint8_t* pa,
+                    const uint8_t* pb, uint8_t* out) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!out) return fail(ctx, S2K_ERR_ARG, "null output buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf dk1, dk2, dpa, dpb, dout;
+  if (k1) HIP_TRY(ctx, dk1.upload(k1, n * 32));
+  if (k2) HIP_TRY(ctx, dk2.upload(k2, n * 32));
+  if (pa) HIP_TRY(ctx, dpa.upload(pa, n * 65));
+  if (pb) HIP_TRY(ctx, dpb.upload(pb, n * 65));
+  HIP_TRY(ctx, dout.alloc(n * 65));
+  int rc = ensure_ws(ctx, n);
+  if (rc) return rc;
+  k_point_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)dk1.p, (const uint8_t*)dk2.p,
+                                     (const uint8_t*)dpa.p, (const uint8_t*)dpb.p, (uint8_t*)dout.p, ctx->gtable,
+                                     (uint32_t*)ctx->ws, lane_stride(n));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 65, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+int s2k_scalar_base_mult_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, uint8_t* out) {
+  if (n && !k) return fail(ctx, S2K_ERR_ARG, "null scalar buffer");
+  return point_op(ctx, PK_BASE_MUL, n, k, nullptr, nullptr, nullptr, out);
+}
+int s2k_scalar_mult_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* points, uint8_t* out) {
+  if (n && (!k || !points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
+  return point_op(ctx, PK_MUL, n, k, nullptr, points, nullptr, out);
+}
+int s2k_double_scalar_mult_basepoint_batch(s2k_ctx* ctx, size_t n, const uint8_t* u1, const uint8_t* u2,
+                                           const uint8_t* points, uint8_t* out) {
+  if (n && (!u1 || !u2 || !points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
+  return point_op(ctx, PK_DOUBLE_MUL, n, u1, u2, points, nullptr, out);
+}
+int s2k_point_add_batch(s2k_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  if (n && (!a || !b)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
+  return point_op(ctx, PK_ADD, n, nullptr, nullptr, a, b, out);
+}
+int s2k_point_double_batch(s2k_ctx* ctx, size_t n, const uint8_t* a, uint8_t* out) {
+  if (n && !a) return fail(ctx, S2K_ERR_ARG, "null input buffer");
+  return point_op(ctx, PK_DOUBLE, n, nullptr, nullptr, a, nullptr, out);
+}
+
+int s2k_point_decode_batch(s2k_ctx* ctx, size_t n, size_t enc_len, const uint8_t* enc, uint8_t* out, uint8_t* ok) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (enc_len != 33 && enc_len != 65) return fail(ctx, S2K_ERR_ARG, "enc_len must be 33 or 65");
+  if (n == 0) return S2K_OK;
+  if (!enc || !out || !ok) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf de, dout, dok;
+  HIP_TRY(ctx, de.upload(enc, n * enc_len));
+  HIP_TRY(ctx, dout.alloc(n * 65));
+  HIP_TRY(ctx, dok.alloc(n));
+  k_point_decode<<<blocks_for(n), 256>>>((uint32_t)n, (uint32_t)enc_len, (const uint8_t*)de.p, (uint8_t*)dout.p,
+                                         (uint8_t*)dok.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 65, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ok, dok.p, n, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+static int field_op(s2k_ctx* ctx, bool is_fp, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out,
+                    uint8_t* out2, size_t out2_bytes) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!a || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  bool binary = (op == S2K_OP_MUL || op == S2K_OP_ADD || op == S2K_OP_SUB);
+  if (binary && !b) return fail(ctx, S2K_ERR_ARG, "binary op needs b");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf da, db, dout, dout2;
+  HIP_TRY(ctx, da.upload(a, n * 32));
+  if (binary) HIP_TRY(ctx, db.upload(b, n * 32));
+  HIP_TRY(ctx, dout.alloc(n * 32));
+  if (out2) HIP_TRY(ctx, dout2.alloc(n * out2_bytes));
+  if (is_fp)
+    k_fp_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)da.p, binary ? (const uint8_t*)db.p : nullptr,
+                                    (uint8_t*)dout.p, (uint8_t*)dout2.p);
+  else
+    k_fn_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)da.p, binary ? (const uint8_t*)db.p : nullptr,
+                                    (uint8_t*)dout.p, (uint8_t*)dout2.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 32, hipMemcpyDeviceToHost));
+  if (out2) HIP_TRY(ctx, hipMemcpy(out2, dout2.p, n * out2_bytes, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+int s2k_fp_op_batch(s2k_ctx* ctx, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* flag) {
+  if (op < S2K_OP_MUL || op > S2K_OP_SQRT) return fail(ctx, S2K_ERR_ARG, "bad op");
+  return field_op(ctx, true, op, n, a, b, out, flag, 1);
+}
+int s2k_fn_op_batch(s2k_ctx* ctx, int op, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* flag) {
+  if (op < S2K_OP_MUL || op > S2K_OP_INV) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (flag) memset(flag, 1, n);
+  return field_op(ctx, false, op, n, a, b, out, nullptr, 0);
+}
+int s2k_fn_split_glv_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, uint8_t* k1, uint8_t* k2) {
+  if (n && !k2) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  return field_op(ctx, false, 100, n, k, nullptr, k1, k2, 32);
+}
+
+int s2k_debug_gtable_entry(s2k_ctx* ctx, unsigned i, unsigned d, uint8_t* out64) {
+  if (!ctx || !out64) return fail(ctx, S2K_ERR_ARG, "null argument");
+  if (i >= (unsigned)GT_WINDOWS || d >= (1u << GT_BITS)) return fail(ctx, S2K_ERR_ARG, "index out of range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf o;
+  HIP_TRY(ctx, o.alloc(64));
+  k_gtable_entry<<<1, 1>>>(ctx->gtable, i, d, (uint8_t*)o.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out64, o.p, 64, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// sc.h — arithmetic modulo the group order n on gfx950, one scalar per lane.
+//
+// Device replacement for the reference's Scalar (scalar.go:46-206), the fiat Fn code
+// (internal/fiat/secp256k1montgomeryscalar/secp256k1montgomeryscalar.go:87) and the GLV
+// split (point_mul_glv.go:59-189).  8 x 32-bit limbs, little-endian, always fully reduced
+// (0 <= v < n).  n has no special form, so products use word-by-word Montgomery
+// reduction with R = 2^256 (the same algorithm fiat generates, on 32-bit words).
+// A value is "plain" or "Montgomery" (x*R mod n) as the function comments say;
+// sc_montmul(plain, mont) yields a plain product.
+#pragma once
+#include "fe.h"
+
+namespace s2k {
+
+struct sc {
+  uint32_t v[8];
+};
+
+__device__ static const uint32_t SC_N[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u,
+                                            0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+constexpr uint32_t SC_N0INV = 0x5588b13fu;   // -n^-1 mod 2^32 (low word of fiat's 0x4b0dff665588b13f)
+__device__ static const uint32_t SC_R2[8] = {0x67d7d140u, 0x896cf214u, 0x0e7cf878u, 0x741496c2u,
+                                             0x5bcd07c6u, 0xe697f5e4u, 0x81c69bc5u, 0x9d671cd5u};
+__device__ static const uint32_t SC_ONE_M[8] = {0x2fc9bebfu, 0x402da173u, 0x50b75fc4u, 0x45512319u,
+                                                0x00000001u, 0, 0, 0};   // R mod n
+__device__ static const uint32_t SC_HALF_N[8] = {0x681b20a0u, 0xdfe92f46u, 0x57a4501du, 0x5d576e73u,
+                                                 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};   // scalar.go:33-38
+// GLV constants (point_mul_glv.go:37-57); the three multipliers are kept in Montgomery form
+__device__ static const uint32_t SC_NEG_LAMBDA_M[8] = {0x06a3d4a3u, 0xcf54734fu, 0x2b820beeu, 0x8e1af539u,
+                                                       0xad96826du, 0x8c5699f9u, 0x7aa729c6u, 0xacd7bfe8u};
+__device__ static const uint32_t SC_NEG_B1_M[8] = {0x0ad9263cu, 0xc50468d0u, 0xfaa6ed42u, 0x1b1c8205u,
+                                                   0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu};
+__device__ static const uint32_t SC_NEG_B2_M[8] = {0x6a144696u, 0x0cac5e50u, 0xf3ba5939u, 0x1e8a8dc5u,
+                                                   0xba244fceu, 0x176cdf65u, 0x8e173580u, 0xc25575ebu};
+__device__ static const uint32_t SC_G1[8] = {0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u,
+                                             0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};
+__device__ static const uint32_t SC_G2[8] = {0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu,
+                                             0x0abfe4c4u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u};
+
+S2K_DEV sc sc_from_limbs(const uint32_t* p) {
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = p[i];
+  return r;
+}
+S2K_DEV sc sc_zero() {
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+  return r;
+}
+S2K_DEV bool sc_is_zero(const sc& a) { return u256_is_zero(a.v); }                 // scalar.go:181
+S2K_DEV bool sc_eq(const sc& a, const sc& b) { return u256_eq(a.v, b.v); }         // scalar.go:176
+S2K_DEV bool sc_is_canonical_raw(const uint32_t a[8]) { return u256_lt(a, SC_N); } // scalar.go:136
+// IsGreaterThanHalfN on a plain value (scalar.go:190-206)
+S2K_DEV bool sc_is_gt_half_n(const sc& a) { return u256_lt(SC_HALF_N, a.v); }
+
+// raw 256-bit value (< 2n) -> reduced (SetBytes, scalar.go:123; reduceSaturated)
+S2K_DEV sc sc_reduce_once(const uint32_t a[8]) {
+  sc r;
+  uint32_t t[8];
+  uint32_t borrow = u256_sub(t, a, SC_N);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = borrow ? a[i] : t[i];
+  return r;
+}
+S2K_DEV sc sc_add(const sc& a, const sc& b) {   // scalar.go:66
+  uint32_t s[8], t[8];
+  uint32_t carry = u256_add(s, a.v, b.v);
+  uint32_t borrow = u256_sub(t, s, SC_N);
+  sc r;
+  bool use_t = carry || !borrow;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = use_t ? t[i] : s[i];
+  return r;
+}
+S2K_DEV sc sc_neg(const sc& a) {   // scalar.go:78
+  uint32_t t[8];
+  u256_sub(t, SC_N, a.v);
+  bool z = sc_is_zero(a);
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = z ? 0u : t[i];
+  return r;
+}
+
+// a * b * R^-1 mod n  (fiat Mul, secp256k1montgomeryscalar.go:87, on 32-bit words)
+__device__ __noinline__ sc sc_montmul(sc a, sc b) {
+  uint32_t t[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint64_t x = (uint64_t)a.v[i] * b.v[j] + t[j] + carry;
+      t[j] = (uint32_t)x;
+      carry = (uint32_t)(x >> 32);
+    }
+    uint64_t x = (uint64_t)t[8] + carry;
+    t[8] = (uint32_t)x;
+    t[9] = (uint32_t)(x >> 32);
+    uint32_t q = t[0] * SC_N0INV;
+    x = (uint64_t)q * SC_N[0] + t[0];
+    carry = (uint32_t)(x >> 32);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      x = (uint64_t)q * SC_N[j] + t[j] + carry;
+      t[j - 1] = (uint32_t)x;
+      carry = (uint32_t)(x >> 32);
+    }
+    x = (uint64_t)t[8] + carry;
+    t[7] = (uint32_t)x;
+    t[8] = t[9] + (uint32_t)(x >> 32);
+  }
+  uint32_t d[8];
+  uint32_t borrow = u256_sub(d, t, SC_N);
+  bool use_d = t[8] != 0 || !borrow;
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = use_d ? d[i] : t[i];
+  return r;
+}
+S2K_DEV sc sc_to_mont(const sc& a) { return sc_montmul(a, sc_from_limbs(SC_R2)); }   // fiat ToMontgomery
+S2K_DEV sc sc_montsqr_n(sc a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = sc_montmul(a, a);
+  return a;
+}
+
+// x^(n-2) in the Montgomery domain (in: x*R, out: x^-1*R); chain of scalar_invert.go:11-303
+// (253 S + 40 M).  Invert(0) = 0.
+__device__ __noinline__ sc sc_mont_inv(sc x) {
+  sc t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;
+  t0 = sc_montmul(x, x);
+  t1 = sc_montmul(x, t0);
+  t2 = sc_montmul(t0, t1);
+  t3 = sc_montmul(t0, t2);
+  t4 = sc_montmul(t0, t3);
+  t5 = sc_montmul(t0, t4);
+  t0 = sc_montmul(t0, t5);
+  t6 = sc_montsqr_n(t0, 2);
+  t6 = sc_montmul(t5, t6);
+  t7 = sc_montmul(t6, t6);
+  t7 = sc_montmul(x, t7);
+  t8 = sc_montmul(t7, t7);
+  t8 = sc_montmul(x, t8);
+  t9 = sc_montsqr_n(t8, 3);
+  t10 = sc_montsqr_n(t9, 2);
+  t11 = sc_montmul(t10, t10);
+  t12 = sc_montmul(t11, t11);
+  t13 = sc_montsqr_n(t12, 7);
+  t11 = sc_montmul(t11, t13);
+  t11 = sc_montsqr_n(t11, 9);
+  t12 = sc_montmul(t12, t11);
+  t11 = sc_montsqr_n(t12, 6);
+  t10 = sc_montmul(t10, t11);
+  t10 = sc_montsqr_n(t10, 26);
+  t12 = sc_montmul(t12, t10);
+  t10 = sc_montsqr_n(t12, 4);
+  t9 = sc_montmul(t9, t10);
+  t9 = sc_montsqr_n(t9, 60);
+  t12 = sc_montmul(t12, t9);
+  t7 = sc_montmul(t7, t12);
+  t7 = sc_montsqr_n(t7, 5);
+  t7 = sc_montmul(t5, t7);
+  t7 = sc_montsqr_n(t7, 3);
+  t7 = sc_montmul(t2, t7);
+  t7 = sc_montsqr_n(t7, 4);
+  t7 = sc_montmul(t2, t7);
+  t7 = sc_montsqr_n(t7, 4);
+  t7 = sc_montmul(t3, t7);
+  t7 = sc_montsqr_n(t7, 5);
+  t7 = sc_montmul(t0, t7);
+  t7 = sc_montsqr_n(t7, 2);
+  t7 = sc_montmul(t1, t7);
+  t7 = sc_montsqr_n(t7, 5);
+  t7 = sc_montmul(t3, t7);
+  t7 = sc_montsqr_n(t7, 6);
+  t7 = sc_montmul(t0, t7);
+  t7 = sc_montsqr_n(t7, 5);
+  t7 = sc_montmul(t5, t7);
+  t7 = sc_montsqr_n(t7, 4);
+  t7 = sc_montmul(t0, t7);
+  t7 = sc_montsqr_n(t7, 3);
+  t7 = sc_montmul(x, t7);
+  t7 = sc_montsqr_n(t7, 6);
+  t2 = sc_montmul(t2, t7);
+  t2 = sc_montsqr_n(t2, 10);
+  t2 = sc_montmul(t3, t2);
+  t2 = sc_montsqr_n(t2, 4);
+  t3 = sc_montmul(t3, t2);
+  t3 = sc_montsqr_n(t3, 9);
+  t8 = sc_montmul(t8, t3);
+  t8 = sc_montsqr_n(t8, 5);
+  t8 = sc_montmul(t4, t8);
+  t8 = sc_montsqr_n(t8, 6);
+  t5 = sc_montmul(t5, t8);
+  t5 = sc_montsqr_n(t5, 4);
+  t5 = sc_montmul(t0, t5);
+  t5 = sc_montsqr_n(t5, 5);
+  t1 = sc_montmul(t1, t5);
+  t1 = sc_montsqr_n(t1, 6);
+  t1 = sc_montmul(t0, t1);
+  t1 = sc_montsqr_n(t1, 10);
+  t0 = sc_montmul(t0, t1);
+  t0 = sc_montsqr_n(t0, 4);
+  t4 = sc_montmul(t4, t0);
+  t4 = sc_montsqr_n(t4, 6);
+  t14 = sc_montmul(x, t4);
+  t14 = sc_montsqr_n(t14, 8);
+  return sc_montmul(t6, t14);
+}
+
+// round(k * g / 2^384) for plain k, g (mulGFlooredDiv, point_mul_glv.go:119-189): < 2^128
+S2K_DEV sc sc_mul_g_floored_div(const sc& k, const uint32_t g[8]) {
+  uint32_t t[16];
+  u256_mul_wide(t, k.v, g);
+  uint32_t add = t[11] >> 31;          // bit 383
+  sc r = sc_zero();
+  unsigned c = 0;
+  r.v[0] = __builtin_addc(t[12], add, c, &c);
+  r.v[1] = __builtin_addc(t[13], 0u, c, &c);
+  r.v[2] = __builtin_addc(t[14], 0u, c, &c);
+  r.v[3] = __builtin_addc(t[15], 0u, c, &c);
+  return r;
+}
+// splitGLV (point_mul_glv.go:59-117) followed by the sign normalisation of
+// scalarMultVartimeGLV (:212-220): k = (-1)^neg1*k1 + (-1)^neg2*k2*lambda (mod n), with
+// k1, k2 < 2^128 (limbs 4..7 zero).
+S2K_DEV void sc_split_glv(const sc& k, sc& k1, bool& neg1, sc& k2, bool& neg2) {
+  sc c1 = sc_mul_g_floored_div(k, SC_G1);
+  sc c2 = sc_mul_g_floored_div(k, SC_G2);
+  k2 = sc_add(sc_montmul(c1, sc_from_limbs(SC_NEG_B1_M)), sc_montmul(c2, sc_from_limbs(SC_NEG_B2_M)));
+  k1 = sc_add(k, sc_montmul(k2, sc_from_limbs(SC_NEG_LAMBDA_M)));
+  neg1 = sc_is_gt_half_n(k1);
+  neg2 = sc_is_gt_half_n(k2);
+  k1 = neg1 ? sc_neg(k1) : k1;
+  k2 = neg2 ? sc_neg(k2) : k2;
+}
+
+}  // namespace s2k

@@ -1,0 +1,286 @@
+"""Parity of the HIP engine (through the C-ABI) with the CPU oracle and the reference's
+golden vectors.  Needs a real MI355X: run with  pytest -m gpu.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import pyref as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+b32 = R.b32
+H = bytes.fromhex
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import secp256k1_voi_amd as S
+    return S.Engine(0)
+
+
+def rows(a):
+    return [bytes(x) for x in np.asarray(a)]
+
+
+FP_EDGE = [0, 1, 2, 3, R.P - 1, R.P - 2, R.P, R.P + 1, 2**256 - 1, 2**255, 2**32 + 977, 2**32 + 976, 2**256 - 2**32 - 978,
+           (R.P + 1) // 2, 2**128 - 1, 2**128, 2**224, 0xFFFFFFFF, 0xFFFFFFFF00000000, R.N, R.N - 1, R.N + 1]
+
+
+def test_fp_ops(eng, oracle):
+    import secp256k1_voi_amd as S
+    rnd = random.Random(21)
+    vals = FP_EDGE + [rnd.randrange(2**256) for _ in range(1500)] + [rnd.randrange(R.P - 2**40, 2**256) for _ in range(300)]
+    a = [b32(v) for v in vals]
+    bvals = list(vals)
+    rnd.shuffle(bvals)
+    b = [b32(v) for v in bvals]
+    ai = [v % R.P for v in vals]
+    bi = [v % R.P for v in bvals]
+    out, _ = eng.fp_op_batch(S.OP_MUL, a, b)
+    assert rows(out) == [b32(x * y % R.P) for x, y in zip(ai, bi)]
+    out, _ = eng.fp_op_batch(S.OP_SQR, a)
+    assert rows(out) == [b32(x * x % R.P) for x in ai]
+    out, _ = eng.fp_op_batch(S.OP_ADD, a, b)
+    assert rows(out) == [b32((x + y) % R.P) for x, y in zip(ai, bi)]
+    out, _ = eng.fp_op_batch(S.OP_SUB, a, b)
+    assert rows(out) == [b32((x - y) % R.P) for x, y in zip(ai, bi)]
+    out, _ = eng.fp_op_batch(S.OP_NEG, a)
+    assert rows(out) == [b32(-x % R.P) for x in ai]
+    out, _ = eng.fp_op_batch(S.OP_INV, a)
+    assert rows(out) == [oracle.fp_inv(b32(x)) for x in ai]
+    out, flag = eng.fp_op_batch(S.OP_SQRT, a)
+    for x, o, f in zip(ai, rows(out), flag):
+        ref, ok = oracle.fp_sqrt(b32(x))
+        assert bool(f) == ok
+        if ok:
+            assert int.from_bytes(o, "big") ** 2 % R.P == x
+        else:
+            assert o == bytes(32)
+
+
+def test_fp_mul_structured(eng):
+    # operands that stress every carry path of the 8x32 product and the folding steps
+    import secp256k1_voi_amd as S
+    pats = [0, 1, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0xFFFFFFFE]
+    rnd = random.Random(22)
+    vals = []
+    for _ in range(4096):
+        v = 0
+        for i in range(8):
+            v |= rnd.choice(pats) << (32 * i)
+        vals.append(v)
+    a = [b32(v) for v in vals]
+    b = [b32(v) for v in reversed(vals)]
+    out, _ = eng.fp_op_batch(S.OP_MUL, a, b)
+    assert rows(out) == [b32(x * y % R.P) for x, y in zip(vals, reversed(vals))]
+    out, _ = eng.fp_op_batch(S.OP_SQR, a)
+    assert rows(out) == [b32(x * x % R.P) for x in vals]
+    out, _ = eng.fp_op_batch(S.OP_ADD, a, b)
+    assert rows(out) == [b32((x + y) % R.P) for x, y in zip(vals, reversed(vals))]
+    out, _ = eng.fp_op_batch(S.OP_SUB, a, b)
+    assert rows(out) == [b32((x - y) % R.P) for x, y in zip(vals, reversed(vals))]
+
+
+def test_fn_ops(eng, oracle):
+    import secp256k1_voi_amd as S
+    rnd = random.Random(23)
+    edge = [0, 1, 2, R.N - 1, R.N - 2, R.N, R.N + 1, 2**256 - 1, R.N // 2, R.N // 2 + 1, 2**128, 2**128 - 1]
+    vals = edge + [rnd.randrange(2**256) for _ in range(600)]
+    a = [b32(v) for v in vals]
+    bv = list(reversed(vals))
+    b = [b32(v) for v in bv]
+    ai = [v - R.N if v >= R.N else v for v in vals]     # SetBytes: a single conditional subtraction (scalar.go:123)
+    bi = [v - R.N if v >= R.N else v for v in bv]
+    out, _ = eng.fn_op_batch(S.OP_MUL, a, b)
+    assert rows(out) == [b32(x * y % R.N) for x, y in zip(ai, bi)]
+    out, _ = eng.fn_op_batch(S.OP_ADD, a, b)
+    assert rows(out) == [b32((x + y) % R.N) for x, y in zip(ai, bi)]
+    out, _ = eng.fn_op_batch(S.OP_SUB, a, b)
+    assert rows(out) == [b32((x - y) % R.N) for x, y in zip(ai, bi)]
+    out, _ = eng.fn_op_batch(S.OP_NEG, a)
+    assert rows(out) == [b32(-x % R.N) for x in ai]
+    out, _ = eng.fn_op_batch(S.OP_INV, a)
+    assert rows(out) == [b32(pow(x, R.N - 2, R.N)) for x in ai]
+    k = load_golden("kats.json")["glv"]
+    sc = [int(s, 16) for s in k["boundary_scalars"]] + [0, 1, R.N - 1] + [rnd.randrange(R.N) for _ in range(500)]
+    k1, k2 = eng.fn_split_glv_batch([b32(v) for v in sc])
+    for v, x, y in zip(sc, rows(k1), rows(k2)):
+        assert (x, y) == oracle.fn_split_glv(b32(v))          # same decomposition as the reference's formula
+        xi, yi = int.from_bytes(x, "big"), int.from_bytes(y, "big")
+        assert (xi + yi * R.LAMBDA) % R.N == v
+        assert min(xi, R.N - xi) < 2**128 and min(yi, R.N - yi) < 2**128
+
+
+def test_generator_table(eng, oracle):
+    # even-numbered 8-bit windows of the reference's blob are entries of the 16-bit tables
+    d = load_golden("gentable.json")
+    hit = 0
+    for s in d["samples"]:
+        if s["i"] % 2 == 0 and s["i"] >= 2:
+            assert eng.gtable_entry(s["i"] // 2, s["j"]).hex() == s["xy"]
+            hit += 1
+    assert hit >= 10
+    S_ = sum(1 << (16 * i) for i in range(1, 16))
+    for dgt in (0, 1, 0xFFFF, 0x1234):
+        exp = R.mul((dgt - S_) % R.N, R.G)
+        assert eng.gtable_entry(0, dgt) == b32(exp[0]) + b32(exp[1])
+        exp = R.mul((dgt + 1) << (16 * 15), R.G)
+        assert eng.gtable_entry(15, dgt) == b32(exp[0]) + b32(exp[1])
+
+
+def test_scalar_base_mult(eng, oracle):
+    rnd = random.Random(24)
+    ks = [0, 1, 2, R.N - 1, R.N, R.N + 5, 2**256 - 1, 0xFFFF, 0x10000, 2**255] + [rnd.randrange(R.N) for _ in range(300)]
+    ks += [sum(rnd.choice([0, 0xFFFF, 1]) << (16 * i) for i in range(16)) for _ in range(50)]
+    out = eng.scalar_base_mult_batch([b32(k) for k in ks])
+    for k, o in zip(ks, rows(out)):
+        assert o == oracle.scalar_base_mult_vartime(b32(k)), hex(k)     # oracle reduces like SetBytes
+
+
+def test_point_add_double(eng, oracle):
+    rnd = random.Random(25)
+    pts = [None] + [R.mul(rnd.randrange(1, R.N), R.G) for _ in range(200)]
+    A = [R.enc65(p) for p in pts]
+    Bp = [pts[rnd.randrange(len(pts))] for _ in pts]
+    Bp[1] = pts[1]                      # a + a
+    Bp[2] = R.neg(pts[2])               # a - a
+    Bp[3] = None
+    B = [R.enc65(p) for p in Bp]
+    out = eng.point_add_batch(A, B)
+    assert rows(out) == [R.enc65(R.add(p, q)) for p, q in zip(pts, Bp)]
+    out = eng.point_double_batch(A)
+    assert rows(out) == [R.enc65(R.add(p, p)) for p in pts]
+
+
+def test_scalar_mult_kats(eng, oracle):
+    kat = load_golden("kats.json")["libsecp256k1_ecmult_const"]
+    out = eng.scalar_mult_batch([H(kat["xn"])], [H(kat["a"])])
+    assert rows(out)[0].hex() == kat["b"]
+    d = load_golden("wycheproof_ecdh.json")
+    pts = [oracle.point_from_bytes(H(c["point"])) for c in d["cases"]]
+    out = eng.scalar_mult_batch([H(c["private"]) for c in d["cases"]], pts)
+    for c, o in zip(d["cases"], rows(out)):
+        assert o[1:33] == H(c["shared"]), c["tcId"]
+    # compressed / uncompressed decode on device
+    enc = [H(c["point"]) for c in d["cases"] if len(c["point"]) == 130]
+    dec, ok = eng.point_decode_batch(enc, 65)
+    assert ok.all() and rows(dec) == enc
+
+
+def test_scalar_mult_random_and_edges(eng, oracle):
+    rnd = random.Random(26)
+    k = load_golden("kats.json")["glv"]
+    ks = [0, 1, 2, R.N - 1, R.N - 2, R.LAMBDA, R.N - R.LAMBDA, 2**128, 2**128 - 1, 2**127] + \
+         [int(s, 16) for s in k["boundary_scalars"]] + [rnd.randrange(R.N) for _ in range(200)]
+    P = [R.enc65(R.mul(rnd.randrange(1, R.N), R.G)) for _ in ks]
+    P[5] = bytes(65)                      # identity input
+    out = eng.scalar_mult_batch([b32(v) for v in ks], P)
+    for v, p, o in zip(ks, P, rows(out)):
+        assert o == oracle.scalar_mult_trivial(b32(v), p), hex(v)
+    u1 = [rnd.randrange(R.N) for _ in ks]
+    out = eng.double_scalar_mult_basepoint_batch([b32(v) for v in u1], [b32(v) for v in ks], P)
+    for a, v, p, o in zip(u1, ks, P, rows(out)):
+        assert o == oracle.double_scalar_mult_basepoint_vartime(b32(a), b32(v), p)
+    # u1*G + u2*Q = identity
+    d = rnd.randrange(1, R.N)
+    q = R.enc65(R.mul(d, R.G))
+    u2 = rnd.randrange(1, R.N)
+    out = eng.double_scalar_mult_basepoint_batch([b32((-u2 * d) % R.N)], [b32(u2)], [q])
+    assert rows(out)[0] == bytes(65)
+
+
+def test_point_decode(eng, oracle):
+    rnd = random.Random(27)
+    enc = []
+    for _ in range(300):
+        x = rnd.randrange(R.P)
+        enc.append(bytes([rnd.choice([2, 3])]) + b32(x))
+    enc += [b"\x02" + b32(R.P), b"\x03" + b32(R.P + 1), b"\x04" + b32(R.GX), b"\x00" + b32(R.GX), b"\x02" + b32(R.GX),
+            b"\x03" + b32(R.GX), b"\x02" + b32(0), b"\x02" + b32(2**256 - 1)]
+    dec, ok = eng.point_decode_batch(enc, 33)
+    for e, o, f in zip(enc, rows(dec), ok):
+        exp = oracle.point_from_bytes(e)
+        assert bool(f) == (exp is not None), e.hex()
+        assert o == (exp if exp is not None else bytes(65))
+    g = oracle.point_generator()
+    bad = bytearray(g)
+    bad[64] ^= 1
+    dec, ok = eng.point_decode_batch([g, bytes(bad), b"\x05" + g[1:], b"\x04" + b32(R.P) + g[33:]], 65)
+    assert ok.tolist() == [1, 0, 0, 0] and rows(dec)[0] == g
+
+
+@pytest.mark.parametrize("fn", ["wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"])
+def test_wycheproof_ecdsa(eng, oracle, fn):
+    # Host side (DER parse) through the oracle's restatement of ParseASN1Signature; the
+    # arithmetic verdict comes from the GPU.  Cases the parser rejects are never valid.
+    d = load_golden(fn)
+    items, exp = [], []
+    for c in d["cases"]:
+        rs = oracle.parse_asn1_signature(H(c["sig"]))
+        if rs is None:
+            assert not c["valid"]
+            continue
+        items.append((H(c["pub"])[1:], H(c["digest"])[:32], rs[0], rs[1]))
+        exp.append(int(c["valid"]))
+    out = eng.ecdsa_verify_batch([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items])
+    assert out.tolist() == exp
+    assert sum(exp) == {"wycheproof_ecdsa_sha256.json": 164, "wycheproof_ecdsa_sha512.json": 233}[fn]
+
+
+def test_ecdsa_kats(eng, oracle):
+    k = load_golden("kats.json")["reused_k_pairs"]
+    Q = oracle.scalar_base_mult_vartime(H(k["private"]))[1:]
+    out = eng.ecdsa_verify_batch([Q, Q], [H(s["digest"]) for s in k["sigs"]], [H(s["r"]) for s in k["sigs"]],
+                                 [H(s["s"]) for s in k["sigs"]])
+    assert out.tolist() == [1, 1]
+    d = load_golden("rfc6979.json")
+    pubs, digs, rs, ss = [], [], [], []
+    for c in d["cases"]:
+        pubs.append(oracle.scalar_base_mult_vartime(H(c["private"]))[1:])
+        digs.append(H(c["digest"]))
+        r, s = oracle.parse_asn1_signature(H(c["sig"]))
+        rs.append(r)
+        ss.append(s)
+    assert eng.ecdsa_verify_batch(pubs, digs, rs, ss).all()
+    assert eng.ecdsa_verify_batch(pubs, digs, rs, ss, reject_malleable=True).all()
+    assert not eng.ecdsa_verify_batch(pubs, digs[1:] + digs[:1], rs, ss).any()
+
+
+@pytest.mark.parametrize("n,seed", [(1, 3), (63, 4), (64, 5), (65, 6), (257, 7), (5000, 8)])
+def test_ecdsa_random_batches(eng, oracle, n, seed):
+    from workload import make_ecdsa_batch
+    w = make_ecdsa_batch(oracle, n, seed=seed, corrupt_every=3, low_s=(seed % 2 == 0))
+    for rm in (False, True):
+        exp = oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], reject_malleable=rm, nthreads=8)
+        got = eng.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], reject_malleable=rm)
+        assert got.tolist() == exp.tolist()
+    plain = oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+    for i, kind in enumerate(w["kinds"]):
+        if kind is None or kind == "high_s":
+            assert plain[i] == 1
+        elif kind != "qx":
+            assert plain[i] == 0, kind
+
+
+def test_ecdsa_empty_and_errors(eng):
+    assert eng.ecdsa_verify_batch(b"", b"", b"", b"").size == 0
+    with pytest.raises(ValueError):
+        eng.ecdsa_verify_batch(bytes(64), bytes(32), bytes(64), bytes(32))      # length mismatch
+    with pytest.raises(ValueError):
+        eng.scalar_mult_batch([bytes(32)] * 2, [bytes(65)])
+
+
+def test_ecdsa_small_r(eng, oracle):
+    # r < p - n takes the second comparison X == (r+n)Z (ecdsa.go:460 wrap); it must not
+    # accept anything the reference rejects.  (Accepting cases are in the Wycheproof files.)
+    rnd = random.Random(31)
+    d = rnd.randrange(1, R.N)
+    q = R.mul(d, R.G)
+    Q = b32(q[0]) + b32(q[1])
+    dig = rnd.randbytes(32)
+    smalls = [1, 2, R.P - R.N - 1, R.P - R.N, R.P - R.N + 1, 2**128]
+    out = eng.ecdsa_verify_batch([Q] * len(smalls), [dig] * len(smalls), [b32(r) for r in smalls], [b32(5)] * len(smalls))
+    exp = [int(oracle.ecdsa_verify_raw(Q, dig, b32(r), b32(5))) for r in smalls]
+    assert out.tolist() == exp
