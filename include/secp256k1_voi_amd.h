@@ -47,6 +47,9 @@ enum {
 
 /* flags for the ECDSA entry points */
 #define S2K_ECDSA_REJECT_MALLEABLE 1u /* ECDSAOptions.RejectMalleable: reject s > n/2 (ecdsa.go:212) */
+/* Diagnostics: send every signature through the complete-formula kernel that normally only
+ * re-does the lanes the fast Jacobian kernel cannot decide.  Same results, ~3x slower. */
+#define S2K_ECDSA_FORCE_COMPLETE 0x80000000u
 
 #define S2K_POINT_RECORD 65
 #define S2K_SCALAR_SIZE 32 /* ScalarSize, scalar.go:17 */

@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libsecp256k1_voi_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 REJECT_MALLEABLE = 1
+FORCE_COMPLETE = 0x80000000
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 
@@ -137,7 +138,8 @@ class Engine:
             raise EngineError(f"engine call failed ({rc}): {self._lib.s2k_last_error(self._h).decode()}")
 
     # ---- hot path -------------------------------------------------------------------
-    def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
+    def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False,
+                           force_complete: bool = False) -> np.ndarray:
         """valid bits (uint8 0/1) for n (pubkey, digest, r, s) tuples; host buffers."""
         r = _arr(r, 32)
         n = r.shape[0]
@@ -145,7 +147,8 @@ class Engine:
         out = np.zeros(n, dtype=np.uint8)
         self._check(self._lib.s2k_ecdsa_verify_batch(self._h, n, pub_xy.ctypes.data, digest32.ctypes.data,
                                                      r.ctypes.data, s.ctypes.data,
-                                                     REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data))
+                                                     (REJECT_MALLEABLE if reject_malleable else 0) |
+                                                     (FORCE_COMPLETE if force_complete else 0), out.ctypes.data))
         return out
 
     def ecdsa_verify_batch_device(self, n, d_pub_xy, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):

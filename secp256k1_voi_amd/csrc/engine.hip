@@ -12,6 +12,7 @@
 
 #include "../../include/secp256k1_voi_amd.h"
 #include "fe.h"
+#include "jacobian.h"
 #include "point.h"
 #include "sc.h"
 
@@ -245,12 +246,10 @@ S2K_DEV pt pt_mul_glv(const sc& k, const apt& q, uint32_t* __restrict__ qt, size
 __device__ static const uint32_t FE_P_MINUS_N[8] = {0x2fc9baeeu, 0x402da172u, 0x50b75fc4u, 0x45512319u,
                                                     0x00000001u, 0, 0, 0};
 
-__global__ void __launch_bounds__(256)
-k_ecdsa_verify(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
-               const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-               uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
-  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
+// one signature, complete formulas only (secec/ecdsa.go:392-470)
+S2K_DEV uint8_t verify_complete(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
+                                const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
+                                const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
   sc r, s;
   uint32_t e_raw[8];
   apt q;
@@ -286,7 +285,272 @@ k_ecdsa_verify(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __res
     u256_add(r2.v, r.v, SC_N);
     match = match || fe_eq(R.x, fe_mul(r2, R.z));
   }
-  out[idx] = (ok && match) ? 1 : 0;
+  return (ok && match) ? 1 : 0;
+}
+
+// every lane through the complete path (S2K_ECDSA_FORCE_COMPLETE; also the round-1 baseline kernel)
+__global__ void __launch_bounds__(256)
+k_ecdsa_verify(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
+               const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
+               uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  out[idx] = verify_complete(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
+}
+
+// the lanes the fast kernel could not decide (final Z = 0): a short worklist, normally empty
+__global__ void __launch_bounds__(256)
+k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ pub,
+                  const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
+                  uint32_t flags, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt,
+                  size_t stride) {
+  uint32_t count = *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    size_t idx = wl[w];
+    out[idx] = verify_complete(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fast path, kernel 1: scalar preparation with batched inversion.
+// Each thread owns PREP_M signatures (i = t, t+T, t+2T, ...): one Fermat inversion
+// (scalar_invert.go:11, 253 S + 40 M) is shared by PREP_M signatures through Montgomery's
+// trick, 3 extra multiplications each, instead of one inversion per signature as in
+// verify (ecdsa.go:428).  Out per signature (word-major, coalesced):
+//   u1 (8 words), |k1|, |k2| (4 words each; u2 = +-k1 +- k2*lambda), flag word.
+// ---------------------------------------------------------------------------------------
+constexpr int PREP_M = 16;
+constexpr int PREP_WORDS = 17;
+enum { PF_OK = 1, PF_NEG1 = 2, PF_NEG2 = 4, PF_EVEN1 = 8, PF_EVEN2 = 16 };
+
+S2K_DEV sc ws_load_sc(const uint32_t* __restrict__ base, size_t stride, size_t i) {
+  sc r;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) r.v[w] = base[(size_t)w * stride + i];
+  return r;
+}
+S2K_DEV void ws_store_sc(uint32_t* __restrict__ base, size_t stride, size_t i, const sc& v) {
+#pragma unroll
+  for (int w = 0; w < 8; ++w) base[(size_t)w * stride + i] = v.v[w];
+}
+
+__global__ void __launch_bounds__(64)
+k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
+              const uint8_t* __restrict__ ssig, uint32_t flags, uint32_t* __restrict__ prep,
+              uint32_t* __restrict__ pref, uint32_t* __restrict__ smont, size_t stride) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  sc one_m = sc_from_limbs(SC_ONE_M);
+  sc acc = one_m;
+#pragma unroll 1
+  for (int j = 0; j < PREP_M; ++j) {
+    size_t i = (size_t)t + (size_t)j * T;
+    if (i >= n) break;
+    sc s;
+    load_be32(s.v, ssig + i * 32);
+    bool ok_s = sc_is_canonical_raw(s.v) && !sc_is_zero(s);
+    if (!ok_s) {   // keep the shared product invertible; the signature is rejected below
+      s = sc_zero();
+      s.v[0] = 1;
+    }
+    sc sm = sc_to_mont(s);
+    ws_store_sc(smont, stride, i, sm);
+    acc = sc_montmul(acc, sm);
+    ws_store_sc(pref, stride, i, acc);
+  }
+  sc inv = sc_mont_inv(acc);
+#pragma unroll 1
+  for (int j = PREP_M - 1; j >= 0; --j) {
+    size_t i = (size_t)t + (size_t)j * T;
+    if (i >= n) continue;
+    sc sm = ws_load_sc(smont, stride, i);
+    sc prev = j > 0 ? ws_load_sc(pref, stride, i - T) : one_m;
+    sc s_inv_m = sc_montmul(inv, prev);            // s_i^-1 * R
+    inv = sc_montmul(inv, sm);
+    sc r, s;
+    uint32_t e_raw[8];
+    load_be32(r.v, rsig + i * 32);
+    load_be32(s.v, ssig + i * 32);
+    load_be32(e_raw, dig + i * 32);
+    bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
+    if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
+    sc e = sc_reduce_once(e_raw);
+    sc u1 = sc_montmul(e, s_inv_m);
+    sc u2 = sc_montmul(r, s_inv_m);
+    sc k1, k2;
+    bool neg1, neg2;
+    sc_split_glv(u2, k1, neg1, k2, neg2);
+    uint32_t f = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) |
+                 ((k1.v[0] & 1u) ? 0 : PF_EVEN1) | ((k2.v[0] & 1u) ? 0 : PF_EVEN2);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) prep[(size_t)w * stride + i] = u1.v[w];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) prep[(size_t)(8 + w) * stride + i] = k1.v[w];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) prep[(size_t)(12 + w) * stride + i] = k2.v[w];
+    prep[(size_t)16 * stride + i] = f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fast path, kernel 2: per-lane table, ladder, generator part, final comparison.
+// Per-lane table {1,3,..,15}*Q brought to one common Z (no inversion): build A_j = A_{j-1} + 2Q
+// on the curve isomorphic by C = Z(2Q), remember H_j (Z_j = Z_{j-1} H_j), then scale entry j
+// by (H_{j+1}...H_7)^{2,3}.  The ladder then only ever adds affine points (8 M + 3 S); its
+// result has the true Z = Z_ladder * Z_7 * C.
+// Table storage: [entry*16 + word][lane] (x limbs then y limbs), H scratch [entry*8 + word][lane].
+// ---------------------------------------------------------------------------------------
+constexpr int FQT_WORDS = QT_ENTRIES * 16;
+constexpr int FHS_WORDS = QT_ENTRIES * 8;
+
+S2K_DEV void fq_store_fe(uint32_t* __restrict__ base, size_t stride, size_t lane, int word0, const fe& v) {
+#pragma unroll
+  for (int w = 0; w < 8; ++w) base[(size_t)(word0 + w) * stride + lane] = v.v[w];
+}
+S2K_DEV fe fq_load_fe(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t word0) {
+  fe r;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) r.v[w] = base[(size_t)(word0 + w) * stride + lane];
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
+              const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ hs,
+              const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
+              uint32_t* __restrict__ wl, size_t stride) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  apt q;
+  load_be32(q.x.v, pub + idx * 64);
+  load_be32(q.y.v, pub + idx * 64 + 32);
+  uint32_t pf = prep[(size_t)16 * stride + idx];
+  bool ok = (pf & PF_OK) && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v) && apt_on_curve(q);
+  if (!ok) {   // keep the arithmetic on the curve; the verdict is already "invalid"
+    q.x = fe_from_limbs(FE_GX);
+    q.y = fe_from_limbs(FE_GY);
+  }
+  const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
+
+  // ---- table ----
+  fe zg;   // Z_7 * C
+  {
+    jpt a0;
+    a0.x = q.x;
+    a0.y = q.y;
+    a0.z = fe_from_u32(1);
+    jpt d = jpt_double(a0);
+    fe c2 = fe_sqr(d.z);
+    fe c3 = fe_mul(c2, d.z);
+    jpt cur;
+    cur.x = fe_mul(q.x, c2);
+    cur.y = fe_mul(q.y, c3);
+    cur.z = fe_from_u32(1);
+    fq_store_fe(qt, stride, idx, 0, cur.x);
+    fq_store_fe(qt, stride, idx, 8, cur.y);
+#pragma unroll 1
+    for (int j = 1; j < QT_ENTRIES; ++j) {
+      fe h;
+      cur = jpt_add_affine(cur, d.x, d.y, &h);
+      fq_store_fe(qt, stride, idx, j * 16, cur.x);
+      fq_store_fe(qt, stride, idx, j * 16 + 8, cur.y);
+      fq_store_fe(hs, stride, idx, j * 8, h);
+    }
+    zg = fe_mul(cur.z, d.z);
+    fe rr = fe_from_u32(1);
+#pragma unroll 1
+    for (int j = QT_ENTRIES - 2; j >= 0; --j) {
+      rr = fe_mul(rr, fq_load_fe(hs, stride, idx, (j + 1) * 8));
+      fe r2 = fe_sqr(rr);
+      fe r3 = fe_mul(r2, rr);
+      fe x = fe_mul(fq_load_fe(qt, stride, idx, j * 16), r2);
+      fe y = fe_mul(fq_load_fe(qt, stride, idx, j * 16 + 8), r3);
+      fq_store_fe(qt, stride, idx, j * 16, x);
+      fq_store_fe(qt, stride, idx, j * 16 + 8, y);
+    }
+  }
+
+  // ---- ladder over |k1|, |k2| ----
+  fe beta = fe_from_limbs(FE_BETA);
+  sc k1 = sc_zero(), k2 = sc_zero();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    k1.v[w] = prep[(size_t)(8 + w) * stride + idx];
+    k2.v[w] = prep[(size_t)(12 + w) * stride + idx];
+  }
+  k1.v[0] |= 1u;
+  k2.v[0] |= 1u;
+  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+  fe t0x = fq_load_fe(qt, stride, idx, 0), t0y = fq_load_fe(qt, stride, idx, 8);
+  jpt acc;
+  acc.x = t0x;
+  acc.y = fe_select(neg1, t0y, fe_neg(t0y));
+  acc.z = fe_from_u32(1);
+  acc = jpt_add_affine(acc, fe_mul(t0x, beta), fe_select(neg2, t0y, fe_neg(t0y)));
+#pragma unroll 1
+  for (int i = 31; i >= 0; --i) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) acc = jpt_double(acc);
+    uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      uint32_t w = t ? w2 : w1;
+      bool neg = (t ? neg2 : neg1) != (w < 8u);
+      uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+      fe x = fq_load_fe(qt, stride, idx, entry * 16), y = fq_load_fe(qt, stride, idx, entry * 16 + 8);
+      if (t) x = fe_mul(x, beta);
+      acc = jpt_add_affine(acc, x, fe_select(neg, y, fe_neg(y)));
+    }
+  }
+  // k' = k | 1: take the extra 1 back out of even halves
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    fe x = t ? fe_mul(t0x, beta) : t0x;
+    bool sneg = !(t ? neg2 : neg1);
+    jpt sum = jpt_add_affine(acc, x, fe_select(sneg, t0y, fe_neg(t0y)));
+    bool even = pf & (t ? PF_EVEN2 : PF_EVEN1);
+    acc.x = fe_select(even, acc.x, sum.x);
+    acc.y = fe_select(even, acc.y, sum.y);
+    acc.z = fe_select(even, acc.z, sum.z);
+  }
+  acc.z = fe_mul(acc.z, zg);   // back on secp256k1 itself
+
+  // ---- generator part: u1*G from the resident tables ----
+  {
+    uint32_t u[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + idx];
+#pragma unroll 1
+    for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
+      apt g = gt_load(gt, w, u[0] & 0xffffu);
+      acc = jpt_add_affine(acc, g.x, g.y);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) u[i] = (u[i] >> 16) | (u[i + 1] << 16);
+      u[7] >>= 16;
+    }
+  }
+
+  // ---- x(R) mod n == r  (ecdsa.go:450-465) ----
+  uint8_t verdict = 0;
+  if (ok) {
+    if (fe_is_zero(acc.z)) {
+      // infinity or an exceptional case along the way: the complete kernel decides
+      uint32_t pos = atomicAdd(wl_count, 1u);
+      wl[pos] = (uint32_t)idx;
+    } else {
+      fe rf;
+      load_be32(rf.v, rsig + idx * 32);
+      fe zz = fe_sqr(acc.z);
+      bool match = fe_eq(acc.x, fe_mul(rf, zz));
+      if (u256_lt(rf.v, FE_P_MINUS_N)) {
+        fe r2;
+        u256_add(r2.v, rf.v, SC_N);
+        match = match || fe_eq(acc.x, fe_mul(r2, zz));
+      }
+      verdict = match ? 1 : 0;
+    }
+  }
+  out[idx] = verdict;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -522,7 +786,18 @@ extern "C" {
 const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
-size_t s2k_ecdsa_workspace_bytes(size_t n) { return lane_stride(n) * QT_WORDS * sizeof(uint32_t); }
+// workspace (32-bit words per lane, lane stride = n rounded up to 64):
+//   [0,192)    per-lane point tables: fast path uses 128 (table) + 64 (H scratch); the complete
+//              path reuses the same 192 words for its projective table
+//   [192,209)  scalar-prep output     [209,217) prefix products     [217,225) s in Montgomery form
+//   then       worklist: 1 counter + n indices
+constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = QT_WORDS, WS_PREF = WS_PREP + PREP_WORDS,
+                 WS_SMONT = WS_PREF + 8, WS_LANE_WORDS = WS_SMONT + 8;
+static_assert(FQT_WORDS + FHS_WORDS == QT_WORDS, "table regions must coincide");
+
+size_t s2k_ecdsa_workspace_bytes(size_t n) {
+  return (lane_stride(n) * WS_LANE_WORDS + 64 + lane_stride(n)) * sizeof(uint32_t);
+}
 
 static int ensure_ws(s2k_ctx* ctx, size_t n) {
   size_t need = s2k_ecdsa_workspace_bytes(n);
@@ -583,9 +858,33 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   int rc = ensure_ws(ctx, n);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)hip_stream;
-  k_ecdsa_verify<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
-                                                (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
-                                                ctx->gtable, (uint32_t*)ctx->ws, lane_stride(n));
+  const size_t stride = lane_stride(n);
+  uint32_t* ws = (uint32_t*)ctx->ws;
+  uint32_t* qt = ws + WS_QT * stride;
+  if (flags & S2K_ECDSA_FORCE_COMPLETE) {
+    k_ecdsa_verify<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
+                                                  (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
+                                                  ctx->gtable, qt, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    return S2K_OK;
+  }
+  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* pref = ws + WS_PREF * stride;
+  uint32_t* smont = ws + WS_SMONT * stride;
+  uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
+  uint32_t* wl = wl_count + 64;
+  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                              (const uint8_t*)d_s, flags, prep, pref, smont, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  k_verify_fast<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, hs,
+                                               ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  k_verify_fallback<<<64, 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
+                                        (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
+                                        ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
@@ -640,7 +939,7 @@ static int point_op(s2k_ctx* ctx, int op, size_t n, const uint8_t* k1, const uin
   if (rc) return rc;
   k_point_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)dk1.p, (const uint8_t*)dk2.p,
                                      (const uint8_t*)dpa.p, (const uint8_t*)dpb.p, (uint8_t*)dout.p, ctx->gtable,
-                                     (uint32_t*)ctx->ws, lane_stride(n));
+                                     (uint32_t*)ctx->ws + WS_QT * lane_stride(n), lane_stride(n));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 65, hipMemcpyDeviceToHost));

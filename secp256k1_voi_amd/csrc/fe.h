@@ -99,6 +99,19 @@ S2K_DEV fe fe_sub(const fe& a, const fe& b) {
   return r;
 }
 S2K_DEV fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
+// a / 2: (a + (a odd ? p : 0)) >> 1, computed on 257 bits
+S2K_DEV fe fe_half(const fe& a) {
+  uint32_t m = 0u - (a.v[0] & 1u);
+  uint32_t t[8];
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_addc(a.v[i], FE_P[i] & m, c, &c);
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  r.v[7] = (t[7] >> 1) | (c << 31);
+  return r;
+}
 S2K_DEV fe fe_dbl(const fe& a) { return fe_add(a, a); }
 
 // canonical representative in [0, p)  (reduceSaturated, field_reduce.go:82-102)

@@ -284,3 +284,60 @@ def test_ecdsa_small_r(eng, oracle):
     out = eng.ecdsa_verify_batch([Q] * len(smalls), [dig] * len(smalls), [b32(r) for r in smalls], [b32(5)] * len(smalls))
     exp = [int(oracle.ecdsa_verify_raw(Q, dig, b32(r), b32(5))) for r in smalls]
     assert out.tolist() == exp
+
+
+# ---- the fast (Jacobian) kernel and its complete fallback ------------------------------------
+def sig_from_u(d, u1, u2):
+    """A signature on key d*G whose verification computes exactly R = u1*G + u2*Q.
+    Returns (Q64, digest, r32, s32, valid) with `valid` from the independent implementation."""
+    q = R.mul(d, R.G)
+    Rp = R.add(R.mul(u1, R.G), R.mul(u2, q))
+    r = (Rp[0] % R.N) if Rp is not None else 1
+    r = r or 1
+    s = r * pow(u2, -1, R.N) % R.N
+    e = u1 * s % R.N
+    return b32(q[0]) + b32(q[1]), b32(e), b32(r), b32(s), R.ecdsa_verify(q, b32(e), r, s)
+
+
+def test_fast_path_exceptional_cases(eng, oracle):
+    rnd = random.Random(41)
+    S_ = sum(1 << (16 * i) for i in range(1, 16))
+    glv = [int(x, 16) for x in load_golden("kats.json")["glv"]["boundary_scalars"]]
+    items = []
+    for it in range(40):
+        d = rnd.randrange(1, R.N)
+        dinv = pow(d, -1, R.N)
+        u1 = rnd.randrange(R.N)
+        t0 = ((u1 & 0xFFFF) - S_) % R.N            # T_0[u1 & 0xffff] = t0*G
+        # (a) R = infinity; (b) u2*Q == first generator-table addend (P + P); (c) == its negative
+        items.append(sig_from_u(d, (-rnd.randrange(1, R.N) * 1) % R.N, 1))
+        u2 = rnd.randrange(1, R.N)
+        items.append(sig_from_u(d, (-u2 * d) % R.N, u2))
+        items.append(sig_from_u(d, u1, t0 * dinv % R.N))
+        items.append(sig_from_u(d, u1, (-t0) * dinv % R.N))
+        # (d) partial sums of the generator part that cancel: u2*Q = -(T_0 + T_1)
+        t1 = (((u1 >> 16) & 0xFFFF) + 1) << 16
+        items.append(sig_from_u(d, u1, (-(t0 + t1)) * dinv % R.N))
+    # (e) tiny / structured u2 and u1: table entries, +-1, lambda, boundary scalars, all-ones windows
+    d = rnd.randrange(1, R.N)
+    small = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, R.N - 1, R.N - 2, R.N - 3, R.N - 15, R.N - 16,
+             R.LAMBDA, R.LAMBDA + 1, R.LAMBDA - 1, R.N - R.LAMBDA, (R.LAMBDA * 3) % R.N, (R.LAMBDA * 15 + 1) % R.N,
+             2**128 - 1, 2**128, 2**128 + 1, 2**127, (1 << 129) - 1] + glv
+    for u2 in small:
+        for u1 in (0, 1, 0xFFFF, 0x10000, S_ % R.N, (S_ + 1) % R.N, R.N - 1, rnd.randrange(R.N)):
+            items.append(sig_from_u(d, u1, u2))
+    pub, dig, rr, ss, exp = zip(*items)
+    got = eng.ecdsa_verify_batch(pub, dig, rr, ss)
+    orc = oracle.ecdsa_verify_batch(b"".join(pub), b"".join(dig), b"".join(rr), b"".join(ss), nthreads=8)
+    assert got.tolist() == orc.tolist() == [int(e) for e in exp]
+    assert 0 < sum(exp) < len(exp)
+    # the diagnostic all-complete path agrees as well
+    assert eng.ecdsa_verify_batch(pub, dig, rr, ss, force_complete=True).tolist() == orc.tolist()
+
+
+def test_force_complete_matches_fast(eng, oracle):
+    from workload import make_ecdsa_batch
+    w = make_ecdsa_batch(oracle, 3000, seed=77, corrupt_every=5)
+    a = eng.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+    b = eng.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], force_complete=True)
+    assert a.tolist() == b.tolist()
