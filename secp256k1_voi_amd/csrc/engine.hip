@@ -400,18 +400,21 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // result has the true Z = Z_ladder * Z_7 * C.
 // Table storage: [entry*16 + word][lane] (x limbs then y limbs), H scratch [entry*8 + word][lane].
 // ---------------------------------------------------------------------------------------
-constexpr int FQT_WORDS = QT_ENTRIES * 16;
-constexpr int FHS_WORDS = QT_ENTRIES * 8;
+constexpr int FQT_WORDS = QT_ENTRIES * 20;
+constexpr int FHS_WORDS = QT_ENTRIES * 10;
 
-S2K_DEV void fq_store_fe(uint32_t* __restrict__ base, size_t stride, size_t lane, int word0, const fe& v) {
+S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int word0, const fe26& v) {
 #pragma unroll
-  for (int w = 0; w < 8; ++w) base[(size_t)(word0 + w) * stride + lane] = v.v[w];
+  for (int w = 0; w < 10; ++w) base[(size_t)(word0 + w) * stride + lane] = v.n[w];
 }
-S2K_DEV fe fq_load_fe(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t word0) {
-  fe r;
+S2K_DEV fe26 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t word0) {
+  fe26 r;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) r.v[w] = base[(size_t)(word0 + w) * stride + lane];
+  for (int w = 0; w < 10; ++w) r.n[w] = base[(size_t)(word0 + w) * stride + lane];
   return r;
+}
+S2K_DEV fe26 fe26_cond_negate1(const fe26& a, bool neg) {   // magnitude 1 in, <= 2 out
+  return fe26_select(neg, a, fe26_negate(a, 1));
 }
 
 __global__ void __launch_bounds__(256)
@@ -421,57 +424,75 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
               uint32_t* __restrict__ wl, size_t stride) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
-  apt q;
-  load_be32(q.x.v, pub + idx * 64);
-  load_be32(q.y.v, pub + idx * 64 + 32);
   uint32_t pf = prep[(size_t)16 * stride + idx];
-  bool ok = (pf & PF_OK) && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v) && apt_on_curve(q);
-  if (!ok) {   // keep the arithmetic on the curve; the verdict is already "invalid"
-    q.x = fe_from_limbs(FE_GX);
-    q.y = fe_from_limbs(FE_GY);
+  bool ok;
+  fe26 qx, qy;
+  {
+    apt q;
+    load_be32(q.x.v, pub + idx * 64);
+    load_be32(q.y.v, pub + idx * 64 + 32);
+    ok = (pf & PF_OK) && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
+    if (!ok) {   // keep the arithmetic on the curve; the verdict is already "invalid"
+      q.x = fe_from_limbs(FE_GX);
+      q.y = fe_from_limbs(FE_GY);
+    }
+    qx = fe26_from_words(q.x.v);
+    qy = fe26_from_words(q.y.v);
+    // y^2 == x^3 + 7 (point_s11n.go:298-307)
+    fe26 rhs = fe26_mul(fe26_sqr(qx), qx);
+    rhs.n[0] += 7;
+    bool on = fe26_eq(fe26_sqr(qy), rhs);
+    if (!on) {
+      ok = false;
+      qx = fe26_from_words(FE_GX);
+      qy = fe26_from_words(FE_GY);
+    }
   }
   const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
 
   // ---- table ----
-  fe zg;   // Z_7 * C
   {
-    jpt a0;
-    a0.x = q.x;
-    a0.y = q.y;
-    a0.z = fe_from_u32(1);
-    jpt d = jpt_double(a0);
-    fe c2 = fe_sqr(d.z);
-    fe c3 = fe_mul(c2, d.z);
-    jpt cur;
-    cur.x = fe_mul(q.x, c2);
-    cur.y = fe_mul(q.y, c3);
-    cur.z = fe_from_u32(1);
-    fq_store_fe(qt, stride, idx, 0, cur.x);
-    fq_store_fe(qt, stride, idx, 8, cur.y);
+    jpt26 a0;
+    a0.x = qx;
+    a0.y = qy;
+    a0.z = fe26_one();
+    jpt26 d = jpt26_double(a0);                      // x [3] y [3] z [1]
+    fe26 c2 = fe26_sqr(d.z);
+    fe26 c3 = fe26_mul(c2, d.z);
+    fe26 dx = fe26_normalize_weak(d.x), dy = fe26_normalize_weak(d.y);   // [1]: used as the affine addend
+    jpt26 cur;
+    cur.x = fe26_mul(qx, c2);
+    cur.y = fe26_mul(qy, c3);
+    cur.z = fe26_one();
+    fq_store(qt, stride, idx, 0, cur.x);
+    fq_store(qt, stride, idx, 10, cur.y);
 #pragma unroll 1
     for (int j = 1; j < QT_ENTRIES; ++j) {
-      fe h;
-      cur = jpt_add_affine(cur, d.x, d.y, &h);
-      fq_store_fe(qt, stride, idx, j * 16, cur.x);
-      fq_store_fe(qt, stride, idx, j * 16 + 8, cur.y);
-      fq_store_fe(hs, stride, idx, j * 8, h);
+      fe26 h;
+      cur = jpt26_add_affine(cur, dx, dy, &h);
+      fq_store(qt, stride, idx, j * 20, cur.x);      // [4]
+      fq_store(qt, stride, idx, j * 20 + 10, cur.y); // [2]
+      fq_store(hs, stride, idx, j * 10, h);          // [6]
     }
-    zg = fe_mul(cur.z, d.z);
-    fe rr = fe_from_u32(1);
+    fq_store(hs, stride, idx, 0, fe26_mul(cur.z, d.z));   // Z_7 * C, parked in the unused H_0 slot
+    // entry 7 as stored has magnitudes 4 / 2: bring it to [1] like the others
+    fq_store(qt, stride, idx, 7 * 20, fe26_normalize_weak(cur.x));
+    fq_store(qt, stride, idx, 7 * 20 + 10, fe26_normalize_weak(cur.y));
+    fe26 rr = fe26_one();
 #pragma unroll 1
     for (int j = QT_ENTRIES - 2; j >= 0; --j) {
-      rr = fe_mul(rr, fq_load_fe(hs, stride, idx, (j + 1) * 8));
-      fe r2 = fe_sqr(rr);
-      fe r3 = fe_mul(r2, rr);
-      fe x = fe_mul(fq_load_fe(qt, stride, idx, j * 16), r2);
-      fe y = fe_mul(fq_load_fe(qt, stride, idx, j * 16 + 8), r3);
-      fq_store_fe(qt, stride, idx, j * 16, x);
-      fq_store_fe(qt, stride, idx, j * 16 + 8, y);
+      rr = fe26_mul(rr, fq_load(hs, stride, idx, (j + 1) * 10));
+      fe26 r2 = fe26_sqr(rr);
+      fe26 r3 = fe26_mul(r2, rr);
+      fe26 x = fe26_mul(fq_load(qt, stride, idx, j * 20), r2);
+      fe26 y = fe26_mul(fq_load(qt, stride, idx, j * 20 + 10), r3);
+      fq_store(qt, stride, idx, j * 20, x);
+      fq_store(qt, stride, idx, j * 20 + 10, y);
     }
   }
 
   // ---- ladder over |k1|, |k2| ----
-  fe beta = fe_from_limbs(FE_BETA);
+  fe26 beta = fe26_from_words(FE_BETA);
   sc k1 = sc_zero(), k2 = sc_zero();
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
@@ -481,39 +502,42 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   k1.v[0] |= 1u;
   k2.v[0] |= 1u;
   digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
-  fe t0x = fq_load_fe(qt, stride, idx, 0), t0y = fq_load_fe(qt, stride, idx, 8);
-  jpt acc;
-  acc.x = t0x;
-  acc.y = fe_select(neg1, t0y, fe_neg(t0y));
-  acc.z = fe_from_u32(1);
-  acc = jpt_add_affine(acc, fe_mul(t0x, beta), fe_select(neg2, t0y, fe_neg(t0y)));
+  jpt26 acc;
+  {
+    fe26 t0x = fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 10);
+    acc.x = t0x;
+    acc.y = fe26_cond_negate1(t0y, neg1);
+    acc.z = fe26_one();
+    acc = jpt26_add_affine(acc, fe26_mul(t0x, beta), fe26_cond_negate1(t0y, neg2));
+  }
 #pragma unroll 1
   for (int i = 31; i >= 0; --i) {
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) acc = jpt_double(acc);
+    for (int j = 0; j < 4; ++j) acc = jpt26_double(acc);
     uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
       uint32_t w = t ? w2 : w1;
       bool neg = (t ? neg2 : neg1) != (w < 8u);
       uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
-      fe x = fq_load_fe(qt, stride, idx, entry * 16), y = fq_load_fe(qt, stride, idx, entry * 16 + 8);
-      if (t) x = fe_mul(x, beta);
-      acc = jpt_add_affine(acc, x, fe_select(neg, y, fe_neg(y)));
+      fe26 x = fq_load(qt, stride, idx, entry * 20), y = fq_load(qt, stride, idx, entry * 20 + 10);
+      if (t) x = fe26_mul(x, beta);
+      acc = jpt26_add_affine(acc, x, fe26_cond_negate1(y, neg));
     }
   }
   // k' = k | 1: take the extra 1 back out of even halves
 #pragma unroll 1
   for (int t = 0; t < 2; ++t) {
-    fe x = t ? fe_mul(t0x, beta) : t0x;
+    fe26 x = fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 10);
+    if (t) x = fe26_mul(x, beta);
     bool sneg = !(t ? neg2 : neg1);
-    jpt sum = jpt_add_affine(acc, x, fe_select(sneg, t0y, fe_neg(t0y)));
+    jpt26 sum = jpt26_add_affine(acc, x, fe26_cond_negate1(t0y, sneg));
     bool even = pf & (t ? PF_EVEN2 : PF_EVEN1);
-    acc.x = fe_select(even, acc.x, sum.x);
-    acc.y = fe_select(even, acc.y, sum.y);
-    acc.z = fe_select(even, acc.z, sum.z);
+    acc.x = fe26_select(even, acc.x, sum.x);
+    acc.y = fe26_select(even, acc.y, sum.y);
+    acc.z = fe26_select(even, acc.z, sum.z);
   }
-  acc.z = fe_mul(acc.z, zg);   // back on secp256k1 itself
+  acc.z = fe26_mul(acc.z, fq_load(hs, stride, idx, 0));   // times Z_7 * C: back on secp256k1 itself
 
   // ---- generator part: u1*G from the resident tables ----
   {
@@ -523,7 +547,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 #pragma unroll 1
     for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
       apt g = gt_load(gt, w, u[0] & 0xffffu);
-      acc = jpt_add_affine(acc, g.x, g.y);
+      acc = jpt26_add_affine(acc, fe26_from_words(g.x.v), fe26_from_words(g.y.v));
 #pragma unroll
       for (int i = 0; i < 7; ++i) u[i] = (u[i] >> 16) | (u[i + 1] << 16);
       u[7] >>= 16;
@@ -533,19 +557,19 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   // ---- x(R) mod n == r  (ecdsa.go:450-465) ----
   uint8_t verdict = 0;
   if (ok) {
-    if (fe_is_zero(acc.z)) {
+    if (fe26_is_zero(acc.z)) {
       // infinity or an exceptional case along the way: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
       wl[pos] = (uint32_t)idx;
     } else {
-      fe rf;
-      load_be32(rf.v, rsig + idx * 32);
-      fe zz = fe_sqr(acc.z);
-      bool match = fe_eq(acc.x, fe_mul(rf, zz));
-      if (u256_lt(rf.v, FE_P_MINUS_N)) {
-        fe r2;
-        u256_add(r2.v, rf.v, SC_N);
-        match = match || fe_eq(acc.x, fe_mul(r2, zz));
+      uint32_t rw[8];
+      load_be32(rw, rsig + idx * 32);
+      fe26 zz = fe26_sqr(acc.z);
+      bool match = fe26_eq(acc.x, fe26_mul(fe26_from_words(rw), zz));
+      if (u256_lt(rw, FE_P_MINUS_N)) {
+        uint32_t r2[8];
+        u256_add(r2, rw, SC_N);
+        match = match || fe26_eq(acc.x, fe26_mul(fe26_from_words(r2), zz));
       }
       verdict = match ? 1 : 0;
     }
@@ -787,13 +811,13 @@ const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
-//   [0,192)    per-lane point tables: fast path uses 128 (table) + 64 (H scratch); the complete
-//              path reuses the same 192 words for its projective table
-//   [192,209)  scalar-prep output     [209,217) prefix products     [217,225) s in Montgomery form
+//   [0,240)    per-lane point tables: fast path uses 160 (8 entries x 2 x 10 limbs) + 80 (H
+//              scratch); the complete path reuses the first 192 words for its projective table
+//   [240,257)  scalar-prep output     [257,265) prefix products     [265,273) s in Montgomery form
 //   then       worklist: 1 counter + n indices
-constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = QT_WORDS, WS_PREF = WS_PREP + PREP_WORDS,
+constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = FQT_WORDS + FHS_WORDS, WS_PREF = WS_PREP + PREP_WORDS,
                  WS_SMONT = WS_PREF + 8, WS_LANE_WORDS = WS_SMONT + 8;
-static_assert(FQT_WORDS + FHS_WORDS == QT_WORDS, "table regions must coincide");
+static_assert(FQT_WORDS + FHS_WORDS >= QT_WORDS, "the complete path's table must fit in the fast path's region");
 
 size_t s2k_ecdsa_workspace_bytes(size_t n) {
   return (lane_stride(n) * WS_LANE_WORDS + 64 + lane_stride(n)) * sizeof(uint32_t);

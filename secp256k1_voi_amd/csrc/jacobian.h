@@ -1,4 +1,5 @@
-// jacobian.h — fast-path group law: Jacobian coordinates (x = X/Z^2, y = Y/Z^3), a = 0.
+// jacobian.h — fast-path group law: Jacobian coordinates (x = X/Z^2, y = Y/Z^3), a = 0,
+// over the lazy 10x26 field of fe26.h.
 //
 // The reference uses complete projective formulas everywhere (point_projective.go).  On the
 // GPU fast path the cheaper incomplete Jacobian formulas are used instead:
@@ -10,44 +11,51 @@
 // case or really ended at infinity; such lanes are re-done by the complete kernel
 // (k_verify_fallback, RCB formulas), everything else is exact.  Results are therefore
 // identical to the reference's for every input.
+//
+// Operation order and magnitudes follow the well-known sequences of libsecp256k1's
+// gej_double / gej_add_ge_var, whose only requirement is that every fe26_mul / fe26_sqr input
+// has magnitude <= 8; the magnitude of each value is given in [brackets].
+// Invariant for points held in `jpt26`: x [<= 4], y [<= 4], z [1].
 #pragma once
-#include "fe.h"
-#include "point.h"
+#include "fe26.h"
 
 namespace s2k {
 
-struct jpt {
-  fe x, y, z;
+struct jpt26 {
+  fe26 x, y, z;
 };
 
-// 2P.  L = 3/2 X^2, S = Y^2, T = X*S, X3 = L^2 - 2T, Y3 = L*(T - X3) - S^2, Z3 = Y*Z
-S2K_DEV jpt jpt_double(const jpt& p) {
-  fe s = fe_sqr(p.y);
-  fe l = fe_sqr(p.x);
-  l = fe_half(fe_add(fe_add(l, l), l));
-  fe t = fe_mul(p.x, s);
-  jpt r;
-  r.z = fe_mul(p.y, p.z);
-  r.x = fe_sub(fe_sqr(l), fe_add(t, t));
-  r.y = fe_sub(fe_mul(l, fe_sub(t, r.x)), fe_sqr(s));
+// 2P.  L = 3/2 X^2, S = Y^2, T = -X*S, X3 = L^2 + 2T, Y3 = -(L*(X3 + T) + S^2), Z3 = Y*Z
+S2K_DEV jpt26 jpt26_double(const jpt26& p) {
+  jpt26 r;
+  r.z = fe26_mul(p.y, p.z);                    // [1]
+  fe26 s = fe26_sqr(p.y);                      // [1]
+  fe26 l = fe26_sqr(p.x);                      // [1]
+  l = fe26_half(fe26_mul_int(l, 3));           // [3] -> [2]
+  fe26 t = fe26_mul(fe26_negate(s, 1), p.x);   // [2]*[4] -> [1]
+  r.x = fe26_add(fe26_add(fe26_sqr(l), t), t); // [3]
+  s = fe26_sqr(s);                             // [1]
+  t = fe26_add(t, r.x);                        // [4]
+  r.y = fe26_negate(fe26_add(fe26_mul(t, l), s), 2);   // [3]
   return r;
 }
 
-// P + (x2, y2) with the addend affine on the same curve.  `h_out` receives H = x2*Z1^2 - X1
-// (Z3 = Z1*H), used when a table is brought to a common Z.
-S2K_DEV jpt jpt_add_affine(const jpt& p, const fe& x2, const fe& y2, fe* h_out = nullptr) {
-  fe zz = fe_sqr(p.z);
-  fe u2 = fe_mul(x2, zz);
-  fe s2 = fe_mul(fe_mul(y2, p.z), zz);
-  fe h = fe_sub(u2, p.x);
-  fe rr = fe_sub(s2, p.y);
-  fe hh = fe_sqr(h);
-  fe hhh = fe_mul(h, hh);
-  fe v = fe_mul(p.x, hh);
-  jpt r;
-  r.z = fe_mul(p.z, h);
-  r.x = fe_sub(fe_sub(fe_sqr(rr), hhh), fe_add(v, v));
-  r.y = fe_sub(fe_mul(rr, fe_sub(v, r.x)), fe_mul(p.y, hhh));
+// P + (bx, by), the addend affine [bx 1, by <= 2] on the same curve.  `h_out` receives
+// H = bx*Z1^2 - X1 [6] (Z3 = Z1*H), used when a table is brought to a common Z.
+S2K_DEV jpt26 jpt26_add_affine(const jpt26& p, const fe26& bx, const fe26& by, fe26* h_out = nullptr) {
+  fe26 zz = fe26_sqr(p.z);                                  // [1]
+  fe26 u2 = fe26_mul(bx, zz);                               // [1]
+  fe26 s2 = fe26_mul(fe26_mul(by, zz), p.z);                // [1]
+  fe26 h = fe26_add(fe26_negate(p.x, 4), u2);               // [6]   U2 - X1
+  fe26 i = fe26_add(fe26_negate(s2, 1), p.y);               // [6]   Y1 - S2
+  jpt26 r;
+  r.z = fe26_mul(p.z, h);                                   // [1]
+  fe26 h2 = fe26_negate(fe26_sqr(h), 1);                    // [2]   -H^2
+  fe26 h3 = fe26_mul(h2, h);                                // [1]   -H^3
+  fe26 t = fe26_mul(p.x, h2);                               // [1]   -X1 H^2
+  r.x = fe26_add(fe26_add(fe26_add(fe26_sqr(i), h3), t), t);   // [4]
+  t = fe26_add(t, r.x);                                     // [5]
+  r.y = fe26_add(fe26_mul(t, i), fe26_mul(h3, p.y));        // [2]
   if (h_out) *h_out = h;
   return r;
 }

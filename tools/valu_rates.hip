@@ -20,14 +20,15 @@ constexpr int INNER  = 32;    // instructions per chain per loop trip
 
 enum Op { MAD_U64_U32, MAD_U64_U32_DEP, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24,
           ADD_CO_PAIR, ADD3_U32, FMA_F64, FMA_F32, MAD64_PLUS_ADDC, LSHL_ADD_U64, PK_MAD_U16,
-          AND_OR, CNDMASK, NUM_OPS };
+          AND_OR, CNDMASK, LSHRREV_B64, ALIGNBIT, AND_B32, ADD_U32, SUB_U32, MAD_I64_I32, BFE_U32, CNDMASK_SGPR, MOV_B32, MAD_U64_NOVCC, NUM_OPS };
 static const char* op_names[NUM_OPS] = {
   "v_mad_u64_u32 (8 indep chains)", "v_mad_u64_u32 (1 dependent chain)", "v_mul_lo_u32", "v_mul_hi_u32",
   "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_add_co_u32+v_addc_co_u32 (per instr)", "v_add3_u32",
   "v_fma_f64", "v_fma_f32", "v_mad_u64_u32+v_addc_co_u32 (per pair)", "v_lshl_add_u64", "v_pk_mad_u16",
-  "v_and_or_b32", "v_cndmask_b32" };
+  "v_and_or_b32", "v_cndmask_b32", "v_lshrrev_b64", "v_alignbit_b32", "v_and_b32", "v_add_u32", "v_sub_u32",
+  "v_mad_i64_i32", "v_bfe_u32", "v_cndmask_b32 (sgpr pair mask)", "v_mov_b32", "v_mad_u64_u32 (carry to s[..], 8 chains)" };
 // instructions issued per "unit" reported
-static const int op_instrs[NUM_OPS] = {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1};
+
 
 template <int OP>
 __global__ void __launch_bounds__(64) rate_kernel(uint32_t* out, unsigned long long* cyc, int trips) {
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(64) rate_kernel(uint32_t* out, unsigned long l
   uint32_t c32[UNROLL];
   for (int i = 0; i < UNROLL; ++i) { acc[i] = a + i; dacc[i] = (double)(a & 0xffff) + i; facc[i] = (float)(b & 0xff) + i; c32[i] = b + i; }
   double da = 1.0000001, db = 0.9999999; float fa = 1.0001f, fb = 0.9999f;
+  uint64_t smask = 0x5555555555555555ull, sdump = 0;
   asm volatile("" : "+v"(a), "+v"(b));
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < trips; ++t) {
@@ -78,6 +80,26 @@ __global__ void __launch_bounds__(64) rate_kernel(uint32_t* out, unsigned long l
           asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(c32[i]) : "v"(a), "v"(b));
         } else if constexpr (OP == CNDMASK) {
           asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(c32[i]) : "v"(a) : );
+        } else if constexpr (OP == LSHRREV_B64) {
+          asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(acc[i]));
+        } else if constexpr (OP == ALIGNBIT) {
+          asm volatile("v_alignbit_b32 %0, %0, %1, 26" : "+v"(c32[i]) : "v"(a));
+        } else if constexpr (OP == AND_B32) {
+          asm volatile("v_and_b32 %0, %0, %1" : "+v"(c32[i]) : "v"(a));
+        } else if constexpr (OP == ADD_U32) {
+          asm volatile("v_add_u32 %0, %0, %1" : "+v"(c32[i]) : "v"(a));
+        } else if constexpr (OP == SUB_U32) {
+          asm volatile("v_sub_u32 %0, %0, %1" : "+v"(c32[i]) : "v"(a));
+        } else if constexpr (OP == MAD_I64_I32) {
+          asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+        } else if constexpr (OP == BFE_U32) {
+          asm volatile("v_bfe_u32 %0, %0, 3, 26" : "+v"(c32[i]));
+        } else if constexpr (OP == CNDMASK_SGPR) {
+          asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(c32[i]) : "v"(a), "s"(smask));
+        } else if constexpr (OP == MOV_B32) {
+          asm volatile("v_mov_b32 %0, %1" : "=v"(c32[i]) : "v"(a));
+        } else if constexpr (OP == MAD_U64_NOVCC) {
+          asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[i]), "=s"(sdump) : "v"(a), "v"(b));
         }
       }
     }
@@ -85,7 +107,7 @@ __global__ void __launch_bounds__(64) rate_kernel(uint32_t* out, unsigned long l
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   uint64_t s = 0;
   for (int i = 0; i < UNROLL; ++i) s += acc[i] + (uint64_t)dacc[i] + (uint64_t)facc[i] + c32[i];
-  out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32);
+  out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32) ^ (uint32_t)sdump;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -140,5 +162,15 @@ int main() {
   sweep<AND_OR>(d_out, d_cyc, n_cu);
   sweep<CNDMASK>(d_out, d_cyc, n_cu);
   sweep<FMA_F64>(d_out, d_cyc, n_cu);
+  sweep<LSHRREV_B64>(d_out, d_cyc, n_cu);
+  sweep<ALIGNBIT>(d_out, d_cyc, n_cu);
+  sweep<AND_B32>(d_out, d_cyc, n_cu);
+  sweep<ADD_U32>(d_out, d_cyc, n_cu);
+  sweep<SUB_U32>(d_out, d_cyc, n_cu);
+  sweep<MAD_I64_I32>(d_out, d_cyc, n_cu);
+  sweep<BFE_U32>(d_out, d_cyc, n_cu);
+  sweep<CNDMASK_SGPR>(d_out, d_cyc, n_cu);
+  sweep<MOV_B32>(d_out, d_cyc, n_cu);
+  sweep<MAD_U64_NOVCC>(d_out, d_cyc, n_cu);
   return 0;
 }
