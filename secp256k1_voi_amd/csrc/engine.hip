@@ -402,6 +402,13 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // ---------------------------------------------------------------------------------------
 constexpr int FQT_WORDS = QT_ENTRIES * 20;
 constexpr int FHS_WORDS = QT_ENTRIES * 10;
+// Layout note (measured on MI355X, 2^20 signatures, profiles/r01_table_layouts.md): these
+// 4-byte planes [word][lane] cost 16.4 GB of fabric reads per batch (a lookup is a per-lane
+// gather, every lane wants a different entry, so ~8 rows x 4 sectors are touched per word) but
+// run the kernel in 11.4 ms; lane-contiguous 80-byte entries cut the reads to 5.9 GB and
+// 16-byte planes to 10.3 GB, yet take 16.2 ms and 15.1 ms: with wide per-lane loads the
+// texture/L1 path, not the VALU, sets the pace.  The reads are served by L2 / Infinity Cache
+// (working set 126 MB), the kernel stays VALU-issue bound, so the fastest layout is kept.
 
 S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int word0, const fe26& v) {
 #pragma unroll

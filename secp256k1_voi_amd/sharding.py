@@ -1,0 +1,85 @@
+"""Multi-GPU sharding of the batch path.
+
+Signatures are independent, so a batch is cut into contiguous index ranges, one per rank
+(one process per GPU); there is no exchange during compute.  The only collectives are at
+the end: an all-gather of the per-rank valid-bitmap shards and an all-reduce (sum) of the
+valid counts.  Works on any torch.distributed backend (nccl = RCCL over xGMI on the GPU
+box, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) of rank `rank` among `world` ranks; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_bitmap(valid: np.ndarray) -> np.ndarray:
+    """0/1 bytes -> bitmap, bit i of byte i//8 (LSB first), zero padded."""
+    return np.packbits(np.asarray(valid, dtype=np.uint8), bitorder="little")
+
+
+def unpack_bitmap(bitmap: np.ndarray, n: int) -> np.ndarray:
+    return np.unpackbits(np.asarray(bitmap, dtype=np.uint8), bitorder="little")[:n]
+
+
+def gather_valid(valid_shard, n_total: int, dist=None, device=None):
+    """All ranks get the full 0/1 vector (length n_total) and the global valid count.
+
+    `valid_shard` is this rank's 0/1 uint8 vector (numpy array or torch tensor) for
+    shard_range(n_total, rank, world).  Collectives: one all_gather of equal-sized, zero
+    padded bitmap shards and one all_reduce of the count.
+    """
+    import torch
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        v = valid_shard.cpu().numpy() if hasattr(valid_shard, "cpu") else np.asarray(valid_shard)
+        return v.astype(np.uint8), int(v.sum())
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(n_total, rank, world)
+    v = valid_shard.cpu().numpy() if hasattr(valid_shard, "cpu") else np.asarray(valid_shard)
+    assert v.shape[0] == hi - lo, "shard length does not match shard_range"
+    per = (n_total + world - 1) // world           # max shard length
+    nbytes = (per + 7) // 8
+    buf = np.zeros(nbytes, dtype=np.uint8)
+    pb = pack_bitmap(v)
+    buf[: pb.size] = pb
+    dev = device if device is not None else torch.device("cpu")
+    mine = torch.from_numpy(buf).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    cnt = torch.tensor([int(v.sum())], dtype=torch.int64, device=dev)
+    dist.all_reduce(cnt)
+    out = np.zeros(n_total, dtype=np.uint8)
+    for r, p in enumerate(parts):
+        a, b = shard_range(n_total, r, world)
+        out[a:b] = unpack_bitmap(p.cpu().numpy(), b - a)
+    return out, int(cnt.item())
+
+
+def gather_valid_device(valid, n_total: int, dist=None):
+    """Device-resident variant used on the hot path: `valid` is this rank's uint8 0/1 torch
+    tensor (equal shard length on every rank, a multiple of 8).  Packs the bitmap on the
+    device, all-gathers the shards and all-reduces the count; returns (bitmap tensor of
+    n_total/8 bytes, count tensor).  No host round trip."""
+    import torch
+
+    n = valid.numel()
+    assert n % 8 == 0
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=valid.device)
+    bitmap = (valid.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8)
+    cnt = valid.sum(dtype=torch.int64).reshape(1)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bitmap, cnt
+    world = dist.get_world_size()
+    assert n * world == n_total, "gather_valid_device needs equal shards"
+    full = torch.empty(bitmap.numel() * world, dtype=torch.uint8, device=valid.device)
+    dist.all_gather_into_tensor(full, bitmap)
+    dist.all_reduce(cnt)
+    return full, cnt

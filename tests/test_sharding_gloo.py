@@ -1,0 +1,81 @@
+"""world_size-2 test of the N > 1 path on CPU (gloo): shard, verify each shard, gather the
+bitmap.  The per-shard verifier here is the oracle standing in for the GPU engine (there is
+no GPU in this container); the sharding / collective code is the product's.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from secp256k1_voi_amd.sharding import pack_bitmap, shard_range, unpack_bitmap
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 9, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                got += list(range(lo, hi)) if n < 2000 else []
+                assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
+            if n < 2000:
+                assert got == list(range(n))
+            assert shard_range(n, world - 1, world)[1] == n
+
+
+def test_bitmap_roundtrip():
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 8, 13, 1000):
+        v = rng.integers(0, 2, n).astype(np.uint8)
+        assert (unpack_bitmap(pack_bitmap(v), n) == v).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, seed, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    import oracle
+    from secp256k1_voi_amd.sharding import gather_valid, shard_range
+    from workload import make_ecdsa_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = make_ecdsa_batch(oracle, n, seed=seed, corrupt_every=4)      # same batch on every rank
+    lo, hi = shard_range(n, rank, world)
+    mine = oracle.ecdsa_verify_batch(w["pub"][lo:hi], w["digest"][lo:hi], w["r"][lo:hi], w["s"][lo:hi])
+    full, count = gather_valid(mine, n, dist)
+    q.put((rank, full.tobytes(), count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 256])
+def test_two_rank_gather(n, oracle):
+    from workload import make_ecdsa_batch
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = make_ecdsa_batch(oracle, n, seed=5, corrupt_every=4)
+    exp = oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+    for rank, full, count in res:
+        assert np.frombuffer(full, dtype=np.uint8).tolist() == exp.tolist()
+        assert count == int(exp.sum())
