@@ -83,6 +83,21 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
 /* Bytes of device workspace the context holds for batches of up to n signatures. */
 size_t s2k_ecdsa_workspace_bytes(size_t n);
 
+/* ---- BIP-340 Schnorr verification (batched) ---------------------------------------- */
+/* For each i < n: bitcoin.SchnorrPublicKey.Verify(msg_i, sig_i) for the x-only key pk_i
+ * (secec/bitcoin/schnorr.go:221-253): valid[i] = 1 iff pk_i is a valid x-only key
+ * (NewSchnorrPublicKey, :257-275), r < p, s < n, and R = s*G - e*P is finite with even y and
+ * x(R) == r, e = tagged hash "BIP0340/challenge" of r || pk || msg reduced mod n (:420-449),
+ * computed on the device.  Messages: either n strings of msg_len bytes each (msg_offsets ==
+ * NULL) or concatenated with msg_offsets[n+1] byte offsets (any lengths, as the reference
+ * allows).  flags: S2K_ECDSA_FORCE_COMPLETE only. */
+int s2k_schnorr_verify_batch(s2k_ctx *ctx, size_t n, const uint8_t *pk /* n*32 */, const uint8_t *msgs,
+                             const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig /* n*64 */,
+                             uint32_t flags, uint8_t *valid /* n */);
+int s2k_schnorr_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pk, const void *d_msgs,
+                                    const void *d_msg_offsets, size_t msg_len, const void *d_sig, uint32_t flags,
+                                    void *d_valid, void *hip_stream);
+
 /* ---- group operations (batched; host pointers) ------------------------------------- */
 /* out[i] = k[i]*G — Point.ScalarBaseMult (point_mul_table.go:168) / scalarBaseMultVartime (:197) */
 int s2k_scalar_base_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k /* n*32 */, uint8_t *out /* n*65 */);

@@ -70,6 +70,8 @@ def load_library() -> C.CDLL:
     lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
     lib.s2k_ecdsa_workspace_bytes.restype = sz
+    lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
+    lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_scalar_base_mult_batch.argtypes = [vp, sz, vp, vp]
     lib.s2k_scalar_mult_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_double_scalar_mult_basepoint_batch.argtypes = [vp, sz, vp, vp, vp, vp]
@@ -87,6 +89,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
+    "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
     "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
     "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry",
@@ -155,6 +158,28 @@ class Engine:
         """Device-pointer form: integer device addresses, enqueued on `stream` (a hipStream_t value)."""
         self._check(self._lib.s2k_ecdsa_verify_batch_device(self._h, int(n), d_pub_xy, d_digest32, d_r, d_s,
                                                             int(flags), d_valid, stream))
+
+    def schnorr_verify_batch(self, pk32, msgs, sig64, force_complete: bool = False) -> np.ndarray:
+        """BIP-340: valid bits for n (x-only key, message, 64-byte signature) triples.
+        `msgs` is a list of byte strings (any lengths) or an (n, L) uint8 array."""
+        pk32 = _arr(pk32, 32)
+        n = pk32.shape[0]
+        sig64 = _arr(sig64, 64, n)
+        flags = FORCE_COMPLETE if force_complete else 0
+        out = np.zeros(n, dtype=np.uint8)
+        if isinstance(msgs, (list, tuple)):
+            if len(msgs) != n:
+                raise ValueError(f"length mismatch: expected {n} messages, got {len(msgs)}")
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+            self._check(self._lib.s2k_schnorr_verify_batch(self._h, n, pk32.ctypes.data, blob.ctypes.data,
+                                                           offs.ctypes.data, 0, sig64.ctypes.data, flags, out.ctypes.data))
+        else:
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+            self._check(self._lib.s2k_schnorr_verify_batch(self._h, n, pk32.ctypes.data, m.ctypes.data if m.size else None,
+                                                           None, m.shape[1], sig64.ctypes.data, flags, out.ctypes.data))
+        return out
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))

@@ -15,6 +15,7 @@
 #include "jacobian.h"
 #include "point.h"
 #include "sc.h"
+#include "sha256.h"
 
 using namespace s2k;
 
@@ -424,6 +425,13 @@ S2K_DEV fe26 fe26_cond_negate1(const fe26& a, bool neg) {   // magnitude 1 in, <
   return fe26_select(neg, a, fe26_negate(a, 1));
 }
 
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1 };
+
+// MODE_ECDSA:   pub = n x 64 (X||Y), rsig = n x 32 (r);      accept iff x(R) mod n == r
+// MODE_SCHNORR: pub = n x 32 (x-only key, BIP-340), rsig = n x 64 signatures (r at offset 0);
+//               P = lift_x(pub) (NewSchnorrPublicKey, schnorr.go:257-275), accept iff R != inf,
+//               y(R) even and x(R) == r (verifySchnorrSignatureR, schnorr.go:451-478)
+template <int MODE>
 __global__ void __launch_bounds__(256)
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ hs,
@@ -434,7 +442,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   uint32_t pf = prep[(size_t)16 * stride + idx];
   bool ok;
   fe26 qx, qy;
-  {
+  if constexpr (MODE == MODE_ECDSA) {
     apt q;
     load_be32(q.x.v, pub + idx * 64);
     load_be32(q.y.v, pub + idx * 64 + 32);
@@ -454,6 +462,25 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       qx = fe26_from_words(FE_GX);
       qy = fe26_from_words(FE_GY);
     }
+  } else {
+    uint32_t xw[8];
+    load_be32(xw, pub + idx * 32);
+    ok = (pf & PF_OK) && fe_is_canonical_raw(xw);
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
+    }
+    qx = fe26_from_words(xw);
+    fe26 rhs = fe26_mul(fe26_sqr(qx), qx);
+    rhs.n[0] += 7;                                    // [1] (+7 on limb 0)
+    bool has = fe26_sqrt(qy, rhs);
+    if (!has) {   // not an x-coordinate of the curve
+      ok = false;
+      qx = fe26_from_words(FE_GX);
+      qy = fe26_from_words(FE_GY);
+    }
+    qy = fe26_normalize(qy);
+    qy = fe26_select((qy.n[0] & 1u) != 0, qy, fe26_normalize_weak(fe26_negate(qy, 1)));   // even y
   }
   const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
 
@@ -561,14 +588,15 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     }
   }
 
-  // ---- x(R) mod n == r  (ecdsa.go:450-465) ----
+  // ---- verdict ----
   uint8_t verdict = 0;
   if (ok) {
     if (fe26_is_zero(acc.z)) {
       // infinity or an exceptional case along the way: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
       wl[pos] = (uint32_t)idx;
-    } else {
+    } else if constexpr (MODE == MODE_ECDSA) {
+      // x(R) mod n == r  (ecdsa.go:450-465)
       uint32_t rw[8];
       load_be32(rw, rsig + idx * 32);
       fe26 zz = fe26_sqr(acc.z);
@@ -579,9 +607,122 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
         match = match || fe26_eq(acc.x, fe26_mul(fe26_from_words(r2), zz));
       }
       verdict = match ? 1 : 0;
+    } else {
+      // affine R: y even and x == r  (schnorr.go:451-478)
+      uint32_t rw[8];
+      load_be32(rw, rsig + idx * 64);
+      fe26 zi = fe26_inv(acc.z);
+      fe26 zi2 = fe26_sqr(zi);
+      fe26 x = fe26_mul(acc.x, zi2);
+      fe26 y = fe26_normalize(fe26_mul(fe26_mul(acc.y, zi2), zi));
+      verdict = ((y.n[0] & 1u) == 0 && fe26_eq(x, fe26_from_words(rw))) ? 1 : 0;
     }
   }
   out[idx] = verdict;
+}
+
+// ---------------------------------------------------------------------------------------
+// BIP-340: scalar preparation (no inversion needed: R = s*G + (-e)*P) and complete fallback
+// ---------------------------------------------------------------------------------------
+S2K_DEV void schnorr_msg(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs, uint32_t msg_len,
+                         size_t i, const uint8_t*& m, uint32_t& len) {
+  if (offs) {
+    m = msgs + offs[i];
+    len = (uint32_t)(offs[i + 1] - offs[i]);
+  } else {
+    m = msgs + i * (size_t)msg_len;
+    len = msg_len;
+  }
+}
+// parseSchnorrSignature (schnorr.go:420-449): r < p, s < n, e = H(r || P || m) mod n.
+// Returns ok; s and e as plain scalars.
+S2K_DEV bool schnorr_parse(size_t i, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
+                           const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs, uint32_t msg_len,
+                           sc& s_out, sc& e_out) {
+  uint32_t r_le[8], pk_le[8];
+  load_be32(r_le, sig + i * 64);
+  load_be32(s_out.v, sig + i * 64 + 32);
+  load_be32(pk_le, pk + i * 32);
+  bool ok = fe_is_canonical_raw(r_le) && sc_is_canonical_raw(s_out.v);
+  uint32_t r_be[8], pk_be[8], dg[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    r_be[w] = r_le[7 - w];
+    pk_be[w] = pk_le[7 - w];
+  }
+  const uint8_t* m;
+  uint32_t len;
+  schnorr_msg(msgs, offs, msg_len, i, m, len);
+  bip340_challenge(dg, r_be, pk_be, m, len);
+  uint32_t e_raw[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) e_raw[w] = dg[7 - w];
+  e_out = sc_reduce_once(e_raw);
+  if (!ok) s_out = sc_zero();
+  return ok;
+}
+
+__global__ void __launch_bounds__(256)
+k_schnorr_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
+               const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs, uint32_t msg_len,
+               uint32_t* __restrict__ prep, size_t stride) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  sc s, e;
+  bool ok = schnorr_parse(i, pk, sig, msgs, offs, msg_len, s, e);
+  sc u2 = sc_neg(e);                                   // schnorr.go:244
+  sc k1, k2;
+  bool neg1, neg2;
+  sc_split_glv(u2, k1, neg1, k2, neg2);
+  uint32_t f = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) |
+               ((k1.v[0] & 1u) ? 0 : PF_EVEN1) | ((k2.v[0] & 1u) ? 0 : PF_EVEN2);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) prep[(size_t)w * stride + i] = s.v[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) prep[(size_t)(8 + w) * stride + i] = k1.v[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) prep[(size_t)(12 + w) * stride + i] = k2.v[w];
+  prep[(size_t)16 * stride + i] = f;
+}
+
+// SchnorrPublicKey.Verify (schnorr.go:221-253) with complete formulas
+S2K_DEV uint8_t schnorr_verify_complete(size_t idx, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
+                                        const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs,
+                                        uint32_t msg_len, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt,
+                                        size_t stride) {
+  sc s, e;
+  bool ok = schnorr_parse(idx, pk, sig, msgs, offs, msg_len, s, e);
+  apt P;
+  load_be32(P.x.v, pk + idx * 32);
+  ok = ok && fe_is_canonical_raw(P.x.v);
+  fe y;
+  bool has = fe_sqrt(y, fe_curve_rhs(P.x));
+  ok = ok && has;
+  if (!ok) {
+    P.x = fe_from_limbs(FE_GX);
+    y = fe_from_limbs(FE_GY);
+  }
+  y = fe_normalize(y);
+  P.y = fe_normalize(fe_select((y.v[0] & 1u) != 0, y, fe_neg(y)));
+  pt R = pt_add_complete(pt_base_mul(gt, s.v), pt_mul_glv(sc_neg(e), P, qt, stride, idx));
+  apt a;
+  bool finite = pt_to_affine(a, R);
+  uint32_t r_le[8];
+  load_be32(r_le, sig + idx * 64);
+  return (ok && finite && (a.y.v[0] & 1u) == 0 && u256_eq(a.x.v, r_le)) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
+                   const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig, const uint8_t* __restrict__ msgs,
+                   const uint64_t* __restrict__ offs, uint32_t msg_len, uint8_t* __restrict__ out,
+                   const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  // all_n != 0: diagnostic mode, every signature through the complete path
+  uint32_t count = all_n ? all_n : *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    size_t idx = all_n ? w : wl[w];
+    out[idx] = schnorr_verify_complete(idx, pk, sig, msgs, offs, msg_len, gt, qt, stride);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -910,12 +1051,53 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
                                               (const uint8_t*)d_s, flags, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
-  k_verify_fast<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, hs,
+  k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, hs,
                                                ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback<<<64, 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                         ctx->gtable, qt, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, const void* d_msgs,
+                                    const void* d_msg_offsets, size_t msg_len, const void* d_sig, uint32_t flags,
+                                    void* d_valid, void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!d_pk || !d_sig || !d_valid || (!d_msgs && (d_msg_offsets || msg_len)))
+    return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_ws(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t stride = lane_stride(n);
+  uint32_t* ws = (uint32_t*)ctx->ws;
+  uint32_t* qt = ws + WS_QT * stride;
+  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
+  uint32_t* wl = wl_count + 64;
+  const uint8_t* pk = (const uint8_t*)d_pk;
+  const uint8_t* sig = (const uint8_t*)d_sig;
+  const uint8_t* msgs = (const uint8_t*)d_msgs;
+  const uint64_t* offs = (const uint64_t*)d_msg_offsets;
+  if (flags & S2K_ECDSA_FORCE_COMPLETE) {
+    k_schnorr_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len,
+                                                      (uint8_t*)d_valid, ctx->gtable, qt, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    return S2K_OK;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, hs, ctx->gtable,
+                                                             (uint8_t*)d_valid, wl_count, wl, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  k_schnorr_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
+                                         ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
@@ -947,6 +1129,29 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   HIP_TRY(ctx, ds.upload(s, n * 32));
   HIP_TRY(ctx, dv.alloc(n));
   int rc = s2k_ecdsa_verify_batch_device(ctx, n, dp.p, dd.p, dr.p, ds.p, flags, dv.p, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(valid, dv.p, n, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs,
+                             const uint64_t* msg_offsets, size_t msg_len, const uint8_t* sig, uint32_t flags,
+                             uint8_t* valid) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!pk || !sig || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  size_t total = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
+  if (total && !msgs) return fail(ctx, S2K_ERR_ARG, "null message buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf dp, dm, dof, dsg, dv;
+  HIP_TRY(ctx, dp.upload(pk, n * 32));
+  HIP_TRY(ctx, dm.upload(msgs, total));
+  if (msg_offsets) HIP_TRY(ctx, dof.upload(msg_offsets, (n + 1) * sizeof(uint64_t)));
+  HIP_TRY(ctx, dsg.upload(sig, n * 64));
+  HIP_TRY(ctx, dv.alloc(n));
+  int rc = s2k_schnorr_verify_batch_device(ctx, n, dp.p, dm.p, msg_offsets ? dof.p : nullptr, msg_len, dsg.p, flags,
+                                           dv.p, nullptr);
   if (rc) return rc;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(valid, dv.p, n, hipMemcpyDeviceToHost));

@@ -209,4 +209,46 @@ S2K_DEV fe26 fe26_mul_tail(uint32_t t[10], uint64_t c, uint64_t d) {
 // magnitude 1.  Generated, fully unrolled.
 #include "fe26_mul_gen.h"
 
+S2K_DEV fe26 fe26_sqr_n(fe26 a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = fe26_sqr(a);
+  return a;
+}
+// x^(2^223 - 1), shared prefix of the inversion and square-root chains ([1] in, [1] out);
+// also returns x^(2^22 - 1) and x^(2^2 - 1)
+S2K_DEV fe26 fe26_pow_x223(const fe26& a, fe26& x22, fe26& x2) {
+  x2 = fe26_mul(fe26_sqr(a), a);
+  fe26 x3 = fe26_mul(fe26_sqr(x2), a);
+  fe26 x6 = fe26_mul(fe26_sqr_n(x3, 3), x3);
+  fe26 x9 = fe26_mul(fe26_sqr_n(x6, 3), x3);
+  fe26 x11 = fe26_mul(fe26_sqr_n(x9, 2), x2);
+  x22 = fe26_mul(fe26_sqr_n(x11, 11), x11);
+  fe26 x44 = fe26_mul(fe26_sqr_n(x22, 22), x22);
+  fe26 x88 = fe26_mul(fe26_sqr_n(x44, 44), x44);
+  fe26 x176 = fe26_mul(fe26_sqr_n(x88, 88), x88);
+  fe26 x220 = fe26_mul(fe26_sqr_n(x176, 44), x44);
+  return fe26_mul(fe26_sqr_n(x220, 3), x3);
+}
+// a^(p-2) (Invert, internal/field/field_invert.go:11; 0 -> 0).  p - 2 = 2^256 - 2^32 - 979:
+// 223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1  (binary tail ...101101)
+__device__ __noinline__ fe26 fe26_inv(fe26 a) {
+  fe26 x22, x2;
+  fe26 x223 = fe26_pow_x223(a, x22, x2);
+  fe26 t = fe26_mul(fe26_sqr_n(x223, 23), x22);
+  t = fe26_mul(fe26_sqr_n(t, 5), a);
+  t = fe26_mul(fe26_sqr_n(t, 3), x2);
+  return fe26_mul(fe26_sqr_n(t, 2), a);
+}
+// square root for p = 3 (mod 4): a^((p+1)/4), verified by squaring (Sqrt,
+// internal/field/field_sqrt_ratio.go:14).  `a` of magnitude 1.  Returns false when no root exists.
+__device__ __noinline__ bool fe26_sqrt(fe26& out, fe26 a) {
+  fe26 x22, x2;
+  fe26 x223 = fe26_pow_x223(a, x22, x2);
+  fe26 t = fe26_mul(fe26_sqr_n(x223, 23), x22);
+  t = fe26_mul(fe26_sqr_n(t, 6), x2);
+  t = fe26_sqr_n(t, 2);
+  out = t;
+  return fe26_eq(fe26_sqr(t), a);
+}
+
 }  // namespace s2k

@@ -1,0 +1,99 @@
+// sha256.h — SHA-256 (FIPS 180-4), one message per lane, for the BIP-340 challenge
+// e = SHA256(SHA256(tag) || SHA256(tag) || r || P || m)  (schnorrTaggedHash,
+// secec/bitcoin/schnorr.go:309-320; the reference uses Go's crypto/sha256).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fe.h"
+
+namespace s2k {
+
+__device__ static const uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__device__ static const uint32_t SHA256_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                                                 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+// SHA256("BIP0340/challenge") as big-endian words
+__device__ static const uint32_t BIP340_CHALLENGE_TAG[8] = {0x7bb52d7au, 0x9fef5832u, 0x3eb1bf7au, 0x407db382u,
+                                                            0xd2f3f2d8u, 0x1bb1224fu, 0x49fe518fu, 0x6d48d37cu};
+
+S2K_DEV uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+// one 64-byte block, w = 16 big-endian words; 16-word rolling schedule
+S2K_DEV void sha256_compress(uint32_t st[8], const uint32_t w_in[16]) {
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = w_in[i];
+  uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+    uint32_t ch = (e & f) ^ (~e & g);
+    uint32_t t1 = h + S1 + ch + SHA256_K[i] + wi;
+    uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+    uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+    uint32_t t2 = S0 + mj;
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+// digest (8 big-endian words) of tag-block || r || pk || msg[0..len)
+// r_be, pk_be: the 8 big-endian words of each 32-byte string, most significant first.
+__device__ __noinline__ void bip340_challenge(uint32_t out[8], const uint32_t r_be[8], const uint32_t pk_be[8],
+                                               const uint8_t* __restrict__ msg, uint32_t len) {
+  uint32_t st[8], w[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st[i] = SHA256_IV[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = w[8 + i] = BIP340_CHALLENGE_TAG[i];
+  sha256_compress(st, w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    w[i] = r_be[i];
+    w[8 + i] = pk_be[i];
+  }
+  sha256_compress(st, w);
+  const uint64_t bits = (uint64_t)(128 + len) * 8;
+  // message blocks, then padding: 0x80, zeros, 64-bit big-endian length
+  uint32_t nblocks = (len + 9 + 63) / 64;
+#pragma unroll 1
+  for (uint32_t blk = 0; blk < nblocks; ++blk) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t pos = blk * 64 + i * 4 + j;
+        uint32_t byte = pos < len ? msg[pos] : (pos == len ? 0x80u : 0u);
+        word = (word << 8) | byte;
+      }
+      w[i] = word;
+    }
+    if (blk == nblocks - 1) {
+      w[14] = (uint32_t)(bits >> 32);
+      w[15] = (uint32_t)bits;
+    }
+    sha256_compress(st, w);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = st[i];
+}
+
+}  // namespace s2k
