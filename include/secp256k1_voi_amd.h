@@ -109,6 +109,15 @@ int s2k_double_scalar_mult_basepoint_batch(s2k_ctx *ctx, size_t n, const uint8_t
 /* out[i] = a[i] + b[i] — Point.Add (point.go:62); out[i] = 2*a[i] — Point.Double (point.go:71) */
 int s2k_point_add_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
 int s2k_point_double_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, uint8_t *out);
+/* out = sum_i k[i] * P[i] — Point.MultiScalarMult / MultiScalarMultVartime
+ * (point_mul_multi.go:25,73).  n == 0 gives the identity.  Pippenger bucket method with
+ * complete additions (the reference uses Straus; same group element).  A malformed point
+ * record is S2K_ERR_ARG.  The device form takes device pointers and synchronises the stream
+ * before returning (it has to read back the status word). */
+int s2k_multi_scalar_mult(s2k_ctx *ctx, size_t n, const uint8_t *k /* n*32 */, const uint8_t *points /* n*65 */,
+                          uint8_t *out /* 65 */);
+int s2k_multi_scalar_mult_device(s2k_ctx *ctx, size_t n, const void *d_k, const void *d_points, void *d_out65,
+                                 void *hip_stream);
 /* SEC1 decode of n fixed-size encodings (enc_len = 33: SetCompressedBytes point_s11n.go:140;
  * enc_len = 65: SetUncompressedBytes :178).  ok[i] = 1 and out[i] = point on success,
  * ok[i] = 0 and out[i] = zeros otherwise. */

@@ -34,13 +34,29 @@ class EngineError(RuntimeError):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "secp256k1_voi_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU): one object
+    per translation unit (in parallel), then one shared library."""
+    from concurrent.futures import ThreadPoolExecutor
+    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "secp256k1_voi_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps):
         return LIB_PATH
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           os.path.join(CSRC, "engine.hip"), "-o", LIB_PATH]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
+
+    def compile_one(u):
+        obj = os.path.join(objdir, u[:-4] + ".o")
+        cmd = ["hipcc", *flags, "-c", os.path.join(CSRC, u), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(units))) as ex:
+        objs = list(ex.map(compile_one, units))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -78,6 +94,8 @@ def load_library() -> C.CDLL:
     lib.s2k_point_add_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_point_double_batch.argtypes = [vp, sz, vp, vp]
     lib.s2k_point_decode_batch.argtypes = [vp, sz, sz, vp, vp, vp]
+    lib.s2k_multi_scalar_mult.argtypes = [vp, sz, vp, vp, vp]
+    lib.s2k_multi_scalar_mult_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.s2k_fp_op_batch.argtypes = [vp, ci, sz, vp, vp, vp, vp]
     lib.s2k_fn_op_batch.argtypes = [vp, ci, sz, vp, vp, vp, vp]
     lib.s2k_fn_split_glv_batch.argtypes = [vp, sz, vp, vp, vp]
@@ -92,6 +110,7 @@ EXPORTED_SYMBOLS = [
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
     "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
+    "s2k_multi_scalar_mult", "s2k_multi_scalar_mult_device",
     "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry",
 ]
 
@@ -224,6 +243,19 @@ class Engine:
         out = self._points_out(a.shape[0])
         self._check(self._lib.s2k_point_double_batch(self._h, a.shape[0], a.ctypes.data, out.ctypes.data))
         return out
+
+    def multi_scalar_mult(self, scalars, points) -> bytes:
+        """sum_i scalars[i] * points[i] as a 65-byte record (MultiScalarMultVartime)."""
+        scalars = _arr(scalars, 32)
+        n = scalars.shape[0]
+        points = _arr(points, 65, n)            # length mismatch raises, like the reference panics
+        out = np.zeros(65, dtype=np.uint8)
+        self._check(self._lib.s2k_multi_scalar_mult(self._h, n, scalars.ctypes.data if n else None,
+                                                    points.ctypes.data if n else None, out.ctypes.data))
+        return out.tobytes()
+
+    def multi_scalar_mult_device(self, n, d_scalars, d_points, d_out65, stream=0):
+        self._check(self._lib.s2k_multi_scalar_mult_device(self._h, int(n), d_scalars, d_points, d_out65, stream))
 
     def point_decode_batch(self, enc, enc_len):
         enc = _arr(enc, enc_len)

@@ -10,7 +10,7 @@
 #include <cstring>
 #include <new>
 
-#include "../../include/secp256k1_voi_amd.h"
+#include "engine_internal.h"
 #include "fe.h"
 #include "jacobian.h"
 #include "point.h"
@@ -30,23 +30,6 @@ using namespace s2k;
 // Infinity Cache the 16-bit version halves the additions.
 // Entry layout: 16 x u32 = X limbs (little-endian words) then Y limbs, 64-byte aligned.
 // ---------------------------------------------------------------------------------------
-constexpr int GT_WINDOWS = 16;
-constexpr int GT_BITS = 16;
-constexpr size_t GT_ENTRIES = (size_t)GT_WINDOWS << GT_BITS;
-__device__ static const uint32_t GT_K0[8] = {0xd0354141u, 0xbfd15e8bu, 0xaf47a03au, 0xbaaddce5u,
-                                             0xfffefffdu, 0xfffefffeu, 0xfffefffeu, 0xfffefffeu};
-
-S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit) {
-  const uint4* p = reinterpret_cast<const uint4*>(gt + ((size_t)((window << GT_BITS) | digit) << 4));
-  uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-  apt r;
-  r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
-  r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
-  r.y.v[0] = c.x; r.y.v[1] = c.y; r.y.v[2] = c.z; r.y.v[3] = c.w;
-  r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
-  return r;
-}
-
 // k*P by MSB-first double-and-add with complete formulas (any 256-bit k, any P).
 // Used to build the tables and by the generic point entry points; not on the hot path.
 S2K_DEV pt pt_mul_generic(const uint32_t k_in[8], const apt& p) {
@@ -728,20 +711,6 @@ k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
 // ---------------------------------------------------------------------------------------
 // Element-wise kernels behind the Point / Scalar / Element entry points
 // ---------------------------------------------------------------------------------------
-S2K_DEV void load_be32_unaligned(uint32_t out[8], const uint8_t* p) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint8_t* q = p + (7 - i) * 4;
-    out[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
-  }
-}
-S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint8_t* q = p + (7 - i) * 4;
-    q[0] = (uint8_t)(in[i] >> 24); q[1] = (uint8_t)(in[i] >> 16); q[2] = (uint8_t)(in[i] >> 8); q[3] = (uint8_t)in[i];
-  }
-}
 // 65-byte record -> projective point.  Returns false (and the identity) for malformed records.
 S2K_DEV bool point_record_load(pt& p, const uint8_t* rec) {
   p = pt_identity();
@@ -924,35 +893,6 @@ __global__ void k_gtable_entry(const uint32_t* __restrict__ gt, uint32_t window,
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-struct s2k_ctx {
-  int device = -1;
-  uint32_t* gtable = nullptr;
-  void* ws = nullptr;           // workspace: per-lane Q tables
-  size_t ws_bytes = 0;
-  char err[512] = {0};
-};
-
-static thread_local char g_err[512];
-
-static int fail(s2k_ctx* ctx, int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", buf);
-  snprintf(g_err, sizeof g_err, "%s", buf);
-  return code;
-}
-#define HIP_TRY(ctx, expr)                                                                       \
-  do {                                                                                           \
-    hipError_t e_ = (expr);                                                                      \
-    if (e_ != hipSuccess) return fail(ctx, S2K_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
-static inline size_t lane_stride(size_t n) { return (n + 63) & ~(size_t)63; }
-
 extern "C" {
 
 const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
@@ -1017,6 +957,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->gtable) (void)hipFree(ctx->gtable);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   delete ctx;
 }
 
@@ -1101,20 +1042,6 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
-
-// small RAII helper for the host-pointer entry points
-struct dev_buf {
-  void* p = nullptr;
-  ~dev_buf() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-  hipError_t upload(const void* src, size_t bytes) {
-    hipError_t e = alloc(bytes);
-    if (e != hipSuccess || !bytes) return e;
-    return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
-  }
-};
 
 int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
                            const uint8_t* s, uint32_t flags, uint8_t* valid) {

@@ -1,0 +1,109 @@
+// engine_internal.h — pieces shared by the translation units of the engine (engine.hip, msm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/secp256k1_voi_amd.h"
+#include "fe.h"
+#include "point.h"
+
+using namespace s2k;
+
+// ---- generator tables (layout: engine.hip) ----
+constexpr int GT_WINDOWS = 16;
+constexpr int GT_BITS = 16;
+constexpr size_t GT_ENTRIES = (size_t)GT_WINDOWS << GT_BITS;
+__device__ static const uint32_t GT_K0[8] = {0xd0354141u, 0xbfd15e8bu, 0xaf47a03au, 0xbaaddce5u,
+                                             0xfffefffdu, 0xfffefffeu, 0xfffefffeu, 0xfffefffeu};
+
+S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit) {
+  const uint4* p = reinterpret_cast<const uint4*>(gt + ((size_t)((window << GT_BITS) | digit) << 4));
+  uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+  apt r;
+  r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
+  r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
+  r.y.v[0] = c.x; r.y.v[1] = c.y; r.y.v[2] = c.z; r.y.v[3] = c.w;
+  r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
+  return r;
+}
+
+
+// big-endian 32-byte strings at arbitrary alignment (65-byte point records)
+S2K_DEV void load_be32_unaligned(uint32_t out[8], const uint8_t* p) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint8_t* q = p + (7 - i) * 4;
+    out[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+}
+S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint8_t* q = p + (7 - i) * 4;
+    q[0] = (uint8_t)(in[i] >> 24); q[1] = (uint8_t)(in[i] >> 16); q[2] = (uint8_t)(in[i] >> 8); q[3] = (uint8_t)in[i];
+  }
+}
+
+// ---- host side ----
+struct s2k_ctx {
+  int device = -1;
+  uint32_t* gtable = nullptr;
+  void* ws = nullptr;           // workspace of the verification path
+  size_t ws_bytes = 0;
+  void* msm_ws = nullptr;       // workspace of the multi-scalar multiplication
+  size_t msm_ws_bytes = 0;
+  char err[512] = {0};
+};
+
+inline thread_local char g_err[512];
+
+inline int fail(s2k_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", buf);
+  snprintf(g_err, sizeof g_err, "%s", buf);
+  return code;
+}
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(ctx, S2K_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// grow-only device buffer owned by the context
+inline int ctx_reserve(s2k_ctx* ctx, void** p, size_t* have, size_t need) {
+  if (need <= *have) return S2K_OK;
+  if (*p) {
+    HIP_TRY(ctx, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(p, need));
+  *have = need;
+  return S2K_OK;
+}
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+static inline size_t lane_stride(size_t n) { return (n + 63) & ~(size_t)63; }
+
+
+// small RAII helper for the host-pointer entry points
+struct dev_buf {
+  void* p = nullptr;
+  ~dev_buf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  hipError_t upload(const void* src, size_t bytes) {
+    hipError_t e = alloc(bytes);
+    if (e != hipSuccess || !bytes) return e;
+    return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+  }
+};
+

@@ -419,3 +419,55 @@ def test_schnorr_edge_scalars(eng, oracle):
         assert a == int(R.schnorr_verify(b32(P[0]), m, s0))
         found += a
     assert found == 0
+
+
+# ---- multi-scalar multiplication (point_mul_multi.go:25-117; tests point_mul_multi_test.go:14-72) ----
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 32, 64, 255, 256, 300, 1000])
+def test_msm_small_vs_oracle(eng, oracle, n):
+    rnd = random.Random(60 + n)
+    ks = [b32(rnd.randrange(R.N)) for _ in range(n)]
+    ps = [oracle.scalar_base_mult_vartime(b32(rnd.randrange(1, R.N))) for _ in range(n)]
+    assert eng.multi_scalar_mult(ks, ps) == oracle.multi_scalar_mult_vartime(ks, ps)
+
+
+def test_msm_edge_cases(eng, oracle):
+    rnd = random.Random(61)
+    P = [oracle.scalar_base_mult_vartime(b32(rnd.randrange(1, R.N))) for _ in range(8)]
+    negP0 = oracle.point_neg(P[0])
+    cases = []
+    # the same point many times in one bucket, a point and its inverse, identity inputs, zero and
+    # maximal scalars, scalars >= n (reduced like SetBytes), digits that are all-ones / zero
+    cases.append(([b32(5)] * 40, [P[0]] * 40))
+    cases.append(([b32(7), b32(7)], [P[0], negP0]))                       # sum = identity
+    cases.append(([b32(1), b32(R.N - 1)], [P[1], P[1]]))                   # identity
+    cases.append(([b32(0)] * 5, P[:5]))
+    cases.append(([b32(3), b32(4)], [bytes(65), P[2]]))
+    cases.append(([b32(R.N - 1), b32(2**256 - 1), b32(R.N), b32(R.N + 1)], P[:4]))
+    cases.append(([b32(sum(0xFFFF << (16 * i) for i in range(0, 16, 2))), b32(1 << 255)], P[4:6]))
+    cases.append(([b32(rnd.randrange(R.N)) for _ in range(70)], [P[i % 2] for i in range(70)]))
+    for ks, ps in cases:
+        exp = oracle.multi_scalar_mult_vartime([oracle.fn_reduce(k)[0] for k in ks], ps)
+        assert eng.multi_scalar_mult(ks, ps) == exp
+    with pytest.raises(ValueError):
+        eng.multi_scalar_mult([b32(1)] * 2, [P[0]])                         # length mismatch (reference panics)
+    import secp256k1_voi_amd as S
+    bad = bytearray(P[0]); bad[64] ^= 1
+    with pytest.raises(S.EngineError):
+        eng.multi_scalar_mult([b32(1)], [bytes(bad)])
+
+
+@pytest.mark.parametrize("log2n", [14, 16])
+def test_msm_large_known_dlog(eng, oracle, log2n):
+    # P_i = d_i * G  =>  sum k_i P_i = (sum k_i d_i mod n) * G   
+    n = 1 << log2n
+    rng = np.random.default_rng(62 + log2n)
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    d[:, 0] &= 0x7F
+    k[:7] = np.frombuffer(b"".join([b32(0), b32(1), b32(R.N - 1), b32(0xFFFF), b32(1 << 240), b32(2), b32(3)]),
+                          dtype=np.uint8).reshape(7, 32)
+    pts = eng.scalar_base_mult_batch(d)
+    di = [int.from_bytes(bytes(x), "big") for x in d]
+    ki = [int.from_bytes(bytes(x), "big") % R.N for x in k]
+    total = sum(a * b for a, b in zip(ki, di)) % R.N
+    assert eng.multi_scalar_mult(k, pts) == oracle.scalar_base_mult_vartime(b32(total))
