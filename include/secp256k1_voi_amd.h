@@ -98,6 +98,19 @@ int s2k_schnorr_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pk, co
                                     const void *d_msg_offsets, size_t msg_len, const void *d_sig, uint32_t flags,
                                     void *d_valid, void *hip_stream);
 
+/* Whole-batch BIP-340 verification as ONE multi-scalar multiplication of 2n+1 terms
+ * ((sum a_i s_i) G - sum a_i R_i - sum a_i e_i P_i == infinity, a_0 = 1, a_i = 128 bits of
+ * SHA-256(seed32 || i)).  *all_valid = 1 iff every signature of the batch verifies (false
+ * accept probability 2^-128 over the secret random seed32, which the caller draws from its
+ * CSPRNG); it does not say which one fails — call s2k_schnorr_verify_batch for that.  The
+ * reference has single verification only (schnorr.go:221); this is BASELINE config 4. */
+int s2k_schnorr_batch_verify_rlc(s2k_ctx *ctx, size_t n, const uint8_t *pk, const uint8_t *msgs,
+                                 const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig,
+                                 const uint8_t *seed32, int *all_valid);
+int s2k_schnorr_batch_verify_rlc_device(s2k_ctx *ctx, size_t n, const void *d_pk, const void *d_msgs,
+                                        const void *d_msg_offsets, size_t msg_len, const void *d_sig,
+                                        const uint8_t *seed32 /* host */, int *all_valid /* host */, void *hip_stream);
+
 /* ---- group operations (batched; host pointers) ------------------------------------- */
 /* out[i] = k[i]*G — Point.ScalarBaseMult (point_mul_table.go:168) / scalarBaseMultVartime (:197) */
 int s2k_scalar_base_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k /* n*32 */, uint8_t *out /* n*65 */);

@@ -88,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.s2k_ecdsa_workspace_bytes.restype = sz
     lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
+    lib.s2k_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci)]
+    lib.s2k_schnorr_batch_verify_rlc_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci), vp]
     lib.s2k_scalar_base_mult_batch.argtypes = [vp, sz, vp, vp]
     lib.s2k_scalar_mult_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_double_scalar_mult_basepoint_batch.argtypes = [vp, sz, vp, vp, vp, vp]
@@ -108,6 +110,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
+    "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
     "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
     "s2k_multi_scalar_mult", "s2k_multi_scalar_mult_device",
@@ -199,6 +202,32 @@ class Engine:
             self._check(self._lib.s2k_schnorr_verify_batch(self._h, n, pk32.ctypes.data, m.ctypes.data if m.size else None,
                                                            None, m.shape[1], sig64.ctypes.data, flags, out.ctypes.data))
         return out
+
+    def schnorr_batch_verify_rlc(self, pk32, msgs, sig64, seed32: bytes | None = None) -> bool:
+        """True iff every (key, message, signature) triple verifies — one MSM of 2n+1 terms."""
+        pk32 = _arr(pk32, 32)
+        n = pk32.shape[0]
+        sig64 = _arr(sig64, 64, n)
+        seed = np.frombuffer(seed32 if seed32 is not None else os.urandom(32), dtype=np.uint8)
+        if seed.size != 32:
+            raise ValueError("seed32 must be 32 bytes")
+        res = C.c_int(0)
+        if isinstance(msgs, (list, tuple)):
+            if len(msgs) != n:
+                raise ValueError(f"length mismatch: expected {n} messages, got {len(msgs)}")
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+            self._check(self._lib.s2k_schnorr_batch_verify_rlc(self._h, n, pk32.ctypes.data, blob.ctypes.data,
+                                                               offs.ctypes.data, 0, sig64.ctypes.data, seed.ctypes.data,
+                                                               C.byref(res)))
+        else:
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+            self._check(self._lib.s2k_schnorr_batch_verify_rlc(self._h, n, pk32.ctypes.data,
+                                                               m.ctypes.data if m.size else None, None,
+                                                               m.shape[1] if n else 0, sig64.ctypes.data,
+                                                               seed.ctypes.data, C.byref(res)))
+        return bool(res.value)
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))

@@ -21,6 +21,7 @@
 #include "engine_internal.h"
 #include "pt26.h"
 #include "sc.h"
+#include "sha256.h"
 
 namespace {
 
@@ -69,10 +70,12 @@ S2K_DEV pt26 pt_select(bool pick_b, const pt26& a, const pt26& b) {
   return r;
 }
 
+// bytes -> words: scalar reduced mod n (plain, little-endian words), affine point words, flag
+// (0 identity, 1 finite, 2 malformed)
 __global__ void __launch_bounds__(256)
-k_msm_prepare(uint32_t n, msm_geom g, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
-              uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag,
-              uint32_t* __restrict__ count, uint32_t* __restrict__ status) {
+k_msm_parse(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
+            uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag,
+            uint32_t* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t raw[8];
@@ -81,7 +84,7 @@ k_msm_prepare(uint32_t n, msm_geom g, const uint8_t* __restrict__ scalars, const
 #pragma unroll
   for (int w = 0; w < 8; ++w) scw[(size_t)w * n + i] = k.v[w];
   const uint8_t* rec = points + i * 65;
-  uint8_t f = 0;                                  // 0 identity, 1 finite, 2 malformed
+  uint8_t f = 0;
   apt a;
   a.x = fe_zero();
   a.y = fe_zero();
@@ -99,7 +102,13 @@ k_msm_prepare(uint32_t n, msm_geom g, const uint8_t* __restrict__ scalars, const
     ptw[(size_t)w * n + i] = a.x.v[w];
     ptw[(size_t)(8 + w) * n + i] = a.y.v[w];
   }
-  if (f != 1) return;
+}
+
+__global__ void __launch_bounds__(256)
+k_msm_histogram(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
+                uint32_t* __restrict__ count) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || flag[i] != 1) return;
   for (uint32_t w = 0; w < g.nw; ++w) {
     uint32_t d = msm_digit(scw, n, i, w, g.c);
     if (d) atomicAdd(&count[(size_t)w * g.nb + d], 1u);
@@ -209,6 +218,7 @@ __global__ void __launch_bounds__(1024) k_msm_tree(msm_geom g, uint32_t* __restr
 
 // Horner over the window sums, then the 65-byte record
 __global__ void k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65) {
+  // out65: the 65-byte record of the sum (all zero for the identity)
   size_t nslots = (size_t)g.nw * g.nchunk;
   pt26 acc = pt_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk);
 #pragma unroll 1
@@ -244,6 +254,212 @@ __global__ void k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, ui
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+struct msm_ws {
+  msm_geom g;
+  size_t nkeys, nslots;
+  uint32_t *status, *count, *cursor, *offset, *scw, *ptw, *list, *buckets, *partial;
+  uint8_t* flag;
+  size_t zero_bytes;   // status + count + cursor, contiguous from the start
+  uint8_t* aux;        // extra caller-requested scratch
+};
+
+// carve the MSM workspace for n terms (+ aux_bytes of scratch for the caller)
+int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
+  msm_geom& g = m.g;
+  g.c = n >= (1u << 14) ? 16 : (n >= 256 ? 12 : 8);
+  g.nw = (256 + g.c - 1) / g.c;
+  g.nb = 1u << g.c;
+  g.nchunk = g.nb / CHUNK;
+  m.nkeys = (size_t)g.nw * g.nb;                     // multiple of 1024 for every c used
+  m.nslots = (size_t)g.nw * g.nchunk;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  size_t o_status = carve(256), o_count = carve((m.nkeys + 1) * 4), o_cursor = carve(m.nkeys * 4),
+         o_offset = carve((m.nkeys + 1) * 4), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
+         o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * 30 * 4),
+         o_partial = carve(m.nslots * 30 * 4), o_aux = carve(aux_bytes);
+  int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
+  if (rc) return rc;
+  uint8_t* ws = (uint8_t*)ctx->msm_ws;
+  m.status = (uint32_t*)(ws + o_status);
+  m.count = (uint32_t*)(ws + o_count);
+  m.cursor = (uint32_t*)(ws + o_cursor);
+  m.offset = (uint32_t*)(ws + o_offset);
+  m.scw = (uint32_t*)(ws + o_scw);
+  m.ptw = (uint32_t*)(ws + o_ptw);
+  m.flag = ws + o_flag;
+  m.list = (uint32_t*)(ws + o_list);
+  m.buckets = (uint32_t*)(ws + o_buckets);
+  m.partial = (uint32_t*)(ws + o_partial);
+  m.aux = ws + o_aux;
+  m.zero_bytes = o_offset;
+  return S2K_OK;
+}
+
+// buckets -> result, given scw / ptw / flag already filled and status/count/cursor zeroed
+int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65) {
+  const msm_geom& g = m.g;
+  k_msm_histogram<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.count);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_scan<<<1, 1024, 0, st>>>(m.count, m.offset, (uint32_t)m.nkeys);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_scatter<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.offset, m.cursor, m.list);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_accumulate<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, (uint32_t)n, m.offset, m.list, m.ptw,
+                                                        m.buckets);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_reduce<<<(unsigned)((m.nslots + 63) / 64), 64, 0, st>>>(g, m.buckets, m.partial);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_tree<<<g.nw, 1024, 0, st>>>(g, m.partial);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_final<<<1, 1, 0, st>>>(g, m.partial, d_out65);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BIP-340 batch verification as ONE multi-scalar multiplication (BIP-340 "Batch Verification"):
+//   (sum a_i s_i) * G  -  sum a_i * R_i  -  sum (a_i e_i) * P_i  ==  infinity,
+// R_i = lift_x(r_i), P_i = lift_x(pk_i), a_0 = 1 and a_i 128-bit values from a keyed PRF
+// (SHA-256(seed || i)); the seed is caller-supplied secret randomness.  The reference has
+// only the single-signature Verify (schnorr.go:221-253); the contract is
+// "batch accepts <=> every single Verify accepts", up to 2^-128.
+// Terms: [0, n) = R_i, [n, 2n) = P_i, 2n = G.
+// ---------------------------------------------------------------------------------------
+S2K_DEV bool lift_x_words(uint32_t yw[8], const uint32_t xw[8]) {
+  if (!fe_is_canonical_raw(xw)) return false;
+  fe26 x = fe26_from_words(xw);
+  fe26 rhs = fe26_mul(fe26_sqr(x), x);
+  rhs.n[0] += 7;
+  fe26 y;
+  if (!fe26_sqrt(y, rhs)) return false;
+  y = fe26_normalize(y);
+  y = fe26_normalize(fe26_select((y.n[0] & 1u) != 0, y, fe26_negate(y, 1)));   // even root
+  yw[0] = y.n[0] | (y.n[1] << 26);
+  yw[1] = (y.n[1] >> 6) | (y.n[2] << 20);
+  yw[2] = (y.n[2] >> 12) | (y.n[3] << 14);
+  yw[3] = (y.n[3] >> 18) | (y.n[4] << 8);
+  yw[4] = (y.n[4] >> 24) | (y.n[5] << 2) | (y.n[6] << 28);
+  yw[5] = (y.n[6] >> 4) | (y.n[7] << 22);
+  yw[6] = (y.n[7] >> 10) | (y.n[8] << 16);
+  yw[7] = (y.n[8] >> 16) | (y.n[9] << 10);
+  return true;
+}
+
+__global__ void __launch_bounds__(256)
+k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
+                   const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs, uint32_t msg_len,
+                   const uint32_t* __restrict__ seed_be, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
+                   uint8_t* __restrict__ flag, uint32_t* __restrict__ as_out, uint32_t* __restrict__ status) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t N = 2 * (size_t)n + 1;   // plane stride of the term arrays
+  uint32_t r_le[8], pk_le[8];
+  sc s;
+  load_be32(r_le, sig + i * 64);
+  load_be32(s.v, sig + i * 64 + 32);
+  load_be32(pk_le, pk + i * 32);
+  bool ok = sc_is_canonical_raw(s.v);
+  uint32_t ry[8], py[8];
+  ok = lift_x_words(ry, r_le) && ok;      // r < p and on the curve (BIP-340 batch: fail if lift fails)
+  ok = lift_x_words(py, pk_le) && ok;
+  if (!ok) atomicOr(status, 2u);
+  // e_i
+  uint32_t r_be[8], pk_be[8], dg[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    r_be[w] = r_le[7 - w];
+    pk_be[w] = pk_le[7 - w];
+  }
+  const uint8_t* m = offs ? msgs + offs[i] : msgs + i * (size_t)msg_len;
+  uint32_t len = offs ? (uint32_t)(offs[i + 1] - offs[i]) : msg_len;
+  bip340_challenge(dg, r_be, pk_be, m, len);
+  uint32_t e_raw[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) e_raw[w] = dg[7 - w];
+  sc e = sc_reduce_once(e_raw);
+  // a_i = low 128 bits of SHA-256(seed || i), a_0 = 1
+  sc a = sc_zero();
+  if (i == 0) {
+    a.v[0] = 1;
+  } else {
+    uint32_t st[8], w[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      st[j] = SHA256_IV[j];
+      w[j] = seed_be[j];
+    }
+    w[8] = (uint32_t)(i >> 32);
+    w[9] = (uint32_t)i;
+    w[10] = 0x80000000u;
+    w[11] = w[12] = w[13] = w[14] = 0;
+    w[15] = 40 * 8;
+    sha256_compress(st, w);
+    a.v[0] = st[7]; a.v[1] = st[6]; a.v[2] = st[5]; a.v[3] = st[4];
+  }
+  sc a_m = sc_to_mont(a);
+  sc ae = sc_montmul(e, a_m), as = sc_montmul(s, a_m);
+  // -a_i * R_i and -(a_i e_i) * P_i are entered as a_i * (-R_i) and (a_i e_i) * (-P_i): negating the
+  // point is free, whereas n - a_i (a_i < 2^128) would put every R term into the same 0xFFFF
+  // buckets of the upper windows and serialise them on single lanes.
+  uint32_t nry[8], npy[8];
+  u256_sub(nry, FE_P, ry);
+  u256_sub(npy, FE_P, py);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    scw[(size_t)w * N + i] = a.v[w];
+    scw[(size_t)w * N + n + i] = ae.v[w];
+    as_out[(size_t)w * n + i] = as.v[w];
+    ptw[(size_t)w * N + i] = r_le[w];
+    ptw[(size_t)(8 + w) * N + i] = nry[w];
+    ptw[(size_t)w * N + n + i] = pk_le[w];
+    ptw[(size_t)(8 + w) * N + n + i] = npy[w];
+  }
+  flag[i] = ok ? 1 : 0;
+  flag[n + i] = ok ? 1 : 0;
+}
+
+// sum of n scalars mod n (one workgroup), written as term 2n together with the point G
+__global__ void __launch_bounds__(1024)
+k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
+                  uint8_t* __restrict__ flag) {
+  __shared__ uint32_t sh[1024][8];
+  const size_t N = 2 * (size_t)n + 1;
+  sc acc = sc_zero();
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    sc v;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v.v[w] = as[(size_t)w * n + i];
+    acc = sc_add(acc, v);
+  }
+#pragma unroll
+  for (int w = 0; w < 8; ++w) sh[threadIdx.x][w] = acc.v[w];
+  __syncthreads();
+  for (uint32_t half = 512; half >= 1; half >>= 1) {
+    if (threadIdx.x < half) {
+      sc a, b;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        a.v[w] = sh[threadIdx.x][w];
+        b.v[w] = sh[threadIdx.x + half][w];
+      }
+      a = sc_add(a, b);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sh[threadIdx.x][w] = a.v[w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      scw[(size_t)w * N + 2 * (size_t)n] = sh[0][w];
+      ptw[(size_t)w * N + 2 * (size_t)n] = FE_GX[w];
+      ptw[(size_t)(8 + w) * N + 2 * (size_t)n] = FE_GY[w];
+    }
+    flag[2 * (size_t)n] = 1;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -253,58 +469,25 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (!d_out65) return fail(ctx, S2K_ERR_ARG, "null output buffer");
   if (n && (!d_scalars || !d_points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n > 0x3fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   if (n == 0) {   // l == 0: identity (point_mul_multi.go:37 v.Identity())
     HIP_TRY(ctx, hipMemsetAsync(d_out65, 0, 65, st));
     return S2K_OK;
   }
-  msm_geom g;
-  g.c = n >= (1u << 14) ? 16 : (n >= 256 ? 12 : 8);
-  g.nw = (256 + g.c - 1) / g.c;
-  g.nb = 1u << g.c;
-  g.nchunk = g.nb / CHUNK;
-  const size_t nkeys = (size_t)g.nw * g.nb;              // multiple of 1024 for every c used
-  const size_t nslots = (size_t)g.nw * g.nchunk;
-  // carve the workspace
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  size_t o_status = carve(256), o_count = carve((nkeys + 1) * 4), o_cursor = carve(nkeys * 4),
-         o_offset = carve((nkeys + 1) * 4), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
-         o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(nkeys * 30 * 4), o_partial = carve(nslots * 30 * 4);
-  int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
+  msm_ws m;
+  int rc = msm_setup(ctx, n, 0, m);
   if (rc) return rc;
-  uint8_t* ws = (uint8_t*)ctx->msm_ws;
-  uint32_t* status = (uint32_t*)(ws + o_status);
-  uint32_t* count = (uint32_t*)(ws + o_count);
-  uint32_t* cursor = (uint32_t*)(ws + o_cursor);
-  uint32_t* offset = (uint32_t*)(ws + o_offset);
-  uint32_t* scw = (uint32_t*)(ws + o_scw);
-  uint32_t* ptw = (uint32_t*)(ws + o_ptw);
-  uint8_t* flag = ws + o_flag;
-  uint32_t* list = (uint32_t*)(ws + o_list);
-  uint32_t* buckets = (uint32_t*)(ws + o_buckets);
-  uint32_t* partial = (uint32_t*)(ws + o_partial);
-  HIP_TRY(ctx, hipMemsetAsync(ws, 0, o_offset, st));      // status, count, cursor
-  k_msm_prepare<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, (const uint8_t*)d_scalars, (const uint8_t*)d_points, scw,
-                                               ptw, flag, count, status);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
+  k_msm_parse<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, m.scw,
+                                             m.ptw, m.flag, m.status);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_scan<<<1, 1024, 0, st>>>(count, offset, (uint32_t)nkeys);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_scatter<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, scw, flag, offset, cursor, list);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_accumulate<<<blocks_for(nkeys), 256, 0, st>>>((uint32_t)nkeys, (uint32_t)n, offset, list, ptw, buckets);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_reduce<<<(unsigned)((nslots + 63) / 64), 64, 0, st>>>(g, buckets, partial);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_tree<<<g.nw, 1024, 0, st>>>(g, partial);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_final<<<1, 1, 0, st>>>(g, partial, (uint8_t*)d_out65);
-  HIP_TRY(ctx, hipGetLastError());
+  rc = msm_core(ctx, st, n, m, (uint8_t*)d_out65);
+  if (rc) return rc;
   // malformed point records are a caller error (the reference cannot even construct such Points)
   uint32_t h_status = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&h_status, status, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&h_status, m.status, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   if (h_status) return fail(ctx, S2K_ERR_ARG, "malformed point record in multi-scalar multiplication input");
   return S2K_OK;
@@ -324,6 +507,73 @@ int s2k_multi_scalar_mult(s2k_ctx* ctx, size_t n, const uint8_t* scalars, const 
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out65, dout.p, 65, hipMemcpyDeviceToHost));
   return S2K_OK;
+}
+
+int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk, const void* d_msgs,
+                                        const void* d_msg_offsets, size_t msg_len, const void* d_sig,
+                                        const uint8_t* seed32, int* all_valid, void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (!all_valid || !seed32) return fail(ctx, S2K_ERR_ARG, "null argument");
+  *all_valid = 0;
+  if (n == 0) {
+    *all_valid = 1;   // an empty batch has no failing signature
+    return S2K_OK;
+  }
+  if (!d_pk || !d_sig || (!d_msgs && (d_msg_offsets || msg_len))) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x1fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t N = 2 * n + 1;
+  msm_ws m;
+  int rc = msm_setup(ctx, N, n * 8 * 4 + 256, m);
+  if (rc) return rc;
+  uint32_t* seed_dev = (uint32_t*)m.aux;
+  uint32_t* as = (uint32_t*)(m.aux + 256);
+  uint32_t seed_be[8];
+  for (int j = 0; j < 8; ++j)
+    seed_be[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) |
+                 seed32[4 * j + 3];
+  HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
+  HIP_TRY(ctx, hipMemcpyAsync(seed_dev, seed_be, 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));   // seed_be is a stack buffer
+  k_schnorr_rlc_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
+                                                    (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
+                                                    (uint32_t)msg_len, seed_dev, m.scw, m.ptw, m.flag, as, m.status);
+  HIP_TRY(ctx, hipGetLastError());
+  k_schnorr_rlc_sum<<<1, 1024, 0, st>>>((uint32_t)n, as, m.scw, m.ptw, m.flag);
+  HIP_TRY(ctx, hipGetLastError());
+  uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
+  rc = msm_core(ctx, st, N, m, d_out);
+  if (rc) return rc;
+  uint8_t h[192];
+  HIP_TRY(ctx, hipMemcpyAsync(h, m.status, 64 + 65, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  uint32_t h_status;
+  memcpy(&h_status, h, 4);
+  *all_valid = (h_status == 0 && h[64] == 0x00) ? 1 : 0;
+  return S2K_OK;
+}
+
+int s2k_schnorr_batch_verify_rlc(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs,
+                                 const uint64_t* msg_offsets, size_t msg_len, const uint8_t* sig,
+                                 const uint8_t* seed32, int* all_valid) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (!all_valid || !seed32) return fail(ctx, S2K_ERR_ARG, "null argument");
+  if (n == 0) {
+    *all_valid = 1;
+    return S2K_OK;
+  }
+  if (!pk || !sig) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  size_t total = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
+  if (total && !msgs) return fail(ctx, S2K_ERR_ARG, "null message buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf dp, dm, dof, dsg;
+  HIP_TRY(ctx, dp.upload(pk, n * 32));
+  HIP_TRY(ctx, dm.upload(msgs, total));
+  if (msg_offsets) HIP_TRY(ctx, dof.upload(msg_offsets, (n + 1) * sizeof(uint64_t)));
+  HIP_TRY(ctx, dsg.upload(sig, n * 64));
+  return s2k_schnorr_batch_verify_rlc_device(ctx, n, dp.p, dm.p, msg_offsets ? dof.p : nullptr, msg_len, dsg.p, seed32,
+                                             all_valid, nullptr);
 }
 
 }  // extern "C"

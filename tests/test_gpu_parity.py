@@ -471,3 +471,48 @@ def test_msm_large_known_dlog(eng, oracle, log2n):
     ki = [int.from_bytes(bytes(x), "big") % R.N for x in k]
     total = sum(a * b for a, b in zip(ki, di)) % R.N
     assert eng.multi_scalar_mult(k, pts) == oracle.scalar_base_mult_vartime(b32(total))
+
+
+# ---- BIP-340 whole-batch verification as one MSM (BASELINE config 4) ---------------------------
+def test_schnorr_rlc_batch(eng, oracle):
+    rnd = random.Random(71)
+    seed = bytes(range(32))
+    for n in (1, 2, 17, 300, 5000):
+        pk, msg, sig = [], [], []
+        for i in range(n):
+            dd = rnd.randrange(1, R.N)
+            m = rnd.randbytes(32 if n > 300 else rnd.choice([0, 5, 32, 70]))
+            pk.append(b32(R.mul(dd, R.G)[0]) if n <= 300 else oracle.scalar_base_mult_vartime(b32(dd))[1:33])
+            msg.append(m)
+            sig.append(R.schnorr_sign(dd, m, rnd.randbytes(32)) if n <= 300 else None)
+        if n > 300:   # signing 5000 messages in pure Python is slow: reuse 50 signers
+            base = [(rnd.randrange(1, R.N)) for _ in range(50)]
+            pk, msg, sig = [], [], []
+            for i in range(n):
+                dd = base[i % 50]
+                m = i.to_bytes(4, "big") * 8
+                pk.append(b32(R.mul(dd, R.G)[0]) if i < 50 else pk[i % 50])
+                msg.append(m)
+                sig.append(R.schnorr_sign(dd, m, bytes(32)) if i < 400 else None)
+            # only the first 400 are freshly signed; fill the rest by repeating valid triples
+            for i in range(400, n):
+                j = i % 400
+                pk[i], msg[i], sig[i] = pk[j], msg[j], sig[j]
+        assert eng.schnorr_batch_verify_rlc(pk, msg, sig, seed) is True
+        assert eng.schnorr_batch_verify_rlc(pk, msg, sig) is True            # fresh random seed
+        assert eng.schnorr_verify_batch(pk, msg, sig).all()
+        # one bad signature anywhere makes the batch fail
+        for pos in {0, n // 2, n - 1}:
+            bad = list(sig)
+            sb = bytearray(bad[pos])
+            sb[40] ^= 1
+            bad[pos] = bytes(sb)
+            assert eng.schnorr_batch_verify_rlc(pk, msg, bad, seed) is False
+            single = eng.schnorr_verify_batch(pk, msg, bad)
+            assert int(single.sum()) == sum(1 for s_ in bad if s_ != bad[pos]) or single[pos] == 0
+        # r not on the curve / key not on the curve -> batch fails
+        bad = list(sig)
+        bad[0] = b32(R.P - 1)[:32] + bad[0][32:]
+        if R.lift_x(R.P - 1, 0) is None:
+            assert eng.schnorr_batch_verify_rlc(pk, msg, bad, seed) is False
+    assert eng.schnorr_batch_verify_rlc([], [], [], seed) is True
