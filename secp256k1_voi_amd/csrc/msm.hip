@@ -115,13 +115,29 @@ k_msm_histogram(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const 
   }
 }
 
-// exclusive scan of `total` counters (total a multiple of 1024) by one 1024-thread workgroup
-__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
-                                                   uint32_t total) {
+// exclusive scan of `total` counters (total a multiple of 1024), three small launches:
+// per-block sums -> scan of the block sums (one workgroup) -> per-block scan + base
+__global__ void __launch_bounds__(256) k_msm_scan_blocks(const uint32_t* __restrict__ count, uint32_t* __restrict__ bsum) {
+  __shared__ uint32_t part[256];
+  const uint4 v = reinterpret_cast<const uint4*>(count)[(size_t)blockIdx.x * 256 + threadIdx.x];
+  part[threadIdx.x] = v.x + v.y + v.z + v.w;
+  __syncthreads();
+  for (uint32_t s = 128; s >= 1; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = part[0];
+}
+// nblocks <= 1024 * 8
+__global__ void __launch_bounds__(1024) k_msm_scan_top(uint32_t* __restrict__ bsum, uint32_t nblocks,
+                                                       uint32_t* __restrict__ total_out) {
   __shared__ uint32_t part[1024];
-  uint32_t per = total / 1024, t = threadIdx.x;
+  uint32_t per = (nblocks + 1023) / 1024, t = threadIdx.x;
   uint32_t sum = 0;
-  for (uint32_t j = 0; j < per; ++j) sum += count[(size_t)t * per + j];
+  for (uint32_t j = 0; j < per; ++j) {
+    uint32_t i = t * per + j;
+    if (i < nblocks) sum += bsum[i];
+  }
   part[t] = sum;
   __syncthreads();
   for (uint32_t s = 1; s < 1024; s <<= 1) {
@@ -132,10 +148,31 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
   }
   uint32_t run = t ? part[t - 1] : 0;
   for (uint32_t j = 0; j < per; ++j) {
-    offset[(size_t)t * per + j] = run;
-    run += count[(size_t)t * per + j];
+    uint32_t i = t * per + j;
+    if (i < nblocks) {
+      uint32_t v = bsum[i];
+      bsum[i] = run;
+      run += v;
+    }
   }
-  if (t == 1023) offset[total] = run;
+  if (t == 1023) *total_out = part[1023];
+}
+__global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* __restrict__ count, const uint32_t* __restrict__ bsum,
+                                                        uint32_t* __restrict__ offset) {
+  __shared__ uint32_t part[256];
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 v = reinterpret_cast<const uint4*>(count)[i4];
+  uint32_t mine = v.x + v.y + v.z + v.w;
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t s = 1; s < 256; s <<= 1) {
+    uint32_t a = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+    __syncthreads();
+    part[threadIdx.x] += a;
+    __syncthreads();
+  }
+  uint32_t base = bsum[blockIdx.x] + part[threadIdx.x] - mine;
+  reinterpret_cast<uint4*>(offset)[i4] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
 }
 
 __global__ void __launch_bounds__(256)
@@ -257,7 +294,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *count, *cursor, *offset, *scw, *ptw, *list, *buckets, *partial;
+  uint32_t *status, *count, *cursor, *offset, *bsum, *scw, *ptw, *list, *buckets, *partial;
   uint8_t* flag;
   size_t zero_bytes;   // status + count + cursor, contiguous from the start
   uint8_t* aux;        // extra caller-requested scratch
@@ -275,7 +312,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   size_t o_status = carve(256), o_count = carve((m.nkeys + 1) * 4), o_cursor = carve(m.nkeys * 4),
-         o_offset = carve((m.nkeys + 1) * 4), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
+         o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((m.nkeys / 1024 + 1) * 4), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * 30 * 4),
          o_partial = carve(m.nslots * 30 * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
@@ -285,6 +322,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.count = (uint32_t*)(ws + o_count);
   m.cursor = (uint32_t*)(ws + o_cursor);
   m.offset = (uint32_t*)(ws + o_offset);
+  m.bsum = (uint32_t*)(ws + o_bsum);
   m.scw = (uint32_t*)(ws + o_scw);
   m.ptw = (uint32_t*)(ws + o_ptw);
   m.flag = ws + o_flag;
@@ -301,7 +339,10 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   const msm_geom& g = m.g;
   k_msm_histogram<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.count);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_scan<<<1, 1024, 0, st>>>(m.count, m.offset, (uint32_t)m.nkeys);
+  const unsigned scan_blocks = (unsigned)(m.nkeys / 1024);
+  k_msm_scan_blocks<<<scan_blocks, 256, 0, st>>>(m.count, m.bsum);
+  k_msm_scan_top<<<1, 1024, 0, st>>>(m.bsum, scan_blocks, m.offset + m.nkeys);
+  k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.count, m.bsum, m.offset);
   HIP_TRY(ctx, hipGetLastError());
   k_msm_scatter<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.offset, m.cursor, m.list);
   HIP_TRY(ctx, hipGetLastError());
