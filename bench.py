@@ -151,7 +151,8 @@ def main():
     pub, digest, r, s = synth_batch(eng, n, min(n, 1 << args.keys_log2), seed=0x5EC9 + rank)
     d_pub, d_dig, d_r, d_s = (torch.from_numpy(x).to(dev) for x in (pub, digest, r, s))
     d_valid = torch.zeros(n, dtype=torch.uint8, device=dev)
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_bitmap = torch.zeros(n // 8, dtype=torch.uint8, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
         st = torch.cuda.current_stream().cuda_stream
@@ -176,7 +177,7 @@ def main():
     for _ in range(args.steps):
         step()
         # the only collective of the path: all-gather of the valid bitmap + all-reduce of the count
-        bitmap, cnt = gather_valid_device(d_valid, n * world, dist)
+        bitmap, cnt = gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count)
     ev1.record()
     sync()
     dt = time.perf_counter() - t0

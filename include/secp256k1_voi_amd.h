@@ -80,6 +80,11 @@ int s2k_ecdsa_verify_batch(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy /* n*64
 int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, const void *d_digest32,
                                   const void *d_r, const void *d_s, uint32_t flags, void *d_valid,
                                   void *hip_stream);
+/* Packs valid[n] (0/1 bytes, device) into a bitmap (bit i of byte i/8, LSB first; (n+7)/8
+ * bytes, device) and writes the number of valid items to *d_count (uint64, device).  This is
+ * the payload of the multi-GPU bitmap all-gather / count all-reduce. */
+int s2k_pack_valid_device(s2k_ctx *ctx, size_t n, const void *d_valid, void *d_bitmap, void *d_count,
+                          void *hip_stream);
 /* Bytes of device workspace the context holds for batches of up to n signatures. */
 size_t s2k_ecdsa_workspace_bytes(size_t n);
 

@@ -84,6 +84,7 @@ def load_library() -> C.CDLL:
     lib.s2k_version.restype = C.c_char_p
     lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
+    lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
     lib.s2k_ecdsa_workspace_bytes.restype = sz
     lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
@@ -109,6 +110,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
+    "s2k_pack_valid_device",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
@@ -228,6 +230,10 @@ class Engine:
                                                                m.shape[1] if n else 0, sig64.ctypes.data,
                                                                seed.ctypes.data, C.byref(res)))
         return bool(res.value)
+
+    def pack_valid_device(self, n, d_valid, d_bitmap, d_count, stream=0):
+        """valid bytes -> bitmap + uint64 count, all device pointers."""
+        self._check(self._lib.s2k_pack_valid_device(self._h, int(n), d_valid, d_bitmap, d_count, stream))
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))

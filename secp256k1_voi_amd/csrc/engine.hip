@@ -884,6 +884,29 @@ k_fn_op(int op, uint32_t n, const uint8_t* __restrict__ a, const uint8_t* __rest
   store_be32(out + idx * 32, r.v);
 }
 
+// valid bytes -> bitmap (bit i of byte i/8, LSB first) + number of valid items.  One lane
+// per 8 items; the count is reduced per wave with a ballot-free popcount sum and one atomic.
+__global__ void __launch_bounds__(256)
+k_pack_valid(uint32_t n, const uint8_t* __restrict__ valid, uint8_t* __restrict__ bitmap,
+             unsigned long long* __restrict__ count) {
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t base = t * 8;
+  uint32_t bits = 0;
+  if (base + 8 <= n) {
+    uint2 v = *reinterpret_cast<const uint2*>(valid + base);
+    uint32_t lo = v.x & 0x01010101u, hi = v.y & 0x01010101u;
+    // gather bit 0 of each byte: multiply trick
+    bits = ((lo * 0x10204080u) >> 28) | (((hi * 0x10204080u) >> 28) << 4);
+  } else if (base < n) {
+    for (uint32_t j = 0; base + j < n; ++j) bits |= (uint32_t)(valid[base + j] & 1u) << j;
+  }
+  if (base < n) bitmap[t] = (uint8_t)bits;
+  uint32_t c = __popc(bits);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
 __global__ void k_gtable_entry(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit, uint8_t* out64) {
   apt a = gt_load(gt, window, digit);
   store_be32(out64, a.x.v);
@@ -1188,6 +1211,21 @@ int s2k_fn_op_batch(s2k_ctx* ctx, int op, size_t n, const uint8_t* a, const uint
 int s2k_fn_split_glv_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, uint8_t* k1, uint8_t* k2) {
   if (n && !k2) return fail(ctx, S2K_ERR_ARG, "null buffer");
   return field_op(ctx, false, 100, n, k, nullptr, k1, k2, 32);
+}
+
+int s2k_pack_valid_device(s2k_ctx* ctx, size_t n, const void* d_valid, void* d_bitmap, void* d_count,
+                          void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (!d_count) return fail(ctx, S2K_ERR_ARG, "null count buffer");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, st));
+  if (n == 0) return S2K_OK;
+  if (!d_valid || !d_bitmap) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  k_pack_valid<<<blocks_for((n + 7) / 8), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_valid, (uint8_t*)d_bitmap,
+                                                        (unsigned long long*)d_count);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
 }
 
 int s2k_debug_gtable_entry(s2k_ctx* ctx, unsigned i, unsigned d, uint8_t* out64) {

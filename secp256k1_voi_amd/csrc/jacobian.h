@@ -34,9 +34,8 @@ S2K_DEV jpt26 jpt26_double(const jpt26& p) {
   l = fe26_half(fe26_mul_int(l, 3));           // [3] -> [2]
   fe26 t = fe26_mul(fe26_negate(s, 1), p.x);   // [2]*[4] -> [1]
   r.x = fe26_add(fe26_add(fe26_sqr(l), t), t); // [3]
-  s = fe26_sqr(s);                             // [1]
   t = fe26_add(t, r.x);                        // [4]
-  r.y = fe26_negate(fe26_add(fe26_mul(t, l), s), 2);   // [3]
+  r.y = fe26_negate(fe26_mul_add_sqr(t, l, s), 1);     // t*l + s^2 with one reduction [1] -> [2]
   return r;
 }
 
@@ -55,7 +54,7 @@ S2K_DEV jpt26 jpt26_add_affine(const jpt26& p, const fe26& bx, const fe26& by, f
   fe26 t = fe26_mul(p.x, h2);                               // [1]   -X1 H^2
   r.x = fe26_add(fe26_add(fe26_add(fe26_sqr(i), h3), t), t);   // [4]
   t = fe26_add(t, r.x);                                     // [5]
-  r.y = fe26_add(fe26_mul(t, i), fe26_mul(h3, p.y));        // [2]
+  r.y = fe26_mul_add_mul(t, i, h3, p.y);                    // [5]*[6] + [1]*[4], one reduction -> [1]
   if (h_out) *h_out = h;
   return r;
 }

@@ -63,23 +63,33 @@ def gather_valid(valid_shard, n_total: int, dist=None, device=None):
     return out, int(cnt.item())
 
 
-def gather_valid_device(valid, n_total: int, dist=None):
+def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None, count=None):
     """Device-resident variant used on the hot path: `valid` is this rank's uint8 0/1 torch
     tensor (equal shard length on every rank, a multiple of 8).  Packs the bitmap on the
-    device, all-gathers the shards and all-reduces the count; returns (bitmap tensor of
-    n_total/8 bytes, count tensor).  No host round trip."""
+    device (engine.pack_valid_device when an Engine is given, torch ops otherwise),
+    all-gathers the shards and all-reduces the count; returns (bitmap tensor of n_total/8
+    bytes, int64 count tensor).  No host round trip.  `bitmap` / `count` may be preallocated
+    (n/8 uint8, 1 int64) to keep the step allocation-free."""
     import torch
 
     n = valid.numel()
     assert n % 8 == 0
-    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=valid.device)
-    bitmap = (valid.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8)
-    cnt = valid.sum(dtype=torch.int64).reshape(1)
+    if bitmap is None:
+        bitmap = torch.empty(n // 8, dtype=torch.uint8, device=valid.device)
+    if count is None:
+        count = torch.zeros(1, dtype=torch.int64, device=valid.device)
+    if engine is not None:
+        engine.pack_valid_device(n, valid.data_ptr(), bitmap.data_ptr(), count.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    else:
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=valid.device)
+        bitmap.copy_((valid.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8))
+        count.copy_(valid.sum(dtype=torch.int64).reshape(1))
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return bitmap, cnt
+        return bitmap, count
     world = dist.get_world_size()
     assert n * world == n_total, "gather_valid_device needs equal shards"
     full = torch.empty(bitmap.numel() * world, dtype=torch.uint8, device=valid.device)
     dist.all_gather_into_tensor(full, bitmap)
-    dist.all_reduce(cnt)
-    return full, cnt
+    dist.all_reduce(count)
+    return full, count

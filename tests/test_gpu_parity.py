@@ -16,6 +16,11 @@ H = bytes.fromhex
 
 @pytest.fixture(scope="module")
 def eng():
+    # torch first: it bundles its own HIP runtime, and the runtime that is loaded first serves
+    # the whole process (the engine library then binds to the same one)
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.init()
     import secp256k1_voi_amd as S
     return S.Engine(0)
 
@@ -516,3 +521,18 @@ def test_schnorr_rlc_batch(eng, oracle):
         if R.lift_x(R.P - 1, 0) is None:
             assert eng.schnorr_batch_verify_rlc(pk, msg, bad, seed) is False
     assert eng.schnorr_batch_verify_rlc([], [], [], seed) is True
+
+
+def test_pack_valid_bitmap(eng):
+    import torch
+    from secp256k1_voi_amd.sharding import gather_valid_device, unpack_bitmap
+    rng = np.random.default_rng(81)
+    for n in (8, 64, 1000 * 8, 1 << 16):
+        v = rng.integers(0, 2, n).astype(np.uint8)
+        dv = torch.from_numpy(v).cuda()
+        bm, cnt = gather_valid_device(dv, n, None, engine=eng)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == int(v.sum())
+        assert (unpack_bitmap(bm.cpu().numpy(), n) == v).all()
+        bm2, cnt2 = gather_valid_device(dv, n, None)            # torch fallback agrees
+        assert int(cnt2.item()) == int(v.sum()) and bool((bm2 == bm).all().item())

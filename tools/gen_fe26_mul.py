@@ -14,8 +14,13 @@ each v_mad_u64_u32 goes to VCC and is never read: the magnitude bounds guarantee
 """
 
 
-def chain(acc, prods, indent="  "):
-    """one asm statement: acc += sum(x*y) for (x, y, kind) in prods; kind 'v' or 's' for y."""
+def chain(acc, prods, indent="  ", maxn=13):
+    """asm statement(s): acc += sum(x*y) for (x, y, kind) in prods; kind 'v' or 's' for y.
+    At most `maxn` products per statement (inline asm takes at most 30 operands)."""
+    if not prods:
+        return ""
+    if len(prods) > maxn:
+        return chain(acc, prods[:maxn], indent, maxn) + chain(acc, prods[maxn:], indent, maxn)
     lines = []
     ops = []
     n = 1
@@ -84,12 +89,68 @@ def gen_sqr():
     return "".join(o)
 
 
+def gen_muladd(name, second):
+    """a*b + (c*d | c^2) with ONE reduction: both products accumulate into the same column sums.
+    Bound: m_a*m_b + m_c*m_d <= 64 keeps every 64-bit column sum below 2^64."""
+    sq = second == "sqr"
+    o = []
+    if sq:
+        o.append(f"S2K_DEV fe26 {name}(const fe26& A, const fe26& B, const fe26& C) {{\n")
+    else:
+        o.append(f"S2K_DEV fe26 {name}(const fe26& A, const fe26& B, const fe26& C, const fe26& D) {{\n")
+    o.append("  const uint32_t* a = A.n;\n  const uint32_t* b = B.n;\n  const uint32_t* c_ = C.n;\n  uint32_t t[10];\n")
+    if sq:
+        o.append("  uint32_t c2[10];\n#pragma unroll\n  for (int i = 0; i < 10; ++i) c2[i] = c_[i] * 2;\n")
+    else:
+        o.append("  const uint32_t* d_ = D.n;\n")
+    o.append("  const uint32_t R0 = F26_R0, R1 = F26_R1;\n")
+
+    def second_terms(K):
+        """products of the second operand pair landing in column K"""
+        out = []
+        if sq:
+            for i in range(0, 10):
+                j = K - i
+                if 0 <= j <= 9 and i < j:
+                    out.append((f"c2[{i}]", f"c_[{j}]", "v"))
+            if K % 2 == 0 and K // 2 <= 9:
+                out.append((f"c_[{K // 2}]", f"c_[{K // 2}]", "v"))
+        else:
+            for i in range(0, 10):
+                j = K - i
+                if 0 <= j <= 9:
+                    out.append((f"c_[{i}]", f"d_[{j}]", "v"))
+        return out
+
+    o.append("  uint64_t d = (uint64_t)a[0] * b[9];\n")
+    o.append(chain("d", [(f"a[{i}]", f"b[{9 - i}]", "v") for i in range(1, 10)]))
+    o.append(chain("d", second_terms(9)))
+    o.append("  t[9] = (uint32_t)d & F26_M;\n  d >>= 26;\n")
+    o.append("  uint64_t c = (uint64_t)a[0] * b[0];\n  uint32_t u, uprev = 0;\n")
+    for k in range(9):
+        hi = [(f"a[{i}]", f"b[{10 + k - i}]", "v") for i in range(k + 1, 10)]
+        o.append(chain("d", hi))
+        o.append(chain("d", second_terms(10 + k)))
+        o.append("  u = (uint32_t)d & F26_M;\n  d >>= 26;\n")
+        lo = []
+        if k > 0:
+            lo.append(("uprev", "R1", "s"))
+        lo += [(f"a[{i}]", f"b[{k - i}]", "v") for i in range(0, k + 1) if not (k == 0 and i == 0)]
+        o.append(chain("c", lo + second_terms(k) + [("u", "R0", "s")]))
+        o.append(f"  t[{k}] = (uint32_t)c & F26_M;\n  c >>= 26;\n  uprev = u;\n")
+    o.append(chain("c", [("uprev", "R1", "s")]))
+    o.append("  return fe26_mul_tail(t, c, d);\n}\n")
+    return "".join(o)
+
+
 def main():
     print("// fe26_mul_gen.h — GENERATED by tools/gen_fe26_mul.py; do not edit by hand.")
     print("// Included by fe26.h inside namespace s2k (needs fe26, F26_*, fe26_mul_tail).")
     print("// clang-format off")
     print(gen_mul())
     print(gen_sqr())
+    print(gen_muladd("fe26_mul_add_mul", "mul"))
+    print(gen_muladd("fe26_mul_add_sqr", "sqr"))
     print("// clang-format on")
 
 
