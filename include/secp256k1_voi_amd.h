@@ -51,6 +51,14 @@ enum {
  * re-does the lanes the fast Jacobian kernel cannot decide.  Same results, ~3x slower. */
 #define S2K_ECDSA_FORCE_COMPLETE 0x80000000u
 
+/* bitcoin.VerifyASN1 (secec/bitcoin/ecdsa_shitcoin.go:29): BIP-0066 shape check, sighash byte
+ * stripped, low-s required, 32-byte digest.  Only for s2k_ecdsa_verify_encoded_batch. */
+#define S2K_ECDSA_BIP0066 2u
+
+/* SignatureEncoding (ecdsa.go:39-53) */
+#define S2K_ENCODING_ASN1 0
+#define S2K_ENCODING_COMPACT 1
+
 #define S2K_POINT_RECORD 65
 #define S2K_SCALAR_SIZE 32 /* ScalarSize, scalar.go:17 */
 #define S2K_COORD_SIZE 32  /* CoordSize, point_s11n.go:27-44 */
@@ -87,6 +95,28 @@ int s2k_pack_valid_device(s2k_ctx *ctx, size_t n, const void *d_valid, void *d_b
                           void *hip_stream);
 /* Bytes of device workspace the context holds for batches of up to n signatures. */
 size_t s2k_ecdsa_workspace_bytes(size_t n);
+
+/* ---- host-side ingest: the reference's byte-level parsing, in batch --------------------- */
+/* ParseASN1Signature (secec/s11n.go:83): strict DER SEQUENCE { r INTEGER, s INTEGER }, r, s in
+ * [1, n).  Returns 0 and fills r, s (32-byte big-endian); 1 = malformed ASN.1
+ * (errInvalidAsn1Sig); 2 = scalar out of range (errInvalidScalar).  Pure host code. */
+int s2k_parse_asn1_signature(const uint8_t *der, size_t len, uint8_t r[32], uint8_t s[32]);
+/* ParseCompactSignature (secec/s11n.go:129): [R | S], 64 bytes.  Same return codes. */
+int s2k_parse_compact_signature(const uint8_t *sig, size_t len, uint8_t r[32], uint8_t s[32]);
+/* bitcoin.IsValidSignatureEncodingBIP0066 (secec/bitcoin/asn1_shitcoin.go:13): 1 / 0. */
+int s2k_is_valid_signature_encoding_bip0066(const uint8_t *sig_with_sighash, size_t len);
+/* PublicKey.Verify(digest, sig, opts) (secec/ecdsa.go:171) for n encoded items: SEC1 public
+ * keys (33 or 65 bytes, as secec.NewPublicKey accepts, secec.go:188), digests, and signatures
+ * in `encoding`, each as a concatenation with n+1 byte offsets.  digest_len = 0 means
+ * opts == nil (any digest of >= 32 bytes); otherwise digests of another length verify false
+ * (ecdsa.go:184-188).  flags: S2K_ECDSA_REJECT_MALLEABLE, S2K_ECDSA_BIP0066,
+ * S2K_ECDSA_FORCE_COMPLETE.  Signatures are parsed on the host, compressed keys are
+ * decompressed and everything is verified on the device.  valid[i] is the bool the
+ * reference's Verify returns; keys it could not even construct give 0. */
+int s2k_ecdsa_verify_encoded_batch(s2k_ctx *ctx, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
+                                   const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,
+                                   const uint64_t *sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                   uint8_t *valid);
 
 /* ---- BIP-340 Schnorr verification (batched) ---------------------------------------- */
 /* For each i < n: bitcoin.SchnorrPublicKey.Verify(msg_i, sig_i) for the x-only key pk_i

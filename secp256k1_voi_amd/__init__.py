@@ -22,7 +22,9 @@ LIB_PATH = os.path.join(_HERE, "libsecp256k1_voi_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 REJECT_MALLEABLE = 1
+BIP0066 = 2
 FORCE_COMPLETE = 0x80000000
+ENCODING_ASN1, ENCODING_COMPACT = 0, 1
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 
@@ -37,8 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU): one object
     per translation unit (in parallel), then one shared library."""
     from concurrent.futures import ThreadPoolExecutor
-    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "secp256k1_voi_amd.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps):
         return LIB_PATH
@@ -47,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 
     def compile_one(u):
-        obj = os.path.join(objdir, u[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
         cmd = ["hipcc", *flags, "-c", os.path.join(CSRC, u), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -87,6 +89,10 @@ def load_library() -> C.CDLL:
     lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
     lib.s2k_ecdsa_workspace_bytes.restype = sz
+    lib.s2k_parse_asn1_signature.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_char_p]
+    lib.s2k_parse_compact_signature.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_char_p]
+    lib.s2k_is_valid_signature_encoding_bip0066.argtypes = [C.c_char_p, sz]
+    lib.s2k_ecdsa_verify_encoded_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, ci, sz, u32, vp]
     lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci)]
@@ -111,6 +117,8 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
     "s2k_pack_valid_device",
+    "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
+    "s2k_ecdsa_verify_encoded_batch",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
@@ -135,6 +143,32 @@ def _arr(x, width, n=None):
         # the reference panics on length mismatch (point_mul_multi.go:27-29)
         raise ValueError(f"length mismatch: expected {n} items, got {a.shape[0]}")
     return np.ascontiguousarray(a)
+
+
+# ---- host-side parsing (no GPU needed) --------------------------------------------------------
+def parse_asn1_signature(der: bytes):
+    """ParseASN1Signature (secec/s11n.go:83): (r, s) as 32-byte strings, or None."""
+    r, s = C.create_string_buffer(32), C.create_string_buffer(32)
+    return (r.raw, s.raw) if load_library().s2k_parse_asn1_signature(der, len(der), r, s) == 0 else None
+
+
+def parse_compact_signature(sig: bytes):
+    """ParseCompactSignature (secec/s11n.go:129)."""
+    r, s = C.create_string_buffer(32), C.create_string_buffer(32)
+    return (r.raw, s.raw) if load_library().s2k_parse_compact_signature(sig, len(sig), r, s) == 0 else None
+
+
+def is_valid_signature_encoding_bip0066(sig: bytes) -> bool:
+    """bitcoin.IsValidSignatureEncodingBIP0066 (secec/bitcoin/asn1_shitcoin.go:13)."""
+    return bool(load_library().s2k_is_valid_signature_encoding_bip0066(sig, len(sig)))
+
+
+def _concat(items):
+    offs = np.zeros(len(items) + 1, dtype=np.uint64)
+    if items:
+        offs[1:] = np.cumsum([len(x) for x in items], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(items) or b"\0", dtype=np.uint8)
+    return blob, offs
 
 
 class Engine:
@@ -176,6 +210,23 @@ class Engine:
                                                      r.ctypes.data, s.ctypes.data,
                                                      (REJECT_MALLEABLE if reject_malleable else 0) |
                                                      (FORCE_COMPLETE if force_complete else 0), out.ctypes.data))
+        return out
+
+    def ecdsa_verify_encoded_batch(self, pubs, digests, sigs, encoding=ENCODING_ASN1, digest_len=0,
+                                   reject_malleable=False, bip0066=False, force_complete=False) -> np.ndarray:
+        """PublicKey.Verify(digest, sig, opts) for lists of SEC1 keys, digests and encoded signatures."""
+        n = len(pubs)
+        if len(digests) != n or len(sigs) != n:
+            raise ValueError("length mismatch")
+        pb, po = _concat(list(pubs))
+        db, do = _concat(list(digests))
+        sb, so = _concat(list(sigs))
+        out = np.zeros(n, dtype=np.uint8)
+        flags = (REJECT_MALLEABLE if reject_malleable else 0) | (BIP0066 if bip0066 else 0) | \
+                (FORCE_COMPLETE if force_complete else 0)
+        self._check(self._lib.s2k_ecdsa_verify_encoded_batch(self._h, n, pb.ctypes.data, po.ctypes.data, db.ctypes.data,
+                                                             do.ctypes.data, sb.ctypes.data, so.ctypes.data, encoding,
+                                                             digest_len, flags, out.ctypes.data))
         return out
 
     def ecdsa_verify_batch_device(self, n, d_pub_xy, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):

@@ -15,6 +15,7 @@ Sources (all relative to /root/reference):
   secec/bitcoin/testdata/bip-0340-test-vectors.csv              (schnorr_test.go:149-245)
   secec/testdata/secp256k1_rfc6979_sha256.csv                   (ecdsa_k_test.go:244-278)
   internal/gentable/point_mul_table.bin                         (hash + sampled entries)
+  secec/bitcoin/testdata/bip-0066-test-vectors.json             (asn1_shitcoin_test.go:43-112)
   in-test KATs quoted as data: point_test.go:39,49,242-261; point_mul_glv_test.go:18,25-45;
   point_mul_glv.go:40-56; scalar_test.go:27-41,76-95; field_test.go:29-41; ecdsa_k_test.go:49-70
 Only data is emitted: inputs and expected outputs.  No reference source text is stored.
@@ -109,6 +110,13 @@ def gentable():
             "sha256": hashlib.sha256(blob).hexdigest(), "size": len(blob), "samples": samples}
 
 
+def bip0066():
+    d = json.load(open(os.path.join(REF, "secec/bitcoin/testdata/bip-0066-test-vectors.json")))
+    return {"source": "secec/bitcoin/testdata/bip-0066-test-vectors.json",
+            "valid": [{"der": v["DER"], "r": v["r"], "s": v["s"]} for v in d["valid"]],
+            "invalid_decode": [{"der": v["DER"], "exception": v["exception"]} for v in d["invalid"]["decode"]]}
+
+
 def kats():
     return {
         "generator": {  # point_test.go:39,49 ; point.go:18-21
@@ -178,6 +186,7 @@ def main():
     dump("bip340.json", bip340())
     dump("rfc6979.json", rfc6979())
     dump("gentable.json", gentable())
+    dump("bip0066.json", bip0066())
     k = kats()
     # messages of the reused-k pairs (ecdsa_k_test.go:38-42), hashed with SHA-256 (secec_test.go:26-29)
     msgs = ["This is Fail(TM). But it's not Epic(TM) yet...", "With private keys you can SIGN THINGS"]

