@@ -587,3 +587,44 @@ def test_encoded_batch_options(eng, oracle):
     got = eng.ecdsa_verify_encoded_batch(bad_pubs, digs[:4], sigs_d[:4])
     assert got.tolist() == [0, 0, 0, 0]
     assert eng.ecdsa_verify_encoded_batch([], [], []).size == 0
+
+
+# ---- BASELINE.json full size (2^20) through size-independent properties -------------------------
+def test_full_size_properties(eng, oracle):
+    from secp256k1_voi_amd.synth import synth_batch
+    n = 1 << 20
+    pub, dig, r, s = synth_batch(eng, n, 1 << 16, seed=1234)
+    valid = eng.ecdsa_verify_batch(pub, dig, r, s)
+    assert valid.all()                                            # every generated signature verifies
+    # a sample against the oracle (the generator is the engine itself)
+    idx = np.random.default_rng(5).choice(n, 512, replace=False)
+    assert oracle.ecdsa_verify_batch(pub[idx], dig[idx], r[idx], s[idx], nthreads=8).all()
+    # seeded 1/64 corruption: one flipped bit in r, s or the digest; the verdict bitmap must be
+    # exactly the complement of the corruption mask
+    rng = np.random.default_rng(6)
+    mask = np.zeros(n, dtype=bool)
+    mask[rng.choice(n, n // 64, replace=False)] = True
+    which = rng.integers(0, 3, n)
+    byte = rng.integers(0, 32, n)
+    bit = (1 << rng.integers(0, 8, n)).astype(np.uint8)
+    arrs = [r.copy(), s.copy(), dig.copy()]
+    for k in range(3):
+        sel = np.nonzero(mask & (which == k))[0]
+        arrs[k][sel, byte[sel]] ^= bit[sel]
+    r2, s2, d2 = arrs
+    v2 = eng.ecdsa_verify_batch(pub, d2, r2, s2)
+    assert (v2 == (~mask).astype(np.uint8)).all()
+    # idempotence and permutation equivariance
+    assert (eng.ecdsa_verify_batch(pub, d2, r2, s2) == v2).all()
+    perm = rng.permutation(n)
+    assert (eng.ecdsa_verify_batch(pub[perm], d2[perm], r2[perm], s2[perm]) == v2[perm]).all()
+    # the complete path agrees on a slice, and the oracle on the corrupted part of it
+    sl = slice(0, 1 << 14)
+    assert (eng.ecdsa_verify_batch(pub[sl], d2[sl], r2[sl], s2[sl], force_complete=True) == v2[sl]).all()
+    bad = np.nonzero(mask[: 1 << 14])[0]
+    assert not oracle.ecdsa_verify_batch(pub[bad], d2[bad], r2[bad], s2[bad], nthreads=8).any()
+    # low-s rule: flipping s -> n - s keeps validity unless RejectMalleable
+    k = 4096
+    sneg, _ = eng.fn_op_batch(4, s[:k])
+    assert eng.ecdsa_verify_batch(pub[:k], dig[:k], r[:k], sneg).all()
+    assert not eng.ecdsa_verify_batch(pub[:k], dig[:k], r[:k], sneg, reject_malleable=True).any()
