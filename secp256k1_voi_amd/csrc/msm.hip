@@ -97,11 +97,13 @@ k_msm_parse(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __re
   }
   if (f == 2) atomicOr(status, 1u);
   flag[i] = f;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    ptw[(size_t)w * n + i] = a.x.v[w];
-    ptw[(size_t)(8 + w) * n + i] = a.y.v[w];
-  }
+  // points as 64-byte records [i][16 words]: the bucket pass gathers them by index, one
+  // contiguous record per lane (planes would cost 16 sparse sectors per gathered point)
+  uint4* rec4 = reinterpret_cast<uint4*>(ptw + i * 16);
+  rec4[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
+  rec4[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
+  rec4[2] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]);
+  rec4[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -199,12 +201,10 @@ k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ offset
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
     size_t i = list[j];
-    uint32_t xw[8], yw[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      xw[w] = ptw[(size_t)w * n + i];
-      yw[w] = ptw[(size_t)(8 + w) * n + i];
-    }
+    const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + i * 16);
+    uint4 a = rec4[0], b = rec4[1], c = rec4[2], d = rec4[3];
+    uint32_t xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t yw[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
     acc = pt26_add_mixed(acc, fe26_from_words(xw), fe26_from_words(yw));
   }
   pt_store(buckets, nkeys, key, acc);
@@ -451,10 +451,10 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
     scw[(size_t)w * N + i] = a.v[w];
     scw[(size_t)w * N + n + i] = ae.v[w];
     as_out[(size_t)w * n + i] = as.v[w];
-    ptw[(size_t)w * N + i] = r_le[w];
-    ptw[(size_t)(8 + w) * N + i] = nry[w];
-    ptw[(size_t)w * N + n + i] = pk_le[w];
-    ptw[(size_t)(8 + w) * N + n + i] = npy[w];
+    ptw[i * 16 + w] = r_le[w];
+    ptw[i * 16 + 8 + w] = nry[w];
+    ptw[(n + i) * 16 + w] = pk_le[w];
+    ptw[(n + i) * 16 + 8 + w] = npy[w];
   }
   flag[i] = ok ? 1 : 0;
   flag[n + i] = ok ? 1 : 0;
@@ -494,8 +494,8 @@ k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restr
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
       scw[(size_t)w * N + 2 * (size_t)n] = sh[0][w];
-      ptw[(size_t)w * N + 2 * (size_t)n] = FE_GX[w];
-      ptw[(size_t)(8 + w) * N + 2 * (size_t)n] = FE_GY[w];
+      ptw[2 * (size_t)n * 16 + w] = FE_GX[w];
+      ptw[2 * (size_t)n * 16 + 8 + w] = FE_GY[w];
     }
     flag[2 * (size_t)n] = 1;
   }
