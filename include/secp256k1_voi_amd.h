@@ -88,6 +88,19 @@ int s2k_ecdsa_verify_batch(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy /* n*64
 int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, const void *d_digest32,
                                   const void *d_r, const void *d_s, uint32_t flags, void *d_valid,
                                   void *hip_stream);
+/* ---- batch public-key recovery ------------------------------------------------------------ */
+/* For each i < n: secec.RecoverPublicKey(digest, r, s, recovery_id) (ecdsa.go:244-282):
+ * R = RecoverPoint(r, id) (point_s11n.go:245-282), Q = (-e/r) G + (s/r) R.  ok[i] = 1 and
+ * pub65[i] = 0x04 || X || Y on success; ok[i] = 0 and a zero record when the reference returns
+ * an error (r or s not in [1, n), id > 3, x = r + n not below p, x not on the curve, Q = infinity).
+ * Like the reference, s > n/2 is accepted here.  flags: S2K_ECDSA_FORCE_COMPLETE only. */
+int s2k_ecdsa_recover_batch(s2k_ctx *ctx, size_t n, const uint8_t *digest32 /* n*32 */, const uint8_t *r /* n*32 */,
+                            const uint8_t *s /* n*32 */, const uint8_t *recovery_id /* n */, uint32_t flags,
+                            uint8_t *pub65 /* n*65 */, uint8_t *ok /* n */);
+int s2k_ecdsa_recover_batch_device(s2k_ctx *ctx, size_t n, const void *d_digest32, const void *d_r, const void *d_s,
+                                   const void *d_recovery_id, uint32_t flags, void *d_pub65, void *d_ok,
+                                   void *hip_stream);
+
 /* Packs valid[n] (0/1 bytes, device) into a bitmap (bit i of byte i/8, LSB first; (n+7)/8
  * bytes, device) and writes the number of valid items to *d_count (uint64, device).  This is
  * the payload of the multi-GPU bitmap all-gather / count all-reduce. */

@@ -39,6 +39,7 @@ def lib() -> C.CDLL:
         _lib.orc_ecdsa_verify_batch.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_void_p, C.c_int]
         _lib.orc_ecdsa_verify_batch.restype = None
+        _lib.orc_ecdsa_recover.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_uint]
         _lib.orc_parse_asn1_signature.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         _lib.orc_ecdsa_verify_asn1.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
         _lib.orc_schnorr_verify.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
@@ -197,6 +198,13 @@ def ecdsa_verify_batch(q, digest, r, s, reject_malleable=False, nthreads=1):
     lib().orc_ecdsa_verify_batch(n, q.ctypes.data, digest.ctypes.data, r.ctypes.data, s.ctypes.data,
                                  int(reject_malleable), out.ctypes.data, int(nthreads))
     return out
+
+
+def ecdsa_recover(digest, r, s, recovery_id):
+    """RecoverPublicKey: the 65-byte uncompressed key, or None."""
+    o = _buf(65)
+    ok = lib().orc_ecdsa_recover(o, digest, len(digest), r, s, int(recovery_id))
+    return o.raw if ok else None
 
 
 def parse_asn1_signature(der):

@@ -934,6 +934,46 @@ void orc_ecdsa_verify_batch(size_t n, const uint8_t *q, const uint8_t *digest32,
     free(jobs);
 }
 
+/* RecoverPoint (point_s11n.go:245-282) + RecoverPublicKey (secec/ecdsa.go:244-282).
+ * Returns 1 and the uncompressed key, or 0 when the reference returns an error. */
+int orc_ecdsa_recover(uint8_t out65[65], const uint8_t *digest, size_t digest_len, const uint8_t r[32],
+                      const uint8_t s[32], unsigned recovery_id) {
+    oracle_init();
+    memset(out65, 0, 65);
+    sc rs, ss;
+    if (sc_set_canonical_bytes(&rs, r) || sc_set_canonical_bytes(&ss, s)) return 0;
+    if (sc_is_zero(&rs) || sc_is_zero(&ss)) return 0;                      /* ecdsa.go:245 */
+    if (recovery_id >= 4) return 0;                                        /* point_s11n.go:246 */
+    unsigned y_is_odd = recovery_id & 1, x_gt_n = (recovery_id >> 1) & 1;
+    fe xfe, xfen, fen;
+    fe_set_canonical_bytes(&xfe, r);                                       /* n < p: cannot fail */
+    { uint8_t nb[32]; u256_to_be(nb, &FN.m); fe_set_canonical_bytes(&fen, nb); }
+    fe_add(&xfen, &xfe, &fen);
+    if (x_gt_n) xfe = xfen;
+    uint8_t xb[32];
+    fe_get_bytes(xb, &xfe);
+    sc chk;
+    int did = sc_set_bytes(&chk, xb);
+    if (!((unsigned)did == x_gt_n && sc_eq(&chk, &rs))) return 0;          /* sanity check, point_s11n.go:266-269 */
+    uint8_t comp[33];
+    comp[0] = (uint8_t)(0x02 + y_is_odd);
+    memcpy(comp + 1, xb, 32);
+    pt R;
+    if (pt_set_bytes(&R, comp, 33)) return 0;
+    if (digest_len < 32) return 0;
+    sc e, neg_e, r_inv, u1, u2;
+    sc_set_bytes(&e, digest);
+    sc_neg(&neg_e, &e);
+    sc_invert(&r_inv, &rs);
+    sc_mul(&u1, &neg_e, &r_inv);
+    sc_mul(&u2, &ss, &r_inv);
+    pt Q;
+    pt_double_scalar_mult_basepoint_vartime(&Q, &u1, &u2, &R);
+    if (pt_is_identity(&Q)) return 0;                                      /* NewPublicKeyFromPoint, secec.go:206-209 */
+    pt_to_buf(out65, &Q);
+    return 1;
+}
+
 /* --- strict DER, restating golang.org/x/crypto v0.11.0 cryptobyte (go.mod:8), which is
  * not vendored in the reference: String.ReadASN1 / ReadASN1Integer(*[]byte) as used at
  * secec/s11n.go:89-96.  Pinned by the Wycheproof flag classes (wycheproof_test.go:349-352). */

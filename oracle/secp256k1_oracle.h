@@ -91,6 +91,9 @@ int  orc_ecdsa_verify_raw(const uint8_t q[64], const uint8_t *digest, size_t dig
 void orc_ecdsa_verify_batch(size_t n, const uint8_t *q /* n*64 */, const uint8_t *digest32 /* n*32 */,
                             const uint8_t *r /* n*32 */, const uint8_t *s /* n*32 */,
                             int reject_malleable, uint8_t *out, int nthreads);
+/* RecoverPublicKey (ecdsa.go:244): 1 and the 65-byte key on success, 0 on any error */
+int  orc_ecdsa_recover(uint8_t out65[65], const uint8_t *digest, size_t digest_len, const uint8_t r[32],
+                       const uint8_t s[32], unsigned recovery_id);
 /* ParseASN1Signature (s11n.go:83): 0 ok, 1 = bad ASN.1, 2 = bad scalar */
 int  orc_parse_asn1_signature(uint8_t r[32], uint8_t s[32], const uint8_t *der, size_t len);
 /* PublicKey.Verify with EncodingASN1 and opts==nil|{RejectMalleable} (ecdsa.go:171);

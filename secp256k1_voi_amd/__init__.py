@@ -86,6 +86,8 @@ def load_library() -> C.CDLL:
     lib.s2k_version.restype = C.c_char_p
     lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
+    lib.s2k_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
+    lib.s2k_ecdsa_recover_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp, vp]
     lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
     lib.s2k_ecdsa_workspace_bytes.restype = sz
@@ -116,7 +118,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
-    "s2k_pack_valid_device",
+    "s2k_pack_valid_device", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
@@ -281,6 +283,20 @@ class Engine:
                                                                m.shape[1] if n else 0, sig64.ctypes.data,
                                                                seed.ctypes.data, C.byref(res)))
         return bool(res.value)
+
+    def ecdsa_recover_batch(self, digest32, r, s, recovery_id, force_complete: bool = False):
+        """RecoverPublicKey over a batch: returns (pub65 (n,65) uint8, ok (n,) uint8)."""
+        r = _arr(r, 32)
+        n = r.shape[0]
+        digest32, s = _arr(digest32, 32, n), _arr(s, 32, n)
+        rid = np.ascontiguousarray(recovery_id, dtype=np.uint8).reshape(-1)
+        if rid.shape[0] != n:
+            raise ValueError("length mismatch")
+        pub, ok = np.zeros((n, 65), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.s2k_ecdsa_recover_batch(self._h, n, digest32.ctypes.data, r.ctypes.data, s.ctypes.data,
+                                                      rid.ctypes.data, FORCE_COMPLETE if force_complete else 0,
+                                                      pub.ctypes.data, ok.ctypes.data))
+        return pub, ok
 
     def pack_valid_device(self, n, d_valid, d_bitmap, d_count, stream=0):
         """valid bytes -> bitmap + uint64 count, all device pointers."""

@@ -318,10 +318,12 @@ S2K_DEV void ws_store_sc(uint32_t* __restrict__ base, size_t stride, size_t i, c
   for (int w = 0; w < 8; ++w) base[(size_t)w * stride + i] = v.v[w];
 }
 
+// recid != nullptr selects public-key recovery (RecoverPublicKey, ecdsa.go:244-282): the shared
+// inversion is of r instead of s, and u1 = -e/r, u2 = s/r.
 __global__ void __launch_bounds__(64)
 k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
-              const uint8_t* __restrict__ ssig, uint32_t flags, uint32_t* __restrict__ prep,
-              uint32_t* __restrict__ pref, uint32_t* __restrict__ smont, size_t stride) {
+              const uint8_t* __restrict__ ssig, const uint8_t* __restrict__ recid, uint32_t flags,
+              uint32_t* __restrict__ prep, uint32_t* __restrict__ pref, uint32_t* __restrict__ smont, size_t stride) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
   sc one_m = sc_from_limbs(SC_ONE_M);
@@ -331,7 +333,7 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
     size_t i = (size_t)t + (size_t)j * T;
     if (i >= n) break;
     sc s;
-    load_be32(s.v, ssig + i * 32);
+    load_be32(s.v, (recid ? rsig : ssig) + i * 32);   // the value whose inverse is needed
     bool ok_s = sc_is_canonical_raw(s.v) && !sc_is_zero(s);
     if (!ok_s) {   // keep the shared product invertible; the signature is rejected below
       s = sc_zero();
@@ -359,13 +361,23 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
     bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
     if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
     sc e = sc_reduce_once(e_raw);
-    sc u1 = sc_montmul(e, s_inv_m);
-    sc u2 = sc_montmul(r, s_inv_m);
+    sc u1, u2;
+    uint32_t rid = 0;
+    if (recid) {
+      rid = recid[i];
+      // RecoverPoint (point_s11n.go:245-282): id in [0,3]; bit 1 means x = r + n, which must stay < p
+      ok = ok && rid < 4 && (!(rid & 2u) || u256_lt(r.v, FE_P_MINUS_N));
+      u1 = sc_montmul(sc_neg(e), s_inv_m);           // -e / r
+      u2 = sc_montmul(s, s_inv_m);                   //  s / r
+    } else {
+      u1 = sc_montmul(e, s_inv_m);
+      u2 = sc_montmul(r, s_inv_m);
+    }
     sc k1, k2;
     bool neg1, neg2;
     sc_split_glv(u2, k1, neg1, k2, neg2);
     uint32_t f = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) |
-                 ((k1.v[0] & 1u) ? 0 : PF_EVEN1) | ((k2.v[0] & 1u) ? 0 : PF_EVEN2);
+                 ((k1.v[0] & 1u) ? 0 : PF_EVEN1) | ((k2.v[0] & 1u) ? 0 : PF_EVEN2) | ((rid & 3u) << 8);
 #pragma unroll
     for (int w = 0; w < 8; ++w) prep[(size_t)w * stride + i] = u1.v[w];
 #pragma unroll
@@ -408,24 +420,48 @@ S2K_DEV fe26 fe26_cond_negate1(const fe26& a, bool neg) {   // magnitude 1 in, <
   return fe26_select(neg, a, fe26_negate(a, 1));
 }
 
-enum { MODE_ECDSA = 0, MODE_SCHNORR = 1 };
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
 
 // MODE_ECDSA:   pub = n x 64 (X||Y), rsig = n x 32 (r);      accept iff x(R) mod n == r
 // MODE_SCHNORR: pub = n x 32 (x-only key, BIP-340), rsig = n x 64 signatures (r at offset 0);
 //               P = lift_x(pub) (NewSchnorrPublicKey, schnorr.go:257-275), accept iff R != inf,
 //               y(R) even and x(R) == r (verifySchnorrSignatureR, schnorr.go:451-478)
+// MODE_RECOVER: pub unused, rsig = n x 32 (r); the point is R = RecoverPoint(r, id) with the id
+//               from the prep flag word; out = ok bytes, out_pts = n x 65 records of
+//               Q = (-e/r) G + (s/r) R (RecoverPublicKey, ecdsa.go:244-282)
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ hs,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
-              uint32_t* __restrict__ wl, size_t stride) {
+              uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   uint32_t pf = prep[(size_t)16 * stride + idx];
   bool ok;
   fe26 qx, qy;
-  if constexpr (MODE == MODE_ECDSA) {
+  if constexpr (MODE == MODE_RECOVER) {
+    uint32_t xw[8];
+    load_be32(xw, rsig + idx * 32);
+    ok = (pf & PF_OK) != 0;
+    if (ok && (pf & 0x200u)) u256_add(xw, xw, SC_N);   // x = r + n (< p, checked by the prep kernel)
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
+    }
+    qx = fe26_from_words(xw);
+    fe26 rhs = fe26_mul(fe26_sqr(qx), qx);
+    rhs.n[0] += 7;
+    bool has = fe26_sqrt(qy, rhs);                      // SetCompressedBytes (point_s11n.go:152-169)
+    if (!has) {
+      ok = false;
+      qx = fe26_from_words(FE_GX);
+      qy = fe26_from_words(FE_GY);
+    }
+    qy = fe26_normalize(qy);
+    bool want_odd = (pf & 0x100u) != 0;
+    qy = fe26_select(((qy.n[0] & 1u) != 0) != want_odd, qy, fe26_normalize_weak(fe26_negate(qy, 1)));
+  } else if constexpr (MODE == MODE_ECDSA) {
     apt q;
     load_be32(q.x.v, pub + idx * 64);
     load_be32(q.y.v, pub + idx * 64 + 32);
@@ -573,11 +609,26 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 
   // ---- verdict ----
   uint8_t verdict = 0;
+  if constexpr (MODE == MODE_RECOVER) {
+    uint8_t* rec = out_pts + idx * 65;
+    for (int i = 0; i < 65; ++i) rec[i] = 0;
+  }
   if (ok) {
     if (fe26_is_zero(acc.z)) {
       // infinity or an exceptional case along the way: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
       wl[pos] = (uint32_t)idx;
+    } else if constexpr (MODE == MODE_RECOVER) {
+      fe26 zi = fe26_inv(acc.z);
+      fe26 zi2 = fe26_sqr(zi);
+      uint32_t xw[8], yw[8];
+      fe26_to_words(xw, fe26_normalize(fe26_mul(acc.x, zi2)));
+      fe26_to_words(yw, fe26_normalize(fe26_mul(fe26_mul(acc.y, zi2), zi)));
+      uint8_t* rec = out_pts + idx * 65;
+      rec[0] = 0x04;
+      store_be32_unaligned(rec + 1, xw);
+      store_be32_unaligned(rec + 33, yw);
+      verdict = 1;
     } else if constexpr (MODE == MODE_ECDSA) {
       // x(R) mod n == r  (ecdsa.go:450-465)
       uint32_t rw[8];
@@ -705,6 +756,61 @@ k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
     size_t idx = all_n ? w : wl[w];
     out[idx] = schnorr_verify_complete(idx, pk, sig, msgs, offs, msg_len, gt, qt, stride);
+  }
+}
+
+// RecoverPublicKey (ecdsa.go:244-282) for one item with complete formulas
+S2K_DEV uint8_t recover_complete(size_t idx, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
+                                 const uint8_t* __restrict__ ssig, const uint8_t* __restrict__ recid,
+                                 uint8_t* __restrict__ out_pts, const uint32_t* __restrict__ gt,
+                                 uint32_t* __restrict__ qt, size_t stride) {
+  sc r, s;
+  uint32_t e_raw[8];
+  load_be32(r.v, rsig + idx * 32);
+  load_be32(s.v, ssig + idx * 32);
+  load_be32(e_raw, dig + idx * 32);
+  uint32_t rid = recid[idx];
+  bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s) && rid < 4 &&
+            (!(rid & 2u) || u256_lt(r.v, FE_P_MINUS_N));
+  apt R;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) R.x.v[i] = r.v[i];
+  if (ok && (rid & 2u)) u256_add(R.x.v, R.x.v, SC_N);
+  fe y;
+  bool has = fe_sqrt(y, fe_curve_rhs(R.x));
+  ok = ok && has;
+  if (!ok) {
+    R.x = fe_from_limbs(FE_GX);
+    y = fe_from_limbs(FE_GY);
+  }
+  y = fe_normalize(y);
+  R.y = fe_normalize(fe_select(((y.v[0] & 1u) != 0) != ((rid & 1u) != 0), y, fe_neg(y)));
+  sc e = sc_reduce_once(e_raw);
+  sc r_inv_m = sc_mont_inv(sc_to_mont(r));
+  sc u1 = sc_montmul(sc_neg(e), r_inv_m), u2 = sc_montmul(s, r_inv_m);
+  pt Q = pt_add_complete(pt_base_mul(gt, u1.v), pt_mul_glv(u2, R, qt, stride, idx));
+  uint8_t* rec = out_pts + idx * 65;
+  apt a;
+  bool finite = pt_to_affine(a, Q);              // identity: NewPublicKeyFromPoint fails (secec.go:206-209)
+  if (!(ok && finite)) {
+    for (int i = 0; i < 65; ++i) rec[i] = 0;
+    return 0;
+  }
+  rec[0] = 0x04;
+  store_be32_unaligned(rec + 1, a.x.v);
+  store_be32_unaligned(rec + 33, a.y.v);
+  return 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_recover_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
+                   const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
+                   const uint8_t* __restrict__ recid, uint8_t* __restrict__ ok_out, uint8_t* __restrict__ out_pts,
+                   const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  uint32_t count = all_n ? all_n : *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    size_t idx = all_n ? w : wl[w];
+    ok_out[idx] = recover_complete(idx, dig, rsig, ssig, recid, out_pts, gt, qt, stride);
   }
 }
 
@@ -1013,15 +1119,76 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
-                                              (const uint8_t*)d_s, flags, prep, pref, smont, stride);
+                                              (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, hs,
-                                               ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride);
+                                               ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback<<<64, 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                         ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, const void* d_r, const void* d_s,
+                                   const void* d_recid, uint32_t flags, void* d_pub65, void* d_ok, void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!d_dig || !d_r || !d_s || !d_recid || !d_pub65 || !d_ok) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_ws(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t stride = lane_stride(n);
+  uint32_t* ws = (uint32_t*)ctx->ws;
+  uint32_t* qt = ws + WS_QT * stride;
+  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* pref = ws + WS_PREF * stride;
+  uint32_t* smont = ws + WS_SMONT * stride;
+  uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
+  uint32_t* wl = wl_count + 64;
+  const uint8_t *dig = (const uint8_t*)d_dig, *r = (const uint8_t*)d_r, *s = (const uint8_t*)d_s,
+                *rid = (const uint8_t*)d_recid;
+  if (flags & S2K_ECDSA_FORCE_COMPLETE) {
+    k_recover_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, dig, r, s, rid, (uint8_t*)d_ok,
+                                                      (uint8_t*)d_pub65, ctx->gtable, qt, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    return S2K_OK;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, hs, ctx->gtable,
+                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65);
+  HIP_TRY(ctx, hipGetLastError());
+  k_recover_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, dig, r, s, rid, (uint8_t*)d_ok, (uint8_t*)d_pub65,
+                                         ctx->gtable, qt, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const uint8_t* r, const uint8_t* s,
+                            const uint8_t* recid, uint32_t flags, uint8_t* pub65, uint8_t* ok) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!dig || !r || !s || !recid || !pub65 || !ok) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dev_buf dd, dr, ds, di, dp, dk;
+  HIP_TRY(ctx, dd.upload(dig, n * 32));
+  HIP_TRY(ctx, dr.upload(r, n * 32));
+  HIP_TRY(ctx, ds.upload(s, n * 32));
+  HIP_TRY(ctx, di.upload(recid, n));
+  HIP_TRY(ctx, dp.alloc(n * 65));
+  HIP_TRY(ctx, dk.alloc(n));
+  int rc = s2k_ecdsa_recover_batch_device(ctx, n, dd.p, dr.p, ds.p, di.p, flags, dp.p, dk.p, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(pub65, dp.p, n * 65, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ok, dk.p, n, hipMemcpyDeviceToHost));
   return S2K_OK;
 }
 
@@ -1058,7 +1225,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, hs, ctx->gtable,
-                                                             (uint8_t*)d_valid, wl_count, wl, stride);
+                                                             (uint8_t*)d_valid, wl_count, wl, stride, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   k_schnorr_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
                                          ctx->gtable, qt, stride);

@@ -64,6 +64,18 @@ S2K_DEV fe26 fe26_from_words(const uint32_t w[8]) {
   return r;
 }
 
+// canonical (fully normalised) limbs -> 8 x 32-bit little-endian words
+S2K_DEV void fe26_to_words(uint32_t w[8], const fe26& a) {
+  w[0] = a.n[0] | (a.n[1] << 26);
+  w[1] = (a.n[1] >> 6) | (a.n[2] << 20);
+  w[2] = (a.n[2] >> 12) | (a.n[3] << 14);
+  w[3] = (a.n[3] >> 18) | (a.n[4] << 8);
+  w[4] = (a.n[4] >> 24) | (a.n[5] << 2) | (a.n[6] << 28);
+  w[5] = (a.n[6] >> 4) | (a.n[7] << 22);
+  w[6] = (a.n[7] >> 10) | (a.n[8] << 16);
+  w[7] = (a.n[8] >> 16) | (a.n[9] << 10);
+}
+
 S2K_DEV fe26 fe26_add(const fe26& a, const fe26& b) {
   fe26 r;
 #pragma unroll

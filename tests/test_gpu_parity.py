@@ -628,3 +628,58 @@ def test_full_size_properties(eng, oracle):
     sneg, _ = eng.fn_op_batch(4, s[:k])
     assert eng.ecdsa_verify_batch(pub[:k], dig[:k], r[:k], sneg).all()
     assert not eng.ecdsa_verify_batch(pub[:k], dig[:k], r[:k], sneg, reject_malleable=True).any()
+
+
+# ---- batch public-key recovery (secec/ecdsa.go:244-282; wycheproof_test.go:417-438) --------------
+def test_recover_wycheproof(eng, oracle):
+    for fn in ("wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"):
+        d = load_golden(fn)
+        dig, rr, ss, ids, meta = [], [], [], [], []
+        for c in d["cases"]:
+            rs = oracle.parse_asn1_signature(H(c["sig"]))
+            if rs is None:
+                continue
+            for rid in range(5):                       # 4 is an invalid id
+                dig.append(H(c["digest"])[:32]); rr.append(rs[0]); ss.append(rs[1]); ids.append(rid)
+                meta.append((c, rid))
+        pub, ok = eng.ecdsa_recover_batch(dig, rr, ss, ids)
+        pub2, ok2 = eng.ecdsa_recover_batch(dig, rr, ss, ids, force_complete=True)
+        assert ok.tolist() == ok2.tolist() and (pub == pub2).all()
+        found = {}
+        for (c, rid), p, k, dg, r_, s_ in zip(meta, rows(pub), ok, dig, rr, ss):
+            exp = oracle.ecdsa_recover(dg, r_, s_, rid)
+            assert (p if k else None) == exp, (fn, c["tcId"], rid)
+            if k and p == H(c["pub"]):
+                found[c["tcId"]] = True
+        for c in d["cases"]:
+            rs = oracle.parse_asn1_signature(H(c["sig"]))
+            if rs is not None:
+                assert found.get(c["tcId"], False) == c["valid"], c["tcId"]
+
+
+def test_recover_random_and_edges(eng, oracle):
+    rnd = random.Random(101)
+    dig, rr, ss, ids, exp = [], [], [], [], []
+    for i in range(400):
+        d = rnd.randrange(1, R.N)
+        dg = rnd.randbytes(32)
+        k = rnd.randrange(1, R.N)
+        r, s = R.ecdsa_sign(d, dg, k)
+        rid = rnd.randrange(4)
+        if i % 7 == 0:
+            r = rnd.choice([0, R.N, R.N + 1, 1, 2, R.P - R.N - 1, R.P - R.N, R.P - R.N + 1])
+        if i % 11 == 0:
+            s = rnd.choice([0, R.N, 1])
+        dig.append(dg); rr.append(b32(r)); ss.append(b32(s)); ids.append(rid)
+        exp.append(oracle.ecdsa_recover(dg, b32(r), b32(s), rid))
+    pub, ok = eng.ecdsa_recover_batch(dig, rr, ss, ids)
+    for p, k, e in zip(rows(pub), ok, exp):
+        assert (p if k else None) == e
+        if not k:
+            assert p == bytes(65)
+    assert 0 < int(ok.sum()) < len(exp)
+    # recovered keys verify the signatures they came from
+    good = [i for i in range(400) if ok[i]]
+    v = eng.ecdsa_verify_batch([rows(pub)[i][1:] for i in good], [dig[i] for i in good], [rr[i] for i in good],
+                               [ss[i] for i in good])
+    assert v.all()

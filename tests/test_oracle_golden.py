@@ -284,3 +284,42 @@ def test_op_counts(oracle):
     assert oracle.ecdsa_verify_raw(b32(q[0]) + b32(q[1]), dig, b32(r), b32(s))
     fp, fn = oracle.counters_get()
     assert 2700 < fp < 3100 and 290 < fn < 320, (fp, fn)
+
+
+# ---- 9. public-key recovery: exhaustive recovery finds the key iff the signature verifies
+#         (secec/wycheproof_test.go:417-438) ----
+@pytest.mark.parametrize("fn", ["wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"])
+def test_wycheproof_recovery(oracle, fn):
+    d = load_golden(fn)
+    n_found = 0
+    for c in d["cases"]:
+        rs = oracle.parse_asn1_signature(H(c["sig"]))
+        if rs is None:
+            continue
+        pub, digest = H(c["pub"]), H(c["digest"])
+        ok = oracle.ecdsa_verify_raw(pub[1:], digest, rs[0], rs[1])
+        found = any(oracle.ecdsa_recover(digest, rs[0], rs[1], rid) == pub for rid in range(4))
+        assert found == ok, (fn, c["tcId"])
+        n_found += found
+        assert oracle.ecdsa_recover(digest, rs[0], rs[1], 4) is None
+    assert n_found > 150
+
+
+def test_recovery_random(oracle):
+    rnd = random.Random(17)
+    for _ in range(30):
+        d = rnd.randrange(1, R.N)
+        q = R.mul(d, R.G)
+        dig = rnd.randbytes(32)
+        k = rnd.randrange(1, R.N)
+        Rp = R.mul(k, R.G)
+        r, s = R.ecdsa_sign(d, dig, k)
+        rid = (Rp[1] & 1) | (2 if Rp[0] >= R.N else 0)
+        assert oracle.ecdsa_recover(dig, b32(r), b32(s), rid) == R.enc65(q)
+        other = oracle.ecdsa_recover(dig, b32(r), b32(s), rid ^ 1)
+        assert other is not None and other != R.enc65(q)
+        assert oracle.ecdsa_recover(dig, bytes(32), b32(s), rid) is None
+        assert oracle.ecdsa_recover(dig, b32(r), bytes(32), rid) is None
+        assert oracle.ecdsa_recover(dig, b32(R.N), b32(s), rid) is None
+        if r >= R.P - R.N:
+            assert oracle.ecdsa_recover(dig, b32(r), b32(s), rid | 2) is None     # r + n >= p
