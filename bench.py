@@ -98,13 +98,21 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    # test hooks (not used by the driver): several ranks on one GPU with the gloo backend, to
+    # exercise the multi-rank flow on a 1-GPU box
+    if "S2K_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["S2K_BENCH_DEVICE"])
+    backend = os.environ.get("S2K_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = 1 << args.batch_log2
     eng = S.Engine(local_rank)

@@ -89,6 +89,12 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
         return bitmap, count
     world = dist.get_world_size()
     assert n * world == n_total, "gather_valid_device needs equal shards"
+    if dist.get_backend() == "gloo":       # CPU collectives (tests on a box without RCCL peers)
+        parts = [torch.empty(bitmap.numel(), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, bitmap.cpu())
+        c = count.cpu()
+        dist.all_reduce(c)
+        return torch.cat(parts).to(valid.device), c.to(valid.device)
     full = torch.empty(bitmap.numel() * world, dtype=torch.uint8, device=valid.device)
     dist.all_gather_into_tensor(full, bitmap)
     dist.all_reduce(count)
