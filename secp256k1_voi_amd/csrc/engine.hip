@@ -429,8 +429,14 @@ enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
 // MODE_RECOVER: pub unused, rsig = n x 32 (r); the point is R = RecoverPoint(r, id) with the id
 //               from the prep flag word; out = ok bytes, out_pts = n x 65 records of
 //               Q = (-e/r) G + (s/r) R (RecoverPublicKey, ecdsa.go:244-282)
+// Waves per SIMD the register allocator must leave room for.  Measured (2^20 signatures):
+// unbounded (240 VGPRs, 2 waves) 11.08 ms; 3 waves (168 VGPRs, no spills) 10.89 ms; 4 waves
+// (128 VGPRs, 96 spilled) 11.45 ms.
+#ifndef S2K_FAST_WAVES
+#define S2K_FAST_WAVES 3
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, S2K_FAST_WAVES)
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ hs,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
