@@ -397,7 +397,7 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // Table storage: [entry*16 + word][lane] (x limbs then y limbs), H scratch [entry*8 + word][lane].
 // ---------------------------------------------------------------------------------------
 constexpr int FQT_WORDS = QT_ENTRIES * 20;
-constexpr int FHS_WORDS = QT_ENTRIES * 10;
+constexpr int FHS_WORDS = QT_ENTRIES * 10 + 10;   // H_j scratch, later beta*x_j; slot 8: Z_7 * C
 // Layout note (measured on MI355X, 2^20 signatures, profiles/r01_table_layouts.md): these
 // 4-byte planes [word][lane] cost 16.4 GB of fabric reads per batch (a lookup is a per-lane
 // gather, every lane wants a different entry, so ~8 rows x 4 sectors are touched per word) but
@@ -533,25 +533,30 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       fq_store(qt, stride, idx, j * 20 + 10, cur.y); // [2]
       fq_store(hs, stride, idx, j * 10, h);          // [6]
     }
-    fq_store(hs, stride, idx, 0, fe26_mul(cur.z, d.z));   // Z_7 * C, parked in the unused H_0 slot
+    fq_store(hs, stride, idx, QT_ENTRIES * 10, fe26_mul(cur.z, d.z));   // Z_7 * C
     // entry 7 as stored has magnitudes 4 / 2: bring it to [1] like the others
-    fq_store(qt, stride, idx, 7 * 20, fe26_normalize_weak(cur.x));
+    fe26 prev_x = fe26_normalize_weak(cur.x);
+    fq_store(qt, stride, idx, 7 * 20, prev_x);
     fq_store(qt, stride, idx, 7 * 20 + 10, fe26_normalize_weak(cur.y));
+    const fe26 beta = fe26_from_words(FE_BETA);
     fe26 rr = fe26_one();
 #pragma unroll 1
     for (int j = QT_ENTRIES - 2; j >= 0; --j) {
       rr = fe26_mul(rr, fq_load(hs, stride, idx, (j + 1) * 10));
+      // H_{j+1} is no longer needed: its slot now takes beta * x_{j+1} (the x of the beta*Q
+      // table, mulBeta point_mul_glv.go:191; one multiplication per entry instead of one per lookup)
+      fq_store(hs, stride, idx, (j + 1) * 10, fe26_mul(prev_x, beta));
       fe26 r2 = fe26_sqr(rr);
       fe26 r3 = fe26_mul(r2, rr);
-      fe26 x = fe26_mul(fq_load(qt, stride, idx, j * 20), r2);
+      prev_x = fe26_mul(fq_load(qt, stride, idx, j * 20), r2);
       fe26 y = fe26_mul(fq_load(qt, stride, idx, j * 20 + 10), r3);
-      fq_store(qt, stride, idx, j * 20, x);
+      fq_store(qt, stride, idx, j * 20, prev_x);
       fq_store(qt, stride, idx, j * 20 + 10, y);
     }
+    fq_store(hs, stride, idx, 0, fe26_mul(prev_x, beta));
   }
 
   // ---- ladder over |k1|, |k2| ----
-  fe26 beta = fe26_from_words(FE_BETA);
   sc k1 = sc_zero(), k2 = sc_zero();
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
@@ -567,7 +572,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     acc.x = t0x;
     acc.y = fe26_cond_negate1(t0y, neg1);
     acc.z = fe26_one();
-    acc = jpt26_add_affine(acc, fe26_mul(t0x, beta), fe26_cond_negate1(t0y, neg2));
+    acc = jpt26_add_affine(acc, fq_load(hs, stride, idx, 0), fe26_cond_negate1(t0y, neg2));
   }
 #pragma unroll 1
   for (int i = 31; i >= 0; --i) {
@@ -579,16 +584,15 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       uint32_t w = t ? w2 : w1;
       bool neg = (t ? neg2 : neg1) != (w < 8u);
       uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
-      fe26 x = fq_load(qt, stride, idx, entry * 20), y = fq_load(qt, stride, idx, entry * 20 + 10);
-      if (t) x = fe26_mul(x, beta);
+      fe26 x = t ? fq_load(hs, stride, idx, entry * 10) : fq_load(qt, stride, idx, entry * 20);
+      fe26 y = fq_load(qt, stride, idx, entry * 20 + 10);
       acc = jpt26_add_affine(acc, x, fe26_cond_negate1(y, neg));
     }
   }
   // k' = k | 1: take the extra 1 back out of even halves
 #pragma unroll 1
   for (int t = 0; t < 2; ++t) {
-    fe26 x = fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 10);
-    if (t) x = fe26_mul(x, beta);
+    fe26 x = t ? fq_load(hs, stride, idx, 0) : fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 10);
     bool sneg = !(t ? neg2 : neg1);
     jpt26 sum = jpt26_add_affine(acc, x, fe26_cond_negate1(t0y, sneg));
     bool even = pf & (t ? PF_EVEN2 : PF_EVEN1);
@@ -596,7 +600,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     acc.y = fe26_select(even, acc.y, sum.y);
     acc.z = fe26_select(even, acc.z, sum.z);
   }
-  acc.z = fe26_mul(acc.z, fq_load(hs, stride, idx, 0));   // times Z_7 * C: back on secp256k1 itself
+  acc.z = fe26_mul(acc.z, fq_load(hs, stride, idx, QT_ENTRIES * 10));   // times Z_7 * C: back on secp256k1 itself
 
   // ---- generator part: u1*G from the resident tables ----
   {
@@ -1034,9 +1038,10 @@ const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
-//   [0,240)    per-lane point tables: fast path uses 160 (8 entries x 2 x 10 limbs) + 80 (H
-//              scratch); the complete path reuses the first 192 words for its projective table
-//   [240,257)  scalar-prep output     [257,265) prefix products     [265,273) s in Montgomery form
+//   [0,250)    per-lane point tables: fast path uses 160 (8 entries x 2 x 10 limbs) + 90 (H
+//              scratch, then the beta*x column and Z_7*C); the complete path reuses the first
+//              192 words for its projective table
+//   [250,267)  scalar-prep output     [267,275) prefix products     [275,283) s in Montgomery form
 //   then       worklist: 1 counter + n indices
 constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = FQT_WORDS + FHS_WORDS, WS_PREF = WS_PREP + PREP_WORDS,
                  WS_SMONT = WS_PREF + 8, WS_LANE_WORDS = WS_SMONT + 8;
