@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + os.environ.get("S2K_EXTRA_FLAGS", "").split()
 
     def compile_one(u):
         obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")

@@ -15,6 +15,7 @@
 #include "jacobian.h"
 #include "point.h"
 #include "sc.h"
+#include "sc26.h"
 #include "sha256.h"
 
 using namespace s2k;
@@ -307,15 +308,15 @@ constexpr int PREP_M = 16;
 constexpr int PREP_WORDS = 17;
 enum { PF_OK = 1, PF_NEG1 = 2, PF_NEG2 = 4, PF_EVEN1 = 8, PF_EVEN2 = 16 };
 
-S2K_DEV sc ws_load_sc(const uint32_t* __restrict__ base, size_t stride, size_t i) {
-  sc r;
+S2K_DEV void ws_store_sc26(uint32_t* __restrict__ base, size_t stride, size_t i, const sc26& v) {
 #pragma unroll
-  for (int w = 0; w < 8; ++w) r.v[w] = base[(size_t)w * stride + i];
-  return r;
+  for (int w = 0; w < 10; ++w) base[(size_t)w * stride + i] = v.n[w];
 }
-S2K_DEV void ws_store_sc(uint32_t* __restrict__ base, size_t stride, size_t i, const sc& v) {
+S2K_DEV sc26 ws_load_sc26(const uint32_t* __restrict__ base, size_t stride, size_t i) {
+  sc26 r;
 #pragma unroll
-  for (int w = 0; w < 8; ++w) base[(size_t)w * stride + i] = v.v[w];
+  for (int w = 0; w < 10; ++w) r.n[w] = base[(size_t)w * stride + i];
+  return r;
 }
 
 // recid != nullptr selects public-key recovery (RecoverPublicKey, ecdsa.go:244-282): the shared
@@ -326,8 +327,9 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
               uint32_t* __restrict__ prep, uint32_t* __restrict__ pref, uint32_t* __restrict__ smont, size_t stride) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
-  sc one_m = sc_from_limbs(SC_ONE_M);
-  sc acc = one_m;
+  // products run on the lazy 10x26 Montgomery form (sc26.h); pref/smont are 10-word planes
+  sc26 one_m = sc26_from_limbs(SC26_ONE_M);
+  sc26 acc = one_m;
 #pragma unroll 1
   for (int j = 0; j < PREP_M; ++j) {
     size_t i = (size_t)t + (size_t)j * T;
@@ -339,20 +341,20 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
       s = sc_zero();
       s.v[0] = 1;
     }
-    sc sm = sc_to_mont(s);
-    ws_store_sc(smont, stride, i, sm);
-    acc = sc_montmul(acc, sm);
-    ws_store_sc(pref, stride, i, acc);
+    sc26 sm = sc26_to_mont(sc26_from_sc(s));
+    ws_store_sc26(smont, stride, i, sm);
+    acc = sc26_mm(acc, sm);
+    ws_store_sc26(pref, stride, i, acc);
   }
-  sc inv = sc_mont_inv(acc);
+  sc26 inv = sc26_mont_inv(acc);
 #pragma unroll 1
   for (int j = PREP_M - 1; j >= 0; --j) {
     size_t i = (size_t)t + (size_t)j * T;
     if (i >= n) continue;
-    sc sm = ws_load_sc(smont, stride, i);
-    sc prev = j > 0 ? ws_load_sc(pref, stride, i - T) : one_m;
-    sc s_inv_m = sc_montmul(inv, prev);            // s_i^-1 * R
-    inv = sc_montmul(inv, sm);
+    sc26 sm = ws_load_sc26(smont, stride, i);
+    sc26 prev = j > 0 ? ws_load_sc26(pref, stride, i - T) : one_m;
+    sc26 s_inv_m = sc26_mm(inv, prev);             // s_i^-1 * R
+    inv = sc26_mm(inv, sm);
     sc r, s;
     uint32_t e_raw[8];
     load_be32(r.v, rsig + i * 32);
@@ -367,11 +369,11 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
       rid = recid[i];
       // RecoverPoint (point_s11n.go:245-282): id in [0,3]; bit 1 means x = r + n, which must stay < p
       ok = ok && rid < 4 && (!(rid & 2u) || u256_lt(r.v, FE_P_MINUS_N));
-      u1 = sc_montmul(sc_neg(e), s_inv_m);           // -e / r
-      u2 = sc_montmul(s, s_inv_m);                   //  s / r
+      u1 = sc26_to_sc(sc26_mm(sc26_from_sc(sc_neg(e)), s_inv_m));   // -e / r
+      u2 = sc26_to_sc(sc26_mm(sc26_from_sc(s), s_inv_m));           //  s / r
     } else {
-      u1 = sc_montmul(e, s_inv_m);
-      u2 = sc_montmul(r, s_inv_m);
+      u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m));
+      u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
     }
     sc k1, k2;
     bool neg1, neg2;
@@ -394,26 +396,59 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // on the curve isomorphic by C = Z(2Q), remember H_j (Z_j = Z_{j-1} H_j), then scale entry j
 // by (H_{j+1}...H_7)^{2,3}.  The ladder then only ever adds affine points (8 M + 3 S); its
 // result has the true Z = Z_ladder * Z_7 * C.
-// Table storage: [entry*16 + word][lane] (x limbs then y limbs), H scratch [entry*8 + word][lane].
+// Table storage (S2K_QT_PLANE = bytes per lane per plane): 16-byte planes [quad][lane], three
+// quads per field element (limbs 0-3 | 4-7 | 8,9,-,-); entry j is x at element 2j, y at 2j+1.
+// The H scratch region holds one element per entry (H_j, later beta*x_j) plus slot 8 = Z_7 * C.
 // ---------------------------------------------------------------------------------------
-constexpr int FQT_WORDS = QT_ENTRIES * 20;
-constexpr int FHS_WORDS = QT_ENTRIES * 10 + 10;   // H_j scratch, later beta*x_j; slot 8: Z_7 * C
-// Layout note (measured on MI355X, 2^20 signatures, profiles/r01_table_layouts.md): these
-// 4-byte planes [word][lane] cost 16.4 GB of fabric reads per batch (a lookup is a per-lane
-// gather, every lane wants a different entry, so ~8 rows x 4 sectors are touched per word) but
-// run the kernel in 11.4 ms; lane-contiguous 80-byte entries cut the reads to 5.9 GB and
-// 16-byte planes to 10.3 GB, yet take 16.2 ms and 15.1 ms: with wide per-lane loads the
-// texture/L1 path, not the VALU, sets the pace.  The reads are served by L2 / Infinity Cache
-// (working set 126 MB), the kernel stays VALU-issue bound, so the fastest layout is kept.
+// Layout note (measured on MI355X, 2^20 signatures, profiles/r01_table_layouts.md): a lookup is a
+// per-lane gather (every lane wants a different entry).  With 3 waves/SIMD and the beta*x
+// column: 4-byte planes 11.0 ms, 8-byte planes 10.5 ms, 16-byte planes 10.3 ms per batch on the
+// same box; lane-contiguous 80-byte entries were far slower (16 ms) in an earlier kernel.  The
+// reads are served by L2 / Infinity Cache, the kernel stays VALU-issue bound; wider planes
+// mostly save address arithmetic and VMEM issue slots.  4 and 8 remain selectable for A/B runs
+// (tools/ab_layout.sh).
+#ifndef S2K_QT_PLANE
+#define S2K_QT_PLANE 16
+#endif
+constexpr int FQT_FE_WORDS = S2K_QT_PLANE == 16 ? 12 : 10;   // storage words per field element
+constexpr int FQT_WORDS = QT_ENTRIES * 2 * FQT_FE_WORDS;
+constexpr int FHS_WORDS = (QT_ENTRIES + 1) * FQT_FE_WORDS;    // H_j scratch, later beta*x_j; slot 8: Z_7 * C
 
 S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int word0, const fe26& v) {
+#if S2K_QT_PLANE == 16
+  // a field element takes three 16-byte planes (12 words, the last two unused)
+  uint4* q = reinterpret_cast<uint4*>(base) + (size_t)(word0 / 10 * 3) * stride + lane;
+  q[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
+  q[stride] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
+  q[2 * stride] = make_uint4(v.n[8], v.n[9], 0u, 0u);
+#elif S2K_QT_PLANE == 8
+  uint2* q = reinterpret_cast<uint2*>(base) + (size_t)(word0 / 2) * stride + lane;
+#pragma unroll
+  for (int w = 0; w < 5; ++w) q[(size_t)w * stride] = make_uint2(v.n[2 * w], v.n[2 * w + 1]);
+#else
 #pragma unroll
   for (int w = 0; w < 10; ++w) base[(size_t)(word0 + w) * stride + lane] = v.n[w];
+#endif
 }
 S2K_DEV fe26 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t word0) {
   fe26 r;
+#if S2K_QT_PLANE == 16
+  const uint4* q = reinterpret_cast<const uint4*>(base) + (size_t)(word0 / 10 * 3) * stride + lane;
+  uint4 a = q[0], b = q[stride], c = q[2 * stride];
+  r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
+  r.n[8] = c.x; r.n[9] = c.y;
+#elif S2K_QT_PLANE == 8
+  const uint2* q = reinterpret_cast<const uint2*>(base) + (size_t)(word0 / 2) * stride + lane;
+#pragma unroll
+  for (int w = 0; w < 5; ++w) {
+    uint2 t = q[(size_t)w * stride];
+    r.n[2 * w] = t.x;
+    r.n[2 * w + 1] = t.y;
+  }
+#else
 #pragma unroll
   for (int w = 0; w < 10; ++w) r.n[w] = base[(size_t)(word0 + w) * stride + lane];
+#endif
   return r;
 }
 S2K_DEV fe26 fe26_cond_negate1(const fe26& a, bool neg) {   // magnitude 1 in, <= 2 out
@@ -974,19 +1009,16 @@ k_fn_op(int op, uint32_t n, const uint8_t* __restrict__ a, const uint8_t* __rest
     load_be32(raw, b + idx * 32);
     y = sc_reduce_once(raw);
   }
+  sc26 one26;   // plain 1: multiplying by it leaves the Montgomery domain
+#pragma unroll
+  for (int i = 0; i < 10; ++i) one26.n[i] = i == 0 ? 1u : 0u;
   switch (op) {
-    case S2K_OP_MUL: r = sc_montmul(x, sc_to_mont(y)); break;
-    case S2K_OP_SQR: r = sc_montmul(x, sc_to_mont(x)); break;
+    case S2K_OP_MUL: r = sc26_to_sc(sc26_mm(sc26_from_sc(x), sc26_to_mont(sc26_from_sc(y)))); break;
+    case S2K_OP_SQR: r = sc26_to_sc(sc26_mm(one26, sc26_montsqr(sc26_to_mont(sc26_from_sc(x))))); break;
     case S2K_OP_ADD: r = sc_add(x, y); break;
     case S2K_OP_SUB: r = sc_add(x, sc_neg(y)); break;
     case S2K_OP_NEG: r = sc_neg(x); break;
-    case S2K_OP_INV: {
-      sc one;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) one.v[i] = i == 0 ? 1u : 0u;
-      r = sc_montmul(sc_mont_inv(sc_to_mont(x)), one);
-      break;
-    }
+    case S2K_OP_INV: r = sc26_to_sc(sc26_mm(sc26_mont_inv(sc26_to_mont(sc26_from_sc(x))), one26)); break;
     default: {   // GLV split, un-normalised (k1, k2 canonical mod n)
       sc k1, k2;
       bool n1, n2;
@@ -1038,13 +1070,15 @@ const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
-//   [0,250)    per-lane point tables: fast path uses 160 (8 entries x 2 x 10 limbs) + 90 (H
-//              scratch, then the beta*x column and Z_7*C); the complete path reuses the first
-//              192 words for its projective table
-//   [250,267)  scalar-prep output     [267,275) prefix products     [275,283) s in Montgomery form
+//   [0,300)    per-lane point tables: fast path uses 192 (8 entries x 2 elements x 12 words) +
+//              108 (H scratch, then the beta*x column and Z_7*C); the complete path reuses the
+//              first 192 words for its projective table
+//   then       17 words of scalar-prep output.  The prep kernel's own scratch (prefix products and
+//              s in Montgomery form, 10 words each) borrows the start of the table region,
+//              which is only written after the prep kernel has finished.
 //   then       worklist: 1 counter + n indices
-constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = FQT_WORDS + FHS_WORDS, WS_PREF = WS_PREP + PREP_WORDS,
-                 WS_SMONT = WS_PREF + 8, WS_LANE_WORDS = WS_SMONT + 8;
+constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = FQT_WORDS + FHS_WORDS, WS_PREF = WS_QT, WS_SMONT = WS_QT + 10,
+                 WS_LANE_WORDS = WS_PREP + PREP_WORDS;
 static_assert(FQT_WORDS + FHS_WORDS >= QT_WORDS, "the complete path's table must fit in the fast path's region");
 
 size_t s2k_ecdsa_workspace_bytes(size_t n) {

@@ -90,7 +90,12 @@ inline int ctx_reserve(s2k_ctx* ctx, void** p, size_t* have, size_t need) {
   return S2K_OK;
 }
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
-static inline size_t lane_stride(size_t n) { return (n + 63) & ~(size_t)63; }
+// lane stride of the [word][lane] planes: n rounded up to a wave, plus S2K_STRIDE_PAD lanes so
+// that consecutive planes need not start at the same power-of-two offset
+#ifndef S2K_STRIDE_PAD
+#define S2K_STRIDE_PAD 0
+#endif
+static inline size_t lane_stride(size_t n) { return ((n + 63) & ~(size_t)63) + S2K_STRIDE_PAD; }
 
 
 // small RAII helper for the host-pointer entry points

@@ -130,87 +130,95 @@ S2K_DEV sc sc_montsqr_n(sc a, int n) {
 }
 
 // x^(n-2) in the Montgomery domain (in: x*R, out: x^-1*R); chain of scalar_invert.go:11-303
-// (253 S + 40 M).  Invert(0) = 0.
+// (253 S + 40 M), generic over the limb representation.  Invert(0) = 0.
+template <class T, class O>
+S2K_DEV T sc_inv_chain(const T& x) {
+  T t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;
+  t0 = O::mul(x, x);
+  t1 = O::mul(x, t0);
+  t2 = O::mul(t0, t1);
+  t3 = O::mul(t0, t2);
+  t4 = O::mul(t0, t3);
+  t5 = O::mul(t0, t4);
+  t0 = O::mul(t0, t5);
+  t6 = O::sqn(t0, 2);
+  t6 = O::mul(t5, t6);
+  t7 = O::mul(t6, t6);
+  t7 = O::mul(x, t7);
+  t8 = O::mul(t7, t7);
+  t8 = O::mul(x, t8);
+  t9 = O::sqn(t8, 3);
+  t10 = O::sqn(t9, 2);
+  t11 = O::mul(t10, t10);
+  t12 = O::mul(t11, t11);
+  t13 = O::sqn(t12, 7);
+  t11 = O::mul(t11, t13);
+  t11 = O::sqn(t11, 9);
+  t12 = O::mul(t12, t11);
+  t11 = O::sqn(t12, 6);
+  t10 = O::mul(t10, t11);
+  t10 = O::sqn(t10, 26);
+  t12 = O::mul(t12, t10);
+  t10 = O::sqn(t12, 4);
+  t9 = O::mul(t9, t10);
+  t9 = O::sqn(t9, 60);
+  t12 = O::mul(t12, t9);
+  t7 = O::mul(t7, t12);
+  t7 = O::sqn(t7, 5);
+  t7 = O::mul(t5, t7);
+  t7 = O::sqn(t7, 3);
+  t7 = O::mul(t2, t7);
+  t7 = O::sqn(t7, 4);
+  t7 = O::mul(t2, t7);
+  t7 = O::sqn(t7, 4);
+  t7 = O::mul(t3, t7);
+  t7 = O::sqn(t7, 5);
+  t7 = O::mul(t0, t7);
+  t7 = O::sqn(t7, 2);
+  t7 = O::mul(t1, t7);
+  t7 = O::sqn(t7, 5);
+  t7 = O::mul(t3, t7);
+  t7 = O::sqn(t7, 6);
+  t7 = O::mul(t0, t7);
+  t7 = O::sqn(t7, 5);
+  t7 = O::mul(t5, t7);
+  t7 = O::sqn(t7, 4);
+  t7 = O::mul(t0, t7);
+  t7 = O::sqn(t7, 3);
+  t7 = O::mul(x, t7);
+  t7 = O::sqn(t7, 6);
+  t2 = O::mul(t2, t7);
+  t2 = O::sqn(t2, 10);
+  t2 = O::mul(t3, t2);
+  t2 = O::sqn(t2, 4);
+  t3 = O::mul(t3, t2);
+  t3 = O::sqn(t3, 9);
+  t8 = O::mul(t8, t3);
+  t8 = O::sqn(t8, 5);
+  t8 = O::mul(t4, t8);
+  t8 = O::sqn(t8, 6);
+  t5 = O::mul(t5, t8);
+  t5 = O::sqn(t5, 4);
+  t5 = O::mul(t0, t5);
+  t5 = O::sqn(t5, 5);
+  t1 = O::mul(t1, t5);
+  t1 = O::sqn(t1, 6);
+  t1 = O::mul(t0, t1);
+  t1 = O::sqn(t1, 10);
+  t0 = O::mul(t0, t1);
+  t0 = O::sqn(t0, 4);
+  t4 = O::mul(t4, t0);
+  t4 = O::sqn(t4, 6);
+  t14 = O::mul(x, t4);
+  t14 = O::sqn(t14, 8);
+  return O::mul(t6, t14);
+}
 __device__ __noinline__ sc sc_mont_inv(sc x) {
-  sc t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14;
-  t0 = sc_montmul(x, x);
-  t1 = sc_montmul(x, t0);
-  t2 = sc_montmul(t0, t1);
-  t3 = sc_montmul(t0, t2);
-  t4 = sc_montmul(t0, t3);
-  t5 = sc_montmul(t0, t4);
-  t0 = sc_montmul(t0, t5);
-  t6 = sc_montsqr_n(t0, 2);
-  t6 = sc_montmul(t5, t6);
-  t7 = sc_montmul(t6, t6);
-  t7 = sc_montmul(x, t7);
-  t8 = sc_montmul(t7, t7);
-  t8 = sc_montmul(x, t8);
-  t9 = sc_montsqr_n(t8, 3);
-  t10 = sc_montsqr_n(t9, 2);
-  t11 = sc_montmul(t10, t10);
-  t12 = sc_montmul(t11, t11);
-  t13 = sc_montsqr_n(t12, 7);
-  t11 = sc_montmul(t11, t13);
-  t11 = sc_montsqr_n(t11, 9);
-  t12 = sc_montmul(t12, t11);
-  t11 = sc_montsqr_n(t12, 6);
-  t10 = sc_montmul(t10, t11);
-  t10 = sc_montsqr_n(t10, 26);
-  t12 = sc_montmul(t12, t10);
-  t10 = sc_montsqr_n(t12, 4);
-  t9 = sc_montmul(t9, t10);
-  t9 = sc_montsqr_n(t9, 60);
-  t12 = sc_montmul(t12, t9);
-  t7 = sc_montmul(t7, t12);
-  t7 = sc_montsqr_n(t7, 5);
-  t7 = sc_montmul(t5, t7);
-  t7 = sc_montsqr_n(t7, 3);
-  t7 = sc_montmul(t2, t7);
-  t7 = sc_montsqr_n(t7, 4);
-  t7 = sc_montmul(t2, t7);
-  t7 = sc_montsqr_n(t7, 4);
-  t7 = sc_montmul(t3, t7);
-  t7 = sc_montsqr_n(t7, 5);
-  t7 = sc_montmul(t0, t7);
-  t7 = sc_montsqr_n(t7, 2);
-  t7 = sc_montmul(t1, t7);
-  t7 = sc_montsqr_n(t7, 5);
-  t7 = sc_montmul(t3, t7);
-  t7 = sc_montsqr_n(t7, 6);
-  t7 = sc_montmul(t0, t7);
-  t7 = sc_montsqr_n(t7, 5);
-  t7 = sc_montmul(t5, t7);
-  t7 = sc_montsqr_n(t7, 4);
-  t7 = sc_montmul(t0, t7);
-  t7 = sc_montsqr_n(t7, 3);
-  t7 = sc_montmul(x, t7);
-  t7 = sc_montsqr_n(t7, 6);
-  t2 = sc_montmul(t2, t7);
-  t2 = sc_montsqr_n(t2, 10);
-  t2 = sc_montmul(t3, t2);
-  t2 = sc_montsqr_n(t2, 4);
-  t3 = sc_montmul(t3, t2);
-  t3 = sc_montsqr_n(t3, 9);
-  t8 = sc_montmul(t8, t3);
-  t8 = sc_montsqr_n(t8, 5);
-  t8 = sc_montmul(t4, t8);
-  t8 = sc_montsqr_n(t8, 6);
-  t5 = sc_montmul(t5, t8);
-  t5 = sc_montsqr_n(t5, 4);
-  t5 = sc_montmul(t0, t5);
-  t5 = sc_montsqr_n(t5, 5);
-  t1 = sc_montmul(t1, t5);
-  t1 = sc_montsqr_n(t1, 6);
-  t1 = sc_montmul(t0, t1);
-  t1 = sc_montsqr_n(t1, 10);
-  t0 = sc_montmul(t0, t1);
-  t0 = sc_montsqr_n(t0, 4);
-  t4 = sc_montmul(t4, t0);
-  t4 = sc_montsqr_n(t4, 6);
-  t14 = sc_montmul(x, t4);
-  t14 = sc_montsqr_n(t14, 8);
-  return sc_montmul(t6, t14);
+  struct ops {
+    static __device__ __forceinline__ sc mul(const sc& a, const sc& b) { return sc_montmul(a, b); }
+    static __device__ __forceinline__ sc sqn(const sc& a, int n) { return sc_montsqr_n(a, n); }
+  };
+  return sc_inv_chain<sc, ops>(x);
 }
 
 // round(k * g / 2^384) for plain k, g (mulGFlooredDiv, point_mul_glv.go:119-189): < 2^128

@@ -23,7 +23,9 @@ def per_kernel(dirname, counter):
     for fn in glob.glob(dirname + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
             if row["Counter_Name"] == counter:
-                acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+                name = name.split("<")[0]          # template instances (k_verify_fast<0>) share an entry
+                acc[name].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
