@@ -12,7 +12,7 @@
 
 #include "engine_internal.h"
 #include "fe.h"
-#include "jacobian.h"
+#include "jacobian29.h"
 #include "point.h"
 #include "sc.h"
 #include "sc26.h"
@@ -397,7 +397,7 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // by (H_{j+1}...H_7)^{2,3}.  The ladder then only ever adds affine points (8 M + 3 S); its
 // result has the true Z = Z_ladder * Z_7 * C.
 // Table storage (S2K_QT_PLANE = bytes per lane per plane): 16-byte planes [quad][lane], three
-// quads per field element (limbs 0-3 | 4-7 | 8,9,-,-); entry j is x at element 2j, y at 2j+1.
+// quads per field element (limbs 0-3 | 4-7 | 8,-,-,-); entry j is x at element 2j, y at 2j+1.
 // The H scratch region holds one element per entry (H_j, later beta*x_j) plus slot 8 = Z_7 * C.
 // ---------------------------------------------------------------------------------------
 // Layout note (measured on MI355X, 2^20 signatures, profiles/r01_table_layouts.md): a lookup is a
@@ -410,49 +410,51 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 #ifndef S2K_QT_PLANE
 #define S2K_QT_PLANE 16
 #endif
-constexpr int FQT_FE_WORDS = S2K_QT_PLANE == 16 ? 12 : 10;   // storage words per field element
+constexpr int FQT_FE_WORDS = S2K_QT_PLANE == 16 ? 12 : (S2K_QT_PLANE == 8 ? 10 : 9);   // storage words per field element
 constexpr int FQT_WORDS = QT_ENTRIES * 2 * FQT_FE_WORDS;
 constexpr int FHS_WORDS = (QT_ENTRIES + 1) * FQT_FE_WORDS;    // H_j scratch, later beta*x_j; slot 8: Z_7 * C
 
-S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int word0, const fe26& v) {
+// element `elem` of a table region: 9 limbs per lane in planes of S2K_QT_PLANE bytes
+S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int elem, const fe29& v) {
 #if S2K_QT_PLANE == 16
-  // a field element takes three 16-byte planes (12 words, the last two unused)
-  uint4* q = reinterpret_cast<uint4*>(base) + (size_t)(word0 / 10 * 3) * stride + lane;
+  uint4* q = reinterpret_cast<uint4*>(base) + (size_t)(elem * 3) * stride + lane;
   q[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
   q[stride] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
-  q[2 * stride] = make_uint4(v.n[8], v.n[9], 0u, 0u);
+  q[2 * stride] = make_uint4(v.n[8], 0u, 0u, 0u);
 #elif S2K_QT_PLANE == 8
-  uint2* q = reinterpret_cast<uint2*>(base) + (size_t)(word0 / 2) * stride + lane;
+  uint2* q = reinterpret_cast<uint2*>(base) + (size_t)(elem * 5) * stride + lane;
 #pragma unroll
-  for (int w = 0; w < 5; ++w) q[(size_t)w * stride] = make_uint2(v.n[2 * w], v.n[2 * w + 1]);
+  for (int w = 0; w < 4; ++w) q[(size_t)w * stride] = make_uint2(v.n[2 * w], v.n[2 * w + 1]);
+  q[(size_t)4 * stride] = make_uint2(v.n[8], 0u);
 #else
 #pragma unroll
-  for (int w = 0; w < 10; ++w) base[(size_t)(word0 + w) * stride + lane] = v.n[w];
+  for (int w = 0; w < 9; ++w) base[(size_t)(elem * 9 + w) * stride + lane] = v.n[w];
 #endif
 }
-S2K_DEV fe26 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t word0) {
-  fe26 r;
+S2K_DEV fe29 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t elem) {
+  fe29 r;
 #if S2K_QT_PLANE == 16
-  const uint4* q = reinterpret_cast<const uint4*>(base) + (size_t)(word0 / 10 * 3) * stride + lane;
-  uint4 a = q[0], b = q[stride], c = q[2 * stride];
+  const uint4* q = reinterpret_cast<const uint4*>(base) + (size_t)(elem * 3) * stride + lane;
+  uint4 a = q[0], b = q[stride];
   r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
-  r.n[8] = c.x; r.n[9] = c.y;
+  r.n[8] = reinterpret_cast<const uint32_t*>(q + 2 * stride)[0];
 #elif S2K_QT_PLANE == 8
-  const uint2* q = reinterpret_cast<const uint2*>(base) + (size_t)(word0 / 2) * stride + lane;
+  const uint2* q = reinterpret_cast<const uint2*>(base) + (size_t)(elem * 5) * stride + lane;
 #pragma unroll
-  for (int w = 0; w < 5; ++w) {
+  for (int w = 0; w < 4; ++w) {
     uint2 t = q[(size_t)w * stride];
     r.n[2 * w] = t.x;
     r.n[2 * w + 1] = t.y;
   }
+  r.n[8] = q[(size_t)4 * stride].x;
 #else
 #pragma unroll
-  for (int w = 0; w < 10; ++w) r.n[w] = base[(size_t)(word0 + w) * stride + lane];
+  for (int w = 0; w < 9; ++w) r.n[w] = base[(size_t)(elem * 9 + w) * stride + lane];
 #endif
   return r;
 }
-S2K_DEV fe26 fe26_cond_negate1(const fe26& a, bool neg) {   // magnitude 1 in, <= 2 out
-  return fe26_select(neg, a, fe26_negate(a, 1));
+S2K_DEV fe29 fe29_cond_negate1(const fe29& a, bool neg) {   // magnitude 1 in, <= 2 out
+  return fe29_select(neg, a, fe29_negate(a, 1));
 }
 
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
@@ -480,7 +482,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   if (idx >= n) return;
   uint32_t pf = prep[(size_t)16 * stride + idx];
   bool ok;
-  fe26 qx, qy;
+  fe29 qx, qy;
   if constexpr (MODE == MODE_RECOVER) {
     uint32_t xw[8];
     load_be32(xw, rsig + idx * 32);
@@ -490,18 +492,18 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 #pragma unroll
       for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
     }
-    qx = fe26_from_words(xw);
-    fe26 rhs = fe26_mul(fe26_sqr(qx), qx);
+    qx = fe29_from_words(xw);
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
     rhs.n[0] += 7;
-    bool has = fe26_sqrt(qy, rhs);                      // SetCompressedBytes (point_s11n.go:152-169)
+    bool has = fe29_sqrt(qy, rhs);                      // SetCompressedBytes (point_s11n.go:152-169)
     if (!has) {
       ok = false;
-      qx = fe26_from_words(FE_GX);
-      qy = fe26_from_words(FE_GY);
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
     }
-    qy = fe26_normalize(qy);
+    qy = fe29_normalize(qy);
     bool want_odd = (pf & 0x100u) != 0;
-    qy = fe26_select(((qy.n[0] & 1u) != 0) != want_odd, qy, fe26_normalize_weak(fe26_negate(qy, 1)));
+    qy = fe29_select(((qy.n[0] & 1u) != 0) != want_odd, qy, fe29_normalize_weak(fe29_negate(qy, 1)));
   } else if constexpr (MODE == MODE_ECDSA) {
     apt q;
     load_be32(q.x.v, pub + idx * 64);
@@ -511,16 +513,16 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       q.x = fe_from_limbs(FE_GX);
       q.y = fe_from_limbs(FE_GY);
     }
-    qx = fe26_from_words(q.x.v);
-    qy = fe26_from_words(q.y.v);
+    qx = fe29_from_words(q.x.v);
+    qy = fe29_from_words(q.y.v);
     // y^2 == x^3 + 7 (point_s11n.go:298-307)
-    fe26 rhs = fe26_mul(fe26_sqr(qx), qx);
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
     rhs.n[0] += 7;
-    bool on = fe26_eq(fe26_sqr(qy), rhs);
+    bool on = fe29_eq(fe29_sqr(qy), rhs);
     if (!on) {
       ok = false;
-      qx = fe26_from_words(FE_GX);
-      qy = fe26_from_words(FE_GY);
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
     }
   } else {
     uint32_t xw[8];
@@ -530,65 +532,62 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 #pragma unroll
       for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
     }
-    qx = fe26_from_words(xw);
-    fe26 rhs = fe26_mul(fe26_sqr(qx), qx);
+    qx = fe29_from_words(xw);
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
     rhs.n[0] += 7;                                    // [1] (+7 on limb 0)
-    bool has = fe26_sqrt(qy, rhs);
+    bool has = fe29_sqrt(qy, rhs);
     if (!has) {   // not an x-coordinate of the curve
       ok = false;
-      qx = fe26_from_words(FE_GX);
-      qy = fe26_from_words(FE_GY);
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
     }
-    qy = fe26_normalize(qy);
-    qy = fe26_select((qy.n[0] & 1u) != 0, qy, fe26_normalize_weak(fe26_negate(qy, 1)));   // even y
+    qy = fe29_normalize(qy);
+    qy = fe29_select((qy.n[0] & 1u) != 0, qy, fe29_normalize_weak(fe29_negate(qy, 1)));   // even y
   }
   const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
 
   // ---- table ----
   {
-    jpt26 a0;
+    jpt29 a0;
     a0.x = qx;
     a0.y = qy;
-    a0.z = fe26_one();
-    jpt26 d = jpt26_double(a0);                      // x [3] y [3] z [1]
-    fe26 c2 = fe26_sqr(d.z);
-    fe26 c3 = fe26_mul(c2, d.z);
-    fe26 dx = fe26_normalize_weak(d.x), dy = fe26_normalize_weak(d.y);   // [1]: used as the affine addend
-    jpt26 cur;
-    cur.x = fe26_mul(qx, c2);
-    cur.y = fe26_mul(qy, c3);
-    cur.z = fe26_one();
+    a0.z = fe29_one();
+    jpt29 d = jpt29_double(a0);                      // x [1] y [2] z [1]
+    fe29 c2 = fe29_sqr(d.z);
+    fe29 c3 = fe29_mul(c2, d.z);
+    const fe29 dx = d.x, dy = d.y;                   // the affine addend on the isomorphic curve
+    jpt29 cur;
+    cur.x = fe29_mul(qx, c2);
+    cur.y = fe29_mul(qy, c3);
+    cur.z = fe29_one();
     fq_store(qt, stride, idx, 0, cur.x);
-    fq_store(qt, stride, idx, 10, cur.y);
+    fq_store(qt, stride, idx, 1, cur.y);
 #pragma unroll 1
     for (int j = 1; j < QT_ENTRIES; ++j) {
-      fe26 h;
-      cur = jpt26_add_affine(cur, dx, dy, &h);
-      fq_store(qt, stride, idx, j * 20, cur.x);      // [4]
-      fq_store(qt, stride, idx, j * 20 + 10, cur.y); // [2]
-      fq_store(hs, stride, idx, j * 10, h);          // [6]
+      fe29 h;
+      cur = jpt29_add_affine(cur, dx, dy, &h);
+      fq_store(qt, stride, idx, 2 * j, cur.x);
+      fq_store(qt, stride, idx, 2 * j + 1, cur.y);
+      fq_store(hs, stride, idx, j, h);
     }
-    fq_store(hs, stride, idx, QT_ENTRIES * 10, fe26_mul(cur.z, d.z));   // Z_7 * C
-    // entry 7 as stored has magnitudes 4 / 2: bring it to [1] like the others
-    fe26 prev_x = fe26_normalize_weak(cur.x);
-    fq_store(qt, stride, idx, 7 * 20, prev_x);
-    fq_store(qt, stride, idx, 7 * 20 + 10, fe26_normalize_weak(cur.y));
-    const fe26 beta = fe26_from_words(FE_BETA);
-    fe26 rr = fe26_one();
+    fq_store(hs, stride, idx, QT_ENTRIES, fe29_mul(cur.z, d.z));   // Z_7 * C
+    fe29 prev_x = cur.x;
+    const fe29 beta = fe29_from_words(FE_BETA);
+    fe29 rr = fe29_one();
 #pragma unroll 1
     for (int j = QT_ENTRIES - 2; j >= 0; --j) {
-      rr = fe26_mul(rr, fq_load(hs, stride, idx, (j + 1) * 10));
+      rr = fe29_mul(rr, fq_load(hs, stride, idx, j + 1));
       // H_{j+1} is no longer needed: its slot now takes beta * x_{j+1} (the x of the beta*Q
       // table, mulBeta point_mul_glv.go:191; one multiplication per entry instead of one per lookup)
-      fq_store(hs, stride, idx, (j + 1) * 10, fe26_mul(prev_x, beta));
-      fe26 r2 = fe26_sqr(rr);
-      fe26 r3 = fe26_mul(r2, rr);
-      prev_x = fe26_mul(fq_load(qt, stride, idx, j * 20), r2);
-      fe26 y = fe26_mul(fq_load(qt, stride, idx, j * 20 + 10), r3);
-      fq_store(qt, stride, idx, j * 20, prev_x);
-      fq_store(qt, stride, idx, j * 20 + 10, y);
+      fq_store(hs, stride, idx, j + 1, fe29_mul(prev_x, beta));
+      fe29 r2 = fe29_sqr(rr);
+      fe29 r3 = fe29_mul(r2, rr);
+      prev_x = fe29_mul(fq_load(qt, stride, idx, 2 * j), r2);
+      fe29 y = fe29_mul(fq_load(qt, stride, idx, 2 * j + 1), r3);
+      fq_store(qt, stride, idx, 2 * j, prev_x);
+      fq_store(qt, stride, idx, 2 * j + 1, y);
     }
-    fq_store(hs, stride, idx, 0, fe26_mul(prev_x, beta));
+    fq_store(hs, stride, idx, 0, fe29_mul(prev_x, beta));
   }
 
   // ---- ladder over |k1|, |k2| ----
@@ -601,41 +600,41 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   k1.v[0] |= 1u;
   k2.v[0] |= 1u;
   digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
-  jpt26 acc;
+  jpt29 acc;
   {
-    fe26 t0x = fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 10);
+    fe29 t0x = fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 1);
     acc.x = t0x;
-    acc.y = fe26_cond_negate1(t0y, neg1);
-    acc.z = fe26_one();
-    acc = jpt26_add_affine(acc, fq_load(hs, stride, idx, 0), fe26_cond_negate1(t0y, neg2));
+    acc.y = fe29_cond_negate1(t0y, neg1);
+    acc.z = fe29_one();
+    acc = jpt29_add_affine(acc, fq_load(hs, stride, idx, 0), fe29_cond_negate1(t0y, neg2));
   }
 #pragma unroll 1
   for (int i = 31; i >= 0; --i) {
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) acc = jpt26_double(acc);
+    for (int j = 0; j < 4; ++j) acc = jpt29_double(acc);
     uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
       uint32_t w = t ? w2 : w1;
       bool neg = (t ? neg2 : neg1) != (w < 8u);
       uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
-      fe26 x = t ? fq_load(hs, stride, idx, entry * 10) : fq_load(qt, stride, idx, entry * 20);
-      fe26 y = fq_load(qt, stride, idx, entry * 20 + 10);
-      acc = jpt26_add_affine(acc, x, fe26_cond_negate1(y, neg));
+      fe29 x = t ? fq_load(hs, stride, idx, entry) : fq_load(qt, stride, idx, 2 * entry);
+      fe29 y = fq_load(qt, stride, idx, 2 * entry + 1);
+      acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
     }
   }
   // k' = k | 1: take the extra 1 back out of even halves
 #pragma unroll 1
   for (int t = 0; t < 2; ++t) {
-    fe26 x = t ? fq_load(hs, stride, idx, 0) : fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 10);
+    fe29 x = t ? fq_load(hs, stride, idx, 0) : fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 1);
     bool sneg = !(t ? neg2 : neg1);
-    jpt26 sum = jpt26_add_affine(acc, x, fe26_cond_negate1(t0y, sneg));
+    jpt29 sum = jpt29_add_affine(acc, x, fe29_cond_negate1(t0y, sneg));
     bool even = pf & (t ? PF_EVEN2 : PF_EVEN1);
-    acc.x = fe26_select(even, acc.x, sum.x);
-    acc.y = fe26_select(even, acc.y, sum.y);
-    acc.z = fe26_select(even, acc.z, sum.z);
+    acc.x = fe29_select(even, acc.x, sum.x);
+    acc.y = fe29_select(even, acc.y, sum.y);
+    acc.z = fe29_select(even, acc.z, sum.z);
   }
-  acc.z = fe26_mul(acc.z, fq_load(hs, stride, idx, QT_ENTRIES * 10));   // times Z_7 * C: back on secp256k1 itself
+  acc.z = fe29_mul(acc.z, fq_load(hs, stride, idx, QT_ENTRIES));   // times Z_7 * C: back on secp256k1 itself
 
   // ---- generator part: u1*G from the resident tables ----
   {
@@ -645,7 +644,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 #pragma unroll 1
     for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
       apt g = gt_load(gt, w, u[0] & 0xffffu);
-      acc = jpt26_add_affine(acc, fe26_from_words(g.x.v), fe26_from_words(g.y.v));
+      acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
 #pragma unroll
       for (int i = 0; i < 7; ++i) u[i] = (u[i] >> 16) | (u[i + 1] << 16);
       u[7] >>= 16;
@@ -659,16 +658,16 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     for (int i = 0; i < 65; ++i) rec[i] = 0;
   }
   if (ok) {
-    if (fe26_is_zero(acc.z)) {
+    if (fe29_is_zero(acc.z)) {
       // infinity or an exceptional case along the way: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
       wl[pos] = (uint32_t)idx;
     } else if constexpr (MODE == MODE_RECOVER) {
-      fe26 zi = fe26_inv(acc.z);
-      fe26 zi2 = fe26_sqr(zi);
+      fe29 zi = fe29_inv(acc.z);
+      fe29 zi2 = fe29_sqr(zi);
       uint32_t xw[8], yw[8];
-      fe26_to_words(xw, fe26_normalize(fe26_mul(acc.x, zi2)));
-      fe26_to_words(yw, fe26_normalize(fe26_mul(fe26_mul(acc.y, zi2), zi)));
+      fe29_to_words(xw, fe29_normalize(fe29_mul(acc.x, zi2)));
+      fe29_to_words(yw, fe29_normalize(fe29_mul(fe29_mul(acc.y, zi2), zi)));
       uint8_t* rec = out_pts + idx * 65;
       rec[0] = 0x04;
       store_be32_unaligned(rec + 1, xw);
@@ -678,23 +677,23 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       // x(R) mod n == r  (ecdsa.go:450-465)
       uint32_t rw[8];
       load_be32(rw, rsig + idx * 32);
-      fe26 zz = fe26_sqr(acc.z);
-      bool match = fe26_eq(acc.x, fe26_mul(fe26_from_words(rw), zz));
+      fe29 zz = fe29_sqr(acc.z);
+      bool match = fe29_eq(acc.x, fe29_mul(fe29_from_words(rw), zz));
       if (u256_lt(rw, FE_P_MINUS_N)) {
         uint32_t r2[8];
         u256_add(r2, rw, SC_N);
-        match = match || fe26_eq(acc.x, fe26_mul(fe26_from_words(r2), zz));
+        match = match || fe29_eq(acc.x, fe29_mul(fe29_from_words(r2), zz));
       }
       verdict = match ? 1 : 0;
     } else {
       // affine R: y even and x == r  (schnorr.go:451-478)
       uint32_t rw[8];
       load_be32(rw, rsig + idx * 64);
-      fe26 zi = fe26_inv(acc.z);
-      fe26 zi2 = fe26_sqr(zi);
-      fe26 x = fe26_mul(acc.x, zi2);
-      fe26 y = fe26_normalize(fe26_mul(fe26_mul(acc.y, zi2), zi));
-      verdict = ((y.n[0] & 1u) == 0 && fe26_eq(x, fe26_from_words(rw))) ? 1 : 0;
+      fe29 zi = fe29_inv(acc.z);
+      fe29 zi2 = fe29_sqr(zi);
+      fe29 x = fe29_mul(acc.x, zi2);
+      fe29 y = fe29_normalize(fe29_mul(fe29_mul(acc.y, zi2), zi));
+      verdict = ((y.n[0] & 1u) == 0 && fe29_eq(x, fe29_from_words(rw))) ? 1 : 0;
     }
   }
   out[idx] = verdict;

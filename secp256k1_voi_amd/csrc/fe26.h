@@ -16,8 +16,9 @@
 // limbs 0..8 are <= 2m * 0x3FFFFFF and limb 9 <= 2m * 0x03FFFFF.  fe26_mul / fe26_sqr accept
 // magnitudes <= 8 and return magnitude 1; add sums magnitudes; negate(a, m) needs
 // magnitude(a) <= m and returns m + 1; mul_int multiplies it; half gives m/2 + 1.  The
-// formulas in jacobian.h carry the magnitude of every intermediate in comments and
-// tests/test_magnitudes.py re-derives the bounds.
+// formulas in pt26.h carry the magnitude of every intermediate in comments and
+// tests/test_magnitudes.py re-derives the bounds.  (The verification ladder itself runs on the
+// 9x29 variant of this field, fe29.h.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,11 +1,13 @@
 """Re-derives the limb bounds of the lazy 10x26 field (secp256k1_voi_amd/csrc/fe26.h) through
-the exact operation sequences of jacobian.h and pt26.h, with interval arithmetic on the limbs:
+the exact operation sequences of pt26.h (the complete formulas of the multiscalar kernels), with
+interval arithmetic on the limbs (tests/test_fe29_model.py does the same for the 9x29 field
+of the verification ladder):
 
   * every 32-bit limb stays below 2^32,
   * every negate() bias dominates its operand limb by limb,
   * every 64-bit column sum of fe26_mul / fe26_sqr / the fused multiply-adds stays below 2^64,
     including the fold terms, and the tail quantities fit the widths the code assumes,
-  * the loop invariants (x,y <= 4, z = 1 for Jacobian; <= 3 for projective) are closed.
+  * the loop invariant (coordinates <= 3 for projective points) is closed.
 
 This is a CPU model of the device code's arithmetic structure, not of its instructions; the
 GPU parity tests check the values.
@@ -118,67 +120,6 @@ def mul_small_norm(a, k):
     out = B([M + x * 0x3D1, M + (x << 6)] + [M] * 7 + [M9])
     assert out.within(1)
     return out
-
-
-# ---- jacobian.h -------------------------------------------------------------------------------
-def jpt_double(x, y, z):
-    z3 = mul(y, z)
-    s = sqr(y)
-    l = sqr(x)
-    l = half(mul_int(l, 3))
-    t = mul(negate(s, 1), x)
-    x3 = add(add(sqr(l), t), t)
-    t = add(t, x3)
-    y3 = negate(mulsum([(t, l), (s, s)]), 1)
-    return x3, y3, z3
-
-
-def jpt_add_affine(x, y, z, bx, by):
-    zz = sqr(z)
-    u2 = mul(bx, zz)
-    s2 = mul(mul(by, zz), z)
-    h = add(negate(x, 4), u2)
-    i = add(negate(s2, 1), y)
-    z3 = mul(z, h)
-    h2 = negate(sqr(h), 1)
-    h3 = mul(h2, h)
-    t = mul(x, h2)
-    x3 = add(add(add(sqr(i), h3), t), t)
-    t = add(t, x3)
-    y3 = mulsum([(t, i), (h3, y)])
-    return x3, y3, z3, h
-
-
-def test_jacobian_invariant_closed():
-    X, Y, Z = B.mag(4), B.mag(4), B.mag(1)
-    bx, by = B.mag(1), B.mag(2)          # table entry; y after a conditional negate
-    x3, y3, z3 = jpt_double(X, Y, Z)
-    assert x3.within(4) and y3.within(4) and z3.within(1)
-    x3, y3, z3, h = jpt_add_affine(X, Y, Z, bx, by)
-    assert x3.within(4) and y3.within(4) and z3.within(1) and h.within(8)
-    # chains as in the ladder: dbl^4 then two adds, repeated
-    x, y, z = B.mag(1), B.mag(2), B.mag(1)
-    for _ in range(3):
-        for _ in range(4):
-            x, y, z = jpt_double(x, y, z)
-            assert x.within(4) and y.within(4) and z.within(1)
-        for _ in range(2):
-            x, y, z, _h = jpt_add_affine(x, y, z, bx, by)
-            assert x.within(4) and y.within(4) and z.within(1)
-
-
-def test_table_build_bounds():
-    # k_verify_fast: d = 2Q from affine, entries scaled by products of stored H values [6]
-    qx, qy, one = B.mag(1), B.mag(1), B.mag(1)
-    dx, dy, dz = jpt_double(qx, qy, one)
-    c2 = sqr(dz)
-    c3 = mul(c2, dz)
-    cur = (mul(qx, c2), mul(qy, c3), one)
-    x, y, z, h = jpt_add_affine(*cur, B.mag(1), B.mag(1))     # dx, dy are weakly normalised first
-    rr = mul(B.mag(1), h)
-    r2 = sqr(rr)
-    r3 = mul(r2, rr)
-    assert mul(x, r2).within(1) and mul(y, r3).within(1)
 
 
 # ---- pt26.h ------------------------------------------------------------------------------------
