@@ -13,8 +13,9 @@
 // identical to the reference's for every input.
 //
 // Units (fe29.h) of every value are given in [brackets]; a product needs the product of its
-// operands' units (summed over fused terms) <= 7.8, which is why a few sums are carry-propagated
-// (fe29_normalize_weak, ~30 cheap 32-bit operations) before they are squared.
+// operands' units (summed over fused terms) <= 7.8.  Sums that are squared next (H, I, X3) would
+// break that, so they are formed inside the preceding product's reduction (fe29_mul_plus /
+// fe29_sqr_plus: the addend's limbs join the column sums) and come out carry-propagated.
 // Invariant for points held in `jpt29`: x [1], y [<= 2], z [1].
 #pragma once
 #include "fe29.h"
@@ -33,7 +34,7 @@ S2K_DEV jpt29 jpt29_double(const jpt29& p) {
   fe29 l = fe29_sqr(p.x);                                        // [1]
   l = fe29_half(fe29_mul_int(l, 3));                             // [3] -> [2]
   fe29 t = fe29_mul(fe29_negate(s, 1), p.x);                     // [2]*[1] -> [1]
-  r.x = fe29_normalize_weak(fe29_add(fe29_add(fe29_sqr(l), t), t));   // [2]^2; [3] -> [1]
+  r.x = fe29_sqr_plus(l, fe29_add(t, t));                        // [2]^2 + [2] -> [1]
   t = fe29_add(t, r.x);                                          // [2]
   r.y = fe29_negate(fe29_mul_add_sqr(t, l, s), 1);               // [2]*[2] + [1]^2, one reduction [1] -> [2]
   return r;
@@ -43,17 +44,16 @@ S2K_DEV jpt29 jpt29_double(const jpt29& p) {
 // H = bx*Z1^2 - X1 [1] (Z3 = Z1*H), used when a table is brought to a common Z.
 S2K_DEV jpt29 jpt29_add_affine(const jpt29& p, const fe29& bx, const fe29& by, fe29* h_out = nullptr) {
   fe29 zz = fe29_sqr(p.z);                                       // [1]
-  fe29 u2 = fe29_mul(bx, zz);                                    // [1]
-  fe29 s2 = fe29_mul(fe29_mul(by, zz), p.z);                     // [2]*[1] -> [1]
   fe29 nx = fe29_negate(p.x, 1);                                 // [2]   -X1
-  fe29 h = fe29_normalize_weak(fe29_add(u2, nx));                // [3] -> [1]   U2 - X1
-  fe29 i = fe29_normalize_weak(fe29_add(fe29_negate(s2, 1), p.y));   // [4] -> [1]   Y1 - S2
+  fe29 h = fe29_mul_plus(bx, zz, nx);                            // [1]*[1] + [2] -> [1]   U2 - X1
+  fe29 ns = fe29_negate(fe29_mul(by, zz), 1);                    // [2]*[1] -> [1] -> [2]   -by Z1^2
+  fe29 i = fe29_mul_plus(ns, p.z, p.y);                          // [2]*[1] + [2] -> [1]   Y1 - S2
   jpt29 r;
   r.z = fe29_mul(p.z, h);                                        // [1]
   fe29 h2 = fe29_sqr(h);                                         // [1]   H^2
   fe29 h3 = fe29_mul(h2, fe29_negate(h, 1));                     // [1]*[2] -> [1]   -H^3
   fe29 t = fe29_mul(nx, h2);                                     // [2]*[1] -> [1]   -X1 H^2
-  r.x = fe29_normalize_weak(fe29_add(fe29_add(fe29_add(fe29_sqr(i), h3), t), t));   // [4] -> [1]
+  r.x = fe29_sqr_plus(i, fe29_add(fe29_add(h3, t), t));          // [1]^2 + [3] -> [1]
   t = fe29_add(t, r.x);                                          // [2]
   r.y = fe29_mul_add_mul(t, i, h3, p.y);                         // [2]*[1] + [1]*[2], one reduction -> [1]
   if (h_out) *h_out = h;

@@ -52,14 +52,18 @@ def conversions():
     return "".join(o)
 
 
-def gen(name, kind):
-    """kind: 'mul' (A*B), 'sqr' (A^2), 'mulmul' (A*B + C*D), 'mulsqr' (A*B + C^2)"""
+def gen(name, kind, addend=False):
+    """kind: 'mul' (A*B), 'sqr' (A^2), 'mulmul' (A*B + C*D), 'mulsqr' (A*B + C^2);
+    addend: + E, a lazy value whose limbs are added to the columns (one multiply-add by 1 each),
+    so that a sum leaves the reduction carry-propagated instead of needing its own pass"""
     first_sq = kind == "sqr"
     second = {"mul": None, "sqr": None, "mulmul": "mul", "mulsqr": "sqr"}[kind]
     o = []
     args = {"mul": "const fe29& A, const fe29& B", "sqr": "const fe29& A",
             "mulmul": "const fe29& A, const fe29& B, const fe29& C, const fe29& D",
             "mulsqr": "const fe29& A, const fe29& B, const fe29& C"}[kind]
+    if addend:
+        args += ", const fe29& E"
     o.append(f"S2K_DEV fe29 {name}({args}) {{\n")
     o.append("  const uint32_t* a = A.n;\n  uint32_t t[9];\n")
     if first_sq:
@@ -91,6 +95,8 @@ def gen(name, kind):
 
     def col(K):
         t = terms(K, "a", "b", first_sq)
+        if addend and K < L:
+            t.append((f"E.n[{K}]", "1", "n"))
         if second:
             t += terms(K, "c_" if second == "mul" else "c", "d_", second == "sqr")
         return t
@@ -129,6 +135,8 @@ def main():
     print(gen("fe29_sqr", "sqr"))
     print(gen("fe29_mul_add_mul", "mulmul"))
     print(gen("fe29_mul_add_sqr", "mulsqr"))
+    print(gen("fe29_mul_plus", "mul", addend=True))
+    print(gen("fe29_sqr_plus", "sqr", addend=True))
     print("// clang-format on")
 
 
