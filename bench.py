@@ -82,6 +82,17 @@ def measured_traffic(kernel="k_verify_fast"):
         return None
 
 
+def measured_valu_instr():
+    """VALU instructions per signature of the path's kernels (PMC counts committed under
+    profiles/r01_valu_counts.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_valu_counts.json")) as f:
+            d = json.load(f)
+        return sum(v["valu_instr_per_signature"] for k, v in d.items() if k.startswith("k_"))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +171,12 @@ def main():
     if rank == 0:
         value = n * world * args.steps / dt
         achieved = BYTES_PER_VERIFY * n / (kern_ms * 1e-3) / 1e9
+        vps = n / (kern_ms * 1e-3)
+        valu = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "verifies_per_s_per_gpu": vps}
+        ipv = measured_valu_instr()
+        if ipv:   # the bound that matters: lane-instructions issued / full-rate VALU peak at 2.4 GHz
+            valu.update({"instr_per_verify": ipv, "achieved_lane_ops_per_s": ipv * vps,
+                         "frac": ipv * vps / VALU_PEAK_LANE_OPS})
         line = {
             "metric": "secp256k1 ECDSA verifications/sec at batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "verifications/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,8 +189,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel_ms": kern_ms, "bytes_per_verify": BYTES_PER_VERIFY,
                          "note": "path is integer-VALU bound; HBM fraction reported as the contract asks",
-                         "valu": {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                                  "verifies_per_s_per_gpu": n / (kern_ms * 1e-3)}},
+                         "valu": valu},
         }
         # host-buffer entry point (hipMalloc + H2D + kernels + D2H); reported, never `value`
         t1 = time.perf_counter()
