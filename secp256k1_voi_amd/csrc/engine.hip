@@ -14,6 +14,7 @@
 #include "fe.h"
 #include "jacobian29.h"
 #include "point.h"
+#include "pt29.h"
 #include "sc.h"
 #include "sc26.h"
 #include "sha256.h"
@@ -887,6 +888,21 @@ S2K_DEV void point_record_store(uint8_t* rec, const pt& p) {
 
 enum { PK_BASE_MUL = 0, PK_MUL = 1, PK_DOUBLE_MUL = 2, PK_ADD = 3, PK_DOUBLE = 4 };
 
+S2K_DEV pt29 pt29_from_pt(const pt& p) {
+  pt29 r;
+  r.x = fe29_from_words(p.x.v);
+  r.y = fe29_from_words(p.y.v);
+  r.z = fe29_from_words(p.z.v);
+  return r;
+}
+S2K_DEV pt pt_from_pt29(const pt29& p) {
+  pt r;
+  fe29_to_words(r.x.v, fe29_normalize(p.x));
+  fe29_to_words(r.y.v, fe29_normalize(p.y));
+  fe29_to_words(r.z.v, fe29_normalize(p.z));
+  return r;
+}
+
 __global__ void __launch_bounds__(256)
 k_point_op(int op, uint32_t n, const uint8_t* __restrict__ k1, const uint8_t* __restrict__ k2,
            const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, uint8_t* __restrict__ out,
@@ -923,14 +939,15 @@ k_point_op(int op, uint32_t n, const uint8_t* __restrict__ k1, const uint8_t* __
       res = rq;
     }
   } else if (op == PK_ADD) {
+    // Point.Add (point.go:62) through the 9x29 complete formulas the multiscalar kernels use
     pt a, b;
     point_record_load(a, pa + idx * 65);
     point_record_load(b, pb + idx * 65);
-    res = pt_add_complete(a, b);
+    res = pt_from_pt29(pt29_add(pt29_from_pt(a), pt29_from_pt(b)));
   } else if (op == PK_DOUBLE) {
     pt a;
     point_record_load(a, pa + idx * 65);
-    res = pt_double_complete(a);
+    res = pt_from_pt29(pt29_double(pt29_from_pt(a)));
   }
   point_record_store(out + idx * 65, res);
 }

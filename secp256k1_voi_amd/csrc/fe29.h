@@ -87,7 +87,7 @@ S2K_DEV fe29 fe29_half(const fe29& a) {
   return r;
 }
 S2K_DEV fe29 fe29_select(bool pick_b, const fe29& a, const fe29& b) {
-  uint32_t m = 0u - (uint32_t)pick_b;   // arithmetic select, see fe26_select
+  uint32_t m = 0u - (uint32_t)pick_b;   // arithmetic select: v_cndmask on VCC is slow on gfx950 (profiles/r01_valu_instruction_rates.txt)
   fe29 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.n[i] = a.n[i] ^ ((a.n[i] ^ b.n[i]) & m);
@@ -182,7 +182,7 @@ S2K_DEV fe29 fe29_sqr_n(fe29 a, int n) {
   for (int i = 0; i < n; ++i) a = fe29_sqr(a);
   return a;
 }
-// x^(2^223 - 1) (1 unit in and out), with x^(2^22 - 1) and x^(2^2 - 1); see fe26_pow_x223
+// x^(2^223 - 1) (1 unit in and out), with x^(2^22 - 1) and x^(2^2 - 1); same chain as the reference field_invert.go
 S2K_DEV fe29 fe29_pow_x223(const fe29& a, fe29& x22, fe29& x2) {
   x2 = fe29_mul(fe29_sqr(a), a);
   fe29 x3 = fe29_mul(fe29_sqr(x2), a);

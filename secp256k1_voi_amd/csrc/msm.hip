@@ -14,12 +14,12 @@
 //                      chunk offset by double-and-add
 //   6. k_msm_tree      one workgroup per window: tree-sum of the chunk results
 //   7. k_msm_final     Horner over the windows, affine result
-// All additions use the complete formulas (pt26.h): buckets receive arbitrary points
+// All additions use the complete formulas (pt29.h): buckets receive arbitrary points
 // (duplicates, inverses, the same point many times), so there is no exceptional case to
 // detect and no fallback.  Window width c is 8 bits for small inputs and 16 bits for large
 // ones (2^20 terms: 16 windows x 65535 buckets, ~16 points per bucket).
 #include "engine_internal.h"
-#include "pt26.h"
+#include "pt29.h"
 #include "sc.h"
 #include "sha256.h"
 
@@ -42,31 +42,32 @@ S2K_DEV uint32_t msm_digit(const uint32_t* __restrict__ scw, size_t n_stride, si
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
-// pt26 in planes [word][slot]
-S2K_DEV void pt_store(uint32_t* __restrict__ base, size_t stride, size_t slot, const pt26& p) {
+// pt29 in planes [word][slot], PT_WORDS words per point
+constexpr int PT_WORDS = 27;
+S2K_DEV void pt_store(uint32_t* __restrict__ base, size_t stride, size_t slot, const pt29& p) {
 #pragma unroll
-  for (int w = 0; w < 10; ++w) base[(size_t)w * stride + slot] = p.x.n[w];
+  for (int w = 0; w < 9; ++w) base[(size_t)w * stride + slot] = p.x.n[w];
 #pragma unroll
-  for (int w = 0; w < 10; ++w) base[(size_t)(10 + w) * stride + slot] = p.y.n[w];
+  for (int w = 0; w < 9; ++w) base[(size_t)(9 + w) * stride + slot] = p.y.n[w];
 #pragma unroll
-  for (int w = 0; w < 10; ++w) base[(size_t)(20 + w) * stride + slot] = p.z.n[w];
+  for (int w = 0; w < 9; ++w) base[(size_t)(18 + w) * stride + slot] = p.z.n[w];
 }
-S2K_DEV pt26 pt_load(const uint32_t* __restrict__ base, size_t stride, size_t slot) {
-  pt26 p;
+S2K_DEV pt29 pt_load(const uint32_t* __restrict__ base, size_t stride, size_t slot) {
+  pt29 p;
 #pragma unroll
-  for (int w = 0; w < 10; ++w) p.x.n[w] = base[(size_t)w * stride + slot];
+  for (int w = 0; w < 9; ++w) p.x.n[w] = base[(size_t)w * stride + slot];
 #pragma unroll
-  for (int w = 0; w < 10; ++w) p.y.n[w] = base[(size_t)(10 + w) * stride + slot];
+  for (int w = 0; w < 9; ++w) p.y.n[w] = base[(size_t)(9 + w) * stride + slot];
 #pragma unroll
-  for (int w = 0; w < 10; ++w) p.z.n[w] = base[(size_t)(20 + w) * stride + slot];
+  for (int w = 0; w < 9; ++w) p.z.n[w] = base[(size_t)(18 + w) * stride + slot];
   return p;
 }
-// keep magnitudes at the pt26 invariant after a select etc.
-S2K_DEV pt26 pt_select(bool pick_b, const pt26& a, const pt26& b) {
-  pt26 r;
-  r.x = fe26_select(pick_b, a.x, b.x);
-  r.y = fe26_select(pick_b, a.y, b.y);
-  r.z = fe26_select(pick_b, a.z, b.z);
+// keep magnitudes at the pt29 invariant after a select etc.
+S2K_DEV pt29 pt_select(bool pick_b, const pt29& a, const pt29& b) {
+  pt29 r;
+  r.x = fe29_select(pick_b, a.x, b.x);
+  r.y = fe29_select(pick_b, a.y, b.y);
+  r.z = fe29_select(pick_b, a.z, b.z);
   return r;
 }
 
@@ -197,7 +198,7 @@ k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ offset
   size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (key >= nkeys) return;
   uint32_t lo = offset[key], hi = offset[key + 1];
-  pt26 acc = pt26_identity();
+  pt29 acc = pt29_identity();
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
     size_t i = list[j];
@@ -205,7 +206,7 @@ k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ offset
     uint4 a = rec4[0], b = rec4[1], c = rec4[2], d = rec4[3];
     uint32_t xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t yw[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    acc = pt26_add_mixed(acc, fe26_from_words(xw), fe26_from_words(yw));
+    acc = pt29_add_mixed(acc, fe29_from_words(xw), fe29_from_words(yw));
   }
   pt_store(buckets, nkeys, key, acc);
 }
@@ -219,24 +220,24 @@ k_msm_reduce(msm_geom g, const uint32_t* __restrict__ buckets, uint32_t* __restr
   uint32_t w = (uint32_t)(id / g.nchunk), j = (uint32_t)(id % g.nchunk);
   size_t nkeys = (size_t)g.nw * g.nb;
   size_t base = (size_t)w * g.nb + (size_t)j * CHUNK;
-  pt26 run = pt26_identity(), tot = pt26_identity();
+  pt29 run = pt29_identity(), tot = pt29_identity();
 #pragma unroll 1
   for (int b = CHUNK - 1; b >= 1; --b) {
-    run = pt26_add(run, pt_load(buckets, nkeys, base + b));
-    tot = pt26_add(tot, run);
+    run = pt29_add(run, pt_load(buckets, nkeys, base + b));
+    tot = pt29_add(tot, run);
   }
-  run = pt26_add(run, pt_load(buckets, nkeys, base));       // S_j (bucket 32j has coefficient 0 in tot)
+  run = pt29_add(run, pt_load(buckets, nkeys, base));       // S_j (bucket 32j has coefficient 0 in tot)
   // tot += (32 j) * S_j :  j * S_j by double-and-add (j < 2^11), then 5 doublings
-  pt26 m = pt26_identity();
+  pt29 m = pt29_identity();
 #pragma unroll 1
   for (int bit = 10; bit >= 0; --bit) {
-    m = pt26_double(m);
-    pt26 s = pt26_add(m, run);
+    m = pt29_double(m);
+    pt29 s = pt29_add(m, run);
     m = pt_select((j >> bit) & 1u, m, s);
   }
 #pragma unroll 1
-  for (int t = 0; t < 5; ++t) m = pt26_double(m);
-  tot = pt26_add(tot, m);
+  for (int t = 0; t < 5; ++t) m = pt29_double(m);
+  tot = pt29_add(tot, m);
   pt_store(partial, nslots, id, tot);
 }
 
@@ -246,8 +247,8 @@ __global__ void __launch_bounds__(1024) k_msm_tree(msm_geom g, uint32_t* __restr
   size_t base = (size_t)blockIdx.x * g.nchunk;
   for (uint32_t half = g.nchunk >> 1; half >= 1; half >>= 1) {
     for (uint32_t t = threadIdx.x; t < half; t += 1024) {
-      pt26 a = pt_load(partial, nslots, base + t), b = pt_load(partial, nslots, base + t + half);
-      pt_store(partial, nslots, base + t, pt26_add(a, b));
+      pt29 a = pt_load(partial, nslots, base + t), b = pt_load(partial, nslots, base + t + half);
+      pt_store(partial, nslots, base + t, pt29_add(a, b));
     }
     __syncthreads();
   }
@@ -257,33 +258,22 @@ __global__ void __launch_bounds__(1024) k_msm_tree(msm_geom g, uint32_t* __restr
 __global__ void k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65) {
   // out65: the 65-byte record of the sum (all zero for the identity)
   size_t nslots = (size_t)g.nw * g.nchunk;
-  pt26 acc = pt_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk);
+  pt29 acc = pt_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk);
 #pragma unroll 1
   for (int w = (int)g.nw - 2; w >= 0; --w) {
 #pragma unroll 1
-    for (uint32_t t = 0; t < g.c; ++t) acc = pt26_double(acc);
-    acc = pt26_add(acc, pt_load(partial, nslots, (size_t)w * g.nchunk));
+    for (uint32_t t = 0; t < g.c; ++t) acc = pt29_double(acc);
+    acc = pt29_add(acc, pt_load(partial, nslots, (size_t)w * g.nchunk));
   }
-  if (fe26_is_zero(acc.z)) {
+  if (fe29_is_zero(acc.z)) {
     for (int i = 0; i < 65; ++i) out65[i] = 0;
     return;
   }
-  fe26 zi = fe26_inv(fe26_normalize_weak(acc.z));
-  fe26 x = fe26_normalize(fe26_mul(acc.x, zi)), y = fe26_normalize(fe26_mul(acc.y, zi));
-  // 10x26 -> 8x32 words -> big-endian bytes
-  auto words = [](const fe26& a, uint32_t w[8]) {
-    w[0] = a.n[0] | (a.n[1] << 26);
-    w[1] = (a.n[1] >> 6) | (a.n[2] << 20);
-    w[2] = (a.n[2] >> 12) | (a.n[3] << 14);
-    w[3] = (a.n[3] >> 18) | (a.n[4] << 8);
-    w[4] = (a.n[4] >> 24) | (a.n[5] << 2) | (a.n[6] << 28);
-    w[5] = (a.n[6] >> 4) | (a.n[7] << 22);
-    w[6] = (a.n[7] >> 10) | (a.n[8] << 16);
-    w[7] = (a.n[8] >> 16) | (a.n[9] << 10);
-  };
+  fe29 zi = fe29_inv(fe29_normalize_weak(acc.z));
+  fe29 x = fe29_normalize(fe29_mul(acc.x, zi)), y = fe29_normalize(fe29_mul(acc.y, zi));
   uint32_t xw[8], yw[8];
-  words(x, xw);
-  words(y, yw);
+  fe29_to_words(xw, x);
+  fe29_to_words(yw, y);
   out65[0] = 0x04;
   store_be32_unaligned(out65 + 1, xw);
   store_be32_unaligned(out65 + 33, yw);
@@ -313,8 +303,8 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   size_t o_status = carve(256), o_count = carve((m.nkeys + 1) * 4), o_cursor = carve(m.nkeys * 4),
          o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((m.nkeys / 1024 + 1) * 4), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
-         o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * 30 * 4),
-         o_partial = carve(m.nslots * 30 * 4), o_aux = carve(aux_bytes);
+         o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * PT_WORDS * 4),
+         o_partial = carve(m.nslots * PT_WORDS * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
@@ -369,21 +359,14 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
 // ---------------------------------------------------------------------------------------
 S2K_DEV bool lift_x_words(uint32_t yw[8], const uint32_t xw[8]) {
   if (!fe_is_canonical_raw(xw)) return false;
-  fe26 x = fe26_from_words(xw);
-  fe26 rhs = fe26_mul(fe26_sqr(x), x);
+  fe29 x = fe29_from_words(xw);
+  fe29 rhs = fe29_mul(fe29_sqr(x), x);
   rhs.n[0] += 7;
-  fe26 y;
-  if (!fe26_sqrt(y, rhs)) return false;
-  y = fe26_normalize(y);
-  y = fe26_normalize(fe26_select((y.n[0] & 1u) != 0, y, fe26_negate(y, 1)));   // even root
-  yw[0] = y.n[0] | (y.n[1] << 26);
-  yw[1] = (y.n[1] >> 6) | (y.n[2] << 20);
-  yw[2] = (y.n[2] >> 12) | (y.n[3] << 14);
-  yw[3] = (y.n[3] >> 18) | (y.n[4] << 8);
-  yw[4] = (y.n[4] >> 24) | (y.n[5] << 2) | (y.n[6] << 28);
-  yw[5] = (y.n[6] >> 4) | (y.n[7] << 22);
-  yw[6] = (y.n[7] >> 10) | (y.n[8] << 16);
-  yw[7] = (y.n[8] >> 16) | (y.n[9] << 10);
+  fe29 y;
+  if (!fe29_sqrt(y, rhs)) return false;
+  y = fe29_normalize(y);
+  y = fe29_normalize(fe29_select((y.n[0] & 1u) != 0, y, fe29_negate(y, 1)));   // even root
+  fe29_to_words(yw, y);
   return true;
 }
 

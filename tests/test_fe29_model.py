@@ -335,6 +335,72 @@ def test_table_build_bounds():
     normalize_weak(s)
 
 
+# ---- pt29.h --------------------------------------------------------------------------------------
+def mul_small_norm(a, k):
+    c = 0
+    for i in range(8):
+        c += a.hi[i] * k
+        assert c < U64
+        c >>= W
+    c += a.hi[8] * k
+    x = c >> 24
+    assert x < U32
+    out = B([M + x * 0x3D1, M + (x << 3)] + [M] * 6 + [M8])
+    assert out.within(1.1)
+    return out
+
+
+def triple_norm(a):
+    return normalize_weak(mul_int(a, 3))
+
+
+def pt_add_tail(t0, t1, t2, t3, t4, y3):
+    t0n = triple_norm(t0)
+    z3 = add(t1, t2)
+    t1m = add(t1, negate(t2, 1))
+    return (mulsum([(t3, t1m), (negate(t4, 1), y3)]), mulsum([(t1m, z3), (y3, t0n)]), mulsum([(z3, t4), (t0n, t3)]))
+
+
+def pt_add_mixed(p, qx, qy):
+    px, py, pz = p
+    t0, t1 = mul(px, qx), mul(py, qy)
+    t3 = mulsum([(add(qx, qy), add(px, py))], negate(add(t0, t1), 2))
+    t4 = mulsum([(qy, pz)], py)
+    y3 = mul_small_norm(mulsum([(qx, pz)], px), 21)
+    t2 = mul_small_norm(pz, 21)
+    return pt_add_tail(t0, t1, t2, t3, t4, y3)
+
+
+def pt_add(p, q):
+    (px, py, pz), (qx, qy, qz) = p, q
+    t0, t1, t2 = mul(px, qx), mul(py, qy), mul(pz, qz)
+    t3 = mulsum([(add(px, py), add(qx, qy))], negate(add(t0, t1), 2))
+    t4 = mulsum([(add(py, pz), add(qy, qz))], negate(add(t1, t2), 2))
+    y3 = mulsum([(add(px, pz), add(qx, qz))], negate(add(t0, t2), 2))
+    return pt_add_tail(t0, t1, mul_small_norm(t2, 21), t3, t4, mul_small_norm(y3, 21))
+
+
+def pt_double(p):
+    px, py, pz = p
+    t0 = sqr(py)
+    z3 = mul_int(normalize_weak(mul_int(t0, 4)), 2)
+    t1 = mul(py, pz)
+    zz = sqr(pz)
+    t2 = mul_small_norm(zz, 21)
+    y3 = add(t0, t2)
+    t0m = normalize_weak(add(t0, negate(mul_small_norm(zz, 63), 1)))
+    return mul(mul_int(t0m, 2), mul(px, py)), mulsum([(t2, z3), (t0m, y3)]), mul(t1, z3)
+
+
+def test_projective_invariant_closed():
+    # coordinates as products leave them (limb 2 a little above 2^29), affine inputs from words
+    inv = B([M, M, M + (1 << 16)] + [M] * 5 + [M8])      # the invariant, with room for limb 2's carry
+    P = (inv, inv, inv)
+    q = B([M] * 8 + [M8])
+    for r in (pt_add(P, P), pt_double(P), pt_add_mixed(P, q, q)):
+        assert all(a <= b for c in r for a, b in zip(c.hi, inv.hi))
+
+
 def test_model_rejects_an_overflow():
     import pytest
     with pytest.raises(AssertionError):

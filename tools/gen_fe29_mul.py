@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates secp256k1_voi_amd/csrc/fe29_mul_gen.h: the 9 x 29-bit field multiply, square and
 fused multiply-adds for gfx950 (v_mad_u64_u32 accumulation chains, one asm statement per
-column as in tools/gen_fe26_mul.py), plus the 8x32 <-> 9x29 limb conversions.
+column tools/gen_chain.py), plus the 8x32 <-> 9x29 limb conversions.
 
 Schedule (the 10x26 one with L = 9 limbs of W = 29 bits): column L-1 first, then for
 k = 0..L-2 the high column L+k is reduced into the low column k with
@@ -11,7 +11,7 @@ of full-size limbs, so (limb bound of a) * (limb bound of b) must stay below 2^6
 
     python tools/gen_fe29_mul.py > secp256k1_voi_amd/csrc/fe29_mul_gen.h
 """
-from gen_fe26_mul import chain
+from gen_chain import chain
 
 L, W = 9, 29
 
@@ -105,21 +105,21 @@ def gen(name, kind, addend=False):
     def fix(ts):
         return [(x.replace("c2[", "c2[").replace("c[", "c_["), y.replace("c[", "c_["), k) for x, y, k in ts]
 
-    top = fix(col(L - 1))
-    o.append(f"  uint64_t d = (uint64_t){top[0][0]} * {top[0][1]};\n")
-    o.append(chain("d", top[1:]))
+    # every product, including the first of each accumulator, is inside an asm chain: no C-level
+    # 64-bit multiply is left for the compiler to narrow (see fe29_mul_small_norm in pt29.h)
+    o.append("  uint64_t d, c;\n")
+    o.append(chain("d", fix(col(L - 1)), init=True))
     o.append(f"  t[{L - 1}] = (uint32_t)d & F29_M;\n  d >>= {W};\n")
-    c0 = fix(col(0))
-    o.append(f"  uint64_t c = (uint64_t){c0[0][0]} * {c0[0][1]};\n  uint32_t u, uprev = 0;\n")
+    o.append("  uint32_t u, uprev = 0;\n")
     for k in range(L - 1):
         o.append(chain("d", fix(col(L + k))))
         o.append(f"  u = (uint32_t)d & F29_M;\n  d >>= {W};\n")
         lo = []
         if k > 0:
             lo.append(("uprev", "R1", "s"))
-        lo += fix(col(k))[1:] if k == 0 else fix(col(k))
+        lo += fix(col(k))
         lo.append(("u", "R0", "s"))
-        o.append(chain("c", lo))
+        o.append(chain("c", lo, init=(k == 0)))
         o.append(f"  t[{k}] = (uint32_t)c & F29_M;\n  c >>= {W};\n  uprev = u;\n")
     o.append(chain("c", [("uprev", "R1", "s")]))
     o.append("  return fe29_mul_tail(t, c, d);\n}\n")
