@@ -83,14 +83,14 @@ def measured_traffic(kernel="k_verify_fast"):
 
 
 def measured_valu_instr():
-    """VALU instructions per signature of the path's kernels (PMC counts committed under
-    profiles/r01_valu_counts.json), or None."""
+    """(VALU instructions per signature of the path's kernels from the committed PMC counts,
+    static per-verification operation counts) from profiles/r01_valu_counts.json, or (None, {})."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_valu_counts.json")) as f:
             d = json.load(f)
-        return sum(v["valu_instr_per_signature"] for k, v in d.items() if k.startswith("k_"))
+        return sum(v["valu_instr_per_signature"] for k, v in d.items() if k.startswith("k_")), d.get("static", {})
     except Exception:
-        return None
+        return None, {}
 
 
 def main():
@@ -173,10 +173,18 @@ def main():
         achieved = BYTES_PER_VERIFY * n / (kern_ms * 1e-3) / 1e9
         vps = n / (kern_ms * 1e-3)
         valu = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "verifies_per_s_per_gpu": vps}
-        ipv = measured_valu_instr()
+        ipv, static = measured_valu_instr()
         if ipv:   # the bound that matters: lane-instructions issued / full-rate VALU peak at 2.4 GHz
             valu.update({"instr_per_verify": ipv, "achieved_lane_ops_per_s": ipv * vps,
                          "frac": ipv * vps / VALU_PEAK_LANE_OPS})
+        if static:   # modular products per verification and the multiply-add rate against its measured peak
+            mad_peak = static["measured_mad_u64_u32_peak_wave_instr_per_us_per_simd"] * 1e6 * 1024 * 64
+            valu.update({"fp_products_per_verify": static["fp_products_per_verify"],
+                         "fn_products_per_verify": static["fn_products_per_verify"],
+                         "mad_u64_u32_per_verify": static["mad_u64_u32_per_verify"],
+                         "mad_u64_u32_lane_ops_per_s": static["mad_u64_u32_per_verify"] * vps,
+                         "mad_u64_u32_peak_lane_ops_per_s": mad_peak,
+                         "mad_frac": static["mad_u64_u32_per_verify"] * vps / mad_peak})
         line = {
             "metric": "secp256k1 ECDSA verifications/sec at batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "verifications/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

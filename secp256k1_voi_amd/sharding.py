@@ -99,3 +99,46 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
     dist.all_gather_into_tensor(full, bitmap)
     dist.all_reduce(count)
     return full, count
+
+
+def msm_sharded(engine, scalars, points, dist=None):
+    """Sum of s_i * P_i with the terms sharded over the ranks: every rank passes
+    ITS shard (lists of 32-byte scalars and 65-byte point records), computes one partial sum
+    with `engine.multi_scalar_mult`, the 65-byte partial sums are all-gathered (point addition is
+    not a reduction RCCL knows) and folded by one more `multi_scalar_mult` with unit scalars.
+    Every rank returns the same 65-byte record (all zero for the identity)."""
+    import torch
+
+    part = engine.multi_scalar_mult(scalars, points)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return part
+    world = dist.get_world_size()
+    mine = torch.tensor(list(part), dtype=torch.uint8)
+    if dist.get_backend() != "gloo":
+        mine = mine.cuda()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    recs = [bytes(p.cpu().numpy().tobytes()) for p in parts]
+    one = (1).to_bytes(32, "big")
+    return engine.multi_scalar_mult([one] * world, recs)
+
+
+def schnorr_batch_verify_sharded(engine, pks, msgs, sigs, seed: bytes, dist=None) -> bool:
+    """Whole-batch BIP-340 verification with the signatures sharded over the ranks: each rank
+    checks its shard as one random-linear-combination multiscalar multiplication
+    (`engine.schnorr_batch_verify_rlc`, independent coefficients per rank: the rank is mixed
+    into the seed) and the verdicts are combined with an all-reduce (min).  Accepts iff every
+    shard accepts, i.e. iff every signature verifies, up to 2^-128 per shard."""
+    import hashlib
+
+    import torch
+
+    rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+    ok = bool(engine.schnorr_batch_verify_rlc(pks, msgs, sigs, hashlib.sha256(seed + rank.to_bytes(4, "big")).digest()))
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return ok
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() != "gloo":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))

@@ -1,6 +1,7 @@
 """Parity of the HIP engine (through the C-ABI) with the CPU oracle and the reference's
 golden vectors.  Needs a real MI355X: run with  pytest -m gpu.
 """
+import os
 import random
 
 import numpy as np

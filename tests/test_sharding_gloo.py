@@ -79,3 +79,73 @@ def test_two_rank_gather(n, oracle):
     for rank, full, count in res:
         assert np.frombuffer(full, dtype=np.uint8).tolist() == exp.tolist()
         assert count == int(exp.sum())
+
+
+class _OracleEngine:
+    """Stands in for the GPU Engine in the CPU collective tests (same method contracts)."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def multi_scalar_mult(self, scalars, points):
+        return self.o.multi_scalar_mult_vartime(list(scalars), list(points))
+
+    def schnorr_batch_verify_rlc(self, pks, msgs, sigs, seed32=None):
+        return all(self.o.schnorr_verify(pk, m, s) == 1 for pk, m, s in zip(pks, msgs, sigs))
+
+
+def _worker_msm(rank, world, port, n, q):
+    import random
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    import oracle
+    import pyref
+    from secp256k1_voi_amd.sharding import msm_sharded, schnorr_batch_verify_sharded, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rnd = random.Random(77)
+    ks = [rnd.randrange(pyref.N).to_bytes(32, "big") for _ in range(n)]
+    ps = [oracle.scalar_base_mult_vartime(rnd.randrange(1, pyref.N).to_bytes(32, "big")) for _ in range(n)]
+    lo, hi = shard_range(n, rank, world)
+    eng = _OracleEngine(oracle)
+    total = msm_sharded(eng, ks[lo:hi], ps[lo:hi], dist)
+    # BIP-340 shards: rank 1's shard carries one bad signature in the second run
+    sk = [rnd.randrange(1, pyref.N) for _ in range(n)]
+    msgs = [rnd.randbytes(32) for _ in range(n)]
+    sigs, pks = [], []
+    for d, m in zip(sk, msgs):
+        pks.append(pyref.b32(pyref.mul(d, pyref.G)[0]))
+        sigs.append(pyref.schnorr_sign(d, m, bytes(32)))
+    ok_all = schnorr_batch_verify_sharded(eng, pks[lo:hi], msgs[lo:hi], sigs[lo:hi], b"seed", dist)
+    bad = list(sigs)
+    bad[n - 1] = bad[n - 1][:63] + bytes([bad[n - 1][63] ^ 1])
+    ok_bad = schnorr_batch_verify_sharded(eng, pks[lo:hi], msgs[lo:hi], bad[lo:hi], b"seed", dist)
+    q.put((rank, total, ok_all, ok_bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_msm_and_schnorr_batch(oracle):
+    import random
+    import pyref
+    n, world, port = 24, 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_msm, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rnd = random.Random(77)
+    ks = [rnd.randrange(pyref.N).to_bytes(32, "big") for _ in range(n)]
+    ps = [oracle.scalar_base_mult_vartime(rnd.randrange(1, pyref.N).to_bytes(32, "big")) for _ in range(n)]
+    exp = oracle.multi_scalar_mult_vartime(ks, ps)
+    for rank, total, ok_all, ok_bad in res:
+        assert total == exp
+        assert ok_all is True and ok_bad is False
