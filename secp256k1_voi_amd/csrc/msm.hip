@@ -5,10 +5,16 @@
 // algorithm for large batches (point_mul_multi.go:16-18, README.md:91); this is that method,
 // laid out for a GPU.  Parity is on the resulting group element (canonical bytes).
 //
-//   1. k_msm_prepare   one lane per term: reduce the scalar, parse the point, histogram of
-//                      (window, digit) keys with atomics
-//   2. k_msm_scan      exclusive prefix sum of the histogram (one workgroup)
-//   3. k_msm_scatter   counting sort: term indices grouped by key
+//   1. k_msm_parse     one lane per term: reduce the scalar, parse and check the point
+//   2. sort of the (window, digit) keys, two levels, all counting done in LDS:
+//      k_msm_coarse_count / scan / k_msm_coarse_scatter  partition the n*nw (key, term) pairs by
+//                      the key's upper bits (1024 keys per coarse bucket): each workgroup counts
+//                      its slice of terms in LDS and publishes one row of a [coarse][workgroup]
+//                      matrix, whose exclusive scan gives every workgroup a private output range
+//                      per coarse bucket (no global atomics)
+//      k_msm_fine_sort one workgroup per coarse bucket: LDS histogram of the 1024 keys, scan,
+//                      scatter of the term indices; emits the per-key counts and offsets
+//   3. k_msm_size_*    order the buckets by decreasing size (load balance, see below)
 //   4. k_msm_accumulate one lane per bucket: complete mixed additions of its points
 //   5. k_msm_reduce    one lane per chunk of 32 buckets: sum_b b*B_b by running sums, plus the
 //                      chunk offset by double-and-add
@@ -107,17 +113,6 @@ k_msm_parse(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __re
   rec4[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
 }
 
-__global__ void __launch_bounds__(256)
-k_msm_histogram(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
-                uint32_t* __restrict__ count) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || flag[i] != 1) return;
-  for (uint32_t w = 0; w < g.nw; ++w) {
-    uint32_t d = msm_digit(scw, n, i, w, g.c);
-    if (d) atomicAdd(&count[(size_t)w * g.nb + d], 1u);
-  }
-}
-
 // exclusive scan of `total` counters (total a multiple of 1024), three small launches:
 // per-block sums -> scan of the block sums (one workgroup) -> per-block scan + base
 __global__ void __launch_bounds__(256) k_msm_scan_blocks(const uint32_t* __restrict__ count, uint32_t* __restrict__ bsum) {
@@ -160,8 +155,9 @@ __global__ void __launch_bounds__(1024) k_msm_scan_top(uint32_t* __restrict__ bs
   }
   if (t == 1023) *total_out = part[1023];
 }
-__global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* __restrict__ count, const uint32_t* __restrict__ bsum,
-                                                        uint32_t* __restrict__ offset) {
+// (count and offset may be the same array: each thread reads its four counters before writing)
+__global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* count, const uint32_t* __restrict__ bsum,
+                                                        uint32_t* offset) {
   __shared__ uint32_t part[256];
   const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
   const uint4 v = reinterpret_cast<const uint4*>(count)[i4];
@@ -178,25 +174,150 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* __restri
   reinterpret_cast<uint4*>(offset)[i4] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
 }
 
-__global__ void __launch_bounds__(256)
-k_msm_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
-              const uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || flag[i] != 1) return;
-  for (uint32_t w = 0; w < g.nw; ++w) {
-    uint32_t d = msm_digit(scw, n, i, w, g.c);
-    if (!d) continue;
-    size_t key = (size_t)w * g.nb + d;
-    uint32_t pos = atomicAdd(&cursor[key], 1u);
-    list[offset[key] + pos] = (uint32_t)i;
+// ---------------------------------------------------------------------------------------
+// Two-level counting sort of the (key, term) pairs, key = window * 2^c + digit (digit 0 skipped).
+// FINE keys per coarse bucket; a sort workgroup owns SORT_TERMS consecutive terms.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t FINE_BITS = 10, FINE = 1u << FINE_BITS;
+constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = 4096;
+constexpr uint32_t MAX_COARSE = 1024;     // nkeys / FINE for c = 16 (the largest geometry)
+
+// matrix[coarse * nblk_pad + block] = pairs of this workgroup's terms falling into `coarse`
+__global__ void __launch_bounds__(SORT_THREADS)
+k_msm_coarse_count(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
+                   uint32_t ncoarse, uint32_t nblk_pad, uint32_t* __restrict__ matrix) {
+  __shared__ uint32_t h[MAX_COARSE];
+  for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) h[t] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * SORT_TERMS;
+  for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
+    size_t i = base + t;
+    if (i >= n || flag[i] != 1) continue;
+    for (uint32_t w = 0; w < g.nw; ++w) {
+      uint32_t d = msm_digit(scw, n, i, w, g.c);
+      if (d) atomicAdd(&h[(w * g.nb + d) >> FINE_BITS], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) matrix[(size_t)t * nblk_pad + blockIdx.x] = h[t];
+}
+// pairs[pos] = (key & (FINE - 1), term), grouped by coarse bucket; `mbase` is the scanned matrix
+__global__ void __launch_bounds__(SORT_THREADS)
+k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
+                     uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint2* __restrict__ pairs) {
+  __shared__ uint32_t cur[MAX_COARSE];
+  for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) cur[t] = mbase[(size_t)t * nblk_pad + blockIdx.x];
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * SORT_TERMS;
+  for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
+    size_t i = base + t;
+    if (i >= n || flag[i] != 1) continue;
+    for (uint32_t w = 0; w < g.nw; ++w) {
+      uint32_t d = msm_digit(scw, n, i, w, g.c);
+      if (!d) continue;
+      uint32_t key = w * g.nb + d;
+      uint32_t pos = atomicAdd(&cur[key >> FINE_BITS], 1u);
+      pairs[pos] = make_uint2(key & (FINE - 1), (uint32_t)i);
+    }
+  }
+}
+// one workgroup per coarse bucket: pairs -> list (term indices grouped by key), count[key],
+// offset[key]; the last workgroup also writes offset[nkeys] = total
+__global__ void __launch_bounds__(SORT_THREADS)
+k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint32_t total_slot,
+                const uint2* __restrict__ pairs, uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
+                uint32_t* __restrict__ list) {
+  __shared__ uint32_t h[FINE], part[FINE];
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  const uint32_t lo = mbase[(size_t)b * nblk_pad];
+  const uint32_t hi = b + 1 < ncoarse ? mbase[(size_t)(b + 1) * nblk_pad] : mbase[total_slot];
+  h[t] = 0;
+  __syncthreads();
+  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS) atomicAdd(&h[pairs[j].x], 1u);
+  __syncthreads();
+  const uint32_t mine = h[t];
+  part[t] = mine;
+  __syncthreads();
+  for (uint32_t s = 1; s < FINE; s <<= 1) {
+    uint32_t a = t >= s ? part[t - s] : 0;
+    __syncthreads();
+    part[t] += a;
+    __syncthreads();
+  }
+  const uint32_t off = lo + part[t] - mine;
+  const size_t key = (size_t)b * FINE + t;
+  count[key] = mine;
+  offset[key] = off;
+  if (b + 1 == ncoarse && t == FINE - 1) offset[key + 1] = hi;
+  h[t] = off;                      // running cursor of key t
+  __syncthreads();
+  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS) {
+    uint2 e = pairs[j];
+    list[atomicAdd(&h[e.x], 1u)] = e.y;
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Load balance of the bucket pass.  A lane owns a bucket and bucket sizes are Poisson
+// distributed (mean n*nw/nkeys = 16 at 2^20 terms), so in bucket order a wave waits for the
+// largest of its 64 buckets (about 28 points: 57 % efficiency).  The buckets are therefore
+// visited in order of decreasing size (a counting sort of the keys by count, SIZE_BINS bins,
+// block-aggregated so that only one global atomic per block and bin is issued): the 64 lanes
+// of a wave then own buckets of (almost) equal size, and the big ones are scheduled first.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t SIZE_BINS = 256;
+S2K_DEV uint32_t size_bin(uint32_t cnt) { return SIZE_BINS - 1 - (cnt < SIZE_BINS - 1 ? cnt : SIZE_BINS - 1); }   // bin 0 = largest
+
 __global__ void __launch_bounds__(256)
-k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ offset, const uint32_t* __restrict__ list,
-                 const uint32_t* __restrict__ ptw, uint32_t* __restrict__ buckets) {
+k_msm_size_hist(uint32_t nkeys, const uint32_t* __restrict__ count, uint32_t* __restrict__ sizehist) {
+  __shared__ uint32_t h[SIZE_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
   size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (key >= nkeys) return;
+  if (key < nkeys) atomicAdd(&h[size_bin(count[key])], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&sizehist[threadIdx.x], h[threadIdx.x]);
+}
+// exclusive scan of the SIZE_BINS totals (one workgroup); also clears the cursors
+__global__ void __launch_bounds__(256) k_msm_size_scan(const uint32_t* __restrict__ sizehist, uint32_t* __restrict__ sizebase,
+                                                       uint32_t* __restrict__ sizecur) {
+  __shared__ uint32_t part[SIZE_BINS];
+  uint32_t t = threadIdx.x, mine = sizehist[t];
+  part[t] = mine;
+  __syncthreads();
+  for (uint32_t s = 1; s < SIZE_BINS; s <<= 1) {
+    uint32_t a = t >= s ? part[t - s] : 0;
+    __syncthreads();
+    part[t] += a;
+    __syncthreads();
+  }
+  sizebase[t] = part[t] - mine;
+  sizecur[t] = 0;
+}
+__global__ void __launch_bounds__(256)
+k_msm_size_scatter(uint32_t nkeys, const uint32_t* __restrict__ count, const uint32_t* __restrict__ sizebase,
+                   uint32_t* __restrict__ sizecur, uint32_t* __restrict__ perm) {
+  __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t bin = 0, rank = 0;
+  if (key < nkeys) {
+    bin = size_bin(count[key]);
+    rank = atomicAdd(&h[bin], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) base[threadIdx.x] = sizebase[threadIdx.x] + atomicAdd(&sizecur[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (key < nkeys) perm[base[bin] + rank] = (uint32_t)key;
+}
+
+__global__ void __launch_bounds__(256)
+k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ offset,
+                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw, uint32_t* __restrict__ buckets) {
+  size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= nkeys) return;
+  size_t key = perm[slot];
   uint32_t lo = offset[key], hi = offset[key + 1];
   pt29 acc = pt29_identity();
 #pragma unroll 1
@@ -284,9 +405,11 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *count, *cursor, *offset, *bsum, *scw, *ptw, *list, *buckets, *partial;
+  uint32_t *status, *count, *matrix, *offset, *bsum, *scw, *ptw, *list, *buckets, *partial, *perm, *sizes;
+  uint2* pairs;
+  uint32_t ncoarse, nsortblk, nblk_pad;
   uint8_t* flag;
-  size_t zero_bytes;   // status + count + cursor, contiguous from the start
+  size_t zero_bytes;   // status + size bins + coarse matrix, contiguous from the start
   uint8_t* aux;        // extra caller-requested scratch
 };
 
@@ -301,16 +424,23 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.nslots = (size_t)g.nw * g.nchunk;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  size_t o_status = carve(256), o_count = carve((m.nkeys + 1) * 4), o_cursor = carve(m.nkeys * 4),
-         o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((m.nkeys / 1024 + 1) * 4), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
+  // status word, then 3 x SIZE_BINS words (size histogram, bases, cursors), zeroed with the counters
+  m.ncoarse = (uint32_t)(m.nkeys >> FINE_BITS);
+  m.nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);
+  m.nblk_pad = (m.nsortblk + 1 + 1023) / 1024 * 1024;   // one spare column: the scan total lands in it
+  const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
+  size_t o_status = carve(256), o_sizes = carve(3 * SIZE_BINS * 4), o_matrix = carve((mat_words + 1) * 4),
+         o_count = carve((m.nkeys + 1) * 4), o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
+         o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * PT_WORDS * 4),
-         o_partial = carve(m.nslots * PT_WORDS * 4), o_aux = carve(aux_bytes);
+         o_partial = carve(m.nslots * PT_WORDS * 4), o_perm = carve(m.nkeys * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
   m.status = (uint32_t*)(ws + o_status);
   m.count = (uint32_t*)(ws + o_count);
-  m.cursor = (uint32_t*)(ws + o_cursor);
+  m.matrix = (uint32_t*)(ws + o_matrix);
+  m.pairs = (uint2*)(ws + o_pairs);
   m.offset = (uint32_t*)(ws + o_offset);
   m.bsum = (uint32_t*)(ws + o_bsum);
   m.scw = (uint32_t*)(ws + o_scw);
@@ -319,24 +449,38 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.list = (uint32_t*)(ws + o_list);
   m.buckets = (uint32_t*)(ws + o_buckets);
   m.partial = (uint32_t*)(ws + o_partial);
+  m.perm = (uint32_t*)(ws + o_perm);
+  m.sizes = (uint32_t*)(ws + o_sizes);
   m.aux = ws + o_aux;
-  m.zero_bytes = o_offset;
+  m.zero_bytes = o_count;   // status, size bins and the coarse matrix
   return S2K_OK;
 }
 
 // buckets -> result, given scw / ptw / flag already filled and status/count/cursor zeroed
 int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65) {
   const msm_geom& g = m.g;
-  k_msm_histogram<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.count);
+  // sort: coarse partition (counts -> scan -> scatter), then one workgroup per coarse bucket
+  k_msm_coarse_count<<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
-  const unsigned scan_blocks = (unsigned)(m.nkeys / 1024);
-  k_msm_scan_blocks<<<scan_blocks, 256, 0, st>>>(m.count, m.bsum);
-  k_msm_scan_top<<<1, 1024, 0, st>>>(m.bsum, scan_blocks, m.offset + m.nkeys);
-  k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.count, m.bsum, m.offset);
+  const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
+  const unsigned scan_blocks = (unsigned)(mat_words / 1024);
+  if (scan_blocks > 8192) return fail(ctx, S2K_ERR_ARG, "batch too large for the multiscalar sort");
+  k_msm_scan_blocks<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum);
+  k_msm_scan_top<<<1, 1024, 0, st>>>(m.bsum, scan_blocks, m.matrix + mat_words);
+  k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_scatter<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.offset, m.cursor, m.list);
+  k_msm_coarse_scatter<<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix,
+                                                            m.pairs);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_accumulate<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, (uint32_t)n, m.offset, m.list, m.ptw,
+  k_msm_fine_sort<<<m.ncoarse, SORT_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, m.pairs, m.count,
+                                                      m.offset, m.list);
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t *sizehist = m.sizes, *sizebase = m.sizes + SIZE_BINS, *sizecur = m.sizes + 2 * SIZE_BINS;
+  k_msm_size_hist<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.count, sizehist);
+  k_msm_size_scan<<<1, SIZE_BINS, 0, st>>>(sizehist, sizebase, sizecur);
+  k_msm_size_scatter<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.count, sizebase, sizecur, m.perm);
+  HIP_TRY(ctx, hipGetLastError());
+  k_msm_accumulate<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, (uint32_t)n, m.perm, m.offset, m.list, m.ptw,
                                                         m.buckets);
   HIP_TRY(ctx, hipGetLastError());
   k_msm_reduce<<<(unsigned)((m.nslots + 63) / 64), 64, 0, st>>>(g, m.buckets, m.partial);
