@@ -22,8 +22,9 @@
 //   7. k_msm_final     Horner over the windows, affine result
 // All additions use the complete formulas (pt29.h): buckets receive arbitrary points
 // (duplicates, inverses, the same point many times), so there is no exceptional case to
-// detect and no fallback.  Window width c is 8 bits for small inputs and 16 bits for large
-// ones (2^20 terms: 16 windows x 65535 buckets, ~16 points per bucket).
+// detect and no fallback.  Every term is first split with the curve endomorphism into two
+// 128-bit terms (below).  Window width c is 8 bits for small inputs and 16 bits for large ones
+// (2^20 inputs: 2^21 terms, 8 windows x 65535 buckets, ~32 points per bucket).
 #include "engine_internal.h"
 #include "pt29.h"
 #include "sc.h"
@@ -31,11 +32,20 @@
 
 namespace {
 
-constexpr int CHUNK = 32;   // buckets per reduction chunk
+#ifndef S2K_MSM_CHUNK_LOG2
+#define S2K_MSM_CHUNK_LOG2 4   // A/B on MI355X at 2^20 terms: 2 -> 2.55, 3 -> 2.43, 4 -> 2.34, 5 -> 2.44 ms
+#endif
+constexpr int CHUNK_LOG2 = S2K_MSM_CHUNK_LOG2, CHUNK = 1 << CHUNK_LOG2;   // buckets per reduction chunk
+// Every input term k*P is split with the curve endomorphism (splitGLV, point_mul_glv.go:59) into
+// |k1| * (+-P) + |k2| * (+-lambda P), |k1|, |k2| < 2^128: twice the terms, half the windows.  The
+// bucket additions stay the same (2n * 8 instead of n * 16 at c = 16) but the serial tail -
+// Horner over the windows, 256 - c doublings on one lane - and the bucket reductions halve.
+constexpr int SCW_WORDS = 5;      // scalar planes per term: 128-bit magnitude + one zero word
+constexpr uint32_t SCALAR_BITS = 128;
 
 struct msm_geom {
   uint32_t c;        // window bits
-  uint32_t nw;       // windows = ceil(256 / c)
+  uint32_t nw;       // windows = ceil(128 / c)
   uint32_t nb;       // keys per window = 2^c (key 0 unused)
   uint32_t nchunk;   // nb / CHUNK
 };
@@ -43,7 +53,7 @@ struct msm_geom {
 S2K_DEV uint32_t msm_digit(const uint32_t* __restrict__ scw, size_t n_stride, size_t i, uint32_t w, uint32_t c) {
   uint32_t bit = w * c, word = bit >> 5, sh = bit & 31;
   uint32_t lo = scw[(size_t)word * n_stride + i];
-  uint32_t hi = word + 1 < 8 ? scw[(size_t)(word + 1) * n_stride + i] : 0u;
+  uint32_t hi = word + 1 < SCW_WORDS ? scw[(size_t)(word + 1) * n_stride + i] : 0u;
   uint64_t v = ((uint64_t)hi << 32) | lo;
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
@@ -77,8 +87,35 @@ S2K_DEV pt29 pt_select(bool pick_b, const pt29& a, const pt29& b) {
   return r;
 }
 
-// bytes -> words: scalar reduced mod n (plain, little-endian words), affine point words, flag
-// (0 identity, 1 finite, 2 malformed)
+// term `t` of a term array with plane stride N: magnitude k (< 2^128), point (x, +-y)
+S2K_DEV void msm_store_term(uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, size_t N, size_t t, const sc& k,
+                            const uint32_t x[8], const uint32_t y[8], bool neg) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) scw[(size_t)w * N + t] = k.v[w];
+  scw[(size_t)4 * N + t] = 0;
+  uint32_t ny[8];
+  u256_sub(ny, FE_P, y);                                   // y != 0 on this curve
+  // points as 64-byte records [t][16 words]: the bucket pass gathers them by index, one
+  // contiguous record per lane (planes would cost 16 sparse sectors per gathered point)
+  uint4* rec4 = reinterpret_cast<uint4*>(ptw + t * 16);
+  rec4[0] = make_uint4(x[0], x[1], x[2], x[3]);
+  rec4[1] = make_uint4(x[4], x[5], x[6], x[7]);
+  rec4[2] = neg ? make_uint4(ny[0], ny[1], ny[2], ny[3]) : make_uint4(y[0], y[1], y[2], y[3]);
+  rec4[3] = neg ? make_uint4(ny[4], ny[5], ny[6], ny[7]) : make_uint4(y[4], y[5], y[6], y[7]);
+}
+// k * (x, y) -> terms t1, t2:  |k1| * (x, +-y) and |k2| * (beta x, +-y)   (mulBeta, point_mul_glv.go:191)
+S2K_DEV void msm_store_split(uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, size_t N, size_t t1, size_t t2,
+                             const sc& k, const uint32_t x[8], const uint32_t y[8]) {
+  sc k1, k2;
+  bool neg1, neg2;
+  sc_split_glv(k, k1, neg1, k2, neg2);
+  msm_store_term(scw, ptw, N, t1, k1, x, y, neg1);
+  fe bx = fe_normalize(fe_mul(fe_from_limbs(x), fe_from_limbs(FE_BETA)));
+  msm_store_term(scw, ptw, N, t2, k2, bx.v, y, neg2);
+}
+
+// bytes -> terms: scalar reduced mod n and split, affine point words; flag per term
+// (0 identity, 1 finite, 2 malformed).  Input i becomes terms i and n + i.
 __global__ void __launch_bounds__(256)
 k_msm_parse(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
             uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag,
@@ -88,8 +125,6 @@ k_msm_parse(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __re
   uint32_t raw[8];
   load_be32(raw, scalars + i * 32);
   sc k = sc_reduce_once(raw);                     // SetBytes semantics (scalar.go:123)
-#pragma unroll
-  for (int w = 0; w < 8; ++w) scw[(size_t)w * n + i] = k.v[w];
   const uint8_t* rec = points + i * 65;
   uint8_t f = 0;
   apt a;
@@ -104,13 +139,8 @@ k_msm_parse(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __re
   }
   if (f == 2) atomicOr(status, 1u);
   flag[i] = f;
-  // points as 64-byte records [i][16 words]: the bucket pass gathers them by index, one
-  // contiguous record per lane (planes would cost 16 sparse sectors per gathered point)
-  uint4* rec4 = reinterpret_cast<uint4*>(ptw + i * 16);
-  rec4[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
-  rec4[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
-  rec4[2] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]);
-  rec4[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
+  flag[(size_t)n + i] = f;
+  if (f == 1) msm_store_split(scw, ptw, 2 * (size_t)n, i, (size_t)n + i, k, a.x.v, a.y.v);
 }
 
 // exclusive scan of `total` counters (total a multiple of 1024), three small launches:
@@ -332,7 +362,7 @@ k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ perm, 
   pt_store(buckets, nkeys, key, acc);
 }
 
-// chunk (w, j): buckets b in [32j, 32j+32) of window w -> sum_b b * B_b
+// chunk (w, j): buckets b in [CHUNK j, CHUNK j + CHUNK) of window w -> sum_b b * B_b
 __global__ void __launch_bounds__(64)
 k_msm_reduce(msm_geom g, const uint32_t* __restrict__ buckets, uint32_t* __restrict__ partial) {
   size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -347,17 +377,17 @@ k_msm_reduce(msm_geom g, const uint32_t* __restrict__ buckets, uint32_t* __restr
     run = pt29_add(run, pt_load(buckets, nkeys, base + b));
     tot = pt29_add(tot, run);
   }
-  run = pt29_add(run, pt_load(buckets, nkeys, base));       // S_j (bucket 32j has coefficient 0 in tot)
-  // tot += (32 j) * S_j :  j * S_j by double-and-add (j < 2^11), then 5 doublings
+  run = pt29_add(run, pt_load(buckets, nkeys, base));       // S_j (bucket CHUNK*j has coefficient 0 in tot)
+  // tot += (CHUNK j) * S_j :  j * S_j by double-and-add, then CHUNK_LOG2 doublings
   pt29 m = pt29_identity();
 #pragma unroll 1
-  for (int bit = 10; bit >= 0; --bit) {
+  for (int bit = 16 - CHUNK_LOG2 - 1; bit >= 0; --bit) {   // j < 2^(c - CHUNK_LOG2), c <= 16
     m = pt29_double(m);
     pt29 s = pt29_add(m, run);
     m = pt_select((j >> bit) & 1u, m, s);
   }
 #pragma unroll 1
-  for (int t = 0; t < 5; ++t) m = pt29_double(m);
+  for (int t = 0; t < CHUNK_LOG2; ++t) m = pt29_double(m);
   tot = pt29_add(tot, m);
   pt_store(partial, nslots, id, tot);
 }
@@ -417,7 +447,7 @@ struct msm_ws {
 int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   msm_geom& g = m.g;
   g.c = n >= (1u << 14) ? 16 : (n >= 256 ? 12 : 8);
-  g.nw = (256 + g.c - 1) / g.c;
+  g.nw = (SCALAR_BITS + g.c - 1) / g.c;
   g.nb = 1u << g.c;
   g.nchunk = g.nb / CHUNK;
   m.nkeys = (size_t)g.nw * g.nb;                     // multiple of 1024 for every c used
@@ -431,7 +461,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
   size_t o_status = carve(256), o_sizes = carve(3 * SIZE_BINS * 4), o_matrix = carve((mat_words + 1) * 4),
          o_count = carve((m.nkeys + 1) * 4), o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
-         o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * 8 * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
+         o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * PT_WORDS * 4),
          o_partial = carve(m.nslots * PT_WORDS * 4), o_perm = carve(m.nkeys * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
@@ -499,7 +529,8 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
 // (SHA-256(seed || i)); the seed is caller-supplied secret randomness.  The reference has
 // only the single-signature Verify (schnorr.go:221-253); the contract is
 // "batch accepts <=> every single Verify accepts", up to 2^-128.
-// Terms: [0, n) = R_i, [n, 2n) = P_i, 2n = G.
+// Terms: [0, n) = a_i * (-R_i); [n, 2n) and [2n, 3n) = the two halves of (a_i e_i) * (-P_i);
+// 3n, 3n + 1 = the two halves of (sum a_i s_i) * G.
 // ---------------------------------------------------------------------------------------
 S2K_DEV bool lift_x_words(uint32_t yw[8], const uint32_t xw[8]) {
   if (!fe_is_canonical_raw(xw)) return false;
@@ -521,7 +552,7 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
                    uint8_t* __restrict__ flag, uint32_t* __restrict__ as_out, uint32_t* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const size_t N = 2 * (size_t)n + 1;   // plane stride of the term arrays
+  const size_t N = 3 * (size_t)n + 2;   // plane stride of the term arrays
   uint32_t r_le[8], pk_le[8];
   sc s;
   load_be32(r_le, sig + i * 64);
@@ -570,40 +601,43 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
   // -a_i * R_i and -(a_i e_i) * P_i are entered as a_i * (-R_i) and (a_i e_i) * (-P_i): negating the
   // point is free, whereas n - a_i (a_i < 2^128) would put every R term into the same 0xFFFF
   // buckets of the upper windows and serialise them on single lanes.
-  uint32_t nry[8], npy[8];
-  u256_sub(nry, FE_P, ry);
+  uint32_t npy[8];
   u256_sub(npy, FE_P, py);
-#pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    scw[(size_t)w * N + i] = a.v[w];
-    scw[(size_t)w * N + n + i] = ae.v[w];
-    as_out[(size_t)w * n + i] = as.v[w];
-    ptw[i * 16 + w] = r_le[w];
-    ptw[i * 16 + 8 + w] = nry[w];
-    ptw[(n + i) * 16 + w] = pk_le[w];
-    ptw[(n + i) * 16 + 8 + w] = npy[w];
+  if (ok) {
+    msm_store_term(scw, ptw, N, i, a, r_le, ry, true);                          // a_i < 2^128 already
+    msm_store_split(scw, ptw, N, (size_t)n + i, 2 * (size_t)n + i, ae, pk_le, npy);
   }
+#pragma unroll
+  for (int w = 0; w < 8; ++w) as_out[(size_t)w * n + i] = as.v[w];
   flag[i] = ok ? 1 : 0;
-  flag[n + i] = ok ? 1 : 0;
+  flag[(size_t)n + i] = ok ? 1 : 0;
+  flag[2 * (size_t)n + i] = ok ? 1 : 0;
 }
 
-// sum of n scalars mod n (one workgroup), written as term 2n together with the point G
-__global__ void __launch_bounds__(1024)
-k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
-                  uint8_t* __restrict__ flag) {
-  __shared__ uint32_t sh[1024][8];
-  const size_t N = 2 * (size_t)n + 1;
+// sum of n scalars mod n in two launches: RLC_SUM_BLOCKS workgroups leave one partial sum each in
+// `part` (8 words each), then one workgroup folds those and writes the result as terms 3n, 3n + 1
+// with the point G (as == nullptr selects the second stage)
+constexpr uint32_t RLC_SUM_BLOCKS = 256;
+__global__ void __launch_bounds__(256)
+k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restrict__ part, uint32_t* __restrict__ scw,
+                  uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag) {
+  __shared__ uint32_t sh[256][8];
   sc acc = sc_zero();
-  for (size_t i = threadIdx.x; i < n; i += 1024) {
-    sc v;
+  if (as) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RLC_SUM_BLOCKS * 256) {
+      sc v;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v.v[w] = as[(size_t)w * n + i];
-    acc = sc_add(acc, v);
+      for (int w = 0; w < 8; ++w) v.v[w] = as[(size_t)w * n + i];
+      acc = sc_add(acc, v);
+    }
+  } else if (threadIdx.x < RLC_SUM_BLOCKS) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) acc.v[w] = part[threadIdx.x * 8 + w];
   }
 #pragma unroll
   for (int w = 0; w < 8; ++w) sh[threadIdx.x][w] = acc.v[w];
   __syncthreads();
-  for (uint32_t half = 512; half >= 1; half >>= 1) {
+  for (uint32_t half = 128; half >= 1; half >>= 1) {
     if (threadIdx.x < half) {
       sc a, b;
 #pragma unroll
@@ -617,14 +651,18 @@ k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restr
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x != 0) return;
+  if (as) {
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      scw[(size_t)w * N + 2 * (size_t)n] = sh[0][w];
-      ptw[2 * (size_t)n * 16 + w] = FE_GX[w];
-      ptw[2 * (size_t)n * 16 + 8 + w] = FE_GY[w];
-    }
-    flag[2 * (size_t)n] = 1;
+    for (int w = 0; w < 8; ++w) part[blockIdx.x * 8 + w] = sh[0][w];
+  } else {
+    const size_t N = 3 * (size_t)n + 2;
+    sc tot;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tot.v[w] = sh[0][w];
+    msm_store_split(scw, ptw, N, 3 * (size_t)n, 3 * (size_t)n + 1, tot, FE_GX, FE_GY);
+    flag[3 * (size_t)n] = 1;
+    flag[3 * (size_t)n + 1] = 1;
   }
 }
 
@@ -637,7 +675,7 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (!d_out65) return fail(ctx, S2K_ERR_ARG, "null output buffer");
   if (n && (!d_scalars || !d_points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
-  if (n > 0x3fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n > 0x1fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   if (n == 0) {   // l == 0: identity (point_mul_multi.go:37 v.Identity())
@@ -645,13 +683,13 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
     return S2K_OK;
   }
   msm_ws m;
-  int rc = msm_setup(ctx, n, 0, m);
+  int rc = msm_setup(ctx, 2 * n, 0, m);   // every input is two terms (endomorphism split)
   if (rc) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
   k_msm_parse<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, m.scw,
                                              m.ptw, m.flag, m.status);
   HIP_TRY(ctx, hipGetLastError());
-  rc = msm_core(ctx, st, n, m, (uint8_t*)d_out65);
+  rc = msm_core(ctx, st, 2 * n, m, (uint8_t*)d_out65);
   if (rc) return rc;
   // malformed point records are a caller error (the reference cannot even construct such Points)
   uint32_t h_status = 0;
@@ -688,15 +726,16 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk
     return S2K_OK;
   }
   if (!d_pk || !d_sig || (!d_msgs && (d_msg_offsets || msg_len))) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x1fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n > 0x0fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
-  const size_t N = 2 * n + 1;
+  const size_t N = 3 * n + 2;
   msm_ws m;
-  int rc = msm_setup(ctx, N, n * 8 * 4 + 256, m);
+  int rc = msm_setup(ctx, N, n * 8 * 4 + 256 + RLC_SUM_BLOCKS * 32, m);
   if (rc) return rc;
   uint32_t* seed_dev = (uint32_t*)m.aux;
-  uint32_t* as = (uint32_t*)(m.aux + 256);
+  uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
+  uint32_t* sum_part = (uint32_t*)(m.aux + 256);
   uint32_t seed_be[8];
   for (int j = 0; j < 8; ++j)
     seed_be[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) |
@@ -708,7 +747,8 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk
                                                     (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
                                                     (uint32_t)msg_len, seed_dev, m.scw, m.ptw, m.flag, as, m.status);
   HIP_TRY(ctx, hipGetLastError());
-  k_schnorr_rlc_sum<<<1, 1024, 0, st>>>((uint32_t)n, as, m.scw, m.ptw, m.flag);
+  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, as, sum_part, m.scw, m.ptw, m.flag);
+  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, nullptr, sum_part, m.scw, m.ptw, m.flag);
   HIP_TRY(ctx, hipGetLastError());
   uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
   rc = msm_core(ctx, st, N, m, d_out);
