@@ -459,6 +459,7 @@ S2K_DEV fe29 fe29_cond_negate1(const fe29& a, bool neg) {   // magnitude 1 in, <
 }
 
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
+constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 
 // MODE_ECDSA:   pub = n x 64 (X||Y), rsig = n x 32 (r);      accept iff x(R) mod n == r
 // MODE_SCHNORR: pub = n x 32 (x-only key, BIP-340), rsig = n x 64 signatures (r at offset 0);
@@ -663,17 +664,13 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       // infinity or an exceptional case along the way: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
       wl[pos] = (uint32_t)idx;
-    } else if constexpr (MODE == MODE_RECOVER) {
-      fe29 zi = fe29_inv(acc.z);
-      fe29 zi2 = fe29_sqr(zi);
-      uint32_t xw[8], yw[8];
-      fe29_to_words(xw, fe29_normalize(fe29_mul(acc.x, zi2)));
-      fe29_to_words(yw, fe29_normalize(fe29_mul(fe29_mul(acc.y, zi2), zi)));
-      uint8_t* rec = out_pts + idx * 65;
-      rec[0] = 0x04;
-      store_be32_unaligned(rec + 1, xw);
-      store_be32_unaligned(rec + 33, yw);
-      verdict = 1;
+    } else if constexpr (MODE != MODE_ECDSA) {
+      // affine epilogue (key bytes / even-y test) needs 1/Z: leave (X, Y, Z) in the lane's table
+      // column and let k_affine_finish share one inversion between 16 lanes
+      fq_store(qt, stride, idx, 0, acc.x);
+      fq_store(qt, stride, idx, 1, acc.y);
+      fq_store(qt, stride, idx, 2, acc.z);
+      verdict = VERDICT_PENDING;
     } else if constexpr (MODE == MODE_ECDSA) {
       // x(R) mod n == r  (ecdsa.go:450-465)
       uint32_t rw[8];
@@ -686,18 +683,62 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
         match = match || fe29_eq(acc.x, fe29_mul(fe29_from_words(r2), zz));
       }
       verdict = match ? 1 : 0;
-    } else {
-      // affine R: y even and x == r  (schnorr.go:451-478)
-      uint32_t rw[8];
-      load_be32(rw, rsig + idx * 64);
-      fe29 zi = fe29_inv(acc.z);
-      fe29 zi2 = fe29_sqr(zi);
-      fe29 x = fe29_mul(acc.x, zi2);
-      fe29 y = fe29_normalize(fe29_mul(fe29_mul(acc.y, zi2), zi));
-      verdict = ((y.n[0] & 1u) == 0 && fe29_eq(x, fe29_from_words(rw))) ? 1 : 0;
     }
   }
   out[idx] = verdict;
+}
+
+// ---------------------------------------------------------------------------------------
+// Affine epilogue of the BIP-340 and recovery paths.  Both need x/Z^2, y/Z^3 of the ladder's
+// result (the reference inverts per point: XBytes / IsYOdd, point_s11n.go:119-134); here one
+// thread takes FIN_M pending lanes (strided, so loads coalesce), multiplies their Z together,
+// inverts once and walks back (Montgomery's trick): 1 inversion per 16 results.
+//   MODE_SCHNORR: valid iff y even and x == r (verifySchnorrSignatureR, schnorr.go:451-478)
+//   MODE_RECOVER: writes the 65-byte key record (RecoverPublicKey, ecdsa.go:244-282)
+// Lanes that are not pending (already rejected, or queued for the complete kernel) ride along
+// with Z = 1.  Scratch: element 0 of the lane's H column takes the prefix product.
+// ---------------------------------------------------------------------------------------
+constexpr int FIN_M = 16;
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_affine_finish(uint32_t n, uint32_t T, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ qt,
+                uint32_t* __restrict__ hs, uint8_t* __restrict__ out, size_t stride, uint8_t* __restrict__ out_pts) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  fe29 acc = fe29_one();
+#pragma unroll 1
+  for (int j = 0; j < FIN_M; ++j) {
+    size_t i = (size_t)t + (size_t)j * T;
+    if (i >= n) break;
+    if (out[i] == VERDICT_PENDING) acc = fe29_mul(acc, fq_load(qt, stride, i, 2));
+    fq_store(hs, stride, i, 0, acc);
+  }
+  fe29 inv = fe29_inv(acc);
+#pragma unroll 1
+  for (int j = FIN_M - 1; j >= 0; --j) {
+    size_t i = (size_t)t + (size_t)j * T;
+    if (i >= n || out[i] != VERDICT_PENDING) continue;
+    fe29 prev = j > 0 ? fq_load(hs, stride, i - T, 0) : fe29_one();
+    fe29 zi = fe29_mul(inv, prev);                     // 1 / Z_i
+    inv = fe29_mul(inv, fq_load(qt, stride, i, 2));
+    fe29 zi2 = fe29_sqr(zi);
+    fe29 x = fe29_mul(fq_load(qt, stride, i, 0), zi2);
+    fe29 y = fe29_normalize(fe29_mul(fe29_mul(fq_load(qt, stride, i, 1), zi2), zi));
+    if constexpr (MODE == MODE_RECOVER) {
+      uint32_t xw[8], yw[8];
+      fe29_to_words(xw, fe29_normalize(x));
+      fe29_to_words(yw, y);
+      uint8_t* rec = out_pts + i * 65;
+      rec[0] = 0x04;
+      store_be32_unaligned(rec + 1, xw);
+      store_be32_unaligned(rec + 33, yw);
+      out[i] = 1;
+    } else {
+      uint32_t rw[8];
+      load_be32(rw, rsig + i * 64);
+      out[i] = ((y.n[0] & 1u) == 0 && fe29_eq(x, fe29_from_words(rw))) ? 1 : 0;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1226,6 +1267,12 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, hs, ctx->gtable,
                                                              (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65);
   HIP_TRY(ctx, hipGetLastError());
+  {
+    const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
+    k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, qt, hs, (uint8_t*)d_ok, stride,
+                                                                 (uint8_t*)d_pub65);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   k_recover_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, dig, r, s, rid, (uint8_t*)d_ok, (uint8_t*)d_pub65,
                                          ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
@@ -1288,6 +1335,11 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, hs, ctx->gtable,
                                                              (uint8_t*)d_valid, wl_count, wl, stride, nullptr);
   HIP_TRY(ctx, hipGetLastError());
+  {
+    const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
+    k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, qt, hs, (uint8_t*)d_valid, stride, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   k_schnorr_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
                                          ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
