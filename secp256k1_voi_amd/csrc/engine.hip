@@ -307,7 +307,7 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
 // ---------------------------------------------------------------------------------------
 constexpr int PREP_M = 16;
 constexpr int PREP_WORDS = 17;
-enum { PF_OK = 1, PF_NEG1 = 2, PF_NEG2 = 4, PF_EVEN1 = 8, PF_EVEN2 = 16 };
+enum { PF_OK = 1, PF_NEG1 = 2, PF_NEG2 = 4, PF_K1_B128 = 8, PF_K2_B128 = 16 };   // bit 128 of the odd half-scalars
 
 S2K_DEV void ws_store_sc26(uint32_t* __restrict__ base, size_t stride, size_t i, const sc26& v) {
 #pragma unroll
@@ -378,9 +378,9 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
     }
     sc k1, k2;
     bool neg1, neg2;
-    sc_split_glv(u2, k1, neg1, k2, neg2);
+    sc_split_glv_odd(u2, k1, neg1, k2, neg2);          // both halves odd, < 2^129
     uint32_t f = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) |
-                 ((k1.v[0] & 1u) ? 0 : PF_EVEN1) | ((k2.v[0] & 1u) ? 0 : PF_EVEN2) | ((rid & 3u) << 8);
+                 (k1.v[4] ? PF_K1_B128 : 0) | (k2.v[4] ? PF_K2_B128 : 0) | ((rid & 3u) << 8);
 #pragma unroll
     for (int w = 0; w < 8; ++w) prep[(size_t)w * stride + i] = u1.v[w];
 #pragma unroll
@@ -599,8 +599,8 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     k1.v[w] = prep[(size_t)(8 + w) * stride + idx];
     k2.v[w] = prep[(size_t)(12 + w) * stride + idx];
   }
-  k1.v[0] |= 1u;
-  k2.v[0] |= 1u;
+  k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;   // odd by construction (sc_split_glv_odd): the signed
+  k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;   // odd-digit recoding is exact, no final correction
   digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
   jpt29 acc;
   {
@@ -624,17 +624,6 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       fe29 y = fq_load(qt, stride, idx, 2 * entry + 1);
       acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
     }
-  }
-  // k' = k | 1: take the extra 1 back out of even halves
-#pragma unroll 1
-  for (int t = 0; t < 2; ++t) {
-    fe29 x = t ? fq_load(hs, stride, idx, 0) : fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 1);
-    bool sneg = !(t ? neg2 : neg1);
-    jpt29 sum = jpt29_add_affine(acc, x, fe29_cond_negate1(t0y, sneg));
-    bool even = pf & (t ? PF_EVEN2 : PF_EVEN1);
-    acc.x = fe29_select(even, acc.x, sum.x);
-    acc.y = fe29_select(even, acc.y, sum.y);
-    acc.z = fe29_select(even, acc.z, sum.z);
   }
   acc.z = fe29_mul(acc.z, fq_load(hs, stride, idx, QT_ENTRIES));   // times Z_7 * C: back on secp256k1 itself
 
@@ -793,9 +782,9 @@ k_schnorr_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __rest
   sc u2 = sc_neg(e);                                   // schnorr.go:244
   sc k1, k2;
   bool neg1, neg2;
-  sc_split_glv(u2, k1, neg1, k2, neg2);
+  sc_split_glv_odd(u2, k1, neg1, k2, neg2);
   uint32_t f = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) |
-               ((k1.v[0] & 1u) ? 0 : PF_EVEN1) | ((k2.v[0] & 1u) ? 0 : PF_EVEN2);
+               (k1.v[4] ? PF_K1_B128 : 0) | (k2.v[4] ? PF_K2_B128 : 0);
 #pragma unroll
   for (int w = 0; w < 8; ++w) prep[(size_t)w * stride + i] = s.v[w];
 #pragma unroll

@@ -248,4 +248,60 @@ S2K_DEV void sc_split_glv(const sc& k, sc& k1, bool& neg1, sc& k2, bool& neg2) {
   k2 = neg2 ? sc_neg(k2) : k2;
 }
 
+
+// ---- odd halves ------------------------------------------------------------------------------
+// The signed-odd-digit ladder of k_verify_fast wants both half-scalars odd.  Instead of forcing
+// the low bit and taking the extra +-Q back out with two more point additions, a short vector of
+// the GLV lattice {(a, b): a + b*lambda = 0 (mod n)} is added to (k1, k2): v1 = (a1, b1) has both
+// components odd, v2 = (a2, b2) is (even, odd), v2 - v1 is (odd, even).  The long component is
+// always added against the sign of the half it could overflow, so |k1|, |k2| < 2^129 (limb 4 of
+// the results is 0 or 1).  Model and bounds: tests/test_glv_odd_model.py.
+__device__ static const uint32_t GLV_A1[5] = {0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u, 0u};
+__device__ static const uint32_t GLV_NB1[5] = {0x0abfe4c3u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u, 0u};   // -b1
+__device__ static const uint32_t GLV_A2[5] = {0x9d44cfd8u, 0x57c1108du, 0xa8e2f3f6u, 0x14ca50f7u, 1u};
+__device__ static const uint32_t GLV_A2_A1[5] = {0x0abfe4c3u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u, 0u};   // a2 - a1
+__device__ static const uint32_t GLV_B2_B1[5] = {0x9d44cfd8u, 0x57c1108du, 0xa8e2f3f6u, 0x14ca50f7u, 1u};   // b2 - b1 = a1 - b1
+
+// (neg, mag) += (cneg, c) on sign-magnitude 160-bit values
+S2K_DEV void sm160_add(uint32_t mag[5], bool& neg, const uint32_t c[5], bool cneg) {
+  uint32_t sum[5], d1[5], d2[5];
+  unsigned cy = 0, bw1 = 0, bw2 = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    sum[i] = __builtin_addc(mag[i], c[i], cy, &cy);
+    d1[i] = __builtin_subc(mag[i], c[i], bw1, &bw1);     // mag - c
+    d2[i] = __builtin_subc(c[i], mag[i], bw2, &bw2);     // c - mag
+  }
+  const bool same = neg == cneg;
+  const bool mag_lt = bw1 != 0;                           // mag < c
+#pragma unroll
+  for (int i = 0; i < 5; ++i) mag[i] = same ? sum[i] : (mag_lt ? d2[i] : d1[i]);
+  neg = same ? neg : (mag_lt ? cneg : neg);
+}
+
+// splitGLV with both halves odd: k = (-1)^neg1 k1 + (-1)^neg2 k2 lambda (mod n), k1, k2 odd,
+// < 2^129 (limbs 0..4, limbs 5..7 zero)
+S2K_DEV void sc_split_glv_odd(const sc& k, sc& k1, bool& neg1, sc& k2, bool& neg2) {
+  sc_split_glv(k, k1, neg1, k2, neg2);
+  uint32_t m1[5] = {k1.v[0], k1.v[1], k1.v[2], k1.v[3], 0u}, m2[5] = {k2.v[0], k2.v[1], k2.v[2], k2.v[3], 0u};
+  const bool odd1 = m1[0] & 1u, odd2 = m2[0] & 1u;
+  if (!odd1 && !odd2) {            // + v1 = (a1, b1), b1 < 0
+    sm160_add(m1, neg1, GLV_A1, false);
+    sm160_add(m2, neg2, GLV_NB1, true);
+  } else if (odd1 && !odd2) {      // -+ v2 = (a2, b2), b2 = a1: against the sign of k1
+    const bool cneg = !neg1;
+    sm160_add(m1, neg1, GLV_A2, cneg);
+    sm160_add(m2, neg2, GLV_A1, cneg);
+  } else if (!odd1 && odd2) {      // -+ (v2 - v1): against the sign of k2
+    const bool cneg = !neg2;
+    sm160_add(m1, neg1, GLV_A2_A1, cneg);
+    sm160_add(m2, neg2, GLV_B2_B1, cneg);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    k1.v[i] = m1[i];
+    k2.v[i] = m2[i];
+  }
+}
+
 }  // namespace s2k
