@@ -203,6 +203,8 @@ int s2k_fn_split_glv_batch(s2k_ctx *ctx, size_t n, const uint8_t *k, uint8_t *k1
 
 /* ---- introspection used by the tests ------------------------------------------------ */
 /* Copies generator-table entry T_i[d] (X‖Y big-endian) to out64.  Layout: DESIGN.md §3. */
+/* window width (bits) of the resident generator tables this library was built with */
+int s2k_generator_window_bits(void);
 int s2k_debug_gtable_entry(s2k_ctx *ctx, unsigned i, unsigned d, uint8_t *out64);
 
 #ifdef __cplusplus

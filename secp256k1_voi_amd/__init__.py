@@ -126,7 +126,7 @@ EXPORTED_SYMBOLS = [
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
     "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
     "s2k_multi_scalar_mult", "s2k_multi_scalar_mult_device",
-    "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry",
+    "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry", "s2k_generator_window_bits",
 ]
 
 
@@ -388,6 +388,9 @@ class Engine:
         k1, k2 = np.zeros((n, 32), dtype=np.uint8), np.zeros((n, 32), dtype=np.uint8)
         self._check(self._lib.s2k_fn_split_glv_batch(self._h, n, k.ctypes.data, k1.ctypes.data, k2.ctypes.data))
         return k1, k2
+
+    def generator_window_bits(self) -> int:
+        return int(self._lib.s2k_generator_window_bits())
 
     def gtable_entry(self, i, d) -> bytes:
         out = np.zeros(64, dtype=np.uint8)

@@ -22,14 +22,15 @@
 using namespace s2k;
 
 // ---------------------------------------------------------------------------------------
-// Generator tables (resident in HBM, 64 MiB):  GT_WINDOWS tables of 2^16 affine points,
-//   T_0[d] = (d - sum_{i>=1} 2^(16 i)) * G          (d + K0, K0 = that constant mod n)
-//   T_i[d] = (d + 1) * 2^(16 i) * G,  i = 1..15
-// so that  u*G = sum_i T_i[(u >> 16 i) & 0xffff]  with 16 mixed additions, no doublings, no
-// zero-digit special case (no entry is the identity) and no final correction.
+// Generator tables, resident in HBM:  GT_WINDOWS = ceil(256 / GT_BITS) tables of 2^GT_BITS affine
+// points (64 MiB at 16 bits, 3 GiB at 22, 11 GiB at 24),
+//   T_0[d] = d * G - sum_{i>=1} B_i,   T_i[d] = (d + 1) * B_i,   B_i = 2^(GT_BITS i) * G,
+// so that  u*G = sum_i T_i[(u >> GT_BITS i) & mask]  with GT_WINDOWS mixed additions, no
+// doublings, no zero-digit special case (no entry is the identity) and no final correction.
 // The reference's scalarBaseMultVartime (point_mul_table.go:197-211) is the same idea with
-// 8-bit windows, sized for a CPU cache (510 KiB); with 288 GB of HBM and a 256 MiB
-// Infinity Cache the 16-bit version halves the additions.
+// 8-bit windows, sized for a CPU cache (510 KiB); HBM capacity buys wider windows here.  At 16
+// bits the even-numbered windows of the reference's table blob are entries of these tables
+// (tests/golden/gentable.json).
 // Entry layout: 16 x u32 = X limbs (little-endian words) then Y limbs, 64-byte aligned.
 // ---------------------------------------------------------------------------------------
 // k*P by MSB-first double-and-add with complete formulas (any 256-bit k, any P).
@@ -52,38 +53,58 @@ S2K_DEV pt pt_mul_generic(const uint32_t k_in[8], const apt& p) {
   return acc;
 }
 
-__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt) {
-  uint32_t id = blockIdx.x * 256 + threadIdx.x;
-  uint32_t window = id >> GT_BITS, digit = id & 0xffffu;
-  uint32_t k[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) k[i] = 0;
-  if (window == 0) {
-    unsigned c = 0;
-    k[0] = __builtin_addc(GT_K0[0], digit, c, &c);
-#pragma unroll
-    for (int i = 1; i < 8; ++i) k[i] = __builtin_addc(GT_K0[i], 0u, c, &c);
-  } else {
-    // (digit + 1) << (16 * window): a 17-bit value at a 16-bit aligned offset
-    uint32_t v = digit + 1;
-    uint32_t limb = window >> 1;
-    uint32_t lo = (window & 1) ? (v << 16) : v;
-    uint32_t hi = (window & 1) ? (v >> 16) : 0u;
-#pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) k[i] = (i == limb) ? lo : ((i == limb + 1) ? hi : 0u);
-    if (window == GT_WINDOWS - 1 && digit == 0xffffu) {
-      // (0xffff + 1) << 240 = 2^256 does not fit: use 2^256 mod n
-#pragma unroll
-      for (int i = 0; i < 8; ++i) k[i] = SC_ONE_M[i];
-    }
-  }
+// bases[i] = B_i (affine, 16 words) for i < GT_WINDOWS; bases[GT_WINDOWS] = -sum_{i>=1} B_i
+__global__ void k_gen_gtable_bases(uint32_t* __restrict__ bases) {
   apt g;
   g.x = fe_from_limbs(FE_GX);
   g.y = fe_from_limbs(FE_GY);
-  pt r = pt_mul_generic(k, g);
+  pt cur = pt_from_affine(g), sum = pt_identity();
+  for (int i = 0; i <= GT_WINDOWS; ++i) {
+    apt a;
+    if (i < GT_WINDOWS) {
+      pt_to_affine(a, cur);
+      if (i >= 1) sum = pt_add_complete(sum, cur);
+      for (int t = 0; t < GT_BITS; ++t) cur = pt_double_complete(cur);
+    } else {
+      pt_to_affine(a, pt_cond_neg(sum, true));
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      bases[i * 16 + w] = a.x.v[w];
+      bases[i * 16 + 8 + w] = a.y.v[w];
+    }
+  }
+}
+// one lane per entry: m * B_w by a GT_BITS-step double-and-add (m = digit, or digit + 1 for w >= 1)
+__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, const uint32_t* __restrict__ bases) {
+  size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t window = (uint32_t)(id >> GT_BITS), digit = (uint32_t)id & GT_MASK;
+  apt b;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    b.x.v[w] = bases[window * 16 + w];
+    b.y.v[w] = bases[window * 16 + 8 + w];
+  }
+  uint32_t m = window ? digit + 1 : digit;      // <= 2^GT_BITS
+  pt acc = pt_identity();
+#pragma unroll 1
+  for (int bit = GT_BITS; bit >= 0; --bit) {
+    acc = pt_double_complete(acc);
+    pt sum = pt_add_mixed(acc, b);
+    acc = pt_select((m >> bit) & 1u, acc, sum);
+  }
+  if (window == 0) {
+    apt c;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      c.x.v[w] = bases[GT_WINDOWS * 16 + w];
+      c.y.v[w] = bases[GT_WINDOWS * 16 + 8 + w];
+    }
+    acc = pt_add_mixed(acc, c);
+  }
   apt a;
-  pt_to_affine(a, r);
-  uint4* o = reinterpret_cast<uint4*>(gt + ((size_t)id << 4));
+  pt_to_affine(a, acc);
+  uint4* o = reinterpret_cast<uint4*>(gt + (id << 4));
   o[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
   o[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
   o[2] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]);
@@ -95,15 +116,9 @@ S2K_DEV pt pt_base_mul(const uint32_t* __restrict__ gt, const uint32_t u_in[8]) 
   uint32_t u[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) u[i] = u_in[i];
-  pt acc = pt_from_affine(gt_load(gt, 0, u[0] & 0xffffu));
+  pt acc = pt_from_affine(gt_load(gt, 0, gt_next_digit(u)));
 #pragma unroll 1
-  for (uint32_t w = 1; w < GT_WINDOWS; ++w) {
-    // shift right by 16
-#pragma unroll
-    for (int i = 0; i < 7; ++i) u[i] = (u[i] >> 16) | (u[i + 1] << 16);
-    u[7] >>= 16;
-    acc = pt_add_mixed(acc, gt_load(gt, w, u[0] & 0xffffu));
-  }
+  for (uint32_t w = 1; w < GT_WINDOWS; ++w) acc = pt_add_mixed(acc, gt_load(gt, w, gt_next_digit(u)));
   return acc;
 }
 
@@ -634,11 +649,8 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + idx];
 #pragma unroll 1
     for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
-      apt g = gt_load(gt, w, u[0] & 0xffffu);
+      apt g = gt_load(gt, w, gt_next_digit(u));
       acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
-#pragma unroll
-      for (int i = 0; i < 7; ++i) u[i] = (u[i] >> 16) | (u[i + 1] << 16);
-      u[7] >>= 16;
     }
   }
 
@@ -1157,11 +1169,15 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   ctx->device = device_index;
   hipError_t e = hipSetDevice(device_index);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->gtable, GT_ENTRIES * 64);
+  uint32_t* bases = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void**)&bases, (GT_WINDOWS + 1) * 64);
   if (e == hipSuccess) {
-    k_gen_gtable<<<(unsigned)(GT_ENTRIES / 256), 256>>>(ctx->gtable);
+    k_gen_gtable_bases<<<1, 1>>>(bases);
+    k_gen_gtable<<<(unsigned)(GT_ENTRIES / 256), 256>>>(ctx->gtable, bases);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (bases) (void)hipFree(bases);
   if (e != hipSuccess) {
     int rc = fail(nullptr, S2K_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
     if (ctx->gtable) (void)hipFree(ctx->gtable);
@@ -1496,6 +1512,8 @@ int s2k_pack_valid_device(s2k_ctx* ctx, size_t n, const void* d_valid, void* d_b
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
+
+int s2k_generator_window_bits(void) { return GT_BITS; }
 
 int s2k_debug_gtable_entry(s2k_ctx* ctx, unsigned i, unsigned d, uint8_t* out64) {
   if (!ctx || !out64) return fail(ctx, S2K_ERR_ARG, "null argument");

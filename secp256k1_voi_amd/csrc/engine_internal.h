@@ -14,14 +14,20 @@
 using namespace s2k;
 
 // ---- generator tables (layout: engine.hip) ----
-constexpr int GT_WINDOWS = 16;
-constexpr int GT_BITS = 16;
+#ifndef S2K_GT_BITS
+// Window width of the resident generator tables.  Same-box A/B on MI355X (tools/ab_gtbits.sh, ms per
+// 2^20 verifications / table size / context creation): 16 bits 9.21 / 64 MiB / 0.05 s, 20 bits 9.10 /
+// 0.8 GiB, 22 bits 9.04 / 3 GiB / 0.3 s, 24 bits 9.03 / 11 GiB / 0.9 s.
+#define S2K_GT_BITS 22
+#endif
+constexpr int GT_BITS = S2K_GT_BITS;
+constexpr int GT_WINDOWS = (256 + GT_BITS - 1) / GT_BITS;
+constexpr uint32_t GT_MASK = (1u << GT_BITS) - 1u;
 constexpr size_t GT_ENTRIES = (size_t)GT_WINDOWS << GT_BITS;
-__device__ static const uint32_t GT_K0[8] = {0xd0354141u, 0xbfd15e8bu, 0xaf47a03au, 0xbaaddce5u,
-                                             0xfffefffdu, 0xfffefffeu, 0xfffefffeu, 0xfffefffeu};
+static_assert(GT_BITS >= 8 && GT_BITS <= 24, "generator window width out of range");
 
 S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit) {
-  const uint4* p = reinterpret_cast<const uint4*>(gt + ((size_t)((window << GT_BITS) | digit) << 4));
+  const uint4* p = reinterpret_cast<const uint4*>(gt + ((((size_t)window << GT_BITS) | digit) << 4));
   uint4 a = p[0], b = p[1], c = p[2], d = p[3];
   apt r;
   r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
@@ -30,7 +36,14 @@ S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t d
   r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
   return r;
 }
-
+// next GT_BITS-wide digit of a 256-bit scalar held in u[0..7] (consumed from the bottom)
+S2K_DEV uint32_t gt_next_digit(uint32_t u[8]) {
+  uint32_t d = u[0] & GT_MASK;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) u[i] = (u[i] >> GT_BITS) | (u[i + 1] << (32 - GT_BITS));
+  u[7] >>= GT_BITS;
+  return d;
+}
 
 // big-endian 32-byte strings at arbitrary alignment (65-byte point records)
 S2K_DEV void load_be32_unaligned(uint32_t out[8], const uint8_t* p) {

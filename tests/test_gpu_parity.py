@@ -120,20 +120,27 @@ def test_fn_ops(eng, oracle):
 
 
 def test_generator_table(eng, oracle):
-    # even-numbered 8-bit windows of the reference's blob are entries of the 16-bit tables
-    d = load_golden("gentable.json")
-    hit = 0
-    for s in d["samples"]:
-        if s["i"] % 2 == 0 and s["i"] >= 2:
-            assert eng.gtable_entry(s["i"] // 2, s["j"]).hex() == s["xy"]
-            hit += 1
-    assert hit >= 10
-    S_ = sum(1 << (16 * i) for i in range(1, 16))
-    for dgt in (0, 1, 0xFFFF, 0x1234):
+    bits = eng.generator_window_bits()
+    nwin = (256 + bits - 1) // bits
+    if bits % 8 == 0:
+        # windows of the reference's 8-bit table blob that are entries of these wider tables
+        d = load_golden("gentable.json")
+        hit = 0
+        for s in d["samples"]:
+            if s["i"] % (bits // 8) == 0 and s["i"] >= bits // 8:
+                assert eng.gtable_entry(s["i"] // (bits // 8), s["j"]).hex() == s["xy"]
+                hit += 1
+        assert hit >= 5
+    S_ = sum(1 << (bits * i) for i in range(1, nwin))
+    top = (1 << (256 - bits * (nwin - 1))) - 1          # largest digit the top window can see
+    for dgt in (0, 1, (1 << bits) - 1, 0x1234):
         exp = R.mul((dgt - S_) % R.N, R.G)
         assert eng.gtable_entry(0, dgt) == b32(exp[0]) + b32(exp[1])
-        exp = R.mul((dgt + 1) << (16 * 15), R.G)
-        assert eng.gtable_entry(15, dgt) == b32(exp[0]) + b32(exp[1])
+        exp = R.mul(((dgt + 1) << bits) % R.N, R.G)
+        assert eng.gtable_entry(1, dgt) == b32(exp[0]) + b32(exp[1])
+    for dgt in (0, 1, top, top // 3):
+        exp = R.mul(((dgt + 1) << (bits * (nwin - 1))) % R.N, R.G)
+        assert eng.gtable_entry(nwin - 1, dgt) == b32(exp[0]) + b32(exp[1])
 
 
 def test_scalar_base_mult(eng, oracle):
