@@ -288,27 +288,35 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// Load balance of the bucket pass.  A lane owns a bucket and bucket sizes are Poisson
-// distributed (mean n*nw/nkeys = 16 at 2^20 terms), so in bucket order a wave waits for the
-// largest of its 64 buckets (about 28 points: 57 % efficiency).  The buckets are therefore
-// visited in order of decreasing size (a counting sort of the keys by count, SIZE_BINS bins,
-// block-aggregated so that only one global atomic per block and bin is issued): the 64 lanes
-// of a wave then own buckets of (almost) equal size, and the big ones are scheduled first.
+// Load balance of the bucket pass.  The unit of work is a SEGMENT: at most seg_len (512) consecutive
+// entries of one bucket (a bucket of up to seg_len points is one segment; a larger one - only
+// adversarial or degenerate inputs produce those at 2^20 terms - is cut into several, so no lane
+// ever adds more than seg_len points).  Bucket sizes are Poisson distributed (mean 32 at 2^20
+// inputs), so in bucket order a wave would wait for the largest of its 64 buckets; the segments
+// are therefore visited in order of decreasing size (a counting sort by size, SIZE_BINS bins,
+// block-aggregated so that only one global atomic per block and bin is issued): the 64 lanes of
+// a wave own (almost) equally full segments, and the big ones are scheduled first.
+// perm[slot] = key | segment << 20;  firstslot[key] = slot of the bucket's segment 0.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t SIZE_BINS = 256;
+constexpr uint32_t SIZE_BINS = 256, SEG_LEN_MIN = 512, KEY_BITS = 20, SEG_BITS = 32 - KEY_BITS;   // seg_len = max(SEG_LEN_MIN, terms / 2^SEG_BITS)
 S2K_DEV uint32_t size_bin(uint32_t cnt) { return SIZE_BINS - 1 - (cnt < SIZE_BINS - 1 ? cnt : SIZE_BINS - 1); }   // bin 0 = largest
+S2K_DEV uint32_t seg_count(uint32_t cnt, uint32_t seg_len) { return cnt <= seg_len ? 1u : (cnt + seg_len - 1) / seg_len; }
 
 __global__ void __launch_bounds__(256)
-k_msm_size_hist(uint32_t nkeys, const uint32_t* __restrict__ count, uint32_t* __restrict__ sizehist) {
+k_msm_size_hist(uint32_t nkeys, uint32_t seg_len, const uint32_t* __restrict__ count, uint32_t* __restrict__ sizehist) {
   __shared__ uint32_t h[SIZE_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
   size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (key < nkeys) atomicAdd(&h[size_bin(count[key])], 1u);
+  if (key < nkeys) {
+    uint32_t cnt = count[key];
+    atomicAdd(&h[size_bin(cnt)], seg_count(cnt, seg_len));
+  }
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&sizehist[threadIdx.x], h[threadIdx.x]);
 }
-// exclusive scan of the SIZE_BINS totals (one workgroup); also clears the cursors
+// exclusive scan of the SIZE_BINS totals (one workgroup); also clears the cursors and leaves the
+// number of segments in sizecur[SIZE_BINS]
 __global__ void __launch_bounds__(256) k_msm_size_scan(const uint32_t* __restrict__ sizehist, uint32_t* __restrict__ sizebase,
                                                        uint32_t* __restrict__ sizecur) {
   __shared__ uint32_t part[SIZE_BINS];
@@ -323,32 +331,43 @@ __global__ void __launch_bounds__(256) k_msm_size_scan(const uint32_t* __restric
   }
   sizebase[t] = part[t] - mine;
   sizecur[t] = 0;
+  if (t == SIZE_BINS - 1) sizecur[SIZE_BINS] = part[t];
 }
 __global__ void __launch_bounds__(256)
-k_msm_size_scatter(uint32_t nkeys, const uint32_t* __restrict__ count, const uint32_t* __restrict__ sizebase,
-                   uint32_t* __restrict__ sizecur, uint32_t* __restrict__ perm) {
+k_msm_size_scatter(uint32_t nkeys, uint32_t seg_len, const uint32_t* __restrict__ count, const uint32_t* __restrict__ sizebase,
+                   uint32_t* __restrict__ sizecur, uint32_t* __restrict__ perm, uint32_t* __restrict__ firstslot) {
   __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
   size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
-  uint32_t bin = 0, rank = 0;
+  uint32_t bin = 0, rank = 0, nseg = 0;
   if (key < nkeys) {
-    bin = size_bin(count[key]);
-    rank = atomicAdd(&h[bin], 1u);
+    uint32_t cnt = count[key];
+    bin = size_bin(cnt);
+    nseg = seg_count(cnt, seg_len);
+    rank = atomicAdd(&h[bin], nseg);
   }
   __syncthreads();
   if (h[threadIdx.x]) base[threadIdx.x] = sizebase[threadIdx.x] + atomicAdd(&sizecur[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
-  if (key < nkeys) perm[base[bin] + rank] = (uint32_t)key;
+  if (key < nkeys) {
+    uint32_t slot = base[bin] + rank;
+    firstslot[key] = slot;
+    for (uint32_t sgm = 0; sgm < nseg; ++sgm) perm[slot + sgm] = (uint32_t)key | (sgm << KEY_BITS);
+  }
 }
 
+// one lane per segment: complete mixed additions of its points -> segsum[slot]
 __global__ void __launch_bounds__(256)
-k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ offset,
-                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw, uint32_t* __restrict__ buckets) {
+k_msm_accumulate(uint32_t cap, uint32_t seg_len, const uint32_t* __restrict__ nseg_total, const uint32_t* __restrict__ perm,
+                 const uint32_t* __restrict__ offset, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
+                 uint32_t* __restrict__ segsum) {
   size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (slot >= nkeys) return;
-  size_t key = perm[slot];
-  uint32_t lo = offset[key], hi = offset[key + 1];
+  if (slot >= *nseg_total) return;
+  uint32_t pk = perm[slot];
+  size_t key = pk & ((1u << KEY_BITS) - 1u);
+  uint32_t lo = offset[key] + (pk >> KEY_BITS) * seg_len, end = offset[key + 1];
+  uint32_t hi = end - lo > seg_len ? lo + seg_len : end;
   pt29 acc = pt29_identity();
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
@@ -359,25 +378,34 @@ k_msm_accumulate(uint32_t nkeys, uint32_t n, const uint32_t* __restrict__ perm, 
     uint32_t yw[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
     acc = pt29_add_mixed(acc, fe29_from_words(xw), fe29_from_words(yw));
   }
-  pt_store(buckets, nkeys, key, acc);
+  pt_store(segsum, cap, slot, acc);
+}
+// the bucket of `key`: its segment sums added up (one segment for every ordinary bucket)
+S2K_DEV pt29 bucket_load(const uint32_t* __restrict__ segsum, size_t cap, uint32_t seg_len, const uint32_t* __restrict__ count,
+                         const uint32_t* __restrict__ firstslot, size_t key) {
+  uint32_t slot = firstslot[key], nseg = seg_count(count[key], seg_len);
+  pt29 r = pt_load(segsum, cap, slot);
+#pragma unroll 1
+  for (uint32_t sgm = 1; sgm < nseg; ++sgm) r = pt29_add(r, pt_load(segsum, cap, slot + sgm));
+  return r;
 }
 
 // chunk (w, j): buckets b in [CHUNK j, CHUNK j + CHUNK) of window w -> sum_b b * B_b
 __global__ void __launch_bounds__(64)
-k_msm_reduce(msm_geom g, const uint32_t* __restrict__ buckets, uint32_t* __restrict__ partial) {
+k_msm_reduce(msm_geom g, const uint32_t* __restrict__ segsum, size_t cap, uint32_t seg_len, const uint32_t* __restrict__ count,
+             const uint32_t* __restrict__ firstslot, uint32_t* __restrict__ partial) {
   size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
   size_t nslots = (size_t)g.nw * g.nchunk;
   if (id >= nslots) return;
   uint32_t w = (uint32_t)(id / g.nchunk), j = (uint32_t)(id % g.nchunk);
-  size_t nkeys = (size_t)g.nw * g.nb;
   size_t base = (size_t)w * g.nb + (size_t)j * CHUNK;
   pt29 run = pt29_identity(), tot = pt29_identity();
 #pragma unroll 1
   for (int b = CHUNK - 1; b >= 1; --b) {
-    run = pt29_add(run, pt_load(buckets, nkeys, base + b));
+    run = pt29_add(run, bucket_load(segsum, cap, seg_len, count, firstslot, base + b));
     tot = pt29_add(tot, run);
   }
-  run = pt29_add(run, pt_load(buckets, nkeys, base));       // S_j (bucket CHUNK*j has coefficient 0 in tot)
+  run = pt29_add(run, bucket_load(segsum, cap, seg_len, count, firstslot, base));       // S_j (bucket CHUNK*j has coefficient 0 in tot)
   // tot += (CHUNK j) * S_j :  j * S_j by double-and-add, then CHUNK_LOG2 doublings
   pt29 m = pt29_identity();
 #pragma unroll 1
@@ -435,7 +463,9 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *count, *matrix, *offset, *bsum, *scw, *ptw, *list, *buckets, *partial, *perm, *sizes;
+  uint32_t *status, *count, *matrix, *offset, *bsum, *scw, *ptw, *list, *segsum, *partial, *perm, *firstslot, *sizes;
+  size_t segcap;       // capacity in segments: nkeys + pairs / seg_len, rounded up
+  uint32_t seg_len;
   uint2* pairs;
   uint32_t ncoarse, nsortblk, nblk_pad;
   uint8_t* flag;
@@ -454,16 +484,18 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.nslots = (size_t)g.nw * g.nchunk;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  // status word, then 3 x SIZE_BINS words (size histogram, bases, cursors), zeroed with the counters
+  m.seg_len = (uint32_t)((n >> SEG_BITS) + 1 > SEG_LEN_MIN ? (n >> SEG_BITS) + 1 : SEG_LEN_MIN);   // at most 2^SEG_BITS segments per bucket
+  m.segcap = align_up(m.nkeys + (n * (size_t)g.nw) / m.seg_len + 1, 256);
+  // status word, then 3 x SIZE_BINS + 1 words (size histogram, bases, cursors, segment total), zeroed with the counters
   m.ncoarse = (uint32_t)(m.nkeys >> FINE_BITS);
   m.nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);
   m.nblk_pad = (m.nsortblk + 1 + 1023) / 1024 * 1024;   // one spare column: the scan total lands in it
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
-  size_t o_status = carve(256), o_sizes = carve(3 * SIZE_BINS * 4), o_matrix = carve((mat_words + 1) * 4),
+  size_t o_status = carve(256), o_sizes = carve((3 * SIZE_BINS + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
          o_count = carve((m.nkeys + 1) * 4), o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
          o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
-         o_list = carve(n * (size_t)g.nw * 4), o_buckets = carve(m.nkeys * PT_WORDS * 4),
-         o_partial = carve(m.nslots * PT_WORDS * 4), o_perm = carve(m.nkeys * 4), o_aux = carve(aux_bytes);
+         o_list = carve(n * (size_t)g.nw * 4), o_segsum = carve(m.segcap * PT_WORDS * 4),
+         o_partial = carve(m.nslots * PT_WORDS * 4), o_perm = carve(m.segcap * 4), o_firstslot = carve(m.nkeys * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
@@ -477,7 +509,8 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.ptw = (uint32_t*)(ws + o_ptw);
   m.flag = ws + o_flag;
   m.list = (uint32_t*)(ws + o_list);
-  m.buckets = (uint32_t*)(ws + o_buckets);
+  m.segsum = (uint32_t*)(ws + o_segsum);
+  m.firstslot = (uint32_t*)(ws + o_firstslot);
   m.partial = (uint32_t*)(ws + o_partial);
   m.perm = (uint32_t*)(ws + o_perm);
   m.sizes = (uint32_t*)(ws + o_sizes);
@@ -506,14 +539,15 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
                                                       m.offset, m.list);
   HIP_TRY(ctx, hipGetLastError());
   uint32_t *sizehist = m.sizes, *sizebase = m.sizes + SIZE_BINS, *sizecur = m.sizes + 2 * SIZE_BINS;
-  k_msm_size_hist<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.count, sizehist);
+  k_msm_size_hist<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.seg_len, m.count, sizehist);
   k_msm_size_scan<<<1, SIZE_BINS, 0, st>>>(sizehist, sizebase, sizecur);
-  k_msm_size_scatter<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.count, sizebase, sizecur, m.perm);
+  k_msm_size_scatter<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.seg_len, m.count, sizebase, sizecur, m.perm,
+                                                          m.firstslot);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_accumulate<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, (uint32_t)n, m.perm, m.offset, m.list, m.ptw,
-                                                        m.buckets);
+  k_msm_accumulate<<<blocks_for(m.segcap), 256, 0, st>>>((uint32_t)m.segcap, m.seg_len, sizecur + SIZE_BINS, m.perm, m.offset, m.list,
+                                                         m.ptw, m.segsum);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_reduce<<<(unsigned)((m.nslots + 63) / 64), 64, 0, st>>>(g, m.buckets, m.partial);
+  k_msm_reduce<<<(unsigned)((m.nslots + 63) / 64), 64, 0, st>>>(g, m.segsum, m.segcap, m.seg_len, m.count, m.firstslot, m.partial);
   HIP_TRY(ctx, hipGetLastError());
   k_msm_tree<<<g.nw, 1024, 0, st>>>(g, m.partial);
   HIP_TRY(ctx, hipGetLastError());

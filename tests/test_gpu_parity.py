@@ -486,6 +486,30 @@ def test_msm_large_known_dlog(eng, oracle, log2n):
     assert eng.multi_scalar_mult(k, pts) == oracle.scalar_base_mult_vartime(b32(total))
 
 
+def test_msm_oversized_buckets(eng, oracle):
+    """Inputs engineered to fill single buckets: every scalar equal (one bucket per window takes all
+    terms), or only two distinct scalars.  Buckets larger than a segment are cut across lanes; the
+    result must not change."""
+    n = 1 << 16
+    rng = np.random.default_rng(99)
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    d[:, 0] &= 0x7F
+    pts = eng.scalar_base_mult_batch(d)
+    di = [int.from_bytes(bytes(x), "big") for x in d]
+    for scal in (0x1234567890ABCDEF << 100 | 0x77, R.N - 1, 1):
+        k = np.frombuffer(b32(scal) * n, dtype=np.uint8).reshape(n, 32)
+        total = scal * sum(di) % R.N
+        assert eng.multi_scalar_mult(k, pts) == oracle.scalar_base_mult_vartime(b32(total))
+    two = [0xDEADBEEF << 200 | 5, 0xC0FFEE << 64 | 9]
+    k = np.frombuffer(b"".join(b32(two[i & 1]) for i in range(n)), dtype=np.uint8).reshape(n, 32)
+    total = sum(two[i & 1] * di[i] for i in range(n)) % R.N
+    assert eng.multi_scalar_mult(k, pts) == oracle.scalar_base_mult_vartime(b32(total))
+    # the same point 2^16 times with equal scalars: doublings inside one bucket
+    same = np.repeat(pts[:1], n, axis=0)
+    k = np.frombuffer(b32(7) * n, dtype=np.uint8).reshape(n, 32)
+    assert eng.multi_scalar_mult(k, same) == oracle.scalar_base_mult_vartime(b32(7 * n * di[0] % R.N))
+
+
 # ---- BIP-340 whole-batch verification as one MSM (BASELINE config 4) ---------------------------
 def test_schnorr_rlc_batch(eng, oracle):
     rnd = random.Random(71)
