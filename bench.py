@@ -65,7 +65,24 @@ def cpu_baseline(pub, digest, r, s, budget_s=15.0):
             best_th, best = cores, rt
     m = int(min(r.shape[0], max(1024, best * budget_s)))
     value = rate(m, best_th)
+
+    # BASELINE config 1: 1024 DER-encoded signatures through the single-signature entry point
+    # (secec.PublicKey.Verify, parse cost included), one thread
+    def der_int(b):
+        b = bytes(b).lstrip(b"\0") or b"\0"
+        if b[0] & 0x80:
+            b = b"\0" + b
+        return b"\x02" + bytes([len(b)]) + b
+
+    t0 = time.perf_counter()
+    for i in range(m1):
+        body = der_int(r[i]) + der_int(s[i])
+        ok = oracle.ecdsa_verify_asn1(b"\x04" + bytes(pub[i]), bytes(digest[i]), b"\x30" + bytes([len(body)]) + body)
+        assert ok == 1
+    config1 = m1 / (time.perf_counter() - t0)
     return {"value": value, "unit": "verifications/s", "cores": best_th, "kind": "port",
+            "config1_der_single_thread": {"value": config1, "unit": "verifications/s", "sample": f"{m1} DER signatures, "
+                                          "single-signature verify incl. parsing"},
             "sample": f"first {m} signatures of the rank-0 batch, {best_th} threads (best of 1..{cores} host cores, "
                       f"static split); single-thread rate {single:.0f}/s",
             "reference_toolchain": "go: " + ("present" if shutil.which("go") else "absent - reference Go path not timed")}
