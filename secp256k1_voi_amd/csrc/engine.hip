@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, c
   o[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
 }
 
-// u*G for a plain scalar u (any 256-bit value): 16 table additions
+// u*G for a plain scalar u (any 256-bit value): GT_WINDOWS table additions
 S2K_DEV pt pt_base_mul(const uint32_t* __restrict__ gt, const uint32_t u_in[8]) {
   uint32_t u[8];
 #pragma unroll
@@ -123,7 +123,8 @@ S2K_DEV pt pt_base_mul(const uint32_t* __restrict__ gt, const uint32_t u_in[8]) 
 }
 
 // ---------------------------------------------------------------------------------------
-// k*Q for a per-lane point: GLV split (point_mul_glv.go:203-254), then one fixed-window
+// k*Q for a per-lane point on the COMPLETE path (8x32 field, RCB formulas; the fast path is
+// k_verify_fast below): GLV split (point_mul_glv.go:203-254), then one fixed-window
 // ladder over both 128-bit halves with signed odd digits:
 //   k' = k | 1 = sum_{i=0..32} d_i 16^i,  d_i = 2*((k' >> (4i+1)) & 15) - 15 for i < 32, d_32 = 1
 // every digit is odd and non-zero, so the per-lane table holds only the 8 odd multiples
