@@ -216,13 +216,16 @@ def main():
                          "note": "path is integer-VALU bound; HBM fraction reported as the contract asks",
                          "valu": valu},
         }
-        # host-buffer entry point (hipMalloc + H2D + kernels + D2H); reported, never `value`
+        # host-buffer entry point (chunked H2D overlapped with the kernels, D2H); reported, never `value`.
+        # One untimed call first: it creates the context's staging buffers and streams.
+        eng.ecdsa_verify_batch(pub, digest, r, s)
         t1 = time.perf_counter()
         hv = eng.ecdsa_verify_batch(pub, digest, r, s)
         dt_host = time.perf_counter() - t1
         assert int(hv.sum()) == n
         line["pcie_inclusive"] = {"value": n / dt_host, "unit": "verifications/s",
-                                  "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch" % args.batch_log2}
+                                  "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch, "
+                                          "second call (staging buffers exist)" % args.batch_log2}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pub, digest, r, s)
         print(json.dumps(line))

@@ -1195,6 +1195,11 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->gtable) (void)hipFree(ctx->gtable);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
+  if (ctx->io) (void)hipFree(ctx->io);
+  for (hipEvent_t e : ctx->ev_copied)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+  if (ctx->s_comp) (void)hipStreamDestroy(ctx->s_comp);
   delete ctx;
 }
 
@@ -1352,22 +1357,53 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   return S2K_OK;
 }
 
+// Host-buffer entry point.  The batch is cut into chunks that are whole rounds of k_verify_fast
+// on this device (3 waves/SIMD x 4 SIMDs x CUs x 64 lanes; two rounds per chunk), and the
+// host-to-device copy of chunk j+1 runs on its own stream while chunk j is verified: for pageable
+// callers' memory the copy costs about half as much as the verification, so most of it hides.
+// Staging buffers and streams live in the context (no hipMalloc per call).
 int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
                            const uint8_t* s, uint32_t flags, uint8_t* valid) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (n == 0) return S2K_OK;
   if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dev_buf dp, dd, dr, ds, dv;
-  HIP_TRY(ctx, dp.upload(pub, n * 64));
-  HIP_TRY(ctx, dd.upload(dig, n * 32));
-  HIP_TRY(ctx, dr.upload(r, n * 32));
-  HIP_TRY(ctx, ds.upload(s, n * 32));
-  HIP_TRY(ctx, dv.alloc(n));
-  int rc = s2k_ecdsa_verify_batch_device(ctx, n, dp.p, dd.p, dr.p, ds.p, flags, dv.p, nullptr);
+  if (!ctx->s_copy) {
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  int rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, n * 161 + 1024);
   if (rc) return rc;
-  HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(valid, dv.p, n, hipMemcpyDeviceToHost));
+  uint8_t* d_pub = (uint8_t*)ctx->io;
+  uint8_t* d_dig = d_pub + n * 64;
+  uint8_t* d_r = d_dig + n * 32;
+  uint8_t* d_s = d_r + n * 32;
+  uint8_t* d_valid = d_s + n * 32;
+  const size_t round = (size_t)S2K_FAST_WAVES * 4 * (size_t)ctx->cu_count * 64;
+  const size_t chunk = n > 3 * round ? 2 * round : n;     // small batches: one shot
+  int k = 0;
+  for (size_t lo = 0; lo < n; lo += chunk, ++k) {
+    const size_t cnt = n - lo < chunk ? n - lo : chunk;
+    // the event of two chunks ago has been waited on by s_comp (in stream order) before it is re-recorded
+    HIP_TRY(ctx, hipMemcpyAsync(d_pub + lo * 64, pub + lo * 64, cnt * 64, hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dig + lo * 32, dig + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipMemcpyAsync(d_r + lo * 32, r + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipMemcpyAsync(d_s + lo * 32, s + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_copied[k & 1], ctx->s_copy));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comp, ctx->ev_copied[k & 1], 0));
+    rc = s2k_ecdsa_verify_batch_device(ctx, cnt, d_pub + lo * 64, d_dig + lo * 32, d_r + lo * 32, d_s + lo * 32, flags,
+                                       d_valid + lo, ctx->s_comp);
+    if (rc) {
+      (void)hipDeviceSynchronize();
+      return rc;
+    }
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, ctx->s_comp));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
   return S2K_OK;
 }
 

@@ -69,6 +69,13 @@ struct s2k_ctx {
   size_t ws_bytes = 0;
   void* msm_ws = nullptr;       // workspace of the multi-scalar multiplication
   size_t msm_ws_bytes = 0;
+  // host-buffer entry point: device staging for inputs / verdicts, a copy stream and a compute
+  // stream, events that chain them (created on first use)
+  void* io = nullptr;
+  size_t io_bytes = 0;
+  hipStream_t s_copy = nullptr, s_comp = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr};
+  int cu_count = 0;
   char err[512] = {0};
 };
 
