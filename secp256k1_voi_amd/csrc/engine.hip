@@ -315,13 +315,19 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
 
 // ---------------------------------------------------------------------------------------
 // Fast path, kernel 1: scalar preparation with batched inversion.
-// Each thread owns PREP_M signatures (i = t, t+T, t+2T, ...): one Fermat inversion
-// (scalar_invert.go:11, 253 S + 40 M) is shared by PREP_M signatures through Montgomery's
-// trick, 3 extra multiplications each, instead of one inversion per signature as in
-// verify (ecdsa.go:428).  Out per signature (word-major, coalesced):
+// Each thread owns PREP_M signatures (i = t, t+T, t+2T, ...): one inversion mod n (safegcd
+// division steps, modinv30.h; the reference's Scalar.Invert is a Fermat chain,
+// scalar_invert.go:11) is shared by PREP_M signatures through Montgomery's trick, 3 extra
+// multiplications each, instead of one inversion per signature as in verify (ecdsa.go:428).
+// PREP_M trades inversions against waves: measured at 2^20 (tools/ab_prep.sh) 2: 413, 3: 340,
+// 4: 285, 6: 276, 8: 299, 16: 356, 32: 450 us (with the Fermat chain: 16: 466 us).
+// Out per signature (word-major, coalesced):
 //   u1 (8 words), |k1|, |k2| (4 words each; u2 = +-k1 +- k2*lambda), flag word.
 // ---------------------------------------------------------------------------------------
-constexpr int PREP_M = 16;
+#ifndef S2K_PREP_M
+#define S2K_PREP_M 6
+#endif
+constexpr int PREP_M = S2K_PREP_M;
 constexpr int PREP_WORDS = 17;
 enum { PF_OK = 1, PF_NEG1 = 2, PF_NEG2 = 4, PF_K1_B128 = 8, PF_K2_B128 = 16 };   // bit 128 of the odd half-scalars
 
