@@ -33,26 +33,6 @@ using namespace s2k;
 // (tests/golden/gentable.json).
 // Entry layout: 16 x u32 = X limbs (little-endian words) then Y limbs, 64-byte aligned.
 // ---------------------------------------------------------------------------------------
-// k*P by MSB-first double-and-add with complete formulas (any 256-bit k, any P).
-// Used to build the tables and by the generic point entry points; not on the hot path.
-S2K_DEV pt pt_mul_generic(const uint32_t k_in[8], const apt& p) {
-  uint32_t k[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) k[i] = k_in[i];
-  pt acc = pt_identity();
-#pragma unroll 1
-  for (int bit = 0; bit < 256; ++bit) {
-    acc = pt_double_complete(acc);
-    bool b = (k[7] >> 31) != 0;
-    pt sum = pt_add_mixed(acc, p);
-    acc = pt_select(b, acc, sum);
-#pragma unroll
-    for (int i = 7; i > 0; --i) k[i] = (k[i] << 1) | (k[i - 1] >> 31);
-    k[0] <<= 1;
-  }
-  return acc;
-}
-
 // bases[i] = B_i (affine, 16 words) for i < GT_WINDOWS; bases[GT_WINDOWS] = -sum_{i>=1} B_i
 __global__ void k_gen_gtable_bases(uint32_t* __restrict__ bases) {
   apt g;
