@@ -259,7 +259,7 @@ class Engine:
         return out
 
     def schnorr_batch_verify_rlc(self, pk32, msgs, sig64, seed32: bytes | None = None) -> bool:
-        """True iff every (key, message, signature) triple verifies — one MSM of 2n+1 terms."""
+        """True iff every (key, message, signature) triple verifies — one MSM of 3n+2 terms."""
         pk32 = _arr(pk32, 32)
         n = pk32.shape[0]
         sig64 = _arr(sig64, 64, n)
@@ -283,6 +283,16 @@ class Engine:
                                                                m.shape[1] if n else 0, sig64.ctypes.data,
                                                                seed.ctypes.data, C.byref(res)))
         return bool(res.value)
+
+    def schnorr_verify_batch_auto(self, pk32, msgs, sig64, seed32: bytes | None = None) -> np.ndarray:
+        """Valid bits like schnorr_verify_batch, at the cost of the whole-batch check when (as usual)
+        everything verifies: one random-linear-combination MSM first, per-signature verification only
+        if that rejects (it says that some signature fails, not which)."""
+        pk32 = _arr(pk32, 32)
+        n = pk32.shape[0]
+        if n and self.schnorr_batch_verify_rlc(pk32, msgs, sig64, seed32):
+            return np.ones(n, dtype=np.uint8)
+        return self.schnorr_verify_batch(pk32, msgs, sig64)
 
     def ecdsa_recover_batch(self, digest32, r, s, recovery_id, force_complete: bool = False):
         """RecoverPublicKey over a batch: returns (pub65 (n,65) uint8, ok (n,) uint8)."""

@@ -555,6 +555,23 @@ def test_schnorr_rlc_batch(eng, oracle):
     assert eng.schnorr_batch_verify_rlc([], [], [], seed) is True
 
 
+def test_schnorr_auto_falls_back_to_bisection(eng, oracle):
+    rnd = random.Random(123)
+    n = 300
+    sk = [rnd.randrange(1, R.N) for _ in range(n)]
+    msgs = [rnd.randbytes(32) for _ in range(n)]
+    pks = [R.b32(R.mul(d, R.G)[0]) for d in sk]
+    sigs = [R.schnorr_sign(d, m, bytes(32)) for d, m in zip(sk, msgs)]
+    assert eng.schnorr_verify_batch_auto(pks, msgs, sigs, b"\x01" * 32).all()
+    bad = list(sigs)
+    for i in (7, 123):
+        bad[i] = bad[i][:40] + bytes([bad[i][40] ^ 0x10]) + bad[i][41:]
+    v = eng.schnorr_verify_batch_auto(pks, msgs, bad, b"\x01" * 32)
+    exp = np.ones(n, dtype=np.uint8)
+    exp[[7, 123]] = 0
+    assert (v == exp).all()
+
+
 def test_pack_valid_bitmap(eng):
     import torch
     from secp256k1_voi_amd.sharding import gather_valid_device, unpack_bitmap
