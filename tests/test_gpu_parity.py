@@ -277,6 +277,42 @@ def test_ecdsa_random_batches(eng, oracle, n, seed):
             assert plain[i] == 0, kind
 
 
+def test_ecdsa_structured_fuzz(eng, oracle):
+    """Differential run on inputs built from boundary values: every field of a valid signature is
+    replaced, with some probability, by a value from a small pool (0, 1, n-1, n, n+1, p-1, p, 2^256-1,
+    n-s, r+n, the generator's coordinates, ...); engine and oracle must agree on all verdicts, with
+    and without the low-s rule."""
+    from workload import make_ecdsa_batch
+    n = 6000
+    w = make_ecdsa_batch(oracle, n, seed=77, n_keys=32, corrupt_every=0, low_s=False)
+    rnd = random.Random(78)
+    P_ = 2**256 - 2**32 - 977
+    pool = [0, 1, 2, R.N - 1, R.N, R.N + 1, R.N - 2, (R.N - 1) // 2, (R.N + 1) // 2, P_ - 1, P_, P_ + 1, 2**256 - 1,
+            P_ - R.N, P_ - R.N - 1, P_ - R.N + 1, 2**128, 2**128 - 1, R.G[0], R.G[1], P_ - R.G[1]]
+    pub, dig, rr, ss = (w[k].copy() for k in ("pub", "digest", "r", "s"))
+    for i in range(n):
+        r_i = int.from_bytes(bytes(rr[i]), "big")
+        s_i = int.from_bytes(bytes(ss[i]), "big")
+        extra = [(R.N - s_i) % R.N, r_i + R.N if r_i + R.N < 2**256 else r_i, s_i ^ 1, r_i ^ 1]
+        if rnd.random() < 0.25:
+            rr[i] = np.frombuffer(b32(rnd.choice(pool + extra) % 2**256), dtype=np.uint8)
+        if rnd.random() < 0.25:
+            ss[i] = np.frombuffer(b32(rnd.choice(pool + extra) % 2**256), dtype=np.uint8)
+        if rnd.random() < 0.15:
+            dig[i] = np.frombuffer(b32(rnd.choice(pool)), dtype=np.uint8)
+        if rnd.random() < 0.1:
+            pub[i, :32] = np.frombuffer(b32(rnd.choice(pool)), dtype=np.uint8)
+        if rnd.random() < 0.1:
+            pub[i, 32:] = np.frombuffer(b32(rnd.choice(pool)), dtype=np.uint8)
+        if rnd.random() < 0.05:      # the generator or its negative as the key
+            pub[i] = np.frombuffer(b32(R.G[0]) + b32(rnd.choice([R.G[1], P_ - R.G[1]])), dtype=np.uint8)
+    for rm in (False, True):
+        got = eng.ecdsa_verify_batch(pub, dig, rr, ss, reject_malleable=rm)
+        exp = oracle.ecdsa_verify_batch(pub, dig, rr, ss, reject_malleable=rm, nthreads=8)
+        assert (got == exp).all(), np.nonzero(got != exp)[0][:10]
+    assert 0 < int(got.sum()) < n
+
+
 def test_ecdsa_empty_and_errors(eng):
     assert eng.ecdsa_verify_batch(b"", b"", b"", b"").size == 0
     with pytest.raises(ValueError):
