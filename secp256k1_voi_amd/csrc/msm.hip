@@ -433,17 +433,57 @@ __global__ void __launch_bounds__(1024) k_msm_tree(msm_geom g, uint32_t* __restr
   }
 }
 
-// Horner over the window sums, then the 65-byte record
-__global__ void k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65) {
+// ---------------------------------------------------------------------------------------
+// Horner over the window sums, then the 65-byte record.  The 128 - c doublings are a serial
+// chain, and a lone wave issues dependent multiply-adds at half rate, so the doubling is spread
+// over the lanes of the (single) wave: all lanes hold the same point; in each of the two layers of
+// Algorithm 9 lane L (mod 4) computes a different product of it (operands selected by lane,
+// one fe29_mul / one fused multiply-add executed by the whole wave), and the results are
+// handed round with v_readlane (a lane's value as a wave-uniform scalar).  305 dependent
+// multiply-adds per doubling instead of 748.
+// ---------------------------------------------------------------------------------------
+S2K_DEV fe29 lane_bcast(const fe29& v, int lane) {
+  fe29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.n[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.n[i], lane);
+  return r;
+}
+S2K_DEV fe29 sel4(uint32_t id, const fe29& a0, const fe29& a1, const fe29& a2, const fe29& a3) {
+  return fe29_select(id >= 2, fe29_select(id == 1, a0, a1), fe29_select(id == 3, a2, a3));
+}
+// 2p, all lanes of the wave holding the same p (pt29_double spread over lanes 0..3 mod 4)
+S2K_DEV pt29 pt29_double_wave(const pt29& p) {
+  const uint32_t id = threadIdx.x & 3u;
+  // layer 1: Y^2 | Y Z | Z^2 | X Y
+  fe29 P = fe29_mul(sel4(id, p.y, p.y, p.z, p.x), sel4(id, p.y, p.z, p.z, p.y));
+  fe29 t0 = lane_bcast(P, 0), t1 = lane_bcast(P, 1), zz = lane_bcast(P, 2), xy = lane_bcast(P, 3);
+  fe29 z3 = fe29_mul_int(fe29_normalize_weak(fe29_mul_int(t0, 4)), 2);                  // [2]   8 Y^2
+  fe29 t2 = fe29_mul_small_norm(zz, 21);                                                // [1]   b3 Z^2
+  fe29 y3 = fe29_add(t0, t2);                                                           // [2]
+  fe29 t0m = fe29_normalize_weak(fe29_add(t0, fe29_negate(fe29_mul_small_norm(zz, 63), 1)));   // [1]   Y^2 - 3 b3 Z^2
+  // layer 2: Y3 = t2 z3 + t0m y3 | Z3 = t1 z3 | X3 = (2 t0m) (X Y)
+  const fe29 zero = fe29_zero();
+  fe29 Q = fe29_mul_add_mul(sel4(id, t2, t1, fe29_mul_int(t0m, 2), zero), sel4(id, z3, z3, xy, zero),
+                            sel4(id, t0m, zero, zero, zero), sel4(id, y3, zero, zero, zero));
+  pt29 r;
+  r.y = lane_bcast(Q, 0);
+  r.z = lane_bcast(Q, 1);
+  r.x = lane_bcast(Q, 2);
+  return r;
+}
+
+// one wave; every lane runs the same Horner recurrence, lane 0 writes the result
+__global__ void __launch_bounds__(64) k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65) {
   // out65: the 65-byte record of the sum (all zero for the identity)
   size_t nslots = (size_t)g.nw * g.nchunk;
   pt29 acc = pt_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk);
 #pragma unroll 1
   for (int w = (int)g.nw - 2; w >= 0; --w) {
 #pragma unroll 1
-    for (uint32_t t = 0; t < g.c; ++t) acc = pt29_double(acc);
+    for (uint32_t t = 0; t < g.c; ++t) acc = pt29_double_wave(acc);
     acc = pt29_add(acc, pt_load(partial, nslots, (size_t)w * g.nchunk));
   }
+  if (threadIdx.x != 0) return;
   if (fe29_is_zero(acc.z)) {
     for (int i = 0; i < 65; ++i) out65[i] = 0;
     return;
@@ -551,7 +591,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   HIP_TRY(ctx, hipGetLastError());
   k_msm_tree<<<g.nw, 1024, 0, st>>>(g, m.partial);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_final<<<1, 1, 0, st>>>(g, m.partial, d_out65);
+  k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
