@@ -78,6 +78,20 @@ def main():
     ms = timed(lambda: lib.s2k_schnorr_batch_verify_rlc_device(h, n, dpk.data_ptr(), dmsg.data_ptr(), None, 32,
                                                                dsig.data_ptr(), seed.ctypes.data, ctypes.byref(res), st))
     out["schnorr_rlc_msm"] = {"sigs": n, "ms": ms, "sigs_per_s": n / (ms * 1e-3), "all_valid": bool(res.value)}
+
+    # ---- public-key recovery: ECDSA signatures of the bench generator, ids found by trial ----
+    from secp256k1_voi_amd.synth import synth_batch
+    pub, dig, r, s = synth_batch(eng, n, 1 << 16, seed=11)
+    rid = np.zeros(n, dtype=np.uint8)
+    rec, ok = eng.ecdsa_recover_batch(dig, r, s, rid)
+    rid[(rec[:, 1:] != pub).any(axis=1)] = 1
+    dd, dr, ds, did = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (dig, r, s, rid))
+    dpub65 = torch.zeros((n, 65), dtype=torch.uint8, device=dev)
+    dok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: lib.s2k_ecdsa_recover_batch_device(h, n, dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), did.data_ptr(), 0,
+                                                          dpub65.data_ptr(), dok.data_ptr(), st))
+    match = bool((dpub65[:, 1:].cpu().numpy() == pub).all()) and bool(dok.all().item())
+    out["ecdsa_recover"] = {"sigs": n, "ms": ms, "sigs_per_s": n / (ms * 1e-3), "all_recovered": match}
     print(json.dumps(out))
 
 
