@@ -123,8 +123,8 @@ int s2k_is_valid_signature_encoding_bip0066(const uint8_t *sig_with_sighash, siz
  * in `encoding`, each as a concatenation with n+1 byte offsets.  digest_len = 0 means
  * opts == nil (any digest of >= 32 bytes); otherwise digests of another length verify false
  * (ecdsa.go:184-188).  flags: S2K_ECDSA_REJECT_MALLEABLE, S2K_ECDSA_BIP0066,
- * S2K_ECDSA_FORCE_COMPLETE.  Signatures are parsed on the host, compressed keys are
- * decompressed and everything is verified on the device.  valid[i] is the bool the
+ * S2K_ECDSA_FORCE_COMPLETE.  The bytes are uploaded as they are; parsing, decompression of
+ * compressed keys and verification all run on the device.  valid[i] is the bool the
  * reference's Verify returns; keys it could not even construct give 0. */
 int s2k_ecdsa_verify_encoded_batch(s2k_ctx *ctx, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
                                    const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,

@@ -1,0 +1,158 @@
+// ingest.hip — the byte-level work the reference does in Go before `verify` runs (signature and
+// public-key (de)serialisation), for whole batches:
+//   PublicKey.Verify option handling                     secec/ecdsa.go:171-228
+//   NewPublicKey length / prefix dispatch                secec/secec.go:188-216, point_s11n.go:215-230
+//   ParseASN1Signature / ParseCompactSignature / BIP-0066 shape check: der.h
+// The single-item parsers are host functions (no GPU needed).  The batch entry point uploads the
+// raw bytes and parses on the device, one lane per item (k_parse_encoded): at 10^8 verifications
+// per second a host loop over DER signatures (about 60 ns each) would be eight times slower than
+// the GPU.  Compressed keys are decompressed in the same kernel (one field square root).
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/secp256k1_voi_amd.h"
+#include "der.h"
+#include "engine_internal.h"
+#include "fe29.h"
+
+namespace {
+
+// one lane per item: bytes -> pub X||Y (64), digest (32), r (32), s (32), all big-endian as the
+// verification entry point takes them.  Items that fail any pre-check get r = 0, which the
+// verifier's range check rejects.
+__global__ void __launch_bounds__(256)
+k_parse_encoded(uint32_t n, const uint8_t* __restrict__ pubs, const uint64_t* __restrict__ pub_off,
+                const uint8_t* __restrict__ digests, const uint64_t* __restrict__ dig_off, const uint8_t* __restrict__ sigs,
+                const uint64_t* __restrict__ sig_off, int encoding, uint32_t digest_len, int bip66, uint8_t* __restrict__ xy,
+                uint8_t* __restrict__ dg, uint8_t* __restrict__ rr, uint8_t* __restrict__ ss) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* pk = pubs + pub_off[i];
+  size_t pk_len = (size_t)(pub_off[i + 1] - pub_off[i]);
+  const uint8_t* d = digests + dig_off[i];
+  size_t d_len = (size_t)(dig_off[i + 1] - dig_off[i]);
+  const uint8_t* sg = sigs + sig_off[i];
+  size_t sg_len = (size_t)(sig_off[i + 1] - sig_off[i]);
+  uint8_t r[32], s[32], q[64];
+  for (int j = 0; j < 32; ++j) r[j] = s[j] = 0;
+  for (int j = 0; j < 64; ++j) q[j] = 0;
+  bool ok = !(digest_len && d_len != digest_len);        // ecdsa.go:186-188
+  ok = ok && d_len >= 32;                                // hashToScalar, ecdsa.go:478-480
+  if (ok && bip66) {
+    ok = s2k_der::is_valid_signature_encoding_bip0066(sg, sg_len) != 0;
+    --sg_len;                                            // drop the sighash byte
+  }
+  if (ok) {
+    int rc = encoding == S2K_ENCODING_ASN1 ? s2k_der::parse_asn1_signature(sg, sg_len, r, s)
+                                           : s2k_der::parse_compact_signature(sg, sg_len, r, s);
+    ok = rc == 0;
+  }
+  if (ok) {
+    if (pk_len == 65 && pk[0] == 0x04) {
+      for (int j = 0; j < 64; ++j) q[j] = pk[1 + j];     // canonical coordinates and the curve equation: k_verify_fast
+    } else if (pk_len == 33 && (pk[0] == 0x02 || pk[0] == 0x03)) {
+      // SetCompressedBytes (point_s11n.go:140-176)
+      uint32_t xw[8];
+      load_be32_unaligned(xw, pk + 1);
+      ok = fe_is_canonical_raw(xw);
+      if (ok) {
+        fe29 x = fe29_from_words(xw);
+        fe29 rhs = fe29_mul(fe29_sqr(x), x);
+        rhs.n[0] += 7;
+        fe29 y;
+        ok = fe29_sqrt(y, rhs);
+        y = fe29_normalize(y);
+        const bool want_odd = pk[0] == 0x03;
+        y = fe29_normalize(fe29_select(((y.n[0] & 1u) != 0) != want_odd, y, fe29_negate(y, 1)));
+        uint32_t yw[8];
+        fe29_to_words(yw, y);
+        for (int j = 0; j < 32; ++j) q[j] = pk[1 + j];
+        store_be32_unaligned(q + 32, yw);
+      }
+    } else {
+      ok = false;                                        // bad length / prefix, or the identity (secec.go:206-209)
+    }
+  }
+  uint8_t* oq = xy + i * 64;
+  for (int j = 0; j < 64; ++j) oq[j] = q[j];
+  for (int j = 0; j < 32; ++j) {
+    dg[i * 32 + j] = (ok && d_len >= 32) ? d[j] : 0;
+    rr[i * 32 + j] = ok ? r[j] : 0;
+    ss[i * 32 + j] = ok ? s[j] : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2k_parse_asn1_signature(const uint8_t* der, size_t len, uint8_t r[32], uint8_t s[32]) {
+  if (!der || !r || !s) return S2K_ERR_ARG;
+  return s2k_der::parse_asn1_signature(der, len, r, s);
+}
+
+int s2k_parse_compact_signature(const uint8_t* sig, size_t len, uint8_t r[32], uint8_t s[32]) {
+  if (!sig || !r || !s) return S2K_ERR_ARG;
+  return s2k_der::parse_compact_signature(sig, len, r, s);
+}
+
+int s2k_is_valid_signature_encoding_bip0066(const uint8_t* d, size_t n) {
+  if (!d) return 0;
+  return s2k_der::is_valid_signature_encoding_bip0066(d, n);
+}
+
+// PublicKey.Verify(digest, sig, opts) for n encoded items (ecdsa.go:171-228).
+//   pubs / digests / sigs: concatenated byte strings with n+1 offsets each
+//   encoding: S2K_ENCODING_ASN1 or S2K_ENCODING_COMPACT (EncodingCompactRecoverable is not a
+//             batch verification: it is public-key recovery, ecdsa.go:220-226)
+//   digest_len: 0 = opts == nil (any length >= 32 is taken, leftmost 32 bytes used);
+//               otherwise opts.Hash.Size(): other lengths verify false (ecdsa.go:184-188)
+//   flags: S2K_ECDSA_REJECT_MALLEABLE, S2K_ECDSA_BIP0066 (bitcoin.VerifyASN1,
+//          ecdsa_shitcoin.go:29-35: shape check, strip the sighash byte, low-s, 32-byte digest)
+// Public keys are any SEC1 encoding NewPublicKey accepts (33 or 65 bytes).  A malformed key or
+// signature makes that item false (the reference could not have constructed the PublicKey / returns
+// false from Verify).
+int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off,
+                                   const uint8_t* digests, const uint64_t* dig_off, const uint8_t* sigs,
+                                   const uint64_t* sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                   uint8_t* valid) {
+  if (!ctx) return S2K_ERR_ARG;
+  if (n == 0) return S2K_OK;
+  if (!pubs || !pub_off || !digests || !dig_off || !sigs || !sig_off || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (encoding != S2K_ENCODING_ASN1 && encoding != S2K_ENCODING_COMPACT) return fail(ctx, S2K_ERR_ARG, "unknown encoding");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  const bool bip66 = (flags & S2K_ECDSA_BIP0066) != 0;
+  if (bip66) {
+    if (encoding != S2K_ENCODING_ASN1) return fail(ctx, S2K_ERR_ARG, "BIP-0066 needs the ASN.1 encoding");
+    digest_len = 32;                                  // optsShitcoin: SHA-256
+    flags |= S2K_ECDSA_REJECT_MALLEABLE;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t pub_bytes = pub_off[n], dig_bytes = dig_off[n], sig_bytes = sig_off[n];
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_pub = 0, o_dig = o_pub + al(pub_bytes), o_sig = o_dig + al(dig_bytes), o_po = o_sig + al(sig_bytes),
+               o_do = o_po + al((n + 1) * 8), o_so = o_do + al((n + 1) * 8), o_xy = o_so + al((n + 1) * 8), o_dg = o_xy + al(n * 64),
+               o_r = o_dg + al(n * 32), o_s = o_r + al(n * 32), o_v = o_s + al(n * 32), total = o_v + al(n);
+  int rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, total);
+  if (rc) return rc;
+  uint8_t* io = (uint8_t*)ctx->io;
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_pub, pubs, pub_bytes, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_dig, digests, dig_bytes, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_sig, sigs, sig_bytes, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_po, pub_off, (n + 1) * 8, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_do, dig_off, (n + 1) * 8, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_so, sig_off, (n + 1) * 8, hipMemcpyHostToDevice, nullptr));
+  k_parse_encoded<<<(unsigned)((n + 255) / 256), 256>>>((uint32_t)n, io + o_pub, (const uint64_t*)(io + o_po), io + o_dig,
+                                                        (const uint64_t*)(io + o_do), io + o_sig, (const uint64_t*)(io + o_so),
+                                                        encoding, (uint32_t)digest_len, bip66 ? 1 : 0, io + o_xy, io + o_dg,
+                                                        io + o_r, io + o_s);
+  HIP_TRY(ctx, hipGetLastError());
+  rc = s2k_ecdsa_verify_batch_device(ctx, n, io + o_xy, io + o_dg, io + o_r, io + o_s,
+                                     flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE), io + o_v, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(valid, io + o_v, n, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+  return S2K_OK;
+}
+
+}  // extern "C"
