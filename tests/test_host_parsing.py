@@ -1,4 +1,4 @@
-"""Host-side logic of the product (secp256k1_voi_amd/csrc/host.cpp) — no GPU needed: strict
+"""Host-side logic of the product (secp256k1_voi_amd/csrc/ingest.hip, der.h) — no GPU needed: strict
 DER / compact signature parsing and the BIP-0066 shape check, against the oracle's
 restatement, the Wycheproof encoding classes and the BIP-0066 vectors.
 """
