@@ -313,6 +313,35 @@ def test_ecdsa_structured_fuzz(eng, oracle):
     assert 0 < int(got.sum()) < n
 
 
+def test_two_contexts_from_two_threads(eng, oracle):
+    """The ABI is re-entrant per context (SURVEY 8b threading): two host threads, each with its own
+    context, verify different batches at the same time."""
+    import threading
+    import secp256k1_voi_amd as S
+    from workload import make_ecdsa_batch
+    batches = [make_ecdsa_batch(oracle, 3000, seed=300 + k, corrupt_every=5) for k in range(2)]
+    exp = [oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], nthreads=4) for w in batches]
+    engines = [eng, S.Engine(0)]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(5):
+                w = batches[k]
+                got[k] = engines[k].ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+                assert (got[k] == exp[k]).all()
+        except Exception as e:      # surfaced in the main thread below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert (got[0] == exp[0]).all() and (got[1] == exp[1]).all()
+
+
 def test_ecdsa_empty_and_errors(eng):
     assert eng.ecdsa_verify_batch(b"", b"", b"", b"").size == 0
     with pytest.raises(ValueError):
