@@ -1354,15 +1354,9 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   if (n == 0) return S2K_OK;
   if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (!ctx->s_copy) {
-    hipDeviceProp_t prop;
-    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
-    for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  int rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, n * 161 + 1024);
+  int rc = ctx_streams(ctx);
+  if (rc) return rc;
+  rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, n * 161 + 1024);
   if (rc) return rc;
   uint8_t* d_pub = (uint8_t*)ctx->io;
   uint8_t* d_dig = d_pub + n * 64;

@@ -119,6 +119,18 @@ static inline size_t lane_stride(size_t n) { return ((n + 63) & ~(size_t)63) + S
 
 
 // small RAII helper for the host-pointer entry points
+// copy / compute streams and the events chaining them, for the host-buffer entry points
+inline int ctx_streams(s2k_ctx* ctx) {
+  if (ctx->s_copy) return S2K_OK;
+  hipDeviceProp_t prop;
+  HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
+  for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return S2K_OK;
+}
+
 struct dev_buf {
   void* p = nullptr;
   ~dev_buf() {

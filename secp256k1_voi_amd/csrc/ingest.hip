@@ -21,12 +21,13 @@ namespace {
 // verification entry point takes them.  Items that fail any pre-check get r = 0, which the
 // verifier's range check rejects.
 __global__ void __launch_bounds__(256)
-k_parse_encoded(uint32_t n, const uint8_t* __restrict__ pubs, const uint64_t* __restrict__ pub_off,
+k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, const uint64_t* __restrict__ pub_off,
                 const uint8_t* __restrict__ digests, const uint64_t* __restrict__ dig_off, const uint8_t* __restrict__ sigs,
                 const uint64_t* __restrict__ sig_off, int encoding, uint32_t digest_len, int bip66, uint8_t* __restrict__ xy,
                 uint8_t* __restrict__ dg, uint8_t* __restrict__ rr, uint8_t* __restrict__ ss) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  i += first;                                            // items [first, first + n) of the batch
   const uint8_t* pk = pubs + pub_off[i];
   size_t pk_len = (size_t)(pub_off[i + 1] - pub_off[i]);
   const uint8_t* d = digests + dig_off[i];
@@ -136,22 +137,37 @@ int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, 
   int rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, total);
   if (rc) return rc;
   uint8_t* io = (uint8_t*)ctx->io;
-  HIP_TRY(ctx, hipMemcpyAsync(io + o_pub, pubs, pub_bytes, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(ctx, hipMemcpyAsync(io + o_dig, digests, dig_bytes, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(ctx, hipMemcpyAsync(io + o_sig, sigs, sig_bytes, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(ctx, hipMemcpyAsync(io + o_po, pub_off, (n + 1) * 8, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(ctx, hipMemcpyAsync(io + o_do, dig_off, (n + 1) * 8, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(ctx, hipMemcpyAsync(io + o_so, sig_off, (n + 1) * 8, hipMemcpyHostToDevice, nullptr));
-  k_parse_encoded<<<(unsigned)((n + 255) / 256), 256>>>((uint32_t)n, io + o_pub, (const uint64_t*)(io + o_po), io + o_dig,
-                                                        (const uint64_t*)(io + o_do), io + o_sig, (const uint64_t*)(io + o_so),
-                                                        encoding, (uint32_t)digest_len, bip66 ? 1 : 0, io + o_xy, io + o_dg,
-                                                        io + o_r, io + o_s);
-  HIP_TRY(ctx, hipGetLastError());
-  rc = s2k_ecdsa_verify_batch_device(ctx, n, io + o_xy, io + o_dg, io + o_r, io + o_s,
-                                     flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE), io + o_v, nullptr);
+  rc = ctx_streams(ctx);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(valid, io + o_v, n, hipMemcpyDeviceToHost, nullptr));
-  HIP_TRY(ctx, hipStreamSynchronize(nullptr));
+  // the offset arrays go up whole (24 bytes per item); the byte strings follow chunk by chunk, each
+  // copy overlapping the parse + verification of the previous chunk (same scheme as
+  // s2k_ecdsa_verify_batch; chunks are two full rounds of k_verify_fast)
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_po, pub_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_copy));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_do, dig_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_copy));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_so, sig_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_copy));
+  const size_t round = (size_t)3 * 4 * (size_t)ctx->cu_count * 64;
+  const size_t chunk = n > 3 * round ? 2 * round : n;
+  int k = 0;
+  for (size_t lo = 0; lo < n; lo += chunk, ++k) {
+    const size_t cnt = n - lo < chunk ? n - lo : chunk, hi = lo + cnt;
+    HIP_TRY(ctx, hipMemcpyAsync(io + o_pub + pub_off[lo], pubs + pub_off[lo], pub_off[hi] - pub_off[lo], hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipMemcpyAsync(io + o_dig + dig_off[lo], digests + dig_off[lo], dig_off[hi] - dig_off[lo], hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipMemcpyAsync(io + o_sig + sig_off[lo], sigs + sig_off[lo], sig_off[hi] - sig_off[lo], hipMemcpyHostToDevice, ctx->s_copy));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_copied[k & 1], ctx->s_copy));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comp, ctx->ev_copied[k & 1], 0));
+    k_parse_encoded<<<(unsigned)((cnt + 255) / 256), 256, 0, ctx->s_comp>>>(
+        (uint32_t)lo, (uint32_t)cnt, io + o_pub, (const uint64_t*)(io + o_po), io + o_dig, (const uint64_t*)(io + o_do), io + o_sig,
+        (const uint64_t*)(io + o_so), encoding, (uint32_t)digest_len, bip66 ? 1 : 0, io + o_xy, io + o_dg, io + o_r, io + o_s);
+    HIP_TRY(ctx, hipGetLastError());
+    rc = s2k_ecdsa_verify_batch_device(ctx, cnt, io + o_xy + lo * 64, io + o_dg + lo * 32, io + o_r + lo * 32, io + o_s + lo * 32,
+                                       flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE), io + o_v + lo, ctx->s_comp);
+    if (rc) {
+      (void)hipDeviceSynchronize();
+      return rc;
+    }
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(valid, io + o_v, n, hipMemcpyDeviceToHost, ctx->s_comp));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
   return S2K_OK;
 }
 
