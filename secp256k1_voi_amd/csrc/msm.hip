@@ -376,7 +376,13 @@ k_msm_accumulate(uint32_t cap, uint32_t seg_len, const uint32_t* __restrict__ ns
     uint4 a = rec4[0], b = rec4[1], c = rec4[2], d = rec4[3];
     uint32_t xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t yw[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    acc = pt29_add_mixed(acc, fe29_from_words(xw), fe29_from_words(yw));
+    if (j == lo) {            // the first point of a segment is the accumulator (Z = 1): no addition
+      acc.x = fe29_from_words(xw);
+      acc.y = fe29_from_words(yw);
+      acc.z = fe29_one();
+    } else {
+      acc = pt29_add_mixed(acc, fe29_from_words(xw), fe29_from_words(yw));
+    }
   }
   pt_store(segsum, cap, slot, acc);
 }
