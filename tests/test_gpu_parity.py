@@ -283,7 +283,7 @@ def test_ecdsa_structured_fuzz(eng, oracle):
     n-s, r+n, the generator's coordinates, ...); engine and oracle must agree on all verdicts, with
     and without the low-s rule."""
     from workload import make_ecdsa_batch
-    n = 6000
+    n = int(os.environ.get("S2K_FUZZ_N", "6000"))          # larger one-off runs: S2K_FUZZ_N=200000
     w = make_ecdsa_batch(oracle, n, seed=77, n_keys=32, corrupt_every=0, low_s=False)
     rnd = random.Random(78)
     P_ = 2**256 - 2**32 - 977
