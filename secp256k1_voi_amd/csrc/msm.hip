@@ -18,7 +18,7 @@
 //   4. k_msm_accumulate one lane per bucket: complete mixed additions of its points
 //   5. k_msm_reduce    one lane per chunk of 32 buckets: sum_b b*B_b by running sums, plus the
 //                      chunk offset by double-and-add
-//   6. k_msm_tree      one workgroup per window: tree-sum of the chunk results
+//   6. k_msm_tree      tree-sum of the chunk results per window (two launches of 256-thread workgroups)
 //   7. k_msm_final     Horner over the windows, affine result
 // All additions use the complete formulas (pt29.h): buckets receive arbitrary points
 // (duplicates, inverses, the same point many times), so there is no exceptional case to
@@ -426,14 +426,18 @@ k_msm_reduce(msm_geom g, const uint32_t* __restrict__ segsum, size_t cap, uint32
   pt_store(partial, nslots, id, tot);
 }
 
-// one workgroup per window: partial[w][0..nchunk) -> partial[w][0]
-__global__ void __launch_bounds__(1024) k_msm_tree(msm_geom g, uint32_t* __restrict__ partial) {
-  size_t nslots = (size_t)g.nw * g.nchunk;
-  size_t base = (size_t)blockIdx.x * g.nchunk;
-  for (uint32_t half = g.nchunk >> 1; half >= 1; half >>= 1) {
-    for (uint32_t t = threadIdx.x; t < half; t += 1024) {
-      pt29 a = pt_load(partial, nslots, base + t), b = pt_load(partial, nslots, base + t + half);
-      pt_store(partial, nslots, base + t, pt29_add(a, b));
+// tree sum of a window's chunk results, partial[w][0..nchunk) -> partial[w][0], in two launches of
+// 256-thread workgroups (a 1024-thread workgroup would cap the kernel at 128 VGPRs and spill):
+// `span` consecutive slots are folded into the first one by each workgroup
+__global__ void __launch_bounds__(256) k_msm_tree(uint32_t nslots_total, uint32_t span, uint32_t stride_slots,
+                                                  uint32_t* __restrict__ partial) {
+  // workgroup b folds slots [b * span * stride_slots, ...) taken every stride_slots
+  const size_t base = (size_t)blockIdx.x * span * stride_slots;
+  for (uint32_t half = span >> 1; half >= 1; half >>= 1) {
+    for (uint32_t t = threadIdx.x; t < half; t += 256) {
+      const size_t ia = base + (size_t)t * stride_slots, ib = base + (size_t)(t + half) * stride_slots;
+      pt29 a = pt_load(partial, nslots_total, ia), c = pt_load(partial, nslots_total, ib);
+      pt_store(partial, nslots_total, ia, pt29_add(a, c));
     }
     __syncthreads();
   }
@@ -595,7 +599,12 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   HIP_TRY(ctx, hipGetLastError());
   k_msm_reduce<<<(unsigned)((m.nslots + 63) / 64), 64, 0, st>>>(g, m.segsum, m.segcap, m.seg_len, m.count, m.firstslot, m.partial);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_tree<<<g.nw, 1024, 0, st>>>(g, m.partial);
+  {
+    // level 1: groups of up to 512 chunk results; level 2: the group sums of each window
+    const uint32_t span1 = g.nchunk < 512 ? g.nchunk : 512, groups = g.nchunk / span1;
+    k_msm_tree<<<g.nw * groups, 256, 0, st>>>((uint32_t)m.nslots, span1, 1u, m.partial);
+    if (groups > 1) k_msm_tree<<<g.nw, 256, 0, st>>>((uint32_t)m.nslots, groups, span1, m.partial);
+  }
   HIP_TRY(ctx, hipGetLastError());
   k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65);
   HIP_TRY(ctx, hipGetLastError());
