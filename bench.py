@@ -1,22 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — secp256k1 ECDSA verifications/s at batch 2^20 per GPU (BASELINE.json metric).
 
-One "step" = one pass of the hot path (s2k_ecdsa_verify_batch_device) over one batch of
-2^20 synthetic signatures per GPU, inputs already resident in HBM.  N > 1: one process per
-GPU (torch.distributed, backend nccl = RCCL); every rank verifies its own shard (no
-data-path collective) and the ranks all-reduce the number of valid signatures per step.
+One "step" = one pass of the hot path (s2k_ecdsa_verify_batch_device + the valid-bitmap
+pack) over one batch of synthetic signatures per GPU, inputs already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-log2 20] [--keys-log2 16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-log2 B] [--keys-log2 16]
 
-Rank 0 prints ONE JSON line.  Extra keys: "roofline" (dominant kernel vs the HBM roofline,
-as the contract asks, plus the integer-VALU roofline that actually bounds this path) and
-"cpu_baseline" (the CPU oracle = port of the reference algorithm, timed on this box's host
-cores on a bounded sample; the reference itself is Go and there is no Go toolchain here).
+N = 1: BASELINE config 2, 2^20 verifications on one MI355X.
+N > 1: BASELINE config 5 shape, 2^21 verifications per GPU (2^24 over 8), one process per GPU
+(torch.distributed, backend nccl = RCCL); every rank verifies its own contiguous shard (no
+data-path collective) and per step the ranks all-gather the packed valid bitmap and
+all-reduce the valid count.  Started without a launcher (`python bench.py --gpus N`, no
+RANK/WORLD_SIZE in the environment) this script starts its N rank processes itself, as fresh
+children, before anything in the parent touches a GPU; started by torch.distributed.run it
+is one of the ranks.  `--oversubscribe` (test hook for a 1-GPU box) puts rank r on device
+r mod device_count and uses gloo for the collectives.
+
+Rank 0 prints ONE JSON line.  Extra keys: "roofline" (the dominant kernel against the
+integer-VALU issue roofline that bounds this path, live HIP-event kernel time and effective
+shader clock; the HBM roofline the contract names as a sub-object), "cpu_baseline" (the CPU
+oracle = port of the reference algorithm, timed on this box's host cores on a bounded sample;
+the reference itself is Go and there is no Go toolchain here), and at N = 1 the other
+BASELINE configurations, each guarded by a full-result check: "msm_2p20" (config 3),
+"schnorr_rlc_2p20" (config 4), plus "distinct_keys" (K = N), "worst_case_all_fallback" and
+"pcie_inclusive".  None of them is `value`.
 """
 import argparse
 import json
 import os
 import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,18 +38,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
-import torch
-
-import secp256k1_voi_amd as S
-from secp256k1_voi_amd.sharding import gather_valid_device
-from secp256k1_voi_amd.synth import synth_batch
-
 BYTES_PER_VERIFY = 160 + 1          # r, s, digest (32 each) + pubkey (64) in, 1 byte out
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (measured: tools/valu_rates.hip)
+SIMDS = 256 * 4                     # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9
+# Full-rate VALU issue: one wave64 instruction per 4 cycles per SIMD (16 lanes/clk).  Settled on the
+# hardware with tools/valu_rates.hip (16 independent accumulators, 2/4/8 waves per SIMD):
+# v_fma_f32 / v_fma_f64 / v_mul_lo_u32 / 64-bit shifts saturate at 1 per 4.3 cycles, v_mad_u64_u32 at
+# 1 per 5.3, VOP2 add/and/sub/mov at 1 per 2.6 (profiles/r02_valu_instruction_rates.txt).
+VALU_PEAK_LANE_OPS = SIMDS * 16 * PEAK_CLOCK_HZ
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch-log2", type=int, default=None, help="signatures per GPU (default 20 at N=1, 21 at N>1)")
+    ap.add_argument("--keys-log2", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe inclusive) measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs 3/4, K=N and the worst case (e.g. under a profiler)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="test hook: allow more ranks than devices (rank r -> device r mod count, gloo collectives)")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: N rank processes, started before this process has touched a GPU
+# ---------------------------------------------------------------------------------------------
+def launch(args):
+    import torch                       # import only; device_count() does not initialise the GPU on this image
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ndev < args.gpus:
+        if not args.oversubscribe:
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible "
+                  "(use --oversubscribe to share devices in a test)", file=sys.stderr)
+            return 2
+        env["S2K_DIST_BACKEND"] = "gloo"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(args.gpus),
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for rank in range(args.gpus):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        if ndev and ndev < args.gpus:
+            e["S2K_BENCH_DEVICE"] = str(rank % ndev)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(pub, digest, r, s, budget_s=15.0):
     """Time the CPU oracle (port of the reference algorithm) on a bounded prefix, with the
     thread count (<= host cores) that gives the best rate on a short probe."""
@@ -88,48 +149,54 @@ def cpu_baseline(pub, digest, r, s, budget_s=15.0):
             "reference_toolchain": "go: " + ("present" if shutil.which("go") else "absent - reference Go path not timed")}
 
 
-def measured_traffic(kernel="k_verify_fast"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_traffic.json, produced by tools/collect_traffic.py), or None."""
+def load_profile_json(name):
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            d = json.load(f)
-        return d[kernel]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
     except Exception:
         return None
 
 
-def measured_valu_instr():
-    """(VALU instructions per signature of the path's kernels from the committed PMC counts,
-    static per-verification operation counts) from profiles/r01_valu_counts.json, or (None, {})."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_valu_counts.json")) as f:
-            d = json.load(f)
-        return sum(v["valu_instr_per_signature"] for k, v in d.items() if k.startswith("k_")), d.get("static", {})
-    except Exception:
-        return None, {}
+def committed_counts():
+    """PMC-derived per-signature figures of the path's kernels (profiles/, newest round first)."""
+    for name in ("r02_valu_counts.json", "r01_valu_counts.json"):
+        d = load_profile_json(name)
+        if d:
+            return d, name
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch-log2", type=int, default=20)
-    ap.add_argument("--keys-log2", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe inclusive) measurement, e.g. under a profiler")
-    args = ap.parse_args()
+def committed_traffic(kernel="k_verify_fast"):
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        d = load_profile_json(name)
+        if d and kernel in d:
+            return d[kernel]["hbm_bytes_per_launch"], name
+    return None, None
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if xs else 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+def worker(args):
+    import numpy as np
+    import torch
+
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.sharding import gather_valid_device
+    from secp256k1_voi_amd.synth import synth_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    # test hooks (not used by the driver): several ranks on one GPU with the gloo backend, to
-    # exercise the multi-rank flow on a 1-GPU box
-    if "S2K_BENCH_DEVICE" in os.environ:
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}", file=sys.stderr)
+        return 2
+    # test hook (not used by the driver): several ranks on one GPU with gloo collectives
+    shared_device = "S2K_BENCH_DEVICE" in os.environ
+    if shared_device:
         local_rank = int(os.environ["S2K_BENCH_DEVICE"])
     backend = os.environ.get("S2K_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
@@ -143,87 +210,134 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    n = 1 << args.batch_log2
+    batch_log2 = args.batch_log2 if args.batch_log2 is not None else (20 if world == 1 else 21)
+    n = 1 << batch_log2
+    n_keys = min(n, 1 << args.keys_log2)
     eng = S.Engine(local_rank)
-    pub, digest, r, s = synth_batch(eng, n, min(n, 1 << args.keys_log2), seed=0x5EC9 + rank)
+    pub, digest, r, s = synth_batch(eng, n, n_keys, seed=0x5EC9 + rank)
     d_pub, d_dig, d_r, d_s = (torch.from_numpy(x).to(dev) for x in (pub, digest, r, s))
     d_valid = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_bitmap = torch.zeros(n // 8, dtype=torch.uint8, device=dev)
     d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        st = torch.cuda.current_stream().cuda_stream
-        eng.ecdsa_verify_batch_device(n, d_pub.data_ptr(), d_dig.data_ptr(), d_r.data_ptr(), d_s.data_ptr(),
+    def step(inputs=None):
+        p, d, rr, ss = inputs or (d_pub, d_dig, d_r, d_s)
+        # verdicts are cleared first, so a step that silently did nothing cannot pass the count check
+        d_valid.zero_()
+        eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(),
                                       d_valid.data_ptr(), 0, st)
+        # the only collective of the path: all-gather of the valid bitmap + all-reduce of the count
+        return gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # parity guard first (one untimed pass): every synthetic signature is valid
-    step()
+    # ---- parity guards (untimed) -------------------------------------------------------------
+    # (1) every synthetic signature is valid, on every rank
+    bitmap, cnt = step()
     sync()
-    assert int(d_valid.sum().item()) == n, "synthetic batch did not verify"
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    assert int(cnt.item()) == n * world and bool((bitmap == 0xFF).all().item()), "synthetic batch did not verify"
+    # (2) a seeded subset corrupted on every rank (one bit of s flipped): the gathered bitmap of the
+    #     whole job must equal the expected pattern, on every rank
+    def corrupt_mask(rk):
+        i = np.arange(n, dtype=np.uint64)
+        return ((i * np.uint64(2654435761) + np.uint64(rk * 7919 + 13)) % np.uint64(61)) == 0
+    mine = torch.from_numpy(np.nonzero(corrupt_mask(rank))[0]).to(dev)
+    d_s[mine, 31] ^= 1
+    bitmap, cnt = step()
+    sync()
+    expect = np.concatenate([np.packbits(~corrupt_mask(rk), bitorder="little") for rk in range(world)])
+    assert np.array_equal(bitmap.cpu().numpy(), expect), "gathered valid bitmap differs from the corrupted pattern"
+    assert int(cnt.item()) == int(sum((~corrupt_mask(rk)).sum() for rk in range(world)))
+    d_s[mine, 31] ^= 1
 
-    # W untimed warm-up steps, then the timed region starts right behind them (only the mandated
-    # barrier + synchronize in between: host-side checks in that gap let the device clock down and
-    # the first timed steps pay for the ramp)
+    # ---- W untimed warm-up steps, then exactly K timed steps ----------------------------------
+    # (only the mandated barrier + synchronize in between: host-side work in that gap lets the
+    # device clock down and the first timed steps pay for the ramp)
+    cnts = torch.zeros(args.steps, dtype=torch.int64, device=dev)
     for _ in range(args.warmup):
         step()
+    eng.profile(True)
     sync()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-        # the only collective of the path: all-gather of the valid bitmap + all-reduce of the count
-        bitmap, cnt = gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count)
-    ev1.record()
+    for k in range(args.steps):
+        bitmap, cnt = step()
+        cnts[k:k + 1].copy_(cnt)
     sync()
     dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-    assert int(cnt.item()) == n * world and bitmap.numel() == n * world // 8
+    prof = eng.profile_read(cap=max(args.steps, 1))
+    eng.profile(False)
+    assert prof["calls"] == min(args.steps, 1024)
+    assert bool((cnts == n * world).all().item()), "a timed step lost verdicts"
+    assert bitmap.numel() == n * world // 8 and bool((bitmap == 0xFF).all().item())
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    rc = 0
     if rank == 0:
+        fast_ms = prof["fast_ms"] / prof["calls"]         # dominant kernel, HIP events on its stream
+        fast_med = median(prof["fast_each"])
+        prep_ms = prof["prep_ms"] / prof["calls"]
+        clock_hz = prof["shader_mhz"] * 1e6
         value = n * world * args.steps / dt
-        achieved = BYTES_PER_VERIFY * n / (kern_ms * 1e-3) / 1e9
-        vps = n / (kern_ms * 1e-3)
-        valu = {"peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "verifies_per_s_per_gpu": vps}
-        ipv, static = measured_valu_instr()
-        if ipv:   # the bound that matters: lane-instructions issued / full-rate VALU peak at 2.4 GHz
-            valu.update({"instr_per_verify": ipv, "achieved_lane_ops_per_s": ipv * vps,
-                         "frac": ipv * vps / VALU_PEAK_LANE_OPS})
-        if static:   # modular products per verification and the multiply-add rate against its measured peak
-            mad_peak = static["measured_mad_u64_u32_peak_wave_instr_per_us_per_simd"] * 1e6 * 1024 * 64
-            valu.update({"fp_products_per_verify": static["fp_products_per_verify"],
-                         "fn_products_per_verify": static["fn_products_per_verify"],
-                         "mad_u64_u32_per_verify": static["mad_u64_u32_per_verify"],
-                         "mad_u64_u32_lane_ops_per_s": static["mad_u64_u32_per_verify"] * vps,
-                         "mad_u64_u32_peak_lane_ops_per_s": mad_peak,
-                         "mad_frac": static["mad_u64_u32_per_verify"] * vps / mad_peak})
+        counts, counts_src = committed_counts()
+        traffic, traffic_src = committed_traffic()
+        roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA>", "kernel_ms": fast_ms, "kernel_ms_median": fast_med,
+                "scalar_prep_ms": prep_ms, "fallback_ms": prof["fallback_ms"] / prof["calls"],
+                "shader_clock_mhz": prof["shader_mhz"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
+                "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
+        if counts:
+            ipv = counts["k_verify_fast"]["valu_instr_per_signature"]
+            st_ = counts.get("static", {})
+            lane_ops = ipv * n / (fast_ms * 1e-3)
+            roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                         "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src})
+            if clock_hz > 0:
+                # the same fraction against the clock the kernel actually ran at: wave-instructions
+                # issued per SIMD per cycle, times the 4 cycles a full-rate instruction takes
+                wave_instr = ipv * n / 64.0
+                roof["frac_at_measured_clock"] = wave_instr / SIMDS / (fast_ms * 1e-3 * clock_hz) * 4.0
+            if st_:
+                mads = st_["mad_u64_u32_per_verify"]
+                mad_peak = st_["measured_mad_u64_u32_peak_wave_instr_per_us_per_simd"] * 1e6 * SIMDS * 64
+                roof.update({"fp_products_per_verify": st_["fp_products_per_verify"],
+                             "mad_u64_u32_per_verify": mads,
+                             "mad_frac_of_measured_mad_peak": mads * n / (fast_ms * 1e-3) / mad_peak})
+        achieved_gbs = BYTES_PER_VERIFY * n / (fast_ms * 1e-3) / 1e9
+        roof["traffic"] = traffic
+        roof["hbm"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved_gbs / HBM_PEAK_GBS, "bytes_per_verify": BYTES_PER_VERIFY,
+                       "traffic_from": ("profiles/" + traffic_src) if traffic_src else None,
+                       "note": "algorithmic bytes / kernel time; the path is VALU-bound, this fraction is ~1e-3 by construction"}
         line = {
-            "metric": "secp256k1 ECDSA verifications/sec at batch=2^%d per GPU" % args.batch_log2,
+            "metric": "secp256k1 ECDSA verifications/sec at batch=2^%d per GPU" % batch_log2,
             "value": value, "unit": "verifications/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "2^%d ECDSA verifies (u1*G+u2*P per lane) per GPU, %d distinct keys, all valid, low-s"
-                                   % (args.batch_log2, min(n, 1 << args.keys_log2)),
-                       "parallelism": "shard%d" % world, "inputs": "resident in HBM"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel_ms": kern_ms, "bytes_per_verify": BYTES_PER_VERIFY,
-                         "note": "path is integer-VALU bound; HBM fraction reported as the contract asks",
-                         "valu": valu},
+            "config": {"workload": "2^%d ECDSA verifies (u1*G+u2*P per lane) per GPU%s, %d distinct keys per GPU, all valid, low-s"
+                                   % (batch_log2, " = 2^%d in total (BASELINE config 5 shape)" % (batch_log2 + world.bit_length() - 1)
+                                      if world > 1 else " (BASELINE config 2)", n_keys),
+                       "parallelism": "shard%d%s" % (world, " (ranks share devices, gloo: test hook)" if shared_device else ""),
+                       "inputs": "resident in HBM", "collective": "all-gather bitmap + all-reduce count per step",
+                       "build": eng._lib.s2k_build_config().decode()},
+            "roofline": roof,
         }
+        extras = world == 1 and not args.no_extras
+        if extras:
+            try:
+                line.update(extra_measurements(eng, dev, n, n_keys, step, sync, st, args))
+            except AssertionError as e:      # a failed guard must be visible, and must fail the run
+                line["extras_error"] = str(e) or "assertion failed"
+                rc = 1
         # host-buffer entry point (chunked H2D overlapped with the kernels, D2H); reported, never `value`.
         # One untimed call first: it creates the context's staging buffers and streams.
-        if not args.no_pcie:
+        if not args.no_pcie and world == 1:
             eng.ecdsa_verify_batch(pub, digest, r, s)
             t1 = time.perf_counter()
             hv = eng.ecdsa_verify_batch(pub, digest, r, s)
@@ -231,13 +345,110 @@ def main():
             assert int(hv.sum()) == n
             line["pcie_inclusive"] = {"value": n / dt_host, "unit": "verifications/s",
                                       "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch, "
-                                              "second call (staging buffers exist)" % args.batch_log2}
-        if not args.no_cpu_baseline:
+                                              "second call (staging buffers exist)" % batch_log2}
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(pub, digest, r, s)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
+    """The other BASELINE configurations and side figures on one GPU; every number is guarded by a
+    check of the full result."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from secp256k1_voi_amd.synth import (synth_all_fallback_batch, synth_batch, synth_msm_terms,
+                                         synth_schnorr_batch)
+    out = {}
+    lib, h = eng._lib, eng._h
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    d_valid = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def verify_on(inputs):
+        p, d, rr, ss = inputs
+        eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(), d_valid.data_ptr(), 0, st)
+
+    # ---- K = N: every signature under its own key (SURVEY 8d "also report K = N") ----
+    if n_keys < n:
+        inp = tuple(torch.from_numpy(x).to(dev) for x in synth_batch(eng, n, n, seed=0xD157))
+        d_valid.zero_()
+        ms = timed(lambda: verify_on(inp), 5)
+        assert int(d_valid.sum().item()) == n, "K = N batch did not verify"
+        out["distinct_keys"] = {"keys": n, "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s"}
+        del inp
+
+    # ---- adversarial worst case: every lane undecided by the fast ladder (u1 G + u2 Q = infinity) ----
+    inp = tuple(torch.from_numpy(x).to(dev) for x in synth_all_fallback_batch(eng, n, n_keys, seed=0xBAD))
+    d_valid.fill_(1)
+    ms = timed(lambda: verify_on(inp), 2)
+    assert int(d_valid.sum().item()) == 0, "R = infinity must reject"
+    out["worst_case_all_fallback"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
+                                      "note": "2^%d signatures built so that u1*G + u2*Q = infinity: all lanes re-done by the "
+                                              "complete-formula worklist kernel; all verdicts 0 (checked)" % (n.bit_length() - 1)}
+    del inp
+
+    # ---- config 3: 2^20-term multi-scalar multiplication, points with known discrete logs ----
+    m = 1 << 20
+    k, pts, tot = synth_msm_terms(eng, m, seed=7)
+    dk, dp = torch.from_numpy(k).to(dev), torch.from_numpy(pts).to(dev)
+    dout = torch.zeros(80, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: eng.multi_scalar_mult_device(m, dk.data_ptr(), dp.data_ptr(), dout.data_ptr(), st), 5)
+    want = eng.scalar_base_mult_batch([tot.to_bytes(32, "big")])[0].tobytes()
+    assert dout[:65].cpu().numpy().tobytes() == want, "2^20-term MSM differs from (sum k_i d_i) G"
+    out["msm_2p20"] = {"terms": m, "ms": ms, "terms_per_s": m / (ms * 1e-3),
+                       "check": "full sum == (sum k_i d_i mod n) * G (big-int on the host, base mult on the device)"}
+    del dk, dp
+
+    # ---- config 4: 2^20 BIP-340 signatures as one random-linear-combination MSM ----
+    pk, msgs, sig = synth_schnorr_batch(eng, m, min(m, 1 << 16), seed=340)
+    dpk, dmsg, dsig = (torch.from_numpy(x).to(dev) for x in (pk, msgs, sig))
+    res = ctypes.c_int(0)
+    seed = np.frombuffer(os.urandom(32), np.uint8)
+
+    def rlc():
+        rc_ = lib.s2k_schnorr_batch_verify_rlc_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32, dsig.data_ptr(),
+                                                      seed.ctypes.data, ctypes.byref(res), st)
+        assert rc_ == 0
+    ms = timed(rlc, 5)
+    assert res.value == 1, "valid BIP-340 batch rejected"
+    bad = int(np.random.default_rng(5).integers(0, m))
+    dsig[bad, 63] ^= 1                       # one bad signature anywhere must reject the batch
+    rlc()
+    assert res.value == 0, "BIP-340 batch with one bad signature accepted"
+    dsig[bad, 63] ^= 1
+    dval = torch.zeros(m, dtype=torch.uint8, device=dev)
+    ms_single = timed(lambda: lib.s2k_schnorr_verify_batch_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32,
+                                                                  dsig.data_ptr(), 0, dval.data_ptr(), st), 3)
+    assert int(dval.sum().item()) == m
+    out["schnorr_rlc_2p20"] = {"sigs": m, "ms": ms, "sigs_per_s": m / (ms * 1e-3),
+                               "per_signature_verify_ms": ms_single,
+                               "check": "accepts the valid batch, rejects it with one flipped bit at index %d; "
+                                        "per-signature verification accepts all" % bad}
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -19,8 +19,13 @@
  *   - per-item results are data (0/1 bytes), never errors — like Verify returning false
  *     (ecdsa.go:186-188).  The int return value reports infrastructure errors only.
  *   - all buffers are caller-owned; nothing is retained after a call returns.
- *   - a context is bound to one GPU; calls on one context are serialised by the caller
- *     (one context per goroutine/thread, like distinct receivers in the reference).
+ *   - a context is bound to one GPU and owns the device workspaces its calls share.  HOST side:
+ *     calls on one context must not run concurrently (one context per goroutine/thread, like
+ *     distinct receivers in the reference).  DEVICE side: the *_device entry points enqueue on
+ *     the caller's stream and return without synchronising; the context chains consecutive
+ *     calls with an event, so a call enqueued on another stream (or a host-buffer entry point,
+ *     which uses the context's own streams) starts only after the previous call's kernels have
+ *     finished — callers may switch streams freely, results are never torn.
  *
  * There is no CPU fallback: every function fails with S2K_ERR_NO_DEVICE / S2K_ERR_HIP
  * when the GPU is not usable.
@@ -70,6 +75,19 @@ int s2k_ctx_create(int device_index, s2k_ctx **out);
 void s2k_ctx_destroy(s2k_ctx *ctx);
 const char *s2k_last_error(const s2k_ctx *ctx);
 const char *s2k_version(void);
+/* Compile-time configuration of this library ("GT_BITS=22 PREP_M=6 ... flags=<S2K_EXTRA_FLAGS>"),
+ * so that a measurement can name the variant it ran (bench.py prints it). */
+const char *s2k_build_config(void);
+/* Measurement hooks (no reference counterpart; bench.py's live roofline).  While enabled, every
+ * s2k_ecdsa_verify_batch_device call records HIP events on its stream around its three kernels
+ * (scalar preparation, ladder, complete-formula worklist) and the ladder kernel stamps the shader
+ * cycle counter against the constant-rate wall clock.  s2k_ctx_profile_read synchronises the
+ * device and returns the summed durations in ms_sum3[0..2], optionally each call's ladder time
+ * in ms_fast_each[0..cap), the number of calls since the last read, and the effective shader
+ * clock (MHz) seen by the last ladder launch. */
+int s2k_ctx_profile(s2k_ctx *ctx, int enable);
+int s2k_ctx_profile_read(s2k_ctx *ctx, double ms_sum3[3], double *ms_fast_each, size_t cap, size_t *calls,
+                         double *shader_mhz);
 
 /* ---- hot path: batch ECDSA verification ------------------------------------------- */
 /* For each i < n: secec.PublicKey.VerifyRaw(digest, r, s) (ecdsa.go:234 -> verify :392)
@@ -167,6 +185,20 @@ int s2k_scalar_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k, const uint8_
 /* out[i] = u1[i]*G + u2[i]*P[i] — Point.DoubleScalarMultBasepointVartime (point_mul_glv.go:307) */
 int s2k_double_scalar_mult_basepoint_batch(s2k_ctx *ctx, size_t n, const uint8_t *u1, const uint8_t *u2,
                                            const uint8_t *points, uint8_t *out);
+/* The same two operations with an implementation selector (for the parity tests, which run the
+ * reference's vectors through BOTH implementations; the entry points above use S2K_IMPL_FAST):
+ *   S2K_IMPL_COMPLETE  the reference's algorithm shape: complete projective formulas on the 8x32
+ *                      field (what k_verify_fallback runs for lanes the ladder cannot decide);
+ *   S2K_IMPL_FAST      the verification ladder itself (k_verify_fast: 9x29 lazy field, common-Z
+ *                      odd-multiple table, signed odd digits of the odd GLV split, Jacobian
+ *                      doublings / mixed additions, resident generator tables) with undecided
+ *                      lanes re-done by the complete path, exactly as in a verification.
+ * u1 == NULL: out[i] = u2[i]*P[i] (scalarMultVartimeGLV).  A record that is neither 0x04||X||Y on
+ * the curve nor the identity record gives S2K_ERR_ARG (the reference cannot construct such Points). */
+#define S2K_IMPL_COMPLETE 0u
+#define S2K_IMPL_FAST 1u
+int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx *ctx, uint32_t impl, size_t n, const uint8_t *u1,
+                                              const uint8_t *u2, const uint8_t *points, uint8_t *out);
 /* out[i] = a[i] + b[i] — Point.Add (point.go:62); out[i] = 2*a[i] — Point.Double (point.go:71) */
 int s2k_point_add_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
 int s2k_point_double_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, uint8_t *out);
@@ -200,6 +232,36 @@ int s2k_fp_op_batch(s2k_ctx *ctx, int op, size_t n, const uint8_t *a, const uint
 int s2k_fn_op_batch(s2k_ctx *ctx, int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *flag);
 /* GLV split (point_mul_glv.go:59): k == k1 + k2*lambda (mod n), both canonical */
 int s2k_fn_split_glv_batch(s2k_ctx *ctx, size_t n, const uint8_t *k, uint8_t *k1, uint8_t *k2);
+
+/* Test access to the arithmetic of the hot kernels (impl must be S2K_IMPL_FAST): the 9x29 lazy
+ * field of the verification ladder incl. its fused products, the Jacobian doubling / mixed
+ * addition (jacobian29.h) and the complete 9x29 formulas of the multiscalar kernels (pt29.h), on
+ * operands put in LAZY form first (same value, unreduced limbs; `lazy` holds a 4-bit code per
+ * operand: bits 1:0 = multiples of p added limb-wise, bit 2 = borrow-spread).  in[0..4] are
+ * n*32-byte big-endian operands a..e (NULL = unused); results are canonical.  Reference symbols
+ * served: fiat Mul/Square/Add/Opp (secp256k1montgomery.go:87,418,750,844), Element.Invert / Sqrt
+ * (field_invert.go:11, field_sqrt_ratio.go:14), addMixed / addComplete / doubleComplete
+ * (point_projective.go:123,24,208).
+ *   MUL a*b | SQR a^2 | MUL_PLUS a*b+c | SQR_PLUS a^2+b | MUL_ADD_MUL a*b+c*d | MUL_ADD_SQR a*b+c^2
+ *   ADD a+b | NEGATE -a | HALF a/2 | NORMALIZE a (flag = a == 0) | COND_NEGATE1 (b odd ? -a : a)
+ *   INV | SQRT (flag = root exists) | EQ (flag) | MUL_SMALL21 21a | NORMALIZE_WEAK a
+ *   JDBL: 2P, JADD: P + (d,e) for P = (a,b) lifted to Jacobian Z = c; out,out2 = affine x,y;
+ *         flag = 0 when the incomplete formulas hit an exceptional case (Z3 = 0)
+ *   PT29_DBL / PT29_ADD / PT29_ADD_MIXED: complete formulas, P = (a:b:1) scaled by Z = c
+ *         (c = 0: the identity), Q = (d,e); flag = 0 when the result is the identity */
+enum {
+  S2K_HP_MUL = 0, S2K_HP_SQR, S2K_HP_MUL_PLUS, S2K_HP_SQR_PLUS, S2K_HP_MUL_ADD_MUL, S2K_HP_MUL_ADD_SQR,
+  S2K_HP_ADD, S2K_HP_NEGATE, S2K_HP_HALF, S2K_HP_NORMALIZE, S2K_HP_COND_NEGATE1, S2K_HP_INV, S2K_HP_SQRT,
+  S2K_HP_EQ, S2K_HP_MUL_SMALL21, S2K_HP_NORMALIZE_WEAK, S2K_HP_JDBL, S2K_HP_JADD, S2K_HP_PT29_DBL,
+  S2K_HP_PT29_ADD, S2K_HP_PT29_ADD_MIXED
+};
+int s2k_fp_op_batch_ex(s2k_ctx *ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t *const in[5],
+                       uint8_t *out, uint8_t *out2, uint8_t *flag);
+/* The odd GLV split the verification ladder uses (sc_split_glv_odd): k == (-1)^s1 k1 + (-1)^s2 k2 lambda
+ * (mod n) with k1, k2 ODD and below 2^129 (32-byte big-endian magnitudes), signs[i] = s1 | s2 << 1.
+ * Serves splitGLV (point_mul_glv.go:59); impl must be S2K_IMPL_FAST. */
+int s2k_fn_split_glv_batch_ex(s2k_ctx *ctx, uint32_t impl, size_t n, const uint8_t *k, uint8_t *k1, uint8_t *k2,
+                              uint8_t *signs);
 
 /* ---- introspection used by the tests ------------------------------------------------ */
 /* Copies generator-table entry T_i[d] (X‖Y big-endian) to out64.  Layout: DESIGN.md §3. */

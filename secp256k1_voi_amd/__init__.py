@@ -27,6 +27,10 @@ FORCE_COMPLETE = 0x80000000
 ENCODING_ASN1, ENCODING_COMPACT = 0, 1
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
+IMPL_COMPLETE, IMPL_FAST = 0, 1
+(HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
+ HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
+ HP_PT29_ADD_MIXED) = range(21)
 
 IDENTITY = bytes(65)
 
@@ -37,16 +41,28 @@ class EngineError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU): one object
-    per translation unit (in parallel), then one shared library."""
+    per translation unit (in parallel), then one shared library.  The variant flags
+    (S2K_EXTRA_FLAGS, e.g. "-DS2K_GT_BITS=16") are recorded next to the objects and compiled into
+    s2k_build_config(); a library built with other flags than the ones asked for now is rebuilt,
+    so an A/B script cannot leave a non-default kernel behind unnoticed."""
     from concurrent.futures import ThreadPoolExecutor
     units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "secp256k1_voi_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps):
-        return LIB_PATH
     objdir = os.path.join(_HERE, "build")
+    stamp = os.path.join(objdir, "flags.stamp")
+    extra = " ".join(os.environ.get("S2K_EXTRA_FLAGS", "").split())
+    try:
+        with open(stamp) as f:
+            built_with = f.read()
+    except OSError:
+        built_with = None
+    fresh = os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps)
+    if not force and fresh and (built_with == extra or (built_with is None and not extra and not os.path.isdir(objdir))):
+        return LIB_PATH
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + os.environ.get("S2K_EXTRA_FLAGS", "").split()
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", '-DS2K_BUILD_FLAGS="%s"' % extra.replace('"', "'")]
+    flags += extra.split()
 
     def compile_one(u):
         obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
@@ -62,6 +78,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(extra)
     return LIB_PATH
 
 
@@ -84,6 +102,9 @@ def load_library() -> C.CDLL:
     lib.s2k_last_error.argtypes = [vp]
     lib.s2k_last_error.restype = C.c_char_p
     lib.s2k_version.restype = C.c_char_p
+    lib.s2k_build_config.restype = C.c_char_p
+    lib.s2k_ctx_profile.argtypes = [vp, ci]
+    lib.s2k_ctx_profile_read.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
@@ -102,6 +123,9 @@ def load_library() -> C.CDLL:
     lib.s2k_scalar_base_mult_batch.argtypes = [vp, sz, vp, vp]
     lib.s2k_scalar_mult_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_double_scalar_mult_basepoint_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.s2k_double_scalar_mult_basepoint_batch_ex.argtypes = [vp, u32, sz, vp, vp, vp, vp]
+    lib.s2k_fp_op_batch_ex.argtypes = [vp, u32, ci, u32, sz, vp, vp, vp, vp]
+    lib.s2k_fn_split_glv_batch_ex.argtypes = [vp, u32, sz, vp, vp, vp, vp]
     lib.s2k_point_add_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_point_double_batch.argtypes = [vp, sz, vp, vp]
     lib.s2k_point_decode_batch.argtypes = [vp, sz, sz, vp, vp, vp]
@@ -116,7 +140,8 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version",
+    "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version", "s2k_build_config",
+    "s2k_ctx_profile", "s2k_ctx_profile_read",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
     "s2k_pack_valid_device", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
@@ -127,6 +152,7 @@ EXPORTED_SYMBOLS = [
     "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
     "s2k_multi_scalar_mult", "s2k_multi_scalar_mult_device",
     "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry", "s2k_generator_window_bits",
+    "s2k_double_scalar_mult_basepoint_batch_ex", "s2k_fp_op_batch_ex", "s2k_fn_split_glv_batch_ex",
 ]
 
 
@@ -312,6 +338,20 @@ class Engine:
         """valid bytes -> bitmap + uint64 count, all device pointers."""
         self._check(self._lib.s2k_pack_valid_device(self._h, int(n), d_valid, d_bitmap, d_count, stream))
 
+    def profile(self, enable: bool = True):
+        """Per-kernel HIP-event timing of ecdsa_verify_batch_device calls (s2k_ctx_profile)."""
+        self._check(self._lib.s2k_ctx_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, cap: int = 1024):
+        """-> dict(calls, prep_ms, fast_ms, fallback_ms (sums), fast_each (ms per call), shader_mhz)."""
+        sums = (C.c_double * 3)()
+        each = (C.c_double * cap)()
+        calls, mhz = C.c_size_t(0), C.c_double(0.0)
+        self._check(self._lib.s2k_ctx_profile_read(self._h, sums, each, cap, C.byref(calls), C.byref(mhz)))
+        k = int(calls.value)
+        return {"calls": k, "prep_ms": sums[0], "fast_ms": sums[1], "fallback_ms": sums[2],
+                "fast_each": [each[i] for i in range(min(k, cap))], "shader_mhz": float(mhz.value)}
+
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))
 
@@ -341,6 +381,38 @@ class Engine:
         self._check(self._lib.s2k_double_scalar_mult_basepoint_batch(self._h, n, u1.ctypes.data, u2.ctypes.data,
                                                                      points.ctypes.data, out.ctypes.data))
         return out
+
+    def double_scalar_mult_basepoint_batch_ex(self, impl, u1, u2, points):
+        """u1*G + u2*P (u1 None: u2*P) with an implementation selector (IMPL_COMPLETE / IMPL_FAST)."""
+        u2 = _arr(u2, 32)
+        n = u2.shape[0]
+        points = _arr(points, 65, n)
+        u1a = _arr(u1, 32, n) if u1 is not None else None
+        out = self._points_out(n)
+        self._check(self._lib.s2k_double_scalar_mult_basepoint_batch_ex(self._h, impl, n,
+                                                                        u1a.ctypes.data if u1a is not None else None,
+                                                                        u2.ctypes.data, points.ctypes.data, out.ctypes.data))
+        return out
+
+    def fp_op_batch_ex(self, op, operands, lazy=0):
+        """Hot-path field / group arithmetic (s2k_fp_op_batch_ex, IMPL_FAST): `operands` is a list of up
+        to five (n,32) operand arrays (None = unused); returns (out, out2, flag)."""
+        ops = [(_arr(x, 32) if x is not None else None) for x in operands] + [None] * (5 - len(operands))
+        n = ops[0].shape[0]
+        ptrs = (C.c_void_p * 5)(*[(x.ctypes.data if x is not None else None) for x in ops])
+        out, out2, flag = (np.zeros((n, 32), dtype=np.uint8), np.zeros((n, 32), dtype=np.uint8), np.zeros(n, dtype=np.uint8))
+        self._check(self._lib.s2k_fp_op_batch_ex(self._h, IMPL_FAST, op, lazy, n, ptrs, out.ctypes.data, out2.ctypes.data,
+                                                 flag.ctypes.data))
+        return out, out2, flag
+
+    def fn_split_glv_odd_batch(self, k):
+        """sc_split_glv_odd: (|k1|, |k2|, signs) with both magnitudes odd and below 2^129."""
+        k = _arr(k, 32)
+        n = k.shape[0]
+        k1, k2, sg = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8), np.zeros(n, np.uint8)
+        self._check(self._lib.s2k_fn_split_glv_batch_ex(self._h, IMPL_FAST, n, k.ctypes.data, k1.ctypes.data, k2.ctypes.data,
+                                                        sg.ctypes.data))
+        return k1, k2, sg
 
     def point_add_batch(self, a, b):
         a = _arr(a, 65)

@@ -319,21 +319,7 @@ S2K_DEV fe29 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t la
 #endif
   return r;
 }
-// neg ? 2p - a : a, for a of 1 unit (result <= 2 units), without a select: with M = all ones when
-// neg, (a ^ M) + (M & (B + 1)) is ~a + B + 1 = B - a limb by limb (B = 2p's limbs), and a when M = 0
-S2K_DEV fe29 fe29_cond_negate1(const fe29& a, bool neg) {
-  const uint32_t M = 0u - (uint32_t)neg;
-  const uint32_t b0 = M & (2u * F29_P0 + 1u), b1 = M & (2u * F29_P1 + 1u), bm = M & (2u * F29_PM + 1u), b8 = M & (2u * F29_P8 + 1u);
-  fe29 r;
-  r.n[0] = (a.n[0] ^ M) + b0;
-  r.n[1] = (a.n[1] ^ M) + b1;
-#pragma unroll
-  for (int i = 2; i < 8; ++i) r.n[i] = (a.n[i] ^ M) + bm;
-  r.n[8] = (a.n[8] ^ M) + b8;
-  return r;
-}
-
-enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 
 // MODE_ECDSA:   pub = n x 64 (X||Y), rsig = n x 32 (r);      accept iff x(R) mod n == r
@@ -343,6 +329,9 @@ constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 // MODE_RECOVER: pub unused, rsig = n x 32 (r); the point is R = RecoverPoint(r, id) with the id
 //               from the prep flag word; out = ok bytes, out_pts = n x 65 records of
 //               Q = (-e/r) G + (s/r) R (RecoverPublicKey, ecdsa.go:244-282)
+// MODE_POINT:   pub = n x 64 (X||Y), rsig unused; out_pts = n x 65 records of u1*G + u2*P with
+//               u1 and the split u2 taken from the prep planes as they are
+//               (DoubleScalarMultBasepointVartime, point_mul_glv.go:307; k_hot_prep)
 // Waves per SIMD the register allocator must leave room for.  Measured (2^20 signatures):
 // unbounded (240 VGPRs, 2 waves) 11.08 ms; 3 waves (168 VGPRs, no spills) 10.89 ms; 4 waves
 // (128 VGPRs, 96 spilled) 11.45 ms.
@@ -354,9 +343,17 @@ __global__ void __launch_bounds__(256, S2K_FAST_WAVES)
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ hs,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
-              uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts) {
+              uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
+  // effective shader clock of this launch (bench.py roofline): wave 0 of workgroup 0 stamps the
+  // shader cycle counter and the constant-rate wall clock when it starts and when it ends
+  const bool stamp = clk != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
+  uint64_t t0c = 0, t0w = 0;
+  if (stamp) {
+    t0c = __builtin_readcyclecounter();
+    t0w = __builtin_amdgcn_s_memrealtime();
+  }
   uint32_t pf = prep[(size_t)16 * stride + idx];
   bool ok;
   fe29 qx, qy;
@@ -381,7 +378,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     qy = fe29_normalize(qy);
     bool want_odd = (pf & 0x100u) != 0;
     qy = fe29_select(((qy.n[0] & 1u) != 0) != want_odd, qy, fe29_normalize_weak(fe29_negate(qy, 1)));
-  } else if constexpr (MODE == MODE_ECDSA) {
+  } else if constexpr (MODE == MODE_ECDSA || MODE == MODE_POINT) {
     apt q;
     load_be32(q.x.v, pub + idx * 64);
     load_be32(q.y.v, pub + idx * 64 + 32);
@@ -516,7 +513,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 
   // ---- verdict ----
   uint8_t verdict = 0;
-  if constexpr (MODE == MODE_RECOVER) {
+  if constexpr (MODE == MODE_RECOVER || MODE == MODE_POINT) {
     uint8_t* rec = out_pts + idx * 65;
     for (int i = 0; i < 65; ++i) rec[i] = 0;
   }
@@ -547,6 +544,12 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     }
   }
   out[idx] = verdict;
+  if (stamp && threadIdx.x == 0) {
+    clk[0] = t0c;
+    clk[1] = __builtin_readcyclecounter();
+    clk[2] = t0w;
+    clk[3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -762,11 +765,107 @@ k_recover_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// u1*G + u2*P for arbitrary (u1, u2, P) through the verification ladder (S2K_IMPL_FAST of
+// s2k_double_scalar_mult_basepoint_batch_ex): the same table, signed-digit ladder and generator
+// additions as a verification, with the affine result written as a 65-byte record.
+//   k_hot_prep          65-byte records -> 64-byte affine points + prep planes (u1, odd GLV
+//                       halves of u2); identity / malformed records go straight to the worklist
+//   k_verify_fast<MODE_POINT>, k_affine_finish<MODE_RECOVER>
+//   k_point_fallback    worklist lanes by the complete path (pt_base_mul + pt_mul_glv)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_hot_prep(uint32_t n, const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
+           uint8_t* __restrict__ pub64, uint32_t* __restrict__ prep, size_t stride, uint32_t* __restrict__ wl_count,
+           uint32_t* __restrict__ wl, uint32_t* __restrict__ status) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* rec = pts65 + i * 65;
+  apt a;
+  load_be32_unaligned(a.x.v, rec + 1);
+  load_be32_unaligned(a.y.v, rec + 33);
+  bool finite = rec[0] == 0x04 && fe_is_canonical_raw(a.x.v) && fe_is_canonical_raw(a.y.v) && apt_on_curve(a);
+  if (!finite && rec[0] != 0x00) atomicOr(status, 1u);   // not a Point the reference could have built
+  if (!finite) {                                          // identity: the complete kernel returns u1*G
+    a.x = fe_from_limbs(FE_GX);
+    a.y = fe_from_limbs(FE_GY);
+    uint32_t pos = atomicAdd(wl_count, 1u);
+    wl[pos] = (uint32_t)i;
+  }
+  store_be32(pub64 + i * 64, a.x.v);
+  store_be32(pub64 + i * 64 + 32, a.y.v);
+  uint32_t raw[8];
+  sc k1, k2, v1 = sc_zero();
+  bool neg1, neg2;
+  if (u1) {
+    load_be32(raw, u1 + i * 32);
+    v1 = sc_reduce_once(raw);
+  }
+  load_be32(raw, u2 + i * 32);
+  sc_split_glv_odd(sc_reduce_once(raw), k1, neg1, k2, neg2);
+  uint32_t f = (finite ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) | (k1.v[4] ? PF_K1_B128 : 0) |
+               (k2.v[4] ? PF_K2_B128 : 0);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) prep[(size_t)w * stride + i] = v1.v[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) prep[(size_t)(8 + w) * stride + i] = k1.v[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) prep[(size_t)(12 + w) * stride + i] = k2.v[w];
+  prep[(size_t)16 * stride + i] = f;
+}
+
+__global__ void __launch_bounds__(256)
+k_point_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
+                 const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
+                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint32_t* __restrict__ status) {
+  uint32_t count = all_n ? all_n : *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    size_t idx = all_n ? w : wl[w];
+    const uint8_t* rec = pts65 + idx * 65;
+    apt a;
+    load_be32_unaligned(a.x.v, rec + 1);
+    load_be32_unaligned(a.y.v, rec + 33);
+    bool finite = rec[0] == 0x04 && fe_is_canonical_raw(a.x.v) && fe_is_canonical_raw(a.y.v) && apt_on_curve(a);
+    if (!finite && rec[0] != 0x00) atomicOr(status, 1u);
+    if (!finite) {   // keep the arithmetic on the curve; the term is masked below
+      a.x = fe_from_limbs(FE_GX);
+      a.y = fe_from_limbs(FE_GY);
+    }
+    uint32_t raw[8];
+    load_be32(raw, u2 + idx * 32);
+    pt res = pt_select(!finite, pt_mul_glv(sc_reduce_once(raw), a, qt, stride, idx), pt_identity());
+    if (u1) {
+      load_be32(raw, u1 + idx * 32);
+      sc v1 = sc_reduce_once(raw);
+      res = pt_add_complete(pt_base_mul(gt, v1.v), res);   // point_mul_glv.go:316
+    }
+    uint8_t* o = out65 + idx * 65;
+    apt r;
+    if (!pt_to_affine(r, res)) {
+      for (int j = 0; j < 65; ++j) o[j] = 0;
+    } else {
+      o[0] = 0x04;
+      store_be32_unaligned(o + 1, r.x.v);
+      store_be32_unaligned(o + 33, r.y.v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
-const char* s2k_version(void) { return "secp256k1_voi_amd 0.1 (gfx950)"; }
+const char* s2k_version(void) { return "secp256k1_voi_amd 0.2 (gfx950)"; }
+#define S2K_STR2(x) #x
+#define S2K_STR(x) S2K_STR2(x)
+#ifndef S2K_BUILD_FLAGS
+#define S2K_BUILD_FLAGS ""
+#endif
+const char* s2k_build_config(void) {
+  return "GT_BITS=" S2K_STR(S2K_GT_BITS) " PREP_M=" S2K_STR(S2K_PREP_M) " QT_PLANE=" S2K_STR(S2K_QT_PLANE)
+         " FAST_WAVES=" S2K_STR(S2K_FAST_WAVES) " STRIDE_PAD=" S2K_STR(S2K_STRIDE_PAD) " flags=[" S2K_BUILD_FLAGS "]";
+}
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
@@ -811,6 +910,12 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   if (!ctx) return fail(nullptr, S2K_ERR_NOMEM, "out of host memory");
   ctx->device = device_index;
   hipError_t e = hipSetDevice(device_index);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_index);
+  if (e == hipSuccess) ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->clk, 64);
+  if (e == hipSuccess) e = hipMemset(ctx->clk, 0, 64);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->gtable, GT_ENTRIES * 64);
   uint32_t* bases = nullptr;
   if (e == hipSuccess) e = hipMalloc((void**)&bases, (GT_WINDOWS + 1) * 64);
@@ -824,6 +929,8 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   if (e != hipSuccess) {
     int rc = fail(nullptr, S2K_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
     if (ctx->gtable) (void)hipFree(ctx->gtable);
+    if (ctx->clk) (void)hipFree(ctx->clk);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     delete ctx;
     return rc;
   }
@@ -838,11 +945,72 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->io) (void)hipFree(ctx->io);
+  if (ctx->clk) (void)hipFree(ctx->clk);
+  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  for (size_t i = 0; i < ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+  delete[] ctx->prof_ev;
   for (hipEvent_t e : ctx->ev_copied)
     if (e) (void)hipEventDestroy(e);
   if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
   if (ctx->s_comp) (void)hipStreamDestroy(ctx->s_comp);
   delete ctx;
+}
+
+// per-kernel timing (s2k_ctx_profile): one event before and after each of the three kernels
+static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
+  if (!ctx->prof_on || ctx->prof_used + 4 > ctx->prof_cap) return;
+  (void)hipEventRecord(ctx->prof_ev[ctx->prof_used + slot], st);
+  if (slot == 3) ctx->prof_used += 4;
+}
+
+int s2k_ctx_profile(s2k_ctx* ctx, int enable) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (enable && !ctx->prof_ev) {
+    const size_t cap = 4 * 1024;   // 1024 verification calls between two reads
+    ctx->prof_ev = new (std::nothrow) hipEvent_t[cap];
+    if (!ctx->prof_ev) return fail(ctx, S2K_ERR_NOMEM, "out of host memory");
+    for (size_t i = 0; i < cap; ++i) {
+      hipError_t e = hipEventCreate(&ctx->prof_ev[i]);
+      if (e != hipSuccess) {
+        for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(ctx->prof_ev[j]);
+        delete[] ctx->prof_ev;
+        ctx->prof_ev = nullptr;
+        return fail(ctx, S2K_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+      }
+    }
+    ctx->prof_cap = cap;
+  }
+  ctx->prof_on = enable != 0;
+  ctx->prof_used = 0;
+  return S2K_OK;
+}
+
+int s2k_ctx_profile_read(s2k_ctx* ctx, double* ms_sum3, double* ms_fast_each, size_t cap, size_t* calls,
+                         double* shader_mhz) {
+  if (!ctx || !ms_sum3 || !calls) return fail(ctx, S2K_ERR_ARG, "null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  ms_sum3[0] = ms_sum3[1] = ms_sum3[2] = 0.0;
+  const size_t k = ctx->prof_used / 4;
+  for (size_t i = 0; i < k; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      float ms = 0.f;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[4 * i + j], ctx->prof_ev[4 * i + j + 1]));
+      ms_sum3[j] += ms;
+      if (j == 1 && ms_fast_each && i < cap) ms_fast_each[i] = ms;
+    }
+  }
+  *calls = k;
+  ctx->prof_used = 0;
+  if (shader_mhz) {
+    uint64_t h[4] = {0, 0, 0, 0};
+    int wall_khz = 0;
+    HIP_TRY(ctx, hipMemcpy(h, ctx->clk, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
+    *shader_mhz = (h[3] > h[2] && wall_khz > 0) ? (double)(h[1] - h[0]) / (double)(h[3] - h[2]) * (wall_khz * 1e-3) : 0.0;
+  }
+  return S2K_OK;
 }
 
 int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const void* d_dig, const void* d_r,
@@ -852,9 +1020,11 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   if (!d_pub || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = s2k_internal_ensure_ws(ctx, n);
-  if (rc) return rc;
   hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  rc = s2k_internal_ensure_ws(ctx, n);
+  if (rc) return rc;
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
@@ -863,7 +1033,7 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
                                                   (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                                   ctx->gtable, qt, stride);
     HIP_TRY(ctx, hipGetLastError());
-    return S2K_OK;
+    return ctx_leave(ctx, st);
   }
   uint32_t* hs = ws + WS_HS * stride;
   uint32_t* prep = ws + WS_PREP * stride;
@@ -873,17 +1043,22 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   uint32_t* wl = wl_count + 64;
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  prof_mark(ctx, st, 0);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
                                               (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
+  prof_mark(ctx, st, 1);
   k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, hs,
-                                               ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr);
+                                               ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr,
+                                               ctx->prof_on ? ctx->clk : nullptr);
   HIP_TRY(ctx, hipGetLastError());
-  k_verify_fallback<<<64, 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
+  prof_mark(ctx, st, 2);
+  k_verify_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                         ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
-  return S2K_OK;
+  prof_mark(ctx, st, 3);
+  return ctx_leave(ctx, st);
 }
 
 int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, const void* d_r, const void* d_s,
@@ -893,9 +1068,11 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   if (!d_dig || !d_r || !d_s || !d_recid || !d_pub65 || !d_ok) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = s2k_internal_ensure_ws(ctx, n);
-  if (rc) return rc;
   hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  rc = s2k_internal_ensure_ws(ctx, n);
+  if (rc) return rc;
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
@@ -911,14 +1088,14 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
     k_recover_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, dig, r, s, rid, (uint8_t*)d_ok,
                                                       (uint8_t*)d_pub65, ctx->gtable, qt, stride);
     HIP_TRY(ctx, hipGetLastError());
-    return S2K_OK;
+    return ctx_leave(ctx, st);
   }
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, hs, ctx->gtable,
-                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65);
+                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
@@ -926,10 +1103,10 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
                                                                  (uint8_t*)d_pub65);
     HIP_TRY(ctx, hipGetLastError());
   }
-  k_recover_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, dig, r, s, rid, (uint8_t*)d_ok, (uint8_t*)d_pub65,
-                                         ctx->gtable, qt, stride);
+  k_recover_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, dig, r, s, rid, (uint8_t*)d_ok,
+                                                              (uint8_t*)d_pub65, ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
-  return S2K_OK;
+  return ctx_leave(ctx, st);
 }
 
 int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const uint8_t* r, const uint8_t* s,
@@ -962,9 +1139,11 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = s2k_internal_ensure_ws(ctx, n);
-  if (rc) return rc;
   hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  rc = s2k_internal_ensure_ws(ctx, n);
+  if (rc) return rc;
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
@@ -980,23 +1159,23 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     k_schnorr_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len,
                                                       (uint8_t*)d_valid, ctx->gtable, qt, stride);
     HIP_TRY(ctx, hipGetLastError());
-    return S2K_OK;
+    return ctx_leave(ctx, st);
   }
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, hs, ctx->gtable,
-                                                             (uint8_t*)d_valid, wl_count, wl, stride, nullptr);
+                                                             (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, qt, hs, (uint8_t*)d_valid, stride, nullptr);
     HIP_TRY(ctx, hipGetLastError());
   }
-  k_schnorr_fallback<<<64, 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
-                                         ctx->gtable, qt, stride);
+  k_schnorr_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len,
+                                                              (uint8_t*)d_valid, ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
-  return S2K_OK;
+  return ctx_leave(ctx, st);
 }
 
 // Host-buffer entry point.  The batch is cut into chunks that are whole rounds of k_verify_fast
@@ -1063,6 +1242,70 @@ int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const ui
   if (rc) return rc;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(valid, dv.p, n, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+// Point.DoubleScalarMultBasepointVartime (point_mul_glv.go:307), or scalarMultVartimeGLV (:203) when
+// u1 == NULL, over a batch of 65-byte records; host pointers.  impl selects the arithmetic (header).
+int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_t n, const uint8_t* u1, const uint8_t* u2,
+                                              const uint8_t* points, uint8_t* out) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (impl != S2K_IMPL_COMPLETE && impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "unknown implementation selector");
+  if (n == 0) return S2K_OK;
+  if (!u2 || !points || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ctx_streams(ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  rc = s2k_internal_ensure_ws(ctx, n);
+  if (rc) return rc;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t o_u1 = 0, o_u2 = pad(n * 32), o_pts = o_u2 + pad(n * 32), o_out = o_pts + pad(n * 65), o_pub = o_out + pad(n * 65),
+               o_ok = o_pub + pad(n * 64), o_status = o_ok + pad(n);
+  rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, o_status + 256);
+  if (rc) return rc;
+  uint8_t* io = (uint8_t*)ctx->io;
+  if (u1) HIP_TRY(ctx, hipMemcpyAsync(io + o_u1, u1, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_u2, u2, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(io + o_pts, points, n * 65, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(io + o_status, 0, 4, st));
+  const uint8_t* d_u1 = u1 ? io + o_u1 : nullptr;
+  const size_t stride = lane_stride(n);
+  uint32_t* ws = (uint32_t*)ctx->ws;
+  uint32_t* qt = ws + WS_QT * stride;
+  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
+  uint32_t* wl = wl_count + 64;
+  uint32_t* status = (uint32_t*)(io + o_status);
+  if (impl == S2K_IMPL_COMPLETE) {
+    k_point_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_out,
+                                                    ctx->gtable, qt, stride, status);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+    k_hot_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_pub, prep, stride, wl_count, wl,
+                                              status);
+    HIP_TRY(ctx, hipGetLastError());
+    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, hs, ctx->gtable,
+                                                             io + o_ok, wl_count, wl, stride, io + o_out, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
+    k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, qt, hs, io + o_ok, stride, io + o_out);
+    HIP_TRY(ctx, hipGetLastError());
+    k_point_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, d_u1, io + o_u2, io + o_pts, io + o_out,
+                                                              ctx->gtable, qt, stride, status);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  uint32_t h_status = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(out, io + o_out, n * 65, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&h_status, status, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
+  if (h_status) return fail(ctx, S2K_ERR_ARG, "malformed point record (not an encoding the reference's Point can hold)");
   return S2K_OK;
 }
 

@@ -76,6 +76,18 @@ struct s2k_ctx {
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr};
   int cu_count = 0;
+  // Calls on one context share its workspaces.  Every enqueue ends by recording ev_done on its
+  // stream, and an enqueue on a different stream than the previous one first waits for it, so
+  // consecutive calls never overlap on the device whatever streams they use.
+  hipEvent_t ev_done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
+  // optional per-kernel timing of the verification path (s2k_ctx_profile): event quadruples
+  // around k_scalar_prep / k_verify_fast / k_verify_fallback, read back by s2k_ctx_profile_read
+  bool prof_on = false;
+  hipEvent_t* prof_ev = nullptr;
+  size_t prof_cap = 0, prof_used = 0;
+  uint64_t* clk = nullptr;      // device: s_memtime / s_memrealtime stamps of one wave of k_verify_fast
   char err[512] = {0};
 };
 
@@ -118,13 +130,27 @@ static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256)
 static inline size_t lane_stride(size_t n) { return ((n + 63) & ~(size_t)63) + S2K_STRIDE_PAD; }
 
 
-// small RAII helper for the host-pointer entry points
+// Serialisation of the calls of one context across streams (see s2k_ctx::ev_done).
+inline int ctx_enter(s2k_ctx* ctx, hipStream_t st) {
+  if (ctx->have_last && ctx->last_stream != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_done, 0));
+  return S2K_OK;
+}
+inline int ctx_leave(s2k_ctx* ctx, hipStream_t st) {
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
+  ctx->last_stream = st;
+  ctx->have_last = true;
+  return S2K_OK;
+}
+// grid of the complete-formula worklist kernels: enough workgroups for the whole batch when
+// every lane is undecided (adversarial input), at most 8 per CU (they loop over the list)
+static inline unsigned fallback_blocks(const s2k_ctx* ctx, size_t n) {
+  size_t want = (n + 255) / 256, cap = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+  return (unsigned)(want < cap ? want : cap);
+}
+
 // copy / compute streams and the events chaining them, for the host-buffer entry points
 inline int ctx_streams(s2k_ctx* ctx) {
   if (ctx->s_copy) return S2K_OK;
-  hipDeviceProp_t prop;
-  HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-  ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
   for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -94,6 +94,20 @@ S2K_DEV fe29 fe29_select(bool pick_b, const fe29& a, const fe29& b) {
   return r;
 }
 
+// neg ? 2p - a : a, for a of 1 unit (result <= 2 units), without a select: with M = all ones when
+// neg, (a ^ M) + (M & (B + 1)) is ~a + B + 1 = B - a limb by limb (B = 2p's limbs), and a when M = 0
+S2K_DEV fe29 fe29_cond_negate1(const fe29& a, bool neg) {
+  const uint32_t M = 0u - (uint32_t)neg;
+  const uint32_t b0 = M & (2u * F29_P0 + 1u), b1 = M & (2u * F29_P1 + 1u), bm = M & (2u * F29_PM + 1u), b8 = M & (2u * F29_P8 + 1u);
+  fe29 r;
+  r.n[0] = (a.n[0] ^ M) + b0;
+  r.n[1] = (a.n[1] ^ M) + b1;
+#pragma unroll
+  for (int i = 2; i < 8; ++i) r.n[i] = (a.n[i] ^ M) + bm;
+  r.n[8] = (a.n[8] ^ M) + b8;
+  return r;
+}
+
 // carry-propagate to 1 unit (not canonical); input limbs < 2^32 - 2^18
 S2K_DEV fe29 fe29_normalize_weak(const fe29& a) {
   uint32_t t[9];

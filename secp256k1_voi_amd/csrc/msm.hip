@@ -771,8 +771,10 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
     HIP_TRY(ctx, hipMemsetAsync(d_out65, 0, 65, st));
     return S2K_OK;
   }
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
   msm_ws m;
-  int rc = msm_setup(ctx, 2 * n, 0, m);   // every input is two terms (endomorphism split)
+  rc = msm_setup(ctx, 2 * n, 0, m);   // every input is two terms (endomorphism split)
   if (rc) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
   k_msm_parse<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, m.scw,
@@ -784,6 +786,7 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
   uint32_t h_status = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&h_status, m.status, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;   // the stream has been synchronised: nothing of this context is in flight
   if (h_status) return fail(ctx, S2K_ERR_ARG, "malformed point record in multi-scalar multiplication input");
   return S2K_OK;
 }
@@ -819,8 +822,10 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   const size_t N = 3 * n + 2;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
   msm_ws m;
-  int rc = msm_setup(ctx, N, n * 8 * 4 + 256 + RLC_SUM_BLOCKS * 32, m);
+  rc = msm_setup(ctx, N, n * 8 * 4 + 256 + RLC_SUM_BLOCKS * 32, m);
   if (rc) return rc;
   uint32_t* seed_dev = (uint32_t*)m.aux;
   uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
@@ -845,6 +850,7 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk
   uint8_t h[192];
   HIP_TRY(ctx, hipMemcpyAsync(h, m.status, 64 + 65, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
   uint32_t h_status;
   memcpy(&h_status, h, 4);
   *all_valid = (h_status == 0 && h[64] == 0x00) ? 1 : 0;

@@ -9,6 +9,7 @@
 
 #include "complete_path.h"
 #include "engine_internal.h"
+#include "jacobian29.h"
 #include "pt29.h"
 #include "sc26.h"
 
@@ -43,7 +44,7 @@ S2K_DEV void point_record_store(uint8_t* rec, const pt& p) {
   store_be32_unaligned(rec + 33, a.y.v);
 }
 
-enum { PK_BASE_MUL = 0, PK_MUL = 1, PK_DOUBLE_MUL = 2, PK_ADD = 3, PK_DOUBLE = 4 };
+enum { PK_BASE_MUL = 0, PK_ADD = 3, PK_DOUBLE = 4 };
 
 S2K_DEV pt29 pt29_from_pt(const pt& p) {
   pt29 r;
@@ -60,52 +61,32 @@ S2K_DEV pt pt_from_pt29(const pt29& p) {
   return r;
 }
 
+// scalar multiplications with a per-item point live in engine.hip (s2k_double_scalar_mult_basepoint_batch_ex)
 __global__ void __launch_bounds__(256)
-k_point_op(int op, uint32_t n, const uint8_t* __restrict__ k1, const uint8_t* __restrict__ k2,
-           const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, uint8_t* __restrict__ out,
-           const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+k_point_op(int op, uint32_t n, const uint8_t* __restrict__ k1, const uint8_t* __restrict__ pa,
+           const uint8_t* __restrict__ pb, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt,
+           uint32_t* __restrict__ status) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   pt res = pt_identity();
+  bool wellformed = true;
   if (op == PK_BASE_MUL) {
     uint32_t raw[8];
     load_be32(raw, k1 + idx * 32);
     sc k = sc_reduce_once(raw);
     res = pt_base_mul(gt, k.v);
-  } else if (op == PK_MUL || op == PK_DOUBLE_MUL) {
-    uint32_t raw[8];
-    pt p;
-    point_record_load(p, pa + idx * 65);
-    bool p_inf = pt_is_identity(p);
-    apt a;
-    a.x = p.x;
-    a.y = p.y;                    // Z = 1 for finite records
-    if (p_inf) {                   // keep the arithmetic on the curve; result is masked below
-      a.x = fe_from_limbs(FE_GX);
-      a.y = fe_from_limbs(FE_GY);
-    }
-    load_be32(raw, (op == PK_MUL ? k1 : k2) + idx * 32);
-    sc k = sc_reduce_once(raw);
-    pt rq = pt_mul_glv(k, a, qt, stride, idx);
-    rq = pt_select(p_inf, rq, pt_identity());
-    if (op == PK_DOUBLE_MUL) {
-      load_be32(raw, k1 + idx * 32);
-      sc u1 = sc_reduce_once(raw);
-      res = pt_add_complete(pt_base_mul(gt, u1.v), rq);
-    } else {
-      res = rq;
-    }
   } else if (op == PK_ADD) {
     // Point.Add (point.go:62) through the 9x29 complete formulas the multiscalar kernels use
     pt a, b;
-    point_record_load(a, pa + idx * 65);
-    point_record_load(b, pb + idx * 65);
+    wellformed = point_record_load(a, pa + idx * 65);
+    wellformed = point_record_load(b, pb + idx * 65) && wellformed;
     res = pt_from_pt29(pt29_add(pt29_from_pt(a), pt29_from_pt(b)));
   } else if (op == PK_DOUBLE) {
     pt a;
-    point_record_load(a, pa + idx * 65);
+    wellformed = point_record_load(a, pa + idx * 65);
     res = pt_from_pt29(pt29_double(pt29_from_pt(a)));
   }
+  if (!wellformed) atomicOr(status, 1u);   // not a Point the reference could hold (SetUncompressedBytes fails, point_s11n.go:178)
   point_record_store(out + idx * 65, res);
 }
 
@@ -205,6 +186,157 @@ k_fn_op(int op, uint32_t n, const uint8_t* __restrict__ a, const uint8_t* __rest
   store_be32(out + idx * 32, r.v);
 }
 
+// ---------------------------------------------------------------------------------------
+// Test access to the arithmetic the verification ladder and the multiscalar kernels actually run
+// (s2k_fp_op_batch_ex, S2K_IMPL_FAST): the 9x29 lazy field incl. its fused products, the Jacobian
+// doubling / mixed addition of jacobian29.h and the complete formulas of pt29.h, on operands in
+// LAZY form — same value, different unreduced limbs (the counterpart of the reference tests'
+// "random Z" re-randomisation, point_test.go:359-373).  Lazy code per operand (4 bits each, operand
+// j in bits 4j..4j+3): bits 1:0 = multiples of p added limb by limb, bit 2 = borrow-spread (limb
+// i + 2^29, limb i+1 - 1 wherever limb i+1 > 0).  The caller keeps the unit budget of fe29.h.
+// ---------------------------------------------------------------------------------------
+S2K_DEV fe29 fe29_lazy_form(fe29 v, uint32_t code) {
+  if (code & 4u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (v.n[i + 1] > 0) {
+        v.n[i + 1] -= 1u;
+        v.n[i] += 1u << 29;
+      }
+    }
+  }
+  const uint32_t k = code & 3u;
+  v.n[0] += k * F29_P0;
+  v.n[1] += k * F29_P1;
+#pragma unroll
+  for (int i = 2; i < 8; ++i) v.n[i] += k * F29_PM;
+  v.n[8] += k * F29_P8;
+  return v;
+}
+S2K_DEV uint32_t lazy_units(uint32_t code) { return 1u + (code & 3u) + ((code & 4u) ? 1u : 0u); }
+
+struct hp_args {
+  const uint8_t* in[5];
+};
+
+__global__ void __launch_bounds__(256)
+k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__ out, uint8_t* __restrict__ out2,
+          uint8_t* __restrict__ flag) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  fe29 v[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    v[j] = fe29_zero();
+    if (args.in[j]) {
+      uint32_t w[8];
+      load_be32(w, args.in[j] + idx * 32);
+      v[j] = fe29_lazy_form(fe29_from_words(w), (lazy >> (4 * j)) & 15u);
+    }
+  }
+  const fe29 &a = v[0], &b = v[1], &c = v[2], &d = v[3], &e = v[4];
+  fe29 r = fe29_zero(), r2 = fe29_zero();
+  uint8_t f = 1;
+  switch (op) {
+    case S2K_HP_MUL: r = fe29_mul(a, b); break;
+    case S2K_HP_SQR: r = fe29_sqr(a); break;
+    case S2K_HP_MUL_PLUS: r = fe29_mul_plus(a, b, c); break;
+    case S2K_HP_SQR_PLUS: r = fe29_sqr_plus(a, b); break;
+    case S2K_HP_MUL_ADD_MUL: r = fe29_mul_add_mul(a, b, c, d); break;
+    case S2K_HP_MUL_ADD_SQR: r = fe29_mul_add_sqr(a, b, c); break;
+    case S2K_HP_ADD: r = fe29_add(a, b); break;
+    case S2K_HP_NEGATE: r = fe29_negate(a, lazy_units(lazy & 15u)); break;
+    case S2K_HP_HALF: r = fe29_half(a); break;
+    case S2K_HP_NORMALIZE: r = a; f = fe29_is_zero(a) ? 1 : 0; break;
+    case S2K_HP_COND_NEGATE1: r = fe29_cond_negate1(a, (b.n[0] & 1u) != 0); break;
+    case S2K_HP_INV: r = fe29_inv(a); break;
+    case S2K_HP_SQRT: f = fe29_sqrt(r, a) ? 1 : 0; if (!f) r = fe29_zero(); break;
+    case S2K_HP_EQ: f = fe29_eq(a, b) ? 1 : 0; break;
+    case S2K_HP_MUL_SMALL21: r = fe29_mul_small_norm(a, 21); break;
+    case S2K_HP_NORMALIZE_WEAK: r = fe29_normalize_weak(a); break;
+    case S2K_HP_JDBL:
+    case S2K_HP_JADD: {
+      // P = (a, b) affine, lifted to Jacobian with Z = c (any non-zero value): X = a c^2, Y = b c^3
+      jpt29 p;
+      fe29 zz = fe29_sqr(c);
+      p.x = fe29_mul(a, zz);
+      p.y = fe29_mul(b, fe29_mul(zz, c));
+      p.z = fe29_normalize_weak(c);
+      jpt29 q = op == S2K_HP_JDBL ? jpt29_double(p) : jpt29_add_affine(p, d, e);
+      if (fe29_is_zero(q.z)) {   // exceptional input of the incomplete formulas (or a true infinity)
+        f = 0;
+      } else {
+        fe29 zi = fe29_inv(q.z), zi2 = fe29_sqr(zi);
+        r = fe29_mul(q.x, zi2);
+        r2 = fe29_mul(fe29_mul(q.y, zi2), zi);
+      }
+      break;
+    }
+    case S2K_HP_PT29_DBL:
+    case S2K_HP_PT29_ADD:
+    case S2K_HP_PT29_ADD_MIXED: {
+      // P = (a : b : 1) scaled by Z = c (c == 0 on input: the identity (0 : 1 : 0)); Q = (d, e) affine,
+      // for PT29_ADD rescaled by the same c
+      pt29 p, q;
+      bool p_inf = fe29_is_zero(c);
+      fe29 cn = fe29_normalize_weak(c);
+      p.x = fe29_mul(a, cn);
+      p.y = fe29_mul(b, cn);
+      p.z = cn;
+      if (p_inf) p = pt29_identity();
+      if (op == S2K_HP_PT29_DBL) {
+        q = pt29_double(p);
+      } else if (op == S2K_HP_PT29_ADD_MIXED) {
+        q = pt29_add_mixed(p, d, e);
+      } else {
+        pt29 t;
+        t.x = fe29_mul(d, cn);
+        t.y = fe29_mul(e, cn);
+        t.z = cn;
+        if (p_inf) {     // c == 0: add the affine point itself, Z = 1
+          t.x = d;
+          t.y = e;
+          t.z = fe29_one();
+        }
+        q = pt29_add(p, t);
+      }
+      if (fe29_is_zero(q.z)) {
+        f = 0;          // the identity
+      } else {
+        fe29 zi = fe29_inv(q.z);
+        r = fe29_mul(q.x, zi);
+        r2 = fe29_mul(q.y, zi);
+      }
+      break;
+    }
+    default: f = 0; break;
+  }
+  uint32_t w[8];
+  fe29_to_words(w, fe29_normalize(r));
+  store_be32(out + idx * 32, w);
+  if (out2) {
+    fe29_to_words(w, fe29_normalize(r2));
+    store_be32(out2 + idx * 32, w);
+  }
+  if (flag) flag[idx] = f;
+}
+
+// odd GLV split of the hot path (sc_split_glv_odd): magnitudes (129 bits) and sign bits
+__global__ void __launch_bounds__(256)
+k_split_glv_odd(uint32_t n, const uint8_t* __restrict__ k, uint8_t* __restrict__ k1o, uint8_t* __restrict__ k2o,
+                uint8_t* __restrict__ signs) {
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  uint32_t raw[8];
+  load_be32(raw, k + idx * 32);
+  sc k1, k2;
+  bool n1, n2;
+  sc_split_glv_odd(sc_reduce_once(raw), k1, n1, k2, n2);
+  store_be32(k1o + idx * 32, k1.v);
+  store_be32(k2o + idx * 32, k2.v);
+  signs[idx] = (n1 ? 1 : 0) | (n2 ? 2 : 0);
+}
+
 // valid bytes -> bitmap (bit i of byte i/8, LSB first) + number of valid items.  One lane
 // per 8 items; the count is reduced per wave with a ballot-free popcount sum and one atomic.
 __global__ void __launch_bounds__(256)
@@ -236,50 +368,51 @@ __global__ void k_gtable_entry(const uint32_t* __restrict__ gt, uint32_t window,
 
 extern "C" {
 
-static int point_op(s2k_ctx* ctx, int op, size_t n, const uint8_t* k1, const uint8_t* k2, const uint8_t* pa,
-                    const uint8_t* pb, uint8_t* out) {
+static int point_op(s2k_ctx* ctx, int op, size_t n, const uint8_t* k1, const uint8_t* pa, const uint8_t* pb, uint8_t* out) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (n == 0) return S2K_OK;
   if (!out) return fail(ctx, S2K_ERR_ARG, "null output buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dev_buf dk1, dk2, dpa, dpb, dout;
+  HIP_TRY(ctx, hipDeviceSynchronize());   // these entry points run on the NULL stream with their own buffers
+  dev_buf dk1, dpa, dpb, dout, dst;
   if (k1) HIP_TRY(ctx, dk1.upload(k1, n * 32));
-  if (k2) HIP_TRY(ctx, dk2.upload(k2, n * 32));
   if (pa) HIP_TRY(ctx, dpa.upload(pa, n * 65));
   if (pb) HIP_TRY(ctx, dpb.upload(pb, n * 65));
   HIP_TRY(ctx, dout.alloc(n * 65));
-  int rc = s2k_internal_ensure_ws(ctx, n);
-  if (rc) return rc;
-  k_point_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)dk1.p, (const uint8_t*)dk2.p,
-                                     (const uint8_t*)dpa.p, (const uint8_t*)dpb.p, (uint8_t*)dout.p, ctx->gtable,
-                                     (uint32_t*)ctx->ws, lane_stride(n));   // the table region starts the workspace
+  HIP_TRY(ctx, dst.alloc(16));
+  HIP_TRY(ctx, hipMemset(dst.p, 0, 16));
+  k_point_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)dk1.p, (const uint8_t*)dpa.p, (const uint8_t*)dpb.p,
+                                     (uint8_t*)dout.p, ctx->gtable, (uint32_t*)dst.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
+  uint32_t h_status = 0;
   HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 65, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(&h_status, dst.p, 4, hipMemcpyDeviceToHost));
+  if (h_status) return fail(ctx, S2K_ERR_ARG, "malformed point record (not an encoding the reference's Point can hold)");
   return S2K_OK;
 }
 
 int s2k_scalar_base_mult_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, uint8_t* out) {
   if (n && !k) return fail(ctx, S2K_ERR_ARG, "null scalar buffer");
-  return point_op(ctx, PK_BASE_MUL, n, k, nullptr, nullptr, nullptr, out);
+  return point_op(ctx, PK_BASE_MUL, n, k, nullptr, nullptr, out);
 }
 int s2k_scalar_mult_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, const uint8_t* points, uint8_t* out) {
   if (n && (!k || !points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
-  return point_op(ctx, PK_MUL, n, k, nullptr, points, nullptr, out);
+  return s2k_double_scalar_mult_basepoint_batch_ex(ctx, S2K_IMPL_FAST, n, nullptr, k, points, out);
 }
 int s2k_double_scalar_mult_basepoint_batch(s2k_ctx* ctx, size_t n, const uint8_t* u1, const uint8_t* u2,
                                            const uint8_t* points, uint8_t* out) {
   if (n && (!u1 || !u2 || !points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
-  return point_op(ctx, PK_DOUBLE_MUL, n, u1, u2, points, nullptr, out);
+  return s2k_double_scalar_mult_basepoint_batch_ex(ctx, S2K_IMPL_FAST, n, u1, u2, points, out);
 }
 int s2k_point_add_batch(s2k_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   if (n && (!a || !b)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
-  return point_op(ctx, PK_ADD, n, nullptr, nullptr, a, b, out);
+  return point_op(ctx, PK_ADD, n, nullptr, a, b, out);
 }
 int s2k_point_double_batch(s2k_ctx* ctx, size_t n, const uint8_t* a, uint8_t* out) {
   if (n && !a) return fail(ctx, S2K_ERR_ARG, "null input buffer");
-  return point_op(ctx, PK_DOUBLE, n, nullptr, nullptr, a, nullptr, out);
+  return point_op(ctx, PK_DOUBLE, n, nullptr, a, nullptr, out);
 }
 
 int s2k_point_decode_batch(s2k_ctx* ctx, size_t n, size_t enc_len, const uint8_t* enc, uint8_t* out, uint8_t* ok) {
@@ -339,6 +472,58 @@ int s2k_fn_op_batch(s2k_ctx* ctx, int op, size_t n, const uint8_t* a, const uint
 int s2k_fn_split_glv_batch(s2k_ctx* ctx, size_t n, const uint8_t* k, uint8_t* k1, uint8_t* k2) {
   if (n && !k2) return fail(ctx, S2K_ERR_ARG, "null buffer");
   return field_op(ctx, false, 100, n, k, nullptr, k1, k2, 32);
+}
+
+int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t* const in[5],
+                       uint8_t* out, uint8_t* out2, uint8_t* flag) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fp_op_batch_ex serves S2K_IMPL_FAST only (8x32: s2k_fp_op_batch)");
+  if (op < 0 || op > S2K_HP_PT29_ADD_MIXED) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (n == 0) return S2K_OK;
+  if (!in || !in[0] || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  dev_buf din[5], dout, dout2, dflag;
+  hp_args args;
+  for (int j = 0; j < 5; ++j) {
+    args.in[j] = nullptr;
+    if (in[j]) {
+      HIP_TRY(ctx, din[j].upload(in[j], n * 32));
+      args.in[j] = (const uint8_t*)din[j].p;
+    }
+  }
+  HIP_TRY(ctx, dout.alloc(n * 32));
+  if (out2) HIP_TRY(ctx, dout2.alloc(n * 32));
+  if (flag) HIP_TRY(ctx, dflag.alloc(n));
+  k_fp29_op<<<blocks_for(n), 256>>>(op, lazy, (uint32_t)n, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 32, hipMemcpyDeviceToHost));
+  if (out2) HIP_TRY(ctx, hipMemcpy(out2, dout2.p, n * 32, hipMemcpyDeviceToHost));
+  if (flag) HIP_TRY(ctx, hipMemcpy(flag, dflag.p, n, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+int s2k_fn_split_glv_batch_ex(s2k_ctx* ctx, uint32_t impl, size_t n, const uint8_t* k, uint8_t* k1, uint8_t* k2, uint8_t* signs) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fn_split_glv_batch_ex serves S2K_IMPL_FAST only");
+  if (n == 0) return S2K_OK;
+  if (!k || !k1 || !k2 || !signs) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  dev_buf dk, d1, d2, ds;
+  HIP_TRY(ctx, dk.upload(k, n * 32));
+  HIP_TRY(ctx, d1.alloc(n * 32));
+  HIP_TRY(ctx, d2.alloc(n * 32));
+  HIP_TRY(ctx, ds.alloc(n));
+  k_split_glv_odd<<<blocks_for(n), 256>>>((uint32_t)n, (const uint8_t*)dk.p, (uint8_t*)d1.p, (uint8_t*)d2.p, (uint8_t*)ds.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(k1, d1.p, n * 32, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(k2, d2.p, n * 32, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(signs, ds.p, n, hipMemcpyDeviceToHost));
+  return S2K_OK;
 }
 
 int s2k_pack_valid_device(s2k_ctx* ctx, size_t n, const void* d_valid, void* d_bitmap, void* d_count,

@@ -115,7 +115,7 @@ def msm_sharded(engine, scalars, points, dist=None):
     world = dist.get_world_size()
     mine = torch.tensor(list(part), dtype=torch.uint8)
     if dist.get_backend() != "gloo":
-        mine = mine.cuda()
+        mine = mine.to(torch.device("cuda", engine.device))   # the engine's GPU, not torch's current device
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     recs = [bytes(p.cpu().numpy().tobytes()) for p in parts]
@@ -139,6 +139,6 @@ def schnorr_batch_verify_sharded(engine, pks, msgs, sigs, seed: bytes, dist=None
         return ok
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
     if dist.get_backend() != "gloo":
-        flag = flag.cuda()
+        flag = flag.to(torch.device("cuda", engine.device))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(int(flag.item()))

@@ -48,3 +48,86 @@ def synth_batch(eng, n, n_keys, seed):
     return np.ascontiguousarray(Q[key_idx]), digest, r, s
 
 
+
+
+def _rand_scalars(rng, m):
+    a = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    a[:, 0] &= 0x7F
+    a[:, 31] |= 1
+    return a
+
+
+def synth_all_fallback_batch(eng, n, n_keys, seed):
+    """Adversarial ECDSA inputs: u1*G + u2*Q = infinity for every item, so the
+    Jacobian ladder ends at Z = 0 in every lane and the whole batch goes through the
+    complete-formula worklist kernel.  Anyone holding a key pair d can make these: pick u2 and r,
+    set u1 = -u2*d, s = r/u2, e = u1*s.  All verdicts are 0 (R = infinity, ecdsa.go:450)."""
+    rng = np.random.default_rng(seed)
+    d = _rand_scalars(rng, n_keys)
+    Q = eng.scalar_base_mult_batch(d)[:, 1:]
+    key_idx = np.arange(n) % n_keys
+    u2 = _rand_scalars(rng, n)
+    r = _rand_scalars(rng, n)
+    u2d, _ = eng.fn_op_batch(OP_MUL, u2, d[key_idx])
+    u1, _ = eng.fn_op_batch(OP_NEG, u2d)
+    u2inv, _ = eng.fn_op_batch(OP_INV, u2)
+    s, _ = eng.fn_op_batch(OP_MUL, r, u2inv)
+    e, _ = eng.fn_op_batch(OP_MUL, u1, s)
+    return np.ascontiguousarray(Q[key_idx]), e, r, s
+
+
+def synth_msm_terms(eng, n, seed):
+    """n points with known discrete logarithms (P_i = d_i*G, 65-byte records) and scalars k_i
+    (uniform plus a sprinkle of edge values: 0, 1, n-1, zero windows), and the expected sum's
+    discrete logarithm sum k_i d_i mod n."""
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    d[:, 0] &= 0x7F
+    d[:, 31] |= 1
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    k[:, 0] &= 0x7F
+    edge = [0, 1, N_ORDER - 1, 1 << 128, (1 << 128) - 1, 0xFFFF << 64, N_ORDER >> 1]
+    for j, v in enumerate(edge):
+        for i in range(j * 7 + 3, n, max(n // 13, 1) + j):
+            k[i] = np.frombuffer(int(v).to_bytes(32, "big"), dtype=np.uint8)
+    pts = eng.scalar_base_mult_batch(d)
+    kb, db = k.tobytes(), d.tobytes()
+    tot = 0
+    for i in range(n):
+        tot += int.from_bytes(kb[32 * i:32 * i + 32], "big") * int.from_bytes(db[32 * i:32 * i + 32], "big")
+    return k, pts, tot % N_ORDER
+
+
+def synth_schnorr_batch(eng, n, n_keys, seed, msg_len=32):
+    """n distinct valid BIP-340 signatures over random messages (schnorr.go:158-218 signing
+    equations: even-y key and nonce points, e = tagged hash, s = k + e d), built with the
+    engine's batched primitives and hashlib.  Returns pk (n,32), msgs (n,msg_len), sig (n,64)."""
+    import hashlib
+    rng = np.random.default_rng(seed)
+    d = _rand_scalars(rng, n_keys)
+    P = eng.scalar_base_mult_batch(d)
+    dneg, _ = eng.fn_op_batch(OP_NEG, d)
+    odd = (P[:, 64] & 1) == 1
+    d[odd] = dneg[odd]
+    key_idx = np.arange(n) % n_keys
+    k = _rand_scalars(rng, n)
+    Rp = eng.scalar_base_mult_batch(k)
+    kneg, _ = eng.fn_op_batch(OP_NEG, k)
+    odd = (Rp[:, 64] & 1) == 1
+    k[odd] = kneg[odd]
+    msgs = rng.integers(0, 256, size=(n, msg_len), dtype=np.uint8)
+    pk = np.ascontiguousarray(P[key_idx, 1:33])
+    rx = np.ascontiguousarray(Rp[:, 1:33])
+    th = hashlib.sha256(b"BIP0340/challenge").digest()
+    h0 = hashlib.sha256(th + th)
+    pre = np.concatenate([rx, pk, msgs], axis=1).tobytes()
+    L = 64 + msg_len
+    e = bytearray(32 * n)
+    for i in range(n):
+        h = h0.copy()
+        h.update(pre[L * i:L * i + L])
+        e[32 * i:32 * i + 32] = h.digest()
+    e = np.frombuffer(bytes(e), dtype=np.uint8).reshape(n, 32)
+    ed, _ = eng.fn_op_batch(OP_MUL, e, d[key_idx])            # inputs are reduced mod n first
+    s, _ = eng.fn_op_batch(OP_ADD, k, ed)
+    return pk, msgs, np.ascontiguousarray(np.concatenate([rx, s], axis=1))

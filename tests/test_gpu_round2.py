@@ -1,0 +1,152 @@
+"""Round-2 GPU tests: the bench's multi-rank flow on one device, the adversarial worst case,
+stream switching on one context, full-size configurations 3 and 4.  Needs a real MI355X.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+b32 = R.b32
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.init()
+    import secp256k1_voi_amd as S
+    return S.Engine(0)
+
+
+def test_bench_two_ranks_one_device():
+    """`python bench.py --gpus 2` from a bare shell: the script starts its own two rank processes
+    (both on GPU 0 here, gloo collectives: --oversubscribe), runs the corrupted-batch bitmap guard
+    on the gathered bitmap and prints one JSON line for the whole job."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--batch-log2", "15",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert "2^16 in total" in d["config"]["workload"]
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["kernel_ms"] > 0
+
+
+def test_worst_case_all_fallback(eng, oracle):
+    """u1*G + u2*Q = infinity in every lane (an adversary with a key pair can mint these): all lanes
+    end on the worklist; the complete kernel must size its grid from the batch, give the reference's
+    verdict (false) for each, and stay within a small factor of the normal step."""
+    import time
+
+    import torch
+    from secp256k1_voi_amd.synth import synth_all_fallback_batch, synth_batch
+    n = 1 << 16
+    pub, e, r, s = synth_all_fallback_batch(eng, n, 256, seed=3)
+    got = eng.ecdsa_verify_batch(pub, e, r, s)
+    assert not got.any()
+    m = 512
+    assert np.array_equal(got[:m], oracle.ecdsa_verify_batch(pub[:m], e[:m], r[:m], s[:m], nthreads=os.cpu_count() or 1))
+    # mixed batch: half adversarial, half valid, interleaved
+    vp, vd, vr, vs = synth_batch(eng, n, 256, seed=4)
+    pub[1::2], e[1::2], r[1::2], s[1::2] = vp[1::2], vd[1::2], vr[1::2], vs[1::2]
+    got = eng.ecdsa_verify_batch(pub, e, r, s)
+    assert not got[0::2].any() and got[1::2].all()
+    # timing at full size: worst case within 5x of the all-valid step
+    n = 1 << 20
+    dev = torch.device("cuda", 0)
+    bad = [torch.from_numpy(x).to(dev) for x in synth_all_fallback_batch(eng, n, 1 << 12, seed=5)]
+    good = [torch.from_numpy(x).to(dev) for x in synth_batch(eng, n, 1 << 12, seed=6)]
+    out = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def run(inp):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.ecdsa_verify_batch_device(n, *(x.data_ptr() for x in inp), out.data_ptr(), 0, 0)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run(good)
+    t_good = min(run(good) for _ in range(3))
+    assert int(out.sum().item()) == n
+    run(bad)
+    t_bad = min(run(bad) for _ in range(2))
+    assert int(out.sum().item()) == 0
+    assert t_bad < 5.0 * t_good, (t_bad, t_good)
+
+
+def test_context_calls_on_alternating_streams(eng, oracle):
+    """Consecutive *_device calls of one context on different streams (and a host-buffer call right
+    after an unsynchronised device call) share the context's workspace; the context chains them
+    with an event, so every call's verdicts are those of the oracle."""
+    import torch
+    from workload import make_ecdsa_batch
+    dev = torch.device("cuda", 0)
+    n = 4096
+    batches = [make_ecdsa_batch(oracle, n, seed=70 + i, corrupt_every=3 + i) for i in range(4)]
+    exp = [oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], nthreads=os.cpu_count() or 1) for w in batches]
+    dbufs = [[torch.from_numpy(w[k]).to(dev) for k in ("pub", "digest", "r", "s")] for w in batches]
+    outs = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in batches]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for i, (b, o) in enumerate(zip(dbufs, outs)):
+            eng.ecdsa_verify_batch_device(n, *(x.data_ptr() for x in b), o.data_ptr(), 0, streams[i & 1].cuda_stream)
+        # host-buffer call (the context's own streams) straight after the unsynchronised device calls
+        w = batches[rep]
+        host = eng.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+        torch.cuda.synchronize()
+        assert np.array_equal(host, exp[rep])
+        for o, e in zip(outs, exp):
+            assert np.array_equal(o.cpu().numpy(), e)
+
+
+def test_msm_full_size_known_dlog(eng, oracle):
+    """BASELINE config 3 at full size: 2^20 terms, the whole sum checked against (sum k_i d_i) G
+    computed by the oracle's base multiplication."""
+    from secp256k1_voi_amd.synth import synth_msm_terms
+    n = 1 << 20
+    k, pts, tot = synth_msm_terms(eng, n, seed=41)
+    got = eng.multi_scalar_mult(k, pts)
+    assert got == oracle.scalar_base_mult_vartime(b32(tot))
+
+
+def test_schnorr_rlc_full_size(eng, oracle):
+    """BASELINE config 4 at full size: 2^20 distinct BIP-340 signatures as one MSM: accept, and
+    reject with a single bad signature (first, middle, last position)."""
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    n = 1 << 20
+    pk, msgs, sig = synth_schnorr_batch(eng, n, 1 << 14, seed=42)
+    for i in (0, 77777, n - 1):      # the synthetic signatures are what the reference's Verify accepts
+        assert oracle.schnorr_verify(bytes(pk[i]), bytes(msgs[i]), bytes(sig[i])) == 1
+    seed = bytes(range(32))
+    assert eng.schnorr_batch_verify_rlc(pk, msgs, sig, seed)
+    for pos in (0, n // 2 + 1, n - 1):
+        sig[pos, 40] ^= 0x10
+        assert not eng.schnorr_batch_verify_rlc(pk, msgs, sig, seed)
+        sig[pos, 40] ^= 0x10
+    assert eng.schnorr_verify_batch(pk[:4096], msgs[:4096], sig[:4096]).all()
+
+
+def test_ecdsa_distinct_keys_full_size(eng):
+    """K = N: 2^20 signatures under 2^20 distinct keys, all valid; swapping two keys flips two verdicts."""
+    from secp256k1_voi_amd.synth import synth_batch
+    n = 1 << 20
+    pub, dig, r, s = synth_batch(eng, n, n, seed=43)
+    assert len({bytes(x) for x in pub[:4096]}) == 4096
+    pub[12345], pub[12346] = pub[12346].copy(), pub[12345].copy()
+    got = eng.ecdsa_verify_batch(pub, dig, r, s)
+    assert got.sum() == n - 2 and not got[12345] and not got[12346]
