@@ -794,12 +794,10 @@ k_hot_prep(uint32_t n, const uint8_t* __restrict__ u1, const uint8_t* __restrict
   store_be32(pub64 + i * 64, a.x.v);
   store_be32(pub64 + i * 64 + 32, a.y.v);
   uint32_t raw[8];
-  sc k1, k2, v1 = sc_zero();
+  sc k1, k2;
   bool neg1, neg2;
-  if (u1) {
-    load_be32(raw, u1 + i * 32);
-    v1 = sc_reduce_once(raw);
-  }
+  load_be32(raw, u1 + i * 32);        // zeros for a plain scalar multiplication
+  sc v1 = sc_reduce_once(raw);
   load_be32(raw, u2 + i * 32);
   sc_split_glv_odd(sc_reduce_once(raw), k1, neg1, k2, neg2);
   uint32_t f = (finite ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) | (k1.v[4] ? PF_K1_B128 : 0) |
@@ -813,14 +811,22 @@ k_hot_prep(uint32_t n, const uint8_t* __restrict__ u1, const uint8_t* __restrict
   prep[(size_t)16 * stride + i] = f;
 }
 
+// ALL: every item (S2K_IMPL_COMPLETE); otherwise the worklist.  u1 is always present (the host
+// passes zeros for a plain scalar multiplication): the conditional form of this kernel
+// (`if (u1)` around the generator part, `all_n ? w : wl[w]` for the index) was miscompiled by
+// hipcc 7.2 -- per-lane garbage for half of the inputs, reproduced standalone in tools/dbg/ --
+// so the kernel keeps to the shape of k_recover_fallback, which is not.
+template <bool ALL>
 __global__ void __launch_bounds__(256)
-k_point_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
+k_point_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
                  uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
-  uint32_t count = all_n ? all_n : *wl_count;
+  uint32_t count;
+  if constexpr (ALL) count = n; else count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
-    size_t idx = all_n ? w : wl[w];
+    size_t idx;
+    if constexpr (ALL) idx = w; else idx = wl[w];
     const uint8_t* rec = pts65 + idx * 65;
     apt a;
     load_be32_unaligned(a.x.v, rec + 1);
@@ -831,14 +837,13 @@ k_point_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restri
       a.x = fe_from_limbs(FE_GX);
       a.y = fe_from_limbs(FE_GY);
     }
-    uint32_t raw[8];
-    load_be32(raw, u2 + idx * 32);
-    pt res = pt_select(!finite, pt_mul_glv(sc_reduce_once(raw), a, qt, stride, idx), pt_identity());
-    if (u1) {
-      load_be32(raw, u1 + idx * 32);
-      sc v1 = sc_reduce_once(raw);
-      res = pt_add_complete(pt_base_mul(gt, v1.v), res);   // point_mul_glv.go:316
-    }
+    uint32_t raw1[8], raw2[8];
+    load_be32(raw1, u1 + idx * 32);
+    load_be32(raw2, u2 + idx * 32);
+    sc v1 = sc_reduce_once(raw1), v2 = sc_reduce_once(raw2);
+    pt rq = pt_mul_glv(v2, a, qt, stride, idx);
+    rq = pt_select(!finite, rq, pt_identity());
+    pt res = pt_add_complete(pt_base_mul(gt, v1.v), rq);   // point_mul_glv.go:316
     uint8_t* o = out65 + idx * 65;
     apt r;
     if (!pt_to_affine(r, res)) {
@@ -1268,11 +1273,14 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
   rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, o_status + 256);
   if (rc) return rc;
   uint8_t* io = (uint8_t*)ctx->io;
-  if (u1) HIP_TRY(ctx, hipMemcpyAsync(io + o_u1, u1, n * 32, hipMemcpyHostToDevice, st));
+  if (u1)
+    HIP_TRY(ctx, hipMemcpyAsync(io + o_u1, u1, n * 32, hipMemcpyHostToDevice, st));
+  else
+    HIP_TRY(ctx, hipMemsetAsync(io + o_u1, 0, n * 32, st));   // plain scalar multiplication: u1 = 0
   HIP_TRY(ctx, hipMemcpyAsync(io + o_u2, u2, n * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(io + o_pts, points, n * 65, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(io + o_status, 0, 4, st));
-  const uint8_t* d_u1 = u1 ? io + o_u1 : nullptr;
+  const uint8_t* d_u1 = io + o_u1;
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
@@ -1282,8 +1290,8 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
   uint32_t* wl = wl_count + 64;
   uint32_t* status = (uint32_t*)(io + o_status);
   if (impl == S2K_IMPL_COMPLETE) {
-    k_point_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_out,
-                                                    ctx->gtable, qt, stride, status);
+    k_point_fallback<true><<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_out,
+                                                          ctx->gtable, qt, stride, status);
     HIP_TRY(ctx, hipGetLastError());
   } else {
     HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
@@ -1296,8 +1304,8 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, qt, hs, io + o_ok, stride, io + o_out);
     HIP_TRY(ctx, hipGetLastError());
-    k_point_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, d_u1, io + o_u2, io + o_pts, io + o_out,
-                                                              ctx->gtable, qt, stride, status);
+    k_point_fallback<false><<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts,
+                                                                     io + o_out, ctx->gtable, qt, stride, status);
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t h_status = 0;

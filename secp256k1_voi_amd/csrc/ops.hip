@@ -257,11 +257,17 @@ k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__
     case S2K_HP_JDBL:
     case S2K_HP_JADD: {
       // P = (a, b) affine, lifted to Jacobian with Z = c (any non-zero value): X = a c^2, Y = b c^3
+      // (lazy code of c with bit 3 set: no lift, P = (a, b, 1) with a, b in their lazy forms: x [1], y [<= 2])
       jpt29 p;
       fe29 zz = fe29_sqr(c);
       p.x = fe29_mul(a, zz);
       p.y = fe29_mul(b, fe29_mul(zz, c));
       p.z = fe29_normalize_weak(c);
+      if ((lazy >> 8) & 8u) {
+        p.x = a;
+        p.y = b;
+        p.z = fe29_one();
+      }
       jpt29 q = op == S2K_HP_JDBL ? jpt29_double(p) : jpt29_add_affine(p, d, e);
       if (fe29_is_zero(q.z)) {   // exceptional input of the incomplete formulas (or a true infinity)
         f = 0;
