@@ -177,10 +177,15 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx *ctx, size_t n, const void *d_pk
                                         const void *d_msg_offsets, size_t msg_len, const void *d_sig,
                                         const uint8_t *seed32 /* host */, int *all_valid /* host */, void *hip_stream);
 
-/* ---- group operations (batched; host pointers) ------------------------------------- */
-/* out[i] = k[i]*G — Point.ScalarBaseMult (point_mul_table.go:168) / scalarBaseMultVartime (:197) */
+/* ---- group operations (batched; host pointers) -------------------------------------
+ * VARIABLE TIME, like everything that runs on the GPU here: these serve the reference's *Vartime
+ * code paths (public scalars: verification, recovery, batch checks).  They must NOT be bound to
+ * Point.ScalarMult / Point.ScalarBaseMult, which the reference keeps constant-time for ECDH and
+ * signing (point_mul_glv.go:257, point_mul_table.go:168): those are served by the s2k_ct_*
+ * functions below, on the host CPU. */
+/* out[i] = k[i]*G — scalarBaseMultVartime (point_mul_table.go:197) */
 int s2k_scalar_base_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k /* n*32 */, uint8_t *out /* n*65 */);
-/* out[i] = k[i]*P[i] — Point.ScalarMult (point_mul_glv.go:257) / scalarMultVartimeGLV (:203) */
+/* out[i] = k[i]*P[i] — scalarMultVartimeGLV (point_mul_glv.go:203) */
 int s2k_scalar_mult_batch(s2k_ctx *ctx, size_t n, const uint8_t *k, const uint8_t *points /* n*65 */, uint8_t *out);
 /* out[i] = u1[i]*G + u2[i]*P[i] — Point.DoubleScalarMultBasepointVartime (point_mul_glv.go:307) */
 int s2k_double_scalar_mult_basepoint_batch(s2k_ctx *ctx, size_t n, const uint8_t *u1, const uint8_t *u2,
@@ -215,6 +220,28 @@ int s2k_multi_scalar_mult_device(s2k_ctx *ctx, size_t n, const void *d_k, const 
  * enc_len = 65: SetUncompressedBytes :178).  ok[i] = 1 and out[i] = point on success,
  * ok[i] = 0 and out[i] = zeros otherwise. */
 int s2k_point_decode_batch(s2k_ctx *ctx, size_t n, size_t enc_len, const uint8_t *enc, uint8_t *out, uint8_t *ok);
+
+/* ---- constant-time twins, host CPU (no GPU, no context) ------------------------------------
+ * What the reference's secret-handling code calls.  No branch, address or
+ * loop count depends on the scalar, the private key or the nonce: masked full-table scans
+ * (lookupProjectivePoint / lookupAffinePoint, point_mul_table_ref.go:11-24), arithmetic selects,
+ * complete formulas.  Point arguments are public (the peer's key) and are validated like
+ * SetUncompressedBytes (point_s11n.go:178); a malformed record is S2K_ERR_ARG. */
+/* out = k*P — Point.ScalarMult (point_mul_glv.go:257-303); k is reduced mod n (SetBytes) */
+int s2k_ct_scalar_mult(const uint8_t k[32], const uint8_t point65[65], uint8_t out65[65]);
+/* out = k*G — Point.ScalarBaseMult (point_mul_table.go:168-194) */
+int s2k_ct_scalar_base_mult(const uint8_t k[32], uint8_t out65[65]);
+/* shared_x = x(d*Q) — PrivateKey.ECDH (secec/secec.go:53-56); d in [1,n), Q a valid public key */
+int s2k_ct_ecdh(const uint8_t priv32[32], const uint8_t pub65[65], uint8_t shared_x[32]);
+/* The arithmetic of PrivateKey.Sign (secec/ecdsa.go:335-390) for a caller-supplied nonce k:
+ * r = x(k*G) mod n, s = (e + r*d)/k mod n normalised to s <= n/2, and the recovery id.  The nonce
+ * derivation (ecdsa.go:284-333) stays in the caller.  S2K_ERR_ARG: d or k outside [1,n), or r == 0
+ * or s == 0 (draw another nonce, as the reference does). */
+int s2k_ct_ecdsa_sign_raw(const uint8_t priv32[32], const uint8_t digest32[32], const uint8_t nonce32[32],
+                          uint8_t r32[32], uint8_t s32[32], uint8_t *recovery_id);
+/* Test instrumentation: field multiplications executed by the calling thread in s2k_ct_* since the
+ * previous call of this function.  The count is the same for every scalar (tests/test_ct_cpu.py). */
+uint64_t s2k_ct_debug_fe_mul_count(void);
 
 /* ---- field / scalar element operations (batched; host pointers) -------------------- */
 /* Element / Scalar methods, for API parity and for the parity tests of the device

@@ -135,6 +135,11 @@ def load_library() -> C.CDLL:
     lib.s2k_fn_op_batch.argtypes = [vp, ci, sz, vp, vp, vp, vp]
     lib.s2k_fn_split_glv_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_debug_gtable_entry.argtypes = [vp, C.c_uint, C.c_uint, vp]
+    lib.s2k_ct_scalar_mult.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.s2k_ct_scalar_base_mult.argtypes = [C.c_char_p, C.c_char_p]
+    lib.s2k_ct_ecdh.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.s2k_ct_debug_fe_mul_count.restype = C.c_uint64
+    lib.s2k_ct_ecdsa_sign_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
     _lib = lib
     return lib
 
@@ -153,6 +158,7 @@ EXPORTED_SYMBOLS = [
     "s2k_multi_scalar_mult", "s2k_multi_scalar_mult_device",
     "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry", "s2k_generator_window_bits",
     "s2k_double_scalar_mult_basepoint_batch_ex", "s2k_fp_op_batch_ex", "s2k_fn_split_glv_batch_ex",
+    "s2k_ct_scalar_mult", "s2k_ct_scalar_base_mult", "s2k_ct_ecdh", "s2k_ct_ecdsa_sign_raw", "s2k_ct_debug_fe_mul_count",
 ]
 
 
@@ -189,6 +195,37 @@ def parse_compact_signature(sig: bytes):
 def is_valid_signature_encoding_bip0066(sig: bytes) -> bool:
     """bitcoin.IsValidSignatureEncodingBIP0066 (secec/bitcoin/asn1_shitcoin.go:13)."""
     return bool(load_library().s2k_is_valid_signature_encoding_bip0066(sig, len(sig)))
+
+
+# ---- constant-time twins on the host CPU (no GPU needed) -------------------------------------
+def ct_scalar_mult(k: bytes, point65: bytes):
+    """Point.ScalarMult (point_mul_glv.go:257), constant time, CPU.  Returns the 65-byte record or None
+    for a malformed point."""
+    out = C.create_string_buffer(65)
+    return out.raw if load_library().s2k_ct_scalar_mult(bytes(k), bytes(point65), out) == 0 else None
+
+
+def ct_scalar_base_mult(k: bytes) -> bytes:
+    """Point.ScalarBaseMult (point_mul_table.go:168), constant time, CPU."""
+    out = C.create_string_buffer(65)
+    rc = load_library().s2k_ct_scalar_base_mult(bytes(k), out)
+    if rc != 0:
+        raise EngineError(f"s2k_ct_scalar_base_mult failed ({rc})")
+    return out.raw
+
+
+def ct_ecdh(priv32: bytes, pub65: bytes):
+    """PrivateKey.ECDH (secec/secec.go:53): the shared x-coordinate, or None for invalid inputs."""
+    out = C.create_string_buffer(32)
+    return out.raw if load_library().s2k_ct_ecdh(bytes(priv32), bytes(pub65), out) == 0 else None
+
+
+def ct_ecdsa_sign_raw(priv32: bytes, digest32: bytes, nonce32: bytes):
+    """(r, s, recovery_id) for a caller-supplied nonce (secec/ecdsa.go:335-390), or None when the
+    nonce has to be redrawn."""
+    r, s, rid = C.create_string_buffer(32), C.create_string_buffer(32), C.c_uint8(0)
+    rc = load_library().s2k_ct_ecdsa_sign_raw(bytes(priv32), bytes(digest32), bytes(nonce32), r, s, C.byref(rid))
+    return (r.raw, s.raw, int(rid.value)) if rc == 0 else None
 
 
 def _concat(items):

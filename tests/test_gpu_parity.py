@@ -122,15 +122,19 @@ def test_fn_ops(eng, oracle):
 def test_generator_table(eng, oracle):
     bits = eng.generator_window_bits()
     nwin = (256 + bits - 1) // bits
-    if bits % 8 == 0:
-        # windows of the reference's 8-bit table blob that are entries of these wider tables
-        d = load_golden("gentable.json")
-        hit = 0
-        for s in d["samples"]:
-            if s["i"] % (bits // 8) == 0 and s["i"] >= bits // 8:
-                assert eng.gtable_entry(s["i"] // (bits // 8), s["j"]).hex() == s["xy"]
-                hit += 1
-        assert hit >= 5
+    # Every sampled entry of the reference's 8-bit table blob, tbl[i][j] = (j+1) * 2^(8i) * G
+    # (internal/gentable/point_mul_table.bin), must equal the sum of the device-table entries its
+    # scalar selects: m*G = sum_w T_w[digit_w(m)] for any window width (no entry is the identity, and
+    # the offsets of T_0 cancel the "+1" of the other windows).
+    d = load_golden("gentable.json")
+    mask = (1 << bits) - 1
+    for s in d["samples"]:
+        m = (s["j"] + 1) << (8 * s["i"])
+        acc = None
+        for w in range(nwin):
+            e = eng.gtable_entry(w, (m >> (bits * w)) & mask)
+            acc = R.add(acc, (int.from_bytes(e[:32], "big"), int.from_bytes(e[32:], "big")))
+        assert (b32(acc[0]) + b32(acc[1])).hex() == s["xy"], (s["i"], s["j"])
     S_ = sum(1 << (bits * i) for i in range(1, nwin))
     top = (1 << (256 - bits * (nwin - 1))) - 1          # largest digit the top window can see
     for dgt in (0, 1, (1 << bits) - 1, 0x1234):
