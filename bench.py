@@ -437,8 +437,22 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
     ms_single = timed(lambda: lib.s2k_schnorr_verify_batch_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32,
                                                                   dsig.data_ptr(), 0, dval.data_ptr(), st), 3)
     assert int(dval.sum().item()) == m
+    # locating one bad signature by bisection on the kept terms (s2k_schnorr_verify_batch_bisect_device)
+    stats = (ctypes.c_uint32 * 4)()
+    dsig[bad, 63] ^= 1
+
+    def locate():
+        rc_ = lib.s2k_schnorr_verify_batch_bisect_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32, dsig.data_ptr(),
+                                                         seed.ctypes.data, dval.data_ptr(), stats, st)
+        assert rc_ == 0
+    ms_locate = timed(locate, 3)
+    assert int(dval.sum().item()) == m - 1 and int(dval[bad].item()) == 0, "bisection did not single out the bad signature"
+    dsig[bad, 63] ^= 1
     out["schnorr_rlc_2p20"] = {"sigs": m, "ms": ms, "sigs_per_s": m / (ms * 1e-3),
                                "per_signature_verify_ms": ms_single,
+                               "locate_one_bad_signature_ms": ms_locate,
+                               "locate_stats": {"sub_combinations": int(stats[0]), "verified_one_by_one": int(stats[1]),
+                                                "levels": int(stats[2])},
                                "check": "accepts the valid batch, rejects it with one flipped bit at index %d; "
                                         "per-signature verification accepts all" % bad}
     return out

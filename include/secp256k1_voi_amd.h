@@ -166,9 +166,11 @@ int s2k_schnorr_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pk, co
 
 /* Whole-batch BIP-340 verification as ONE multi-scalar multiplication of 2n+1 terms
  * ((sum a_i s_i) G - sum a_i R_i - sum a_i e_i P_i == infinity, a_0 = 1, a_i = 128 bits of
- * SHA-256(seed32 || i)).  *all_valid = 1 iff every signature of the batch verifies (false
- * accept probability 2^-128 over the secret random seed32, which the caller draws from its
- * CSPRNG); it does not say which one fails — call s2k_schnorr_verify_batch for that.  The
+ * SHA-256(key || i), key = SHA-256(seed32 || 32 bytes of getrandom(2))).  *all_valid = 1 iff every
+ * signature of the batch verifies (false accept probability 2^-128).  seed32 should be fresh CSPRNG
+ * output; because the library mixes in operating-system randomness of its own, a reused or
+ * predictable seed does not make the coefficients predictable.  It does not say which signature
+ * fails — s2k_schnorr_verify_batch_bisect does.  The
  * reference has single verification only (schnorr.go:221); this is BASELINE config 4. */
 int s2k_schnorr_batch_verify_rlc(s2k_ctx *ctx, size_t n, const uint8_t *pk, const uint8_t *msgs,
                                  const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig,
@@ -176,6 +178,23 @@ int s2k_schnorr_batch_verify_rlc(s2k_ctx *ctx, size_t n, const uint8_t *pk, cons
 int s2k_schnorr_batch_verify_rlc_device(s2k_ctx *ctx, size_t n, const void *d_pk, const void *d_msgs,
                                         const void *d_msg_offsets, size_t msg_len, const void *d_sig,
                                         const uint8_t *seed32 /* host */, int *all_valid /* host */, void *hip_stream);
+
+/* Per-signature BIP-340 verdicts at the price of the whole-batch check when everything verifies
+ * (the usual case): one combination over the batch; when it is rejected, the failing signatures
+ * are located by bisection — the lifted points, challenges and coefficients of the whole batch are
+ * kept, a half-range is re-checked as a multiscalar multiplication of its own terms, the other
+ * half's error point follows by subtraction, and ranges of <= 2^14 signatures (or everything left,
+ * once more than 8 ranges fail on one level) go through s2k_schnorr_verify_batch.  valid[i] is
+ * what SchnorrPublicKey.Verify returns for item i (schnorr.go:221-253), up to a false accept
+ * probability of 2^-128 per combination.  stats (host, may be NULL): [0] sub-range combinations,
+ * [1] signatures verified one by one, [2] levels descended, [3] 1 = bisection abandoned. */
+int s2k_schnorr_verify_batch_bisect(s2k_ctx *ctx, size_t n, const uint8_t *pk, const uint8_t *msgs,
+                                    const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig,
+                                    const uint8_t *seed32, uint8_t *valid, uint32_t stats[4]);
+int s2k_schnorr_verify_batch_bisect_device(s2k_ctx *ctx, size_t n, const void *d_pk, const void *d_msgs,
+                                           const void *d_msg_offsets, size_t msg_len, const void *d_sig,
+                                           const uint8_t *seed32 /* host */, void *d_valid, uint32_t stats[4] /* host */,
+                                           void *hip_stream);
 
 /* ---- group operations (batched; host pointers) -------------------------------------
  * VARIABLE TIME, like everything that runs on the GPU here: these serve the reference's *Vartime

@@ -18,7 +18,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsecp256k1_voi_amd.so")
+# S2K_LIB: load another build of the library (a compile-time variant made with build(variant=...)), for
+# same-box A/B runs that must not spend GPU time compiling
+LIB_PATH = os.environ.get("S2K_LIB") or os.path.join(_HERE, "libsecp256k1_voi_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 REJECT_MALLEABLE = 1
@@ -39,6 +41,30 @@ class EngineError(RuntimeError):
     pass
 
 
+def build_variant(name: str, extra_flags: str, verbose: bool = False) -> str:
+    """Build libsecp256k1_voi_amd.<name>.so with `extra_flags` next to the default library (own object
+    directory); select it at run time with S2K_LIB=<path>."""
+    from concurrent.futures import ThreadPoolExecutor
+    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
+    objdir = os.path.join(_HERE, "build", "variant_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(_HERE, f"libsecp256k1_voi_amd.{name}.so")
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", '-DS2K_BUILD_FLAGS="%s"' % extra_flags.replace('"', "'")]
+    flags += extra_flags.split()
+
+    def compile_one(u):
+        obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
+        subprocess.check_call(["hipcc", *flags, "-c", os.path.join(CSRC, u), "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(units))) as ex:
+        objs = list(ex.map(compile_one, units))
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    if verbose:
+        print("built", out)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU): one object
     per translation unit (in parallel), then one shared library.  The variant flags
@@ -49,6 +75,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     units = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "secp256k1_voi_amd.h"))
+    if os.environ.get("S2K_LIB"):      # a prebuilt variant was selected: nothing to build
+        return LIB_PATH
     objdir = os.path.join(_HERE, "build")
     stamp = os.path.join(objdir, "flags.stamp")
     extra = " ".join(os.environ.get("S2K_EXTRA_FLAGS", "").split())
@@ -120,6 +148,8 @@ def load_library() -> C.CDLL:
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci)]
     lib.s2k_schnorr_batch_verify_rlc_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci), vp]
+    lib.s2k_schnorr_verify_batch_bisect.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.s2k_schnorr_verify_batch_bisect_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp]
     lib.s2k_scalar_base_mult_batch.argtypes = [vp, sz, vp, vp]
     lib.s2k_scalar_mult_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_double_scalar_mult_basepoint_batch.argtypes = [vp, sz, vp, vp, vp, vp]
@@ -153,6 +183,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ecdsa_verify_encoded_batch",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
+    "s2k_schnorr_verify_batch_bisect", "s2k_schnorr_verify_batch_bisect_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
     "s2k_point_add_batch", "s2k_point_double_batch", "s2k_point_decode_batch",
     "s2k_multi_scalar_mult", "s2k_multi_scalar_mult_device",
@@ -347,15 +378,36 @@ class Engine:
                                                                seed.ctypes.data, C.byref(res)))
         return bool(res.value)
 
-    def schnorr_verify_batch_auto(self, pk32, msgs, sig64, seed32: bytes | None = None) -> np.ndarray:
+    def schnorr_verify_batch_auto(self, pk32, msgs, sig64, seed32: bytes | None = None, return_stats: bool = False):
         """Valid bits like schnorr_verify_batch, at the cost of the whole-batch check when (as usual)
-        everything verifies: one random-linear-combination MSM first, per-signature verification only
-        if that rejects (it says that some signature fails, not which)."""
+        everything verifies: one random-linear-combination MSM first; if that rejects, the failing
+        signatures are located by bisection on the kept terms (s2k_schnorr_verify_batch_bisect)."""
         pk32 = _arr(pk32, 32)
         n = pk32.shape[0]
-        if n and self.schnorr_batch_verify_rlc(pk32, msgs, sig64, seed32):
-            return np.ones(n, dtype=np.uint8)
-        return self.schnorr_verify_batch(pk32, msgs, sig64)
+        sig64 = _arr(sig64, 64, n)
+        seed = np.frombuffer(seed32 if seed32 is not None else os.urandom(32), dtype=np.uint8)
+        if seed.size != 32:
+            raise ValueError("seed32 must be 32 bytes")
+        out = np.zeros(n, dtype=np.uint8)
+        stats = np.zeros(4, dtype=np.uint32)
+        if isinstance(msgs, (list, tuple)):
+            if len(msgs) != n:
+                raise ValueError(f"length mismatch: expected {n} messages, got {len(msgs)}")
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+            self._check(self._lib.s2k_schnorr_verify_batch_bisect(self._h, n, pk32.ctypes.data, blob.ctypes.data, offs.ctypes.data,
+                                                                  0, sig64.ctypes.data, seed.ctypes.data, out.ctypes.data,
+                                                                  stats.ctypes.data))
+        else:
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+            self._check(self._lib.s2k_schnorr_verify_batch_bisect(self._h, n, pk32.ctypes.data, m.ctypes.data if m.size else None,
+                                                                  None, m.shape[1] if n else 0, sig64.ctypes.data,
+                                                                  seed.ctypes.data, out.ctypes.data, stats.ctypes.data))
+        if return_stats:
+            return out, {"sub_combinations": int(stats[0]), "verified_one_by_one": int(stats[1]), "levels": int(stats[2]),
+                         "abandoned": bool(stats[3])}
+        return out
 
     def ecdsa_recover_batch(self, digest32, r, s, recovery_id, force_complete: bool = False):
         """RecoverPublicKey over a batch: returns (pub65 (n,65) uint8, ok (n,) uint8)."""

@@ -555,6 +555,16 @@ void ct_scalar_base_mult(pt& v, const sc& s) {
 
 extern "C" {
 
+// out = a - b on 65-byte records (public data: the error points of the batch bisection, msm.hip)
+__attribute__((visibility("hidden"))) int s2k_internal_point_sub65(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  pt pa, pb, r;
+  if (!pt_from_record(pa, a) || !pt_from_record(pb, b)) return 1;
+  pt_cneg(pb, ~(u64)0);
+  pt_add(r, pa, pb);
+  pt_to_record(out, r);
+  return 0;
+}
+
 // field multiplications executed by this thread since the last call (test instrumentation)
 uint64_t s2k_ct_debug_fe_mul_count(void) {
   uint64_t c = g_fe_mul_count;

@@ -262,63 +262,80 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // on the curve isomorphic by C = Z(2Q), remember H_j (Z_j = Z_{j-1} H_j), then scale entry j
 // by (H_{j+1}...H_7)^{2,3}.  The ladder then only ever adds affine points (8 M + 3 S); its
 // result has the true Z = Z_ladder * Z_7 * C.
-// Table storage (S2K_QT_PLANE = bytes per lane per plane): 16-byte planes [quad][lane], three
-// quads per field element (limbs 0-3 | 4-7 | 8,-,-,-); entry j is x at element 2j, y at 2j+1.
-// The H scratch region holds one element per entry (H_j, later beta*x_j) plus slot 8 = Z_7 * C.
+// Table storage: tb_* below.  Z_7 * C and the results handed to k_affine_finish go to the lane's
+// "fin" elements.
 // ---------------------------------------------------------------------------------------
-// Layout note (measured on MI355X, 2^20 signatures, profiles/r01_table_layouts.md): a lookup is a
-// per-lane gather (every lane wants a different entry).  With 3 waves/SIMD and the beta*x
-// column: 4-byte planes 11.0 ms, 8-byte planes 10.5 ms, 16-byte planes 10.3 ms per batch on the
-// same box; lane-contiguous 80-byte entries were far slower (16 ms) in an earlier kernel.  The
-// reads are served by L2 / Infinity Cache, the kernel stays VALU-issue bound; wider planes
-// mostly save address arithmetic and VMEM issue slots.  4 and 8 remain selectable for A/B runs
-// (tools/ab_layout.sh).
-#ifndef S2K_QT_PLANE
-#define S2K_QT_PLANE 16
-#endif
-constexpr int FQT_FE_WORDS = S2K_QT_PLANE == 16 ? 12 : (S2K_QT_PLANE == 8 ? 10 : 9);   // storage words per field element
-constexpr int FQT_WORDS = QT_ENTRIES * 2 * FQT_FE_WORDS;
-constexpr int FHS_WORDS = (QT_ENTRIES + 1) * FQT_FE_WORDS;    // H_j scratch, later beta*x_j; slot 8: Z_7 * C
-
-// element `elem` of a table region: 9 limbs per lane in planes of S2K_QT_PLANE bytes
+// Small per-lane scratch elements ("fin" region, 4 elements): 16-byte planes [quad][lane], three quads
+// per field element (limbs 0-3 | 4-7 | 8,-,-,-).  Element 0-2: (X, Y, Z) handed to k_affine_finish,
+// element 3: Z_7 * C during the ladder, then the prefix products of the shared inversion.
+constexpr int FQT_FE_WORDS = 12;
+constexpr int FIN_ELEMS = 4, FIN_WORDS = FIN_ELEMS * FQT_FE_WORDS;
+constexpr int TBL_WORDS = 8 * 8 * 4;          // per-lane table: 8 entries x 8 quads (7 used)
 S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int elem, const fe29& v) {
-#if S2K_QT_PLANE == 16
   uint4* q = reinterpret_cast<uint4*>(base) + (size_t)(elem * 3) * stride + lane;
   q[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
   q[stride] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
   q[2 * stride] = make_uint4(v.n[8], 0u, 0u, 0u);
-#elif S2K_QT_PLANE == 8
-  uint2* q = reinterpret_cast<uint2*>(base) + (size_t)(elem * 5) * stride + lane;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) q[(size_t)w * stride] = make_uint2(v.n[2 * w], v.n[2 * w + 1]);
-  q[(size_t)4 * stride] = make_uint2(v.n[8], 0u);
-#else
-#pragma unroll
-  for (int w = 0; w < 9; ++w) base[(size_t)(elem * 9 + w) * stride + lane] = v.n[w];
-#endif
 }
 S2K_DEV fe29 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t elem) {
   fe29 r;
-#if S2K_QT_PLANE == 16
   const uint4* q = reinterpret_cast<const uint4*>(base) + (size_t)(elem * 3) * stride + lane;
   uint4 a = q[0], b = q[stride];
   r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
   r.n[8] = reinterpret_cast<const uint32_t*>(q + 2 * stride)[0];
-#elif S2K_QT_PLANE == 8
-  const uint2* q = reinterpret_cast<const uint2*>(base) + (size_t)(elem * 5) * stride + lane;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    uint2 t = q[(size_t)w * stride];
-    r.n[2 * w] = t.x;
-    r.n[2 * w + 1] = t.y;
-  }
-  r.n[8] = q[(size_t)4 * stride].x;
-#else
-#pragma unroll
-  for (int w = 0; w < 9; ++w) r.n[w] = base[(size_t)(elem * 9 + w) * stride + lane];
-#endif
   return r;
 }
+// Per-signature table.  Entry j (of 8 odd multiples) is seven quads of 16 bytes,
+//   [x limbs 0-3][x 4-7][y 0-3][y 4-7][beta*x 0-3][beta*x 4-7][x8, y8, (beta*x)8, -]
+// so that a ladder lookup (x or beta*x, and y) is five 16-byte loads.  During the table build the
+// beta*x slot of entry j holds H_j.  Where the quads live (S2K_QT_PACK):
+//   2 (default)  the quads of one (entry, lane) pair are CONTIGUOUS: 128 bytes = one cache line per
+//                lookup, [entry][lane][8 quads]
+//   1            planes [entry * 7 + quad][lane] (a wave's access to one quad is contiguous, but every
+//                lane of a lookup lands in a different line of five different planes)
+// Measured on MI355X, 2^20 signatures, same box (tools/ab_libs.sh; profiles/r02_table_layouts.md): the
+// round-1 layout (three 16-byte planes per element, separate beta*x column: six loads per lookup,
+// 1200 bytes per signature) 7.93-8.04 ms and 16.2 GB of L2-miss reads per launch (FETCH_SIZE, raw);
+// planes of packed entries 7.76-7.86 ms, 12.4 GB; contiguous entries 7.61-7.66 ms, 4.7 GB.
+#ifndef S2K_QT_PACK
+#define S2K_QT_PACK 2
+#endif
+enum { TB_X = 0, TB_Y = 1, TB_BX = 2 };
+constexpr int TB_ZC_ELEM = 3;   // in the fin region
+#if S2K_QT_PACK == 2
+#define TB_ENTRY(base4, stride, lane, entry) ((base4) + ((size_t)(entry) * (stride) + (lane)) * 8)
+#define TB_Q(stride, q) ((size_t)(q))
+#else
+#define TB_ENTRY(base4, stride, lane, entry) ((base4) + (size_t)((entry) * 7) * (stride) + (lane))
+#define TB_Q(stride, q) ((size_t)(q) * (stride))
+#endif
+S2K_DEV void tb_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int entry, int which, const fe29& v) {
+  uint4* e = TB_ENTRY(reinterpret_cast<uint4*>(base), stride, lane, entry);
+  uint4* q = e + TB_Q(stride, which * 2);
+  q[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
+  q[TB_Q(stride, 1)] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
+  reinterpret_cast<uint32_t*>(e + TB_Q(stride, 6))[which] = v.n[8];
+}
+S2K_DEV fe29 tb_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t entry, int which) {
+  const uint4* e = TB_ENTRY(reinterpret_cast<const uint4*>(base), stride, lane, entry);
+  const uint4* q = e + TB_Q(stride, which * 2);
+  uint4 a = q[0], b = q[TB_Q(stride, 1)];
+  fe29 r;
+  r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
+  r.n[8] = reinterpret_cast<const uint32_t*>(e + TB_Q(stride, 6))[which];
+  return r;
+}
+// the ladder's lookup: x (lam: beta*x) and y of one entry
+S2K_DEV void tb_load_xy(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t entry, bool lam, fe29& x, fe29& y) {
+  const uint4* e = TB_ENTRY(reinterpret_cast<const uint4*>(base), stride, lane, entry);
+  const uint4* qx = e + TB_Q(stride, lam ? 4 : 0);
+  uint4 a = qx[0], b = qx[TB_Q(stride, 1)], c = e[TB_Q(stride, 2)], d = e[TB_Q(stride, 3)], t = e[TB_Q(stride, 6)];
+  x.n[0] = a.x; x.n[1] = a.y; x.n[2] = a.z; x.n[3] = a.w; x.n[4] = b.x; x.n[5] = b.y; x.n[6] = b.z; x.n[7] = b.w;
+  y.n[0] = c.x; y.n[1] = c.y; y.n[2] = c.z; y.n[3] = c.w; y.n[4] = d.x; y.n[5] = d.y; y.n[6] = d.z; y.n[7] = d.w;
+  x.n[8] = lam ? t.z : t.x;
+  y.n[8] = t.y;
+}
+
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 
@@ -341,7 +358,7 @@ constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 template <int MODE>
 __global__ void __launch_bounds__(256, S2K_FAST_WAVES)
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
-              const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ hs,
+              const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -434,34 +451,32 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     cur.x = fe29_mul(qx, c2);
     cur.y = fe29_mul(qy, c3);
     cur.z = fe29_one();
-    fq_store(qt, stride, idx, 0, cur.x);
-    fq_store(qt, stride, idx, 1, cur.y);
+    tb_store(qt, stride, idx, 0, TB_X, cur.x);
+    tb_store(qt, stride, idx, 0, TB_Y, cur.y);
 #pragma unroll 1
     for (int j = 1; j < QT_ENTRIES; ++j) {
       fe29 h;
       cur = jpt29_add_affine(cur, dx, dy, &h);
-      fq_store(qt, stride, idx, 2 * j, cur.x);
-      fq_store(qt, stride, idx, 2 * j + 1, cur.y);
-      fq_store(hs, stride, idx, j, h);
+      tb_store(qt, stride, idx, j, TB_X, cur.x);
+      tb_store(qt, stride, idx, j, TB_Y, cur.y);
+      tb_store(qt, stride, idx, j, TB_BX, h);          // H_j, replaced by beta * x_j below
     }
-    fq_store(hs, stride, idx, QT_ENTRIES, fe29_mul(cur.z, d.z));   // Z_7 * C
+    fq_store(fin, stride, idx, TB_ZC_ELEM, fe29_mul(cur.z, d.z));   // Z_7 * C
     fe29 prev_x = cur.x;
     const fe29 beta = fe29_from_words(FE_BETA);
     fe29 rr = fe29_one();
 #pragma unroll 1
     for (int j = QT_ENTRIES - 2; j >= 0; --j) {
-      rr = fe29_mul(rr, fq_load(hs, stride, idx, j + 1));
-      // H_{j+1} is no longer needed: its slot now takes beta * x_{j+1} (the x of the beta*Q
-      // table, mulBeta point_mul_glv.go:191; one multiplication per entry instead of one per lookup)
-      fq_store(hs, stride, idx, j + 1, fe29_mul(prev_x, beta));
+      rr = fe29_mul(rr, tb_load(qt, stride, idx, j + 1, TB_BX));
+      tb_store(qt, stride, idx, j + 1, TB_BX, fe29_mul(prev_x, beta));
       fe29 r2 = fe29_sqr(rr);
       fe29 r3 = fe29_mul(r2, rr);
-      prev_x = fe29_mul(fq_load(qt, stride, idx, 2 * j), r2);
-      fe29 y = fe29_mul(fq_load(qt, stride, idx, 2 * j + 1), r3);
-      fq_store(qt, stride, idx, 2 * j, prev_x);
-      fq_store(qt, stride, idx, 2 * j + 1, y);
+      prev_x = fe29_mul(tb_load(qt, stride, idx, j, TB_X), r2);
+      fe29 y = fe29_mul(tb_load(qt, stride, idx, j, TB_Y), r3);
+      tb_store(qt, stride, idx, j, TB_X, prev_x);
+      tb_store(qt, stride, idx, j, TB_Y, y);
     }
-    fq_store(hs, stride, idx, 0, fe29_mul(prev_x, beta));
+    tb_store(qt, stride, idx, 0, TB_BX, fe29_mul(prev_x, beta));
   }
 
   // ---- ladder over |k1|, |k2| ----
@@ -476,11 +491,11 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
   jpt29 acc;
   {
-    fe29 t0x = fq_load(qt, stride, idx, 0), t0y = fq_load(qt, stride, idx, 1);
+    fe29 t0x = tb_load(qt, stride, idx, 0, TB_X), t0y = tb_load(qt, stride, idx, 0, TB_Y), t0bx = tb_load(qt, stride, idx, 0, TB_BX);
     acc.x = t0x;
     acc.y = fe29_cond_negate1(t0y, neg1);
     acc.z = fe29_one();
-    acc = jpt29_add_affine(acc, fq_load(hs, stride, idx, 0), fe29_cond_negate1(t0y, neg2));
+    acc = jpt29_add_affine(acc, t0bx, fe29_cond_negate1(t0y, neg2));
   }
 #pragma unroll 1
   for (int i = 31; i >= 0; --i) {
@@ -492,12 +507,12 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       uint32_t w = t ? w2 : w1;
       bool neg = (t ? neg2 : neg1) != (w < 8u);
       uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
-      fe29 x = t ? fq_load(hs, stride, idx, entry) : fq_load(qt, stride, idx, 2 * entry);
-      fe29 y = fq_load(qt, stride, idx, 2 * entry + 1);
+      fe29 x, y;
+      tb_load_xy(qt, stride, idx, entry, t != 0, x, y);
       acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
     }
   }
-  acc.z = fe29_mul(acc.z, fq_load(hs, stride, idx, QT_ENTRIES));   // times Z_7 * C: back on secp256k1 itself
+  acc.z = fe29_mul(acc.z, fq_load(fin, stride, idx, TB_ZC_ELEM));   // times Z_7 * C: back on secp256k1 itself
 
   // ---- generator part: u1*G from the resident tables ----
   {
@@ -525,9 +540,9 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     } else if constexpr (MODE != MODE_ECDSA) {
       // affine epilogue (key bytes / even-y test) needs 1/Z: leave (X, Y, Z) in the lane's table
       // column and let k_affine_finish share one inversion between 16 lanes
-      fq_store(qt, stride, idx, 0, acc.x);
-      fq_store(qt, stride, idx, 1, acc.y);
-      fq_store(qt, stride, idx, 2, acc.z);
+      fq_store(fin, stride, idx, 0, acc.x);
+      fq_store(fin, stride, idx, 1, acc.y);
+      fq_store(fin, stride, idx, 2, acc.z);
       verdict = VERDICT_PENDING;
     } else if constexpr (MODE == MODE_ECDSA) {
       // x(R) mod n == r  (ecdsa.go:450-465)
@@ -560,13 +575,13 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
 //   MODE_SCHNORR: valid iff y even and x == r (verifySchnorrSignatureR, schnorr.go:451-478)
 //   MODE_RECOVER: writes the 65-byte key record (RecoverPublicKey, ecdsa.go:244-282)
 // Lanes that are not pending (already rejected, or queued for the complete kernel) ride along
-// with Z = 1.  Scratch: element 0 of the lane's H column takes the prefix product.
+// with Z = 1.  Scratch: element 3 of the lane's fin region takes the prefix product.
 // ---------------------------------------------------------------------------------------
 constexpr int FIN_M = 16;
 template <int MODE>
 __global__ void __launch_bounds__(64)
-k_affine_finish(uint32_t n, uint32_t T, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ qt,
-                uint32_t* __restrict__ hs, uint8_t* __restrict__ out, size_t stride, uint8_t* __restrict__ out_pts) {
+k_affine_finish(uint32_t n, uint32_t T, const uint8_t* __restrict__ rsig, uint32_t* __restrict__ fin,
+                uint8_t* __restrict__ out, size_t stride, uint8_t* __restrict__ out_pts) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
   fe29 acc = fe29_one();
@@ -574,20 +589,20 @@ k_affine_finish(uint32_t n, uint32_t T, const uint8_t* __restrict__ rsig, const 
   for (int j = 0; j < FIN_M; ++j) {
     size_t i = (size_t)t + (size_t)j * T;
     if (i >= n) break;
-    if (out[i] == VERDICT_PENDING) acc = fe29_mul(acc, fq_load(qt, stride, i, 2));
-    fq_store(hs, stride, i, 0, acc);
+    if (out[i] == VERDICT_PENDING) acc = fe29_mul(acc, fq_load(fin, stride, i, 2));
+    fq_store(fin, stride, i, 3, acc);
   }
   fe29 inv = fe29_inv(acc);
 #pragma unroll 1
   for (int j = FIN_M - 1; j >= 0; --j) {
     size_t i = (size_t)t + (size_t)j * T;
     if (i >= n || out[i] != VERDICT_PENDING) continue;
-    fe29 prev = j > 0 ? fq_load(hs, stride, i - T, 0) : fe29_one();
+    fe29 prev = j > 0 ? fq_load(fin, stride, i - T, 3) : fe29_one();
     fe29 zi = fe29_mul(inv, prev);                     // 1 / Z_i
-    inv = fe29_mul(inv, fq_load(qt, stride, i, 2));
+    inv = fe29_mul(inv, fq_load(fin, stride, i, 2));
     fe29 zi2 = fe29_sqr(zi);
-    fe29 x = fe29_mul(fq_load(qt, stride, i, 0), zi2);
-    fe29 y = fe29_normalize(fe29_mul(fe29_mul(fq_load(qt, stride, i, 1), zi2), zi));
+    fe29 x = fe29_mul(fq_load(fin, stride, i, 0), zi2);
+    fe29 y = fe29_normalize(fe29_mul(fe29_mul(fq_load(fin, stride, i, 1), zi2), zi));
     if constexpr (MODE == MODE_RECOVER) {
       uint32_t xw[8], yw[8];
       fe29_to_words(xw, fe29_normalize(x));
@@ -868,22 +883,23 @@ const char* s2k_version(void) { return "secp256k1_voi_amd 0.2 (gfx950)"; }
 #define S2K_BUILD_FLAGS ""
 #endif
 const char* s2k_build_config(void) {
-  return "GT_BITS=" S2K_STR(S2K_GT_BITS) " PREP_M=" S2K_STR(S2K_PREP_M) " QT_PLANE=" S2K_STR(S2K_QT_PLANE)
-         " FAST_WAVES=" S2K_STR(S2K_FAST_WAVES) " STRIDE_PAD=" S2K_STR(S2K_STRIDE_PAD) " flags=[" S2K_BUILD_FLAGS "]";
+  return "GT_BITS=" S2K_STR(S2K_GT_BITS) " PREP_M=" S2K_STR(S2K_PREP_M)
+         " QT_PACK=" S2K_STR(S2K_QT_PACK) " FAST_WAVES=" S2K_STR(S2K_FAST_WAVES) " STRIDE_PAD=" S2K_STR(S2K_STRIDE_PAD)
+         " flags=[" S2K_BUILD_FLAGS "]";
 }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
-//   [0,300)    per-lane point tables: fast path uses 192 (8 entries x 2 elements x 12 words) +
-//              108 (H scratch, then the beta*x column and Z_7*C); the complete path reuses the
-//              first 192 words for its projective table
+//   [0,256)    per-lane point table of the fast path: 8 entries x 8 quads (tb_*); the complete path
+//              uses the first 192 words for its projective table
+//   [256,304)  four scratch field elements ("fin": X, Y, Z for k_affine_finish; Z_7*C / prefix products)
 //   then       17 words of scalar-prep output.  The prep kernel's own scratch (prefix products and
 //              s in Montgomery form, 10 words each) borrows the start of the table region,
 //              which is only written after the prep kernel has finished.
 //   then       worklist: 1 counter + n indices
-constexpr size_t WS_QT = 0, WS_HS = FQT_WORDS, WS_PREP = FQT_WORDS + FHS_WORDS, WS_PREF = WS_QT, WS_SMONT = WS_QT + 10,
+constexpr size_t WS_QT = 0, WS_FIN = TBL_WORDS, WS_PREP = TBL_WORDS + FIN_WORDS, WS_PREF = WS_QT, WS_SMONT = WS_QT + 10,
                  WS_LANE_WORDS = WS_PREP + PREP_WORDS;
-static_assert(FQT_WORDS + FHS_WORDS >= QT_WORDS, "the complete path's table must fit in the fast path's region");
+static_assert(TBL_WORDS >= QT_WORDS, "the complete path's table must fit in the fast path's region");
 
 size_t s2k_ecdsa_workspace_bytes(size_t n) {
   return (lane_stride(n) * WS_LANE_WORDS + 64 + lane_stride(n)) * sizeof(uint32_t);
@@ -949,6 +965,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->gtable) (void)hipFree(ctx->gtable);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
+  if (ctx->rlc_save) (void)hipFree(ctx->rlc_save);
   if (ctx->io) (void)hipFree(ctx->io);
   if (ctx->clk) (void)hipFree(ctx->clk);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
@@ -1040,7 +1057,7 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
-  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* fin = ws + WS_FIN * stride;
   uint32_t* prep = ws + WS_PREP * stride;
   uint32_t* pref = ws + WS_PREF * stride;
   uint32_t* smont = ws + WS_SMONT * stride;
@@ -1053,7 +1070,7 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
                                               (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 1);
-  k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, hs,
+  k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
                                                ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr,
                                                ctx->prof_on ? ctx->clk : nullptr);
   HIP_TRY(ctx, hipGetLastError());
@@ -1081,7 +1098,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
-  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* fin = ws + WS_FIN * stride;
   uint32_t* prep = ws + WS_PREP * stride;
   uint32_t* pref = ws + WS_PREF * stride;
   uint32_t* smont = ws + WS_SMONT * stride;
@@ -1099,12 +1116,12 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
-  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, hs, ctx->gtable,
+  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, ctx->gtable,
                                                              (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
-    k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, qt, hs, (uint8_t*)d_ok, stride,
+    k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, fin, (uint8_t*)d_ok, stride,
                                                                  (uint8_t*)d_pub65);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1120,18 +1137,26 @@ int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const ui
   if (n == 0) return S2K_OK;
   if (!dig || !r || !s || !recid || !pub65 || !ok) return fail(ctx, S2K_ERR_ARG, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dev_buf dd, dr, ds, di, dp, dk;
-  HIP_TRY(ctx, dd.upload(dig, n * 32));
-  HIP_TRY(ctx, dr.upload(r, n * 32));
-  HIP_TRY(ctx, ds.upload(s, n * 32));
-  HIP_TRY(ctx, di.upload(recid, n));
-  HIP_TRY(ctx, dp.alloc(n * 65));
-  HIP_TRY(ctx, dk.alloc(n));
-  int rc = s2k_ecdsa_recover_batch_device(ctx, n, dd.p, dr.p, ds.p, di.p, flags, dp.p, dk.p, nullptr);
+  int rc = ctx_streams(ctx);
   if (rc) return rc;
-  HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(pub65, dp.p, n * 65, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(ok, dk.p, n, hipMemcpyDeviceToHost));
+  // staged in the context's buffers on its compute stream (no allocation per call)
+  const size_t sizes[6] = {n * 32, n * 32, n * 32, n, n * 65, n};
+  uint8_t* d[6];
+  rc = ctx_stage(ctx, sizes, 6, d);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d[0], dig, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[1], r, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[2], s, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[3], recid, n, hipMemcpyHostToDevice, st));
+  rc = s2k_ecdsa_recover_batch_device(ctx, n, d[0], d[1], d[2], d[3], flags, d[4], d[5], st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(pub65, d[4], n * 65, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ok, d[5], n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
   return S2K_OK;
 }
 
@@ -1152,7 +1177,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
-  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* fin = ws + WS_FIN * stride;
   uint32_t* prep = ws + WS_PREP * stride;
   uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
   uint32_t* wl = wl_count + 64;
@@ -1169,12 +1194,12 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
   HIP_TRY(ctx, hipGetLastError());
-  k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, hs, ctx->gtable,
+  k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
                                                              (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
-    k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, qt, hs, (uint8_t*)d_valid, stride, nullptr);
+    k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, fin, (uint8_t*)d_valid, stride, nullptr);
     HIP_TRY(ctx, hipGetLastError());
   }
   k_schnorr_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len,
@@ -1236,17 +1261,24 @@ int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const ui
   size_t total = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
   if (total && !msgs) return fail(ctx, S2K_ERR_ARG, "null message buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dev_buf dp, dm, dof, dsg, dv;
-  HIP_TRY(ctx, dp.upload(pk, n * 32));
-  HIP_TRY(ctx, dm.upload(msgs, total));
-  if (msg_offsets) HIP_TRY(ctx, dof.upload(msg_offsets, (n + 1) * sizeof(uint64_t)));
-  HIP_TRY(ctx, dsg.upload(sig, n * 64));
-  HIP_TRY(ctx, dv.alloc(n));
-  int rc = s2k_schnorr_verify_batch_device(ctx, n, dp.p, dm.p, msg_offsets ? dof.p : nullptr, msg_len, dsg.p, flags,
-                                           dv.p, nullptr);
+  int rc = ctx_streams(ctx);
   if (rc) return rc;
-  HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(valid, dv.p, n, hipMemcpyDeviceToHost));
+  const size_t sizes[5] = {n * 32, total ? total : 16, (n + 1) * sizeof(uint64_t), n * 64, n};
+  uint8_t* d[5];
+  rc = ctx_stage(ctx, sizes, 5, d);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d[0], pk, n * 32, hipMemcpyHostToDevice, st));
+  if (total) HIP_TRY(ctx, hipMemcpyAsync(d[1], msgs, total, hipMemcpyHostToDevice, st));
+  if (msg_offsets) HIP_TRY(ctx, hipMemcpyAsync(d[2], msg_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[3], sig, n * 64, hipMemcpyHostToDevice, st));
+  rc = s2k_schnorr_verify_batch_device(ctx, n, d[0], d[1], msg_offsets ? d[2] : nullptr, msg_len, d[3], flags, d[4], st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
   return S2K_OK;
 }
 
@@ -1284,7 +1316,7 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
-  uint32_t* hs = ws + WS_HS * stride;
+  uint32_t* fin = ws + WS_FIN * stride;
   uint32_t* prep = ws + WS_PREP * stride;
   uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
   uint32_t* wl = wl_count + 64;
@@ -1298,11 +1330,11 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
     k_hot_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_pub, prep, stride, wl_count, wl,
                                               status);
     HIP_TRY(ctx, hipGetLastError());
-    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, hs, ctx->gtable,
+    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, fin, ctx->gtable,
                                                              io + o_ok, wl_count, wl, stride, io + o_out, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
-    k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, qt, hs, io + o_ok, stride, io + o_out);
+    k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, fin, io + o_ok, stride, io + o_out);
     HIP_TRY(ctx, hipGetLastError());
     k_point_fallback<false><<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts,
                                                                      io + o_out, ctx->gtable, qt, stride, status);

@@ -69,6 +69,8 @@ struct s2k_ctx {
   size_t ws_bytes = 0;
   void* msm_ws = nullptr;       // workspace of the multi-scalar multiplication
   size_t msm_ws_bytes = 0;
+  void* rlc_save = nullptr;     // kept terms of a rejected BIP-340 batch while its failing signatures are located
+  size_t rlc_save_bytes = 0;
   // host-buffer entry point: device staging for inputs / verdicts, a copy stream and a compute
   // stream, events that chain them (created on first use)
   void* io = nullptr;
@@ -154,6 +156,21 @@ inline int ctx_streams(s2k_ctx* ctx) {
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
   for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return S2K_OK;
+}
+
+// carve `count` buffers (256-byte aligned) out of the context's staging allocation, grown on demand:
+// the host-buffer entry points stage their inputs and outputs here instead of allocating per call
+inline int ctx_stage(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** ptrs) {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) total += (sizes[i] + 255) & ~(size_t)255;
+  int rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, total + 256);
+  if (rc) return rc;
+  size_t off = 0;
+  for (int i = 0; i < count; ++i) {
+    ptrs[i] = (uint8_t*)ctx->io + off;
+    off += (sizes[i] + 255) & ~(size_t)255;
+  }
   return S2K_OK;
 }
 

@@ -25,6 +25,10 @@
 // detect and no fallback.  Every term is first split with the curve endomorphism into two
 // 128-bit terms (below).  Window width c is 8 bits for small inputs and 16 bits for large ones
 // (2^20 inputs: 2^21 terms, 8 windows x 65535 buckets, ~32 points per bucket).
+#include <sys/random.h>
+
+#include <vector>
+
 #include "engine_internal.h"
 #include "pt29.h"
 #include "sc.h"
@@ -526,7 +530,9 @@ struct msm_ws {
 // carve the MSM workspace for n terms (+ aux_bytes of scratch for the caller)
 int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   msm_geom& g = m.g;
-  g.c = n >= (1u << 14) ? 16 : (n >= 256 ? 12 : 8);
+  // window width by additions: n * nw into buckets plus about 2 * nw * 2^c in the bucket reductions;
+  // 8n + 2^20 (c = 16) undercuts 11n + 90k (c = 12) from n = 3 * 10^5 terms on
+  g.c = n >= (1u << 18) ? 16 : (n >= 256 ? 12 : 8);
   g.nw = (SCALAR_BITS + g.c - 1) / g.c;
   g.nb = 1u << g.c;
   g.nchunk = g.nb / CHUNK;
@@ -634,10 +640,13 @@ S2K_DEV bool lift_x_words(uint32_t yw[8], const uint32_t xw[8]) {
   return true;
 }
 
+struct rlc_key {   // PRF key of the coefficients, passed by value as a kernel argument
+  uint32_t w[8];
+};
 __global__ void __launch_bounds__(256)
 k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
                    const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs, uint32_t msg_len,
-                   const uint32_t* __restrict__ seed_be, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
+                   rlc_key seed_be, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
                    uint8_t* __restrict__ flag, uint32_t* __restrict__ as_out, uint32_t* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -675,7 +684,7 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       st[j] = SHA256_IV[j];
-      w[j] = seed_be[j];
+      w[j] = seed_be.w[j];
     }
     w[8] = (uint32_t)(i >> 32);
     w[9] = (uint32_t)i;
@@ -696,8 +705,9 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
     msm_store_term(scw, ptw, N, i, a, r_le, ry, true);                          // a_i < 2^128 already
     msm_store_split(scw, ptw, N, (size_t)n + i, 2 * (size_t)n + i, ae, pk_le, npy);
   }
+  // a signature whose r or key does not lift is invalid on its own; it takes no part in the combination
 #pragma unroll
-  for (int w = 0; w < 8; ++w) as_out[(size_t)w * n + i] = as.v[w];
+  for (int w = 0; w < 8; ++w) as_out[(size_t)w * n + i] = ok ? as.v[w] : 0u;
   flag[i] = ok ? 1 : 0;
   flag[(size_t)n + i] = ok ? 1 : 0;
   flag[2 * (size_t)n + i] = ok ? 1 : 0;
@@ -707,16 +717,17 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
 // `part` (8 words each), then one workgroup folds those and writes the result as terms 3n, 3n + 1
 // with the point G (as == nullptr selects the second stage)
 constexpr uint32_t RLC_SUM_BLOCKS = 256;
+// (`as` has plane stride `stride`; a sub-range of a saved batch passes as + lo with the batch's stride)
 __global__ void __launch_bounds__(256)
-k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restrict__ part, uint32_t* __restrict__ scw,
-                  uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag) {
+k_schnorr_rlc_sum(uint32_t n, size_t stride, const uint32_t* __restrict__ as, uint32_t* __restrict__ part,
+                  uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag) {
   __shared__ uint32_t sh[256][8];
   sc acc = sc_zero();
   if (as) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RLC_SUM_BLOCKS * 256) {
       sc v;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v.v[w] = as[(size_t)w * n + i];
+      for (int w = 0; w < 8; ++w) v.v[w] = as[(size_t)w * stride + i];
       acc = sc_add(acc, v);
     }
   } else if (threadIdx.x < RLC_SUM_BLOCKS) {
@@ -753,6 +764,53 @@ k_schnorr_rlc_sum(uint32_t n, const uint32_t* __restrict__ as, uint32_t* __restr
     flag[3 * (size_t)n] = 1;
     flag[3 * (size_t)n + 1] = 1;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Locating the failing signatures of a rejected batch.  The terms of the whole
+// batch (coefficients, challenges times coefficients, lifted points: the expensive part of the
+// preparation) are kept; a sub-range [lo, lo + m) of the signatures is re-checked by gathering its
+// 3m terms into a fresh term array, summing its a_i s_i for the generator term and running the
+// multiscalar core on 3m + 2 terms.  The result is the range's error point E = sum of the
+// coefficients times the individual errors; E_right = E_parent - E_left, so every level costs one
+// multiscalar multiplication of half its parent's size.
+// Saved layout: s_scw [4][3n] (magnitudes), s_ptw [3n][16], s_flag [n], s_as [8][n].
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rlc_gather(uint32_t lo, uint32_t m, uint32_t n, const uint32_t* __restrict__ s_scw, const uint32_t* __restrict__ s_ptw,
+             const uint8_t* __restrict__ s_flag, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
+             uint8_t* __restrict__ flag) {
+  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;     // destination term among the 3m
+  if (j >= 3 * (size_t)m) return;
+  const size_t part = j / m, i = j - part * m;            // 0: R terms, 1 and 2: the halves of the P terms
+  const size_t src = part * n + lo + i, N = 3 * (size_t)m + 2, NS = 3 * (size_t)n;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) scw[(size_t)w * N + j] = s_scw[(size_t)w * NS + src];
+  scw[(size_t)4 * N + j] = 0;
+  const uint4* a = reinterpret_cast<const uint4*>(s_ptw + src * 16);
+  uint4* b = reinterpret_cast<uint4*>(ptw + j * 16);
+  b[0] = a[0]; b[1] = a[1]; b[2] = a[2]; b[3] = a[3];
+  flag[j] = s_flag[lo + i];
+}
+// terms of the whole batch -> saved arrays (3n + 2 -> 3n: the generator terms are rebuilt per range)
+__global__ void __launch_bounds__(256)
+k_rlc_save(uint32_t n, const uint32_t* __restrict__ scw, const uint32_t* __restrict__ ptw, const uint8_t* __restrict__ flag,
+           uint32_t* __restrict__ s_scw, uint32_t* __restrict__ s_ptw, uint8_t* __restrict__ s_flag) {
+  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= 3 * (size_t)n) return;
+  const size_t N = 3 * (size_t)n + 2, NS = 3 * (size_t)n;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) s_scw[(size_t)w * NS + j] = scw[(size_t)w * N + j];
+  const uint4* a = reinterpret_cast<const uint4*>(ptw + j * 16);
+  uint4* b = reinterpret_cast<uint4*>(s_ptw + j * 16);
+  b[0] = a[0]; b[1] = a[1]; b[2] = a[2]; b[3] = a[3];
+  if (j < n) s_flag[j] = flag[j];
+}
+// valid[lo + i] = ok-to-lift flag of signature lo + i (a range the combination has cleared)
+__global__ void __launch_bounds__(256)
+k_rlc_mark_valid(uint32_t lo, uint32_t m, const uint8_t* __restrict__ s_flag, uint8_t* __restrict__ valid) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < m) valid[lo + i] = s_flag[lo + i];
 }
 
 }  // namespace
@@ -796,14 +854,107 @@ int s2k_multi_scalar_mult(s2k_ctx* ctx, size_t n, const uint8_t* scalars, const 
   if (!out65) return fail(ctx, S2K_ERR_ARG, "null output buffer");
   if (n && (!scalars || !points)) return fail(ctx, S2K_ERR_ARG, "null input buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dev_buf dk, dp, dout;
-  HIP_TRY(ctx, dk.upload(scalars, n * 32));
-  HIP_TRY(ctx, dp.upload(points, n * 65));
-  HIP_TRY(ctx, dout.alloc(80));
-  int rc = s2k_multi_scalar_mult_device(ctx, n, dk.p, dp.p, dout.p, nullptr);
+  int rc = ctx_streams(ctx);
   if (rc) return rc;
-  HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(out65, dout.p, 65, hipMemcpyDeviceToHost));
+  const size_t sizes[3] = {n * 32 + 16, n * 65 + 16, 128};
+  uint8_t* d[3];
+  rc = ctx_stage(ctx, sizes, 3, d);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  if (n) {
+    HIP_TRY(ctx, hipMemcpyAsync(d[0], scalars, n * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d[1], points, n * 65, hipMemcpyHostToDevice, st));
+  }
+  rc = s2k_multi_scalar_mult_device(ctx, n, d[0], d[1], d[2], st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out65, d[2], 65, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return S2K_OK;
+}
+
+// SHA-256 on the host (FIPS 180-4), for mixing the caller's seed with operating-system randomness
+static void host_sha256(uint8_t out[32], const uint8_t* msg, size_t len) {
+  static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint8_t buf[128];
+  size_t full = len / 64, rem = len % 64;
+  auto block = [&](const uint8_t* b) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+    auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    for (int i = 16; i < 64; ++i) {
+      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], bb = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], hh = st[7];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
+      uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & bb) ^ (a & c) ^ (bb & c), t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += bb; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += hh;
+  };
+  for (size_t i = 0; i < full; ++i) block(msg + 64 * i);
+  memset(buf, 0, sizeof buf);
+  memcpy(buf, msg + 64 * full, rem);
+  buf[rem] = 0x80;
+  size_t padded = rem + 9 <= 64 ? 64 : 128;
+  uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; ++i) buf[padded - 1 - i] = (uint8_t)(bits >> (8 * i));
+  block(buf);
+  if (padded == 128) block(buf + 64);
+  for (int i = 0; i < 8; ++i) {
+    out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
+  }
+}
+
+// ct_cpu.cpp: out = a - b on 65-byte records (host; public data)
+extern "C" __attribute__((visibility("hidden"))) int s2k_internal_point_sub65(const uint8_t* a, const uint8_t* b, uint8_t* out);
+
+static int stage_schnorr(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs, const uint64_t* msg_offsets, size_t msg_len,
+                         const uint8_t* sig, uint8_t* d[5], hipStream_t* st_out);
+
+// whole-batch combination: preparation, generator term, multiscalar core; leaves the 129 bytes
+// [status word .. 64: error point record] in h.  The caller's seed is mixed with 32 bytes from the
+// operating system's CSPRNG, so a reused or predictable seed does not weaken the check (the
+// coefficients have to be unpredictable to whoever chose the signatures).
+static int rlc_run_full(s2k_ctx* ctx, hipStream_t st, size_t n, const void* d_pk, const void* d_msgs,
+                        const void* d_msg_offsets, size_t msg_len, const void* d_sig, const uint8_t* seed32, msm_ws& m,
+                        uint32_t** as_out, uint8_t h[192]) {
+  const size_t N = 3 * n + 2;
+  int rc = msm_setup(ctx, N, n * 8 * 4 + 256 + RLC_SUM_BLOCKS * 32, m);
+  if (rc) return rc;
+  uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
+  uint32_t* sum_part = (uint32_t*)(m.aux + 256);
+  uint8_t mix[64], key[32];
+  memcpy(mix, seed32, 32);
+  if (getrandom(mix + 32, 32, 0) != 32) return fail(ctx, S2K_ERR_HIP, "getrandom failed: no randomness for the batch coefficients");
+  host_sha256(key, mix, 64);
+  rlc_key seed_be;
+  for (int j = 0; j < 8; ++j)
+    seed_be.w[j] = ((uint32_t)key[4 * j] << 24) | ((uint32_t)key[4 * j + 1] << 16) | ((uint32_t)key[4 * j + 2] << 8) | key[4 * j + 3];
+  HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
+  k_schnorr_rlc_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
+                                                    (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
+                                                    (uint32_t)msg_len, seed_be, m.scw, m.ptw, m.flag, as, m.status);
+  HIP_TRY(ctx, hipGetLastError());
+  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, n, as, sum_part, m.scw, m.ptw, m.flag);
+  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, n, nullptr, sum_part, m.scw, m.ptw, m.flag);
+  HIP_TRY(ctx, hipGetLastError());
+  uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
+  rc = msm_core(ctx, st, N, m, d_out);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(h, m.status, 64 + 65, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
+  if (as_out) *as_out = as;
   return S2K_OK;
 }
 
@@ -821,39 +972,173 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk
   if (n > 0x0fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
-  const size_t N = 3 * n + 2;
   int rc = ctx_enter(ctx, st);
   if (rc) return rc;
   msm_ws m;
-  rc = msm_setup(ctx, N, n * 8 * 4 + 256 + RLC_SUM_BLOCKS * 32, m);
-  if (rc) return rc;
-  uint32_t* seed_dev = (uint32_t*)m.aux;
-  uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
-  uint32_t* sum_part = (uint32_t*)(m.aux + 256);
-  uint32_t seed_be[8];
-  for (int j = 0; j < 8; ++j)
-    seed_be[j] = ((uint32_t)seed32[4 * j] << 24) | ((uint32_t)seed32[4 * j + 1] << 16) | ((uint32_t)seed32[4 * j + 2] << 8) |
-                 seed32[4 * j + 3];
-  HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
-  HIP_TRY(ctx, hipMemcpyAsync(seed_dev, seed_be, 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));   // seed_be is a stack buffer
-  k_schnorr_rlc_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
-                                                    (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
-                                                    (uint32_t)msg_len, seed_dev, m.scw, m.ptw, m.flag, as, m.status);
-  HIP_TRY(ctx, hipGetLastError());
-  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, as, sum_part, m.scw, m.ptw, m.flag);
-  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, nullptr, sum_part, m.scw, m.ptw, m.flag);
-  HIP_TRY(ctx, hipGetLastError());
-  uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
-  rc = msm_core(ctx, st, N, m, d_out);
-  if (rc) return rc;
   uint8_t h[192];
-  HIP_TRY(ctx, hipMemcpyAsync(h, m.status, 64 + 65, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  ctx->have_last = false;
+  rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, nullptr, h);
+  if (rc) return rc;
   uint32_t h_status;
   memcpy(&h_status, h, 4);
   *all_valid = (h_status == 0 && h[64] == 0x00) ? 1 : 0;
+  return S2K_OK;
+}
+
+// Per-signature verdicts at the price of the whole-batch check when (as usual) everything verifies:
+// one combination over the batch; if it is rejected, the failing signatures are located by
+// bisection on the kept terms (header).  stats (host, optional): [0] sub-range multiscalar
+// multiplications, [1] signatures verified one by one, [2] levels descended, [3] 1 = gave up
+// bisecting (many failing ranges) and verified the rest one by one.
+int s2k_schnorr_verify_batch_bisect_device(s2k_ctx* ctx, size_t n, const void* d_pk, const void* d_msgs,
+                                           const void* d_msg_offsets, size_t msg_len, const void* d_sig,
+                                           const uint8_t* seed32, void* d_valid, uint32_t* stats, void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (!seed32) return fail(ctx, S2K_ERR_ARG, "null argument");
+  if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  if (n == 0) return S2K_OK;
+  if (!d_pk || !d_sig || !d_valid || (!d_msgs && (d_msg_offsets || msg_len))) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x0fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  const uint8_t *pk = (const uint8_t*)d_pk, *sig = (const uint8_t*)d_sig, *msgs = (const uint8_t*)d_msgs;
+  const uint64_t* offs = (const uint64_t*)d_msg_offsets;
+  uint8_t* valid = (uint8_t*)d_valid;
+  constexpr uint32_t LEAF = 1u << 14;      // below this a range is verified signature by signature
+  constexpr size_t MAX_FAILING = 8;        // more failing ranges than this on one level: stop bisecting
+  auto verify_each = [&](uint32_t lo, uint32_t cnt) -> int {
+    if (stats) stats[1] += cnt;
+    return s2k_schnorr_verify_batch_device(ctx, cnt, pk + (size_t)lo * 32, offs ? msgs : (msgs ? msgs + (size_t)lo * msg_len : nullptr),
+                                           offs ? offs + lo : nullptr, msg_len, sig + (size_t)lo * 64, 0, valid + lo, st);
+  };
+  if (n <= LEAF) return verify_each(0, (uint32_t)n);
+
+  msm_ws m;
+  uint32_t* as = nullptr;
+  uint8_t h[192];
+  rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, &as, h);
+  if (rc) return rc;
+  if (h[64] == 0x00) {   // the combination of every liftable signature vanishes: those are all valid
+    k_rlc_mark_valid<<<blocks_for(n), 256, 0, st>>>(0u, (uint32_t)n, m.flag, valid);
+    HIP_TRY(ctx, hipGetLastError());
+    return ctx_leave(ctx, st);
+  }
+  // keep the terms: the sub-range runs re-carve the multiscalar workspace
+  const size_t NS = 3 * n;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t o_scw = 0, o_ptw = pad(NS * 4 * 4), o_flag = o_ptw + pad(NS * 16 * 4), o_as = o_flag + pad(n),
+               total = o_as + pad(n * 8 * 4);
+  rc = ctx_reserve(ctx, &ctx->rlc_save, &ctx->rlc_save_bytes, total);
+  if (rc) return rc;
+  uint8_t* sv = (uint8_t*)ctx->rlc_save;
+  uint32_t *s_scw = (uint32_t*)(sv + o_scw), *s_ptw = (uint32_t*)(sv + o_ptw), *s_as = (uint32_t*)(sv + o_as);
+  uint8_t* s_flag = sv + o_flag;
+  k_rlc_save<<<blocks_for(NS), 256, 0, st>>>((uint32_t)n, m.scw, m.ptw, m.flag, s_scw, s_ptw, s_flag);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(s_as, as, n * 8 * 4, hipMemcpyDeviceToDevice, st));
+
+  // error point of a sub-range
+  auto sub = [&](uint32_t lo, uint32_t cnt, uint8_t E[65]) -> int {
+    msm_ws w;
+    const size_t N = 3 * (size_t)cnt + 2;
+    int r = msm_setup(ctx, N, 256 + RLC_SUM_BLOCKS * 32, w);
+    if (r) return r;
+    uint32_t* sum_part = (uint32_t*)w.aux;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, w.zero_bytes, st));
+    k_rlc_gather<<<blocks_for(3 * (size_t)cnt), 256, 0, st>>>(lo, cnt, (uint32_t)n, s_scw, s_ptw, s_flag, w.scw, w.ptw, w.flag);
+    k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>(cnt, n, s_as + lo, sum_part, w.scw, w.ptw, w.flag);
+    k_schnorr_rlc_sum<<<1, 256, 0, st>>>(cnt, n, nullptr, sum_part, w.scw, w.ptw, w.flag);
+    HIP_TRY(ctx, hipGetLastError());
+    uint8_t* d_out = (uint8_t*)w.status + 64;
+    r = msm_core(ctx, st, N, w, d_out);
+    if (r) return r;
+    HIP_TRY(ctx, hipMemcpyAsync(E, d_out, 65, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (stats) stats[0] += 1;
+    return S2K_OK;
+  };
+  struct range {
+    uint32_t lo, cnt;
+    uint8_t E[65];
+  };
+  std::vector<range> cur(1), next;
+  cur[0].lo = 0;
+  cur[0].cnt = (uint32_t)n;
+  memcpy(cur[0].E, h + 64, 65);
+  while (!cur.empty()) {
+    if (cur.size() > MAX_FAILING) {   // errors everywhere: bisection would cost more than it saves
+      if (stats) stats[3] = 1;
+      for (const range& r : cur) {
+        rc = verify_each(r.lo, r.cnt);
+        if (rc) return rc;
+      }
+      break;
+    }
+    next.clear();
+    for (const range& r : cur) {
+      if (r.cnt <= LEAF) {
+        rc = verify_each(r.lo, r.cnt);
+        if (rc) return rc;
+        continue;
+      }
+      range left, right;
+      left.lo = r.lo;
+      left.cnt = r.cnt / 2;
+      right.lo = r.lo + left.cnt;
+      right.cnt = r.cnt - left.cnt;
+      rc = sub(left.lo, left.cnt, left.E);
+      if (rc) return rc;
+      if (s2k_internal_point_sub65(r.E, left.E, right.E) != 0) return fail(ctx, S2K_ERR_HIP, "internal: bad error point");
+      for (const range* h2 : {&left, &right}) {
+        if (h2->E[0] == 0x00) {
+          k_rlc_mark_valid<<<blocks_for(h2->cnt), 256, 0, st>>>(h2->lo, h2->cnt, s_flag, valid);
+          HIP_TRY(ctx, hipGetLastError());
+        } else {
+          next.push_back(*h2);
+        }
+      }
+    }
+    if (stats && !next.empty()) stats[2] += 1;
+    cur.swap(next);
+  }
+  return ctx_leave(ctx, st);
+}
+
+int s2k_schnorr_verify_batch_bisect(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                    size_t msg_len, const uint8_t* sig, const uint8_t* seed32, uint8_t* valid, uint32_t* stats) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!pk || !sig || !valid || !seed32) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  uint8_t* d[5];
+  hipStream_t st;
+  int rc = stage_schnorr(ctx, n, pk, msgs, msg_offsets, msg_len, sig, d, &st);
+  if (rc) return rc;
+  rc = s2k_schnorr_verify_batch_bisect_device(ctx, n, d[0], d[1], msg_offsets ? d[2] : nullptr, msg_len, d[3], seed32, d[4], stats, st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
+  return S2K_OK;
+}
+
+// stage (pk, msgs, offsets, sig [, valid]) of a BIP-340 batch in the context's buffers on its compute stream
+static int stage_schnorr(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs, const uint64_t* msg_offsets, size_t msg_len,
+                         const uint8_t* sig, uint8_t* d[5], hipStream_t* st_out) {
+  size_t total = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
+  if (total && !msgs) return fail(ctx, S2K_ERR_ARG, "null message buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ctx_streams(ctx);
+  if (rc) return rc;
+  const size_t sizes[5] = {n * 32, total ? total : 16, (n + 1) * sizeof(uint64_t), n * 64, n};
+  rc = ctx_stage(ctx, sizes, 5, d);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  HIP_TRY(ctx, hipMemcpyAsync(d[0], pk, n * 32, hipMemcpyHostToDevice, st));
+  if (total) HIP_TRY(ctx, hipMemcpyAsync(d[1], msgs, total, hipMemcpyHostToDevice, st));
+  if (msg_offsets) HIP_TRY(ctx, hipMemcpyAsync(d[2], msg_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[3], sig, n * 64, hipMemcpyHostToDevice, st));
+  *st_out = st;
   return S2K_OK;
 }
 
@@ -867,16 +1152,11 @@ int s2k_schnorr_batch_verify_rlc(s2k_ctx* ctx, size_t n, const uint8_t* pk, cons
     return S2K_OK;
   }
   if (!pk || !sig) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  size_t total = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
-  if (total && !msgs) return fail(ctx, S2K_ERR_ARG, "null message buffer");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dev_buf dp, dm, dof, dsg;
-  HIP_TRY(ctx, dp.upload(pk, n * 32));
-  HIP_TRY(ctx, dm.upload(msgs, total));
-  if (msg_offsets) HIP_TRY(ctx, dof.upload(msg_offsets, (n + 1) * sizeof(uint64_t)));
-  HIP_TRY(ctx, dsg.upload(sig, n * 64));
-  return s2k_schnorr_batch_verify_rlc_device(ctx, n, dp.p, dm.p, msg_offsets ? dof.p : nullptr, msg_len, dsg.p, seed32,
-                                             all_valid, nullptr);
+  uint8_t* d[5];
+  hipStream_t st;
+  int rc = stage_schnorr(ctx, n, pk, msgs, msg_offsets, msg_len, sig, d, &st);
+  if (rc) return rc;
+  return s2k_schnorr_batch_verify_rlc_device(ctx, n, d[0], d[1], msg_offsets ? d[2] : nullptr, msg_len, d[3], seed32, all_valid, st);
 }
 
 }  // extern "C"

@@ -150,3 +150,69 @@ def test_ecdsa_distinct_keys_full_size(eng):
     pub[12345], pub[12346] = pub[12346].copy(), pub[12345].copy()
     got = eng.ecdsa_verify_batch(pub, dig, r, s)
     assert got.sum() == n - 2 and not got[12345] and not got[12346]
+
+
+@pytest.mark.parametrize("log2n", [16, 20])
+def test_schnorr_bisection_locates_bad_signatures(eng, oracle, log2n):
+    """Failing BIP-340 batches: the verdicts of the bisecting entry point equal those of
+    per-signature verification for 1, 2 and sqrt(n) bad signatures, for signatures whose r or key does
+    not lift, and the work done is what bisection promises (few sub-combinations, few signatures
+    verified one by one)."""
+    import time
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    n = 1 << log2n
+    pk, msgs, sig = synth_schnorr_batch(eng, n, 1 << 12, seed=50 + log2n)
+    seed = bytes(range(32))
+    v, st = eng.schnorr_verify_batch_auto(pk, msgs, sig, seed, return_stats=True)
+    assert v.all() and st == {"sub_combinations": 0, "verified_one_by_one": 0, "levels": 0, "abandoned": False}
+    rng = np.random.default_rng(51)
+    timings = {}
+    for label, nbad in (("1", 1), ("2", 2), ("sqrt_n", 1 << (log2n // 2))):
+        bad_idx = np.sort(rng.choice(n, size=nbad, replace=False))
+        bad = sig.copy()
+        bad[bad_idx, 32 + (bad_idx % 31)] ^= 0x04           # corrupt s
+        t0 = time.perf_counter()
+        v, st = eng.schnorr_verify_batch_auto(pk, msgs, bad, seed, return_stats=True)
+        timings[label] = (time.perf_counter() - t0, st)
+        exp = np.ones(n, dtype=np.uint8)
+        exp[bad_idx] = 0
+        assert np.array_equal(v, exp), (label, st)
+        if nbad <= 2:
+            assert not st["abandoned"] and st["verified_one_by_one"] <= nbad << 14 and st["sub_combinations"] <= nbad * (log2n - 14)
+    # corrupt r so that it no longer lifts (and one that still lifts but is wrong), and a key that is not on the curve
+    bad = sig.copy()
+    pkb = pk.copy()
+    not_x = next(x for x in range(2, 100) if R.lift_x(x, 0) is None)
+    bad[5, :32] = np.frombuffer(b32(not_x), np.uint8)
+    bad[n - 7, :32] = np.frombuffer(b32(R.P), np.uint8)          # r >= p
+    pkb[n // 3, :] = np.frombuffer(b32(not_x), np.uint8)
+    bad[n // 2, 3] ^= 1
+    v = eng.schnorr_verify_batch_auto(pkb, msgs, bad, seed)
+    m = 4096                                                      # the reference's verdicts around the touched items
+    for lo in (0, n // 3 - 5, n // 2 - 5, n - m):
+        sl = slice(lo, lo + m if lo else m)
+        assert np.array_equal(v[sl], eng.schnorr_verify_batch(pkb[sl], msgs[sl], bad[sl]))
+    assert v.sum() == n - 4 and not v[5] and not v[n - 7] and not v[n // 3] and not v[n // 2]
+    for i in (5, n - 7, n // 3, n // 2):
+        assert oracle.schnorr_verify(bytes(pkb[i]), bytes(msgs[i]), bytes(bad[i])) != 1     # false, or the key does not even parse
+    print("bisection timings (host pointers, s):", {k: (round(t, 4), s) for k, (t, s) in timings.items()})
+
+
+def test_schnorr_bisection_variable_length_messages(eng, oracle):
+    rnd = __import__("random").Random(77)
+    n = 20000
+    sk = [rnd.randrange(1, R.N) for _ in range(64)]
+    trip = []
+    for i in range(256):
+        m = rnd.randbytes(rnd.choice([0, 1, 31, 32, 33, 64, 100]))
+        d = sk[i % 64]
+        trip.append((b32(R.mul(d, R.G)[0]), m, R.schnorr_sign(d, m, bytes(32))))
+    pks = [trip[i % 256][0] for i in range(n)]
+    msgs = [trip[i % 256][1] for i in range(n)]
+    sigs = [trip[i % 256][2] for i in range(n)]
+    for i in (3, 9999, 19999):
+        sigs[i] = sigs[i][:50] + bytes([sigs[i][50] ^ 2]) + sigs[i][51:]
+    v = eng.schnorr_verify_batch_auto(pks, msgs, sigs, b"\x07" * 32)
+    exp = np.ones(n, dtype=np.uint8)
+    exp[[3, 9999, 19999]] = 0
+    assert np.array_equal(v, exp)

@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of per-signature table layouts on the GPU box: rebuilds engine.o per variant and runs the bench.
+# whatever variant ran last, leave the DEFAULT build behind (build() also rebuilds when the recorded flags differ)
+trap 'S2K_EXTRA_FLAGS="" python -c "import secp256k1_voi_amd as S; S.build(force=True)" > /dev/null 2>&1' EXIT
 set -e
 for v in "-DS2K_QT_PLANE=8 -DS2K_STRIDE_PAD=1088" "-DS2K_QT_PLANE=16 -DS2K_STRIDE_PAD=1088" "-DS2K_QT_PLANE=16 -DS2K_STRIDE_PAD=0" "-DS2K_QT_PLANE=8 -DS2K_STRIDE_PAD=64" "-DS2K_QT_PLANE=8 -DS2K_STRIDE_PAD=4160" "-DS2K_QT_PLANE=8 -DS2K_STRIDE_PAD=16448"; do
   S2K_EXTRA_FLAGS="$v" python -c "import secp256k1_voi_amd as S; S.build(force=True)" > /dev/null 2>&1

@@ -1,5 +1,7 @@
 #!/bin/bash
 # same-box A/B of the scalar preparation variants: kernel time of k_scalar_prep at 2^20
+# whatever variant ran last, leave the DEFAULT build behind (build() also rebuilds when the recorded flags differ)
+trap 'S2K_EXTRA_FLAGS="" python -c "import secp256k1_voi_amd as S; S.build(force=True)" > /dev/null 2>&1' EXIT
 for v in "$@"; do
   S2K_EXTRA_FLAGS="$v" python -c "import secp256k1_voi_amd as S; S.build(force=True)" > /dev/null 2>&1
   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null

@@ -1,5 +1,7 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of k_verify_fast for a compile-time variant:  bash tools/traffic_variant.sh "<flags>"
+# whatever variant ran last, leave the DEFAULT build behind (build() also rebuilds when the recorded flags differ)
+trap 'S2K_EXTRA_FLAGS="" python -c "import secp256k1_voi_amd as S; S.build(force=True)" > /dev/null 2>&1' EXIT
 S2K_EXTRA_FLAGS="$1" python -c "import secp256k1_voi_amd as S; S.build(force=True)" > /dev/null 2>&1
 REPO=$PWD; cd /tmp && export TMPDIR=/tmp; cd $REPO
 rm -rf gpurun_out/tv_fetch gpurun_out/tv_write
