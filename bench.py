@@ -297,18 +297,24 @@ def worker(args):
             st_ = counts.get("static", {})
             lane_ops = ipv * n / (fast_ms * 1e-3)
             roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
-                         "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src})
+                         "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src,
+                         "frac_def": "VALU instructions per verification (PMC) x verifications/s of the kernel / peak; every VALU "
+                                     "instruction of this kernel is priced at the 4-cycle issue interval measured for its mix "
+                                     "(profiles/r02_valu_instruction_rates.txt)"})
             if clock_hz > 0:
-                # the same fraction against the clock the kernel actually ran at: wave-instructions
-                # issued per SIMD per cycle, times the 4 cycles a full-rate instruction takes
+                # the same fraction against the clock the kernel actually ran at: SIMD issue cycles used / available
                 wave_instr = ipv * n / 64.0
-                roof["frac_at_measured_clock"] = wave_instr / SIMDS / (fast_ms * 1e-3 * clock_hz) * 4.0
+                cyc_avail = SIMDS * fast_ms * 1e-3 * clock_hz
+                roof["frac_at_measured_clock"] = wave_instr * 4.0 / cyc_avail
+                if st_:
+                    roof["mad_issue_frac_at_measured_clock"] = st_["mad_u64_u32_per_verify"] * n / 64.0 * 4.0 / cyc_avail
             if st_:
-                mads = st_["mad_u64_u32_per_verify"]
-                mad_peak = st_["measured_mad_u64_u32_peak_wave_instr_per_us_per_simd"] * 1e6 * SIMDS * 64
                 roof.update({"fp_products_per_verify": st_["fp_products_per_verify"],
-                             "mad_u64_u32_per_verify": mads,
-                             "mad_frac_of_measured_mad_peak": mads * n / (fast_ms * 1e-3) / mad_peak})
+                             "mad_u64_u32_per_verify": st_["mad_u64_u32_per_verify"],
+                             "mad_u64_u32_per_s": st_["mad_u64_u32_per_verify"] * n / (fast_ms * 1e-3)})
+            # the guide's nominal VALU rate (one wave64 instruction per 2 cycles per SIMD) is reached by pure
+            # VOP2 / f32 streams only; against it the kernel sits at half the figure above
+            roof["frac_of_2cycle_nominal_peak"] = lane_ops / (2 * VALU_PEAK_LANE_OPS)
         achieved_gbs = BYTES_PER_VERIFY * n / (fast_ms * 1e-3) / 1e9
         roof["traffic"] = traffic
         roof["hbm"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

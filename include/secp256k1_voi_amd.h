@@ -183,7 +183,7 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx *ctx, size_t n, const void *d_pk
  * (the usual case): one combination over the batch; when it is rejected, the failing signatures
  * are located by bisection — the lifted points, challenges and coefficients of the whole batch are
  * kept, a half-range is re-checked as a multiscalar multiplication of its own terms, the other
- * half's error point follows by subtraction, and ranges of <= 2^14 signatures (or everything left,
+ * half's error point follows by subtraction, and ranges of <= 2^17 signatures (or everything left,
  * once more than 8 ranges fail on one level) go through s2k_schnorr_verify_batch.  valid[i] is
  * what SchnorrPublicKey.Verify returns for item i (schnorr.go:221-253), up to a false accept
  * probability of 2^-128 per combination.  stats (host, may be NULL): [0] sub-range combinations,

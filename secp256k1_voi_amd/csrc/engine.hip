@@ -13,6 +13,7 @@
 #include "engine_internal.h"
 #include "fe.h"
 #include "jacobian29.h"
+#include "pt29.h"
 #include "complete_path.h"
 #include "point.h"
 #include "sc.h"
@@ -143,6 +144,139 @@ k_ecdsa_verify(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __res
   out[idx] = verify_complete(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
 }
 
+// ---------------------------------------------------------------------------------------
+// The worklist verifier: one signature with COMPLETE formulas on the 9x29 field (pt29.h: the
+// Renes-Costello-Batina addition, mixed addition and doubling, point_projective.go:24,123,208).
+// Same verdict as verify_complete for every input (tests run both), about a third of its cost:
+// lanes whose Jacobian ladder hit an exceptional case are re-done at close to the fast path's own
+// speed, so a batch crafted to send EVERY lane here (u1*G + u2*Q = infinity; anyone with a key
+// pair can mint those) costs a small multiple of a normal batch instead of serialising on the
+// 8x32 reference-shaped path.
+// Ladder: odd GLV halves (sc_split_glv_odd), signed odd digits, projective table of the 8 odd
+// multiples {1,3,..,15}*Q in planes [entry*27 + limb][lane] of the lane's table region; the
+// lambda-half multiplies X by beta at the lookup.
+// ---------------------------------------------------------------------------------------
+S2K_DEV void p29_store(uint32_t* __restrict__ qt, size_t stride, size_t lane, int entry, const pt29& p) {
+  uint32_t* b = qt + (size_t)(entry * 27) * stride + lane;
+#pragma unroll
+  for (int w = 0; w < 9; ++w) {
+    b[(size_t)w * stride] = p.x.n[w];
+    b[(size_t)(9 + w) * stride] = p.y.n[w];
+    b[(size_t)(18 + w) * stride] = p.z.n[w];
+  }
+}
+S2K_DEV pt29 p29_load(const uint32_t* __restrict__ qt, size_t stride, size_t lane, uint32_t entry) {
+  const uint32_t* b = qt + (size_t)(entry * 27) * stride + lane;
+  pt29 p;
+#pragma unroll
+  for (int w = 0; w < 9; ++w) {
+    p.x.n[w] = b[(size_t)w * stride];
+    p.y.n[w] = b[(size_t)(9 + w) * stride];
+    p.z.n[w] = b[(size_t)(18 + w) * stride];
+  }
+  return p;
+}
+static_assert(QT_ENTRIES * 27 <= 8 * 8 * 4, "projective 9x29 table must fit in the lane's table region");
+
+S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
+                                  const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
+                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  sc r, s;
+  uint32_t e_raw[8];
+  apt q;
+  load_be32(r.v, rsig + idx * 32);
+  load_be32(s.v, ssig + idx * 32);
+  load_be32(e_raw, dig + idx * 32);
+  load_be32(q.x.v, pub + idx * 64);
+  load_be32(q.y.v, pub + idx * 64 + 32);
+  bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
+  if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
+  ok = ok && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
+  if (!ok) {   // keep the arithmetic well defined; the verdict is already "invalid"
+    q.x = fe_from_limbs(FE_GX);
+    q.y = fe_from_limbs(FE_GY);
+    s = sc_zero();
+    s.v[0] = 1;
+  }
+  fe29 qx = fe29_from_words(q.x.v), qy = fe29_from_words(q.y.v);
+  {
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
+    rhs.n[0] += 7;
+    if (!fe29_eq(fe29_sqr(qy), rhs)) {   // not on the curve (point_s11n.go:298-307)
+      ok = false;
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
+    }
+  }
+  sc e = sc_reduce_once(e_raw);
+  sc26 s_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(s)));   // s^-1 * R (safegcd, modinv30.h)
+  sc u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m)), u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
+  sc k1, k2;
+  bool neg1, neg2;
+  sc_split_glv_odd(u2, k1, neg1, k2, neg2);
+
+  // table of odd multiples (projective): T[j] = (2j + 1) Q
+  pt29 q1;
+  q1.x = qx;
+  q1.y = qy;
+  q1.z = fe29_one();
+  {
+    pt29 q2 = pt29_double(q1), cur = q1;
+    p29_store(qt, stride, idx, 0, cur);
+#pragma unroll 1
+    for (int j = 1; j < QT_ENTRIES; ++j) {
+      cur = pt29_add(cur, q2);
+      p29_store(qt, stride, idx, j, cur);
+    }
+  }
+  const fe29 beta = fe29_from_words(FE_BETA);
+  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+  // top digits are +1: acc = s1 * Q + s2 * lambda Q
+  pt29 acc = q1;
+  acc.y = fe29_cond_negate1(qy, neg1);
+  acc.y = fe29_normalize_weak(acc.y);
+  {
+    fe29 bx = fe29_mul(qx, beta);
+    acc = pt29_add_mixed(acc, bx, fe29_normalize_weak(fe29_cond_negate1(qy, neg2)));
+  }
+#pragma unroll 1
+  for (int i = 31; i >= 0; --i) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) acc = pt29_double(acc);
+    uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      uint32_t w = t ? w2 : w1;
+      bool neg = (t ? neg2 : neg1) != (w < 8u);
+      uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+      pt29 a = p29_load(qt, stride, idx, entry);
+      if (t) a.x = fe29_mul(a.x, beta);
+      a.y = fe29_normalize_weak(fe29_cond_negate1(a.y, neg));
+      acc = pt29_add(acc, a);
+    }
+  }
+  // generator part (complete mixed additions; no table entry is the identity)
+  {
+    uint32_t u[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) u[w] = u1.v[w];
+#pragma unroll 1
+    for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
+      apt g = gt_load(gt, w, gt_next_digit(u));
+      acc = pt29_add_mixed(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
+    }
+  }
+  ok = ok && !fe29_is_zero(acc.z);                   // ecdsa.go:450
+  // x(R) mod n == r  <=>  X == r*Z  or  (r + n < p and X == (r + n)*Z)   (ecdsa.go:459-465)
+  bool match = fe29_eq(acc.x, fe29_mul(fe29_from_words(r.v), acc.z));
+  if (u256_lt(r.v, FE_P_MINUS_N)) {
+    uint32_t r2[8];
+    u256_add(r2, r.v, SC_N);
+    match = match || fe29_eq(acc.x, fe29_mul(fe29_from_words(r2), acc.z));
+  }
+  return (ok && match) ? 1 : 0;
+}
+
 // the lanes the fast kernel could not decide (final Z = 0): a short worklist, normally empty
 __global__ void __launch_bounds__(256)
 k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ pub,
@@ -152,7 +286,7 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
     size_t idx = wl[w];
-    out[idx] = verify_complete(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
+    out[idx] = verify_complete29(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
   }
 }
 

@@ -27,6 +27,8 @@
 // (2^20 inputs: 2^21 terms, 8 windows x 65535 buckets, ~32 points per bucket).
 #include <sys/random.h>
 
+#include <cstdlib>
+
 #include <vector>
 
 #include "engine_internal.h"
@@ -530,9 +532,15 @@ struct msm_ws {
 // carve the MSM workspace for n terms (+ aux_bytes of scratch for the caller)
 int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   msm_geom& g = m.g;
-  // window width by additions: n * nw into buckets plus about 2 * nw * 2^c in the bucket reductions;
-  // 8n + 2^20 (c = 16) undercuts 11n + 90k (c = 12) from n = 3 * 10^5 terms on
-  g.c = n >= (1u << 18) ? 16 : (n >= 256 ? 12 : 8);
+  // window width: measured (tools/msm_sweep.py, MI355X, ms for 2^11 .. 2^20 inputs = twice as many terms):
+  // 16-bit windows from 2^13 terms on: 0.83 0.75 0.75 0.76 0.78 0.80 0.89 1.01 1.31 1.95; 12-bit windows up to
+  // 2^17 terms: 0.84 1.04 1.26 1.78 2.70 then as above (big buckets serialise on their lanes); the floor of
+  // about 0.75 ms is the reduction of 8 x 65535 buckets
+  static const int c16_from_log2 = [] {   // tuning hook: S2K_MSM_C16_FROM_LOG2 overrides the measured default
+    const char* e = getenv("S2K_MSM_C16_FROM_LOG2");
+    return e ? atoi(e) : 13;
+  }();
+  g.c = n >= ((size_t)1 << c16_from_log2) ? 16 : (n >= 256 ? 12 : 8);
   g.nw = (SCALAR_BITS + g.c - 1) / g.c;
   g.nb = 1u << g.c;
   g.nchunk = g.nb / CHUNK;
@@ -1005,7 +1013,9 @@ int s2k_schnorr_verify_batch_bisect_device(s2k_ctx* ctx, size_t n, const void* d
   const uint8_t *pk = (const uint8_t*)d_pk, *sig = (const uint8_t*)d_sig, *msgs = (const uint8_t*)d_msgs;
   const uint64_t* offs = (const uint64_t*)d_msg_offsets;
   uint8_t* valid = (uint8_t*)d_valid;
-  constexpr uint32_t LEAF = 1u << 14;      // below this a range is verified signature by signature
+  // Below LEAF signatures a range is verified signature by signature: a combination costs at least the
+  // multiscalar floor (0.75 ms + preparation), per-signature verification 0.56 ms per 2^16 signatures.
+  constexpr uint32_t LEAF = 1u << 17;
   constexpr size_t MAX_FAILING = 8;        // more failing ranges than this on one level: stop bisecting
   auto verify_each = [&](uint32_t lo, uint32_t cnt) -> int {
     if (stats) stats[1] += cnt;
