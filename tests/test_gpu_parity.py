@@ -801,18 +801,3 @@ def test_recover_random_and_edges(eng, oracle):
     v = eng.ecdsa_verify_batch([rows(pub)[i][1:] for i in good], [dig[i] for i in good], [rr[i] for i in good],
                                [ss[i] for i in good])
     assert v.all()
-
-
-@pytest.mark.gpu
-def test_device_selftest_pt29(tmp_path):
-    """tools/pt29_selftest.hip: the 9x29 field primitives and the complete group formulas of
-    pt29.h, step by step against the 8x32 complete-formula path, on the device."""
-    import shutil
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    exe = str(tmp_path / "pt29_selftest")
-    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(root, "secp256k1_voi_amd", "csrc"),
-                           "-I", os.path.join(root, "include"), os.path.join(root, "tools", "pt29_selftest.hip"), "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
-    assert "done" in out and "MISMATCH" not in out, out
