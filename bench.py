@@ -290,7 +290,8 @@ def worker(args):
         traffic, traffic_src = committed_traffic()
         roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA>", "kernel_ms": fast_ms, "kernel_ms_median": fast_med,
                 "scalar_prep_ms": prep_ms, "fallback_ms": prof["fallback_ms"] / prof["calls"],
-                "shader_clock_mhz": prof["shader_mhz"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
+                "shader_clock_mhz": prof["shader_mhz"], "shader_clock_mhz_first_wave": prof["shader_mhz_first_wave"],
+                "shader_clock_mhz_last_round": prof["shader_mhz_last_round"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
                 "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
         if counts:
             ipv = counts["k_verify_fast"]["valu_instr_per_signature"]

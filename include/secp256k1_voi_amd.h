@@ -84,10 +84,11 @@ const char *s2k_build_config(void);
  * cycle counter against the constant-rate wall clock.  s2k_ctx_profile_read synchronises the
  * device and returns the summed durations in ms_sum3[0..2], optionally each call's ladder time
  * in ms_fast_each[0..cap), the number of calls since the last read, and the effective shader
- * clock (MHz) seen by the last ladder launch. */
+ * clock (MHz) of the last ladder launch: shader_mhz[0] from its first wave, shader_mhz[1] from a wave
+ * of its final round (the clock sags under power during a launch). */
 int s2k_ctx_profile(s2k_ctx *ctx, int enable);
 int s2k_ctx_profile_read(s2k_ctx *ctx, double ms_sum3[3], double *ms_fast_each, size_t cap, size_t *calls,
-                         double *shader_mhz);
+                         double shader_mhz[2]);
 
 /* ---- hot path: batch ECDSA verification ------------------------------------------- */
 /* For each i < n: secec.PublicKey.VerifyRaw(digest, r, s) (ecdsa.go:234 -> verify :392)

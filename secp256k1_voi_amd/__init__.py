@@ -432,14 +432,17 @@ class Engine:
         self._check(self._lib.s2k_ctx_profile(self._h, 1 if enable else 0))
 
     def profile_read(self, cap: int = 1024):
-        """-> dict(calls, prep_ms, fast_ms, fallback_ms (sums), fast_each (ms per call), shader_mhz)."""
+        """-> dict(calls, prep_ms, fast_ms, fallback_ms (sums), fast_each (ms per call), shader_mhz = mean of
+        the clock seen by the first wave and by a wave of the final round of the last ladder launch)."""
         sums = (C.c_double * 3)()
         each = (C.c_double * cap)()
-        calls, mhz = C.c_size_t(0), C.c_double(0.0)
-        self._check(self._lib.s2k_ctx_profile_read(self._h, sums, each, cap, C.byref(calls), C.byref(mhz)))
+        calls, mhz = C.c_size_t(0), (C.c_double * 2)()
+        self._check(self._lib.s2k_ctx_profile_read(self._h, sums, each, cap, C.byref(calls), mhz))
         k = int(calls.value)
+        both = [m for m in (mhz[0], mhz[1]) if m > 0]
         return {"calls": k, "prep_ms": sums[0], "fast_ms": sums[1], "fallback_ms": sums[2],
-                "fast_each": [each[i] for i in range(min(k, cap))], "shader_mhz": float(mhz.value)}
+                "fast_each": [each[i] for i in range(min(k, cap))], "shader_mhz": sum(both) / len(both) if both else 0.0,
+                "shader_mhz_first_wave": float(mhz[0]), "shader_mhz_last_round": float(mhz[1])}
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))

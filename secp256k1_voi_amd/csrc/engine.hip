@@ -499,7 +499,9 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   if (idx >= n) return;
   // effective shader clock of this launch (bench.py roofline): wave 0 of workgroup 0 stamps the
   // shader cycle counter and the constant-rate wall clock when it starts and when it ends
-  const bool stamp = clk != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
+  // (and wave 0 of the LAST workgroup, which runs in the launch's final round: the clock sags under power
+  // over the 8 ms of a launch)
+  const bool stamp = clk != nullptr && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x < 64;
   uint64_t t0c = 0, t0w = 0;
   if (stamp) {
     t0c = __builtin_readcyclecounter();
@@ -694,10 +696,11 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   }
   out[idx] = verdict;
   if (stamp && threadIdx.x == 0) {
-    clk[0] = t0c;
-    clk[1] = __builtin_readcyclecounter();
-    clk[2] = t0w;
-    clk[3] = __builtin_amdgcn_s_memrealtime();
+    uint64_t* c = clk + (blockIdx.x == 0 ? 0 : 4);
+    c[0] = t0c;
+    c[1] = __builtin_readcyclecounter();
+    c[2] = t0w;
+    c[3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -1159,12 +1162,15 @@ int s2k_ctx_profile_read(s2k_ctx* ctx, double* ms_sum3, double* ms_fast_each, si
   }
   *calls = k;
   ctx->prof_used = 0;
-  if (shader_mhz) {
-    uint64_t h[4] = {0, 0, 0, 0};
+  if (shader_mhz) {   // [0]: first wave of the last ladder launch, [1]: a wave of its final round
+    uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int wall_khz = 0;
     HIP_TRY(ctx, hipMemcpy(h, ctx->clk, sizeof h, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
-    *shader_mhz = (h[3] > h[2] && wall_khz > 0) ? (double)(h[1] - h[0]) / (double)(h[3] - h[2]) * (wall_khz * 1e-3) : 0.0;
+    for (int j = 0; j < 2; ++j) {
+      const uint64_t* c = h + 4 * j;
+      shader_mhz[j] = (c[3] > c[2] && wall_khz > 0) ? (double)(c[1] - c[0]) / (double)(c[3] - c[2]) * (wall_khz * 1e-3) : 0.0;
+    }
   }
   return S2K_OK;
 }
@@ -1343,7 +1349,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
 }
 
 // Host-buffer entry point.  The batch is cut into chunks that are whole rounds of k_verify_fast
-// on this device (3 waves/SIMD x 4 SIMDs x CUs x 64 lanes; two rounds per chunk), and the
+// on this device (3 waves/SIMD x 4 SIMDs x CUs x 64 lanes; one round first, then two per chunk), and the
 // host-to-device copy of chunk j+1 runs on its own stream while chunk j is verified: for pageable
 // callers' memory the copy costs about half as much as the verification, so most of it hides.
 // Staging buffers and streams live in the context (no hipMalloc per call).
@@ -1363,10 +1369,14 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   uint8_t* d_s = d_r + n * 32;
   uint8_t* d_valid = d_s + n * 32;
   const size_t round = (size_t)S2K_FAST_WAVES * 4 * (size_t)ctx->cu_count * 64;
-  const size_t chunk = n > 3 * round ? 2 * round : n;     // small batches: one shot
+  // chunks are whole rounds of the ladder kernel; the first one is a single round, because its copy is
+  // the only one nothing hides (63 -> 31 MB up front at 256 CUs), the others two rounds
+  const bool chunked = n > 3 * round;                      // small batches: one shot
   int k = 0;
-  for (size_t lo = 0; lo < n; lo += chunk, ++k) {
-    const size_t cnt = n - lo < chunk ? n - lo : chunk;
+  for (size_t lo = 0, chunk = 0; lo < n; lo += chunk, ++k) {
+    chunk = !chunked ? n : (lo == 0 ? round : 2 * round);
+    if (n - lo < chunk + round) chunk = n - lo;            // no launch of less than a round at the end
+    const size_t cnt = chunk;
     // the event of two chunks ago has been waited on by s_comp (in stream order) before it is re-recorded
     HIP_TRY(ctx, hipMemcpyAsync(d_pub + lo * 64, pub + lo * 64, cnt * 64, hipMemcpyHostToDevice, ctx->s_copy));
     HIP_TRY(ctx, hipMemcpyAsync(d_dig + lo * 32, dig + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->s_copy));
