@@ -178,39 +178,9 @@ S2K_DEV pt29 p29_load(const uint32_t* __restrict__ qt, size_t stride, size_t lan
 }
 static_assert(QT_ENTRIES * 27 <= 8 * 8 * 4, "projective 9x29 table must fit in the lane's table region");
 
-S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
-                                  const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
-  sc r, s;
-  uint32_t e_raw[8];
-  apt q;
-  load_be32(r.v, rsig + idx * 32);
-  load_be32(s.v, ssig + idx * 32);
-  load_be32(e_raw, dig + idx * 32);
-  load_be32(q.x.v, pub + idx * 64);
-  load_be32(q.y.v, pub + idx * 64 + 32);
-  bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
-  if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
-  ok = ok && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
-  if (!ok) {   // keep the arithmetic well defined; the verdict is already "invalid"
-    q.x = fe_from_limbs(FE_GX);
-    q.y = fe_from_limbs(FE_GY);
-    s = sc_zero();
-    s.v[0] = 1;
-  }
-  fe29 qx = fe29_from_words(q.x.v), qy = fe29_from_words(q.y.v);
-  {
-    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
-    rhs.n[0] += 7;
-    if (!fe29_eq(fe29_sqr(qy), rhs)) {   // not on the curve (point_s11n.go:298-307)
-      ok = false;
-      qx = fe29_from_words(FE_GX);
-      qy = fe29_from_words(FE_GY);
-    }
-  }
-  sc e = sc_reduce_once(e_raw);
-  sc26 s_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(s)));   // s^-1 * R (safegcd, modinv30.h)
-  sc u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m)), u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
+// u1*G + u2*Q (Q affine, on the curve) with complete formulas: the projective result (X : Y : Z)
+S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe29& qy, const uint32_t* __restrict__ gt,
+                            uint32_t* __restrict__ qt, size_t stride, size_t idx) {
   sc k1, k2;
   bool neg1, neg2;
   sc_split_glv_odd(u2, k1, neg1, k2, neg2);
@@ -266,6 +236,43 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, c
       acc = pt29_add_mixed(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
   }
+  return acc;
+}
+
+S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
+                                  const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
+                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+  sc r, s;
+  uint32_t e_raw[8];
+  apt q;
+  load_be32(r.v, rsig + idx * 32);
+  load_be32(s.v, ssig + idx * 32);
+  load_be32(e_raw, dig + idx * 32);
+  load_be32(q.x.v, pub + idx * 64);
+  load_be32(q.y.v, pub + idx * 64 + 32);
+  bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
+  if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
+  ok = ok && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
+  if (!ok) {   // keep the arithmetic well defined; the verdict is already "invalid"
+    q.x = fe_from_limbs(FE_GX);
+    q.y = fe_from_limbs(FE_GY);
+    s = sc_zero();
+    s.v[0] = 1;
+  }
+  fe29 qx = fe29_from_words(q.x.v), qy = fe29_from_words(q.y.v);
+  {
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
+    rhs.n[0] += 7;
+    if (!fe29_eq(fe29_sqr(qy), rhs)) {   // not on the curve (point_s11n.go:298-307)
+      ok = false;
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
+    }
+  }
+  sc e = sc_reduce_once(e_raw);
+  sc26 s_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(s)));   // s^-1 * R (safegcd, modinv30.h)
+  sc u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m)), u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
+  pt29 acc = dsm_complete29(u1, u2, qx, qy, gt, qt, stride, idx);
   ok = ok && !fe29_is_zero(acc.z);                   // ecdsa.go:450
   // x(R) mod n == r  <=>  X == r*Z  or  (r + n < p and X == (r + n)*Z)   (ecdsa.go:459-465)
   bool match = fe29_eq(acc.x, fe29_mul(fe29_from_words(r.v), acc.z));
@@ -916,6 +923,108 @@ k_recover_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
   }
 }
 
+// x/Z, y/Z of a projective 9x29 point (canonical words); false for the identity
+S2K_DEV bool p29_to_affine_words(uint32_t xw[8], uint32_t yw[8], const pt29& p) {
+  if (fe29_is_zero(p.z)) return false;
+  fe29 zi = fe29_inv(fe29_normalize_weak(p.z));
+  fe29_to_words(xw, fe29_normalize(fe29_mul(p.x, zi)));
+  fe29_to_words(yw, fe29_normalize(fe29_mul(p.y, zi)));
+  return true;
+}
+// lift_x on the 9x29 field: y with the wanted parity for a canonical x (words), or false
+S2K_DEV bool lift_x29(fe29& x, fe29& y, const uint32_t xw[8], bool want_odd) {
+  x = fe29_from_words(xw);
+  fe29 rhs = fe29_mul(fe29_sqr(x), x);
+  rhs.n[0] += 7;
+  if (!fe29_sqrt(y, rhs)) return false;
+  y = fe29_normalize(y);
+  y = fe29_select(((y.n[0] & 1u) != 0) != want_odd, y, fe29_normalize_weak(fe29_negate(y, 1)));
+  return true;
+}
+
+// The worklists of the BIP-340 and recovery paths, same verifier core (9x29 complete formulas) as
+// the ECDSA worklist; the reference-shaped 8x32 versions above stay for S2K_ECDSA_FORCE_COMPLETE.
+__global__ void __launch_bounds__(256)
+k_schnorr_worklist(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ pk,
+                   const uint8_t* __restrict__ sig, const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs,
+                   uint32_t msg_len, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt,
+                   size_t stride) {
+  const uint32_t count = *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    const size_t idx = wl[w];
+    sc s, e;
+    bool ok = schnorr_parse(idx, pk, sig, msgs, offs, msg_len, s, e);
+    uint32_t xw[8];
+    load_be32(xw, pk + idx * 32);
+    ok = ok && fe_is_canonical_raw(xw);
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
+    }
+    fe29 px, py;
+    if (!lift_x29(px, py, xw, false)) {   // not an x-coordinate of the curve (NewSchnorrPublicKey, schnorr.go:257-275)
+      ok = false;
+      px = fe29_from_words(FE_GX);
+      py = fe29_from_words(FE_GY);
+    }
+    pt29 R = dsm_complete29(s, sc_neg(e), px, py, gt, qt, stride, idx);   // s*G - e*P (schnorr.go:244)
+    uint32_t rx[8], ry[8], r_le[8];
+    bool finite = p29_to_affine_words(rx, ry, R);
+    load_be32(r_le, sig + idx * 64);
+    out[idx] = (ok && finite && (ry[0] & 1u) == 0 && u256_eq(rx, r_le)) ? 1 : 0;   // verifySchnorrSignatureR (:451-478)
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_recover_worklist(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ dig,
+                   const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, const uint8_t* __restrict__ recid,
+                   uint8_t* __restrict__ ok_out, uint8_t* __restrict__ out_pts, const uint32_t* __restrict__ gt,
+                   uint32_t* __restrict__ qt, size_t stride) {
+  const uint32_t count = *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    const size_t idx = wl[w];
+    sc r, s;
+    uint32_t e_raw[8], xw[8];
+    load_be32(r.v, rsig + idx * 32);
+    load_be32(s.v, ssig + idx * 32);
+    load_be32(e_raw, dig + idx * 32);
+    const uint32_t rid = recid[idx];
+    bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s) && rid < 4 &&
+              (!(rid & 2u) || u256_lt(r.v, FE_P_MINUS_N));   // RecoverPoint (point_s11n.go:245-282)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xw[i] = r.v[i];
+    if (ok && (rid & 2u)) u256_add(xw, xw, SC_N);
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
+      r = sc_zero();
+      r.v[0] = 1;
+    }
+    fe29 px, py;
+    if (!lift_x29(px, py, xw, (rid & 1u) != 0)) {
+      ok = false;
+      px = fe29_from_words(FE_GX);
+      py = fe29_from_words(FE_GY);
+    }
+    sc e = sc_reduce_once(e_raw);
+    sc26 r_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(r)));
+    sc u1 = sc26_to_sc(sc26_mm(sc26_from_sc(sc_neg(e)), r_inv_m)), u2 = sc26_to_sc(sc26_mm(sc26_from_sc(s), r_inv_m));
+    pt29 Q = dsm_complete29(u1, u2, px, py, gt, qt, stride, idx);   // (-e/r) G + (s/r) R (ecdsa.go:244-282)
+    uint32_t qxw[8], qyw[8];
+    bool finite = p29_to_affine_words(qxw, qyw, Q);   // identity: NewPublicKeyFromPoint fails (secec.go:206-209)
+    uint8_t* rec = out_pts + idx * 65;
+    if (!(ok && finite)) {
+      for (int i = 0; i < 65; ++i) rec[i] = 0;
+      ok_out[idx] = 0;
+    } else {
+      rec[0] = 0x04;
+      store_be32_unaligned(rec + 1, qxw);
+      store_be32_unaligned(rec + 33, qyw);
+      ok_out[idx] = 1;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // u1*G + u2*P for arbitrary (u1, u2, P) through the verification ladder (S2K_IMPL_FAST of
 // s2k_double_scalar_mult_basepoint_batch_ex): the same table, signed-digit ladder and generator
@@ -1265,8 +1374,8 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
                                                                  (uint8_t*)d_pub65);
     HIP_TRY(ctx, hipGetLastError());
   }
-  k_recover_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, dig, r, s, rid, (uint8_t*)d_ok,
-                                                              (uint8_t*)d_pub65, ctx->gtable, qt, stride);
+  k_recover_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, dig, r, s, rid, (uint8_t*)d_ok, (uint8_t*)d_pub65,
+                                                              ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return ctx_leave(ctx, st);
 }
@@ -1342,7 +1451,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, fin, (uint8_t*)d_valid, stride, nullptr);
     HIP_TRY(ctx, hipGetLastError());
   }
-  k_schnorr_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, 0u, pk, sig, msgs, offs, (uint32_t)msg_len,
+  k_schnorr_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, pk, sig, msgs, offs, (uint32_t)msg_len,
                                                               (uint8_t*)d_valid, ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return ctx_leave(ctx, st);

@@ -217,3 +217,65 @@ def test_schnorr_bisection_variable_length_messages(eng, oracle):
     exp = np.ones(n, dtype=np.uint8)
     exp[[3, 9999, 19999]] = 0
     assert np.array_equal(v, exp)
+
+
+def test_schnorr_and_recovery_worklists(eng, oracle):
+    """BIP-340 signatures with s*G - e*P = infinity and recovery inputs with (-e/r)*G + (s/r)*R = infinity
+    (both mintable by anyone who knows a discrete log) put every lane on the worklist of their paths; the
+    complete-formula worklist kernels must give the reference's verdict (false / no key) for all of them,
+    and the right verdict for valid items mixed in."""
+    import hashlib
+    rnd = __import__("random").Random(88)
+    n = 3000
+    pk, msgs, sigs, exp = [], [], [], []
+    th = hashlib.sha256(b"BIP0340/challenge").digest()
+    for i in range(n):
+        d = rnd.randrange(1, R.N)
+        P = R.mul(d, R.G)
+        if P[1] & 1:
+            d = R.N - d
+        m = rnd.randbytes(32)
+        if i % 3 == 0:          # a valid signature
+            sg = R.schnorr_sign(d, m, bytes(32))
+            ok = 1
+        else:                   # R = s*G - e*P = infinity: s = e*d for the challenge of an arbitrary liftable r
+            while True:
+                rx = rnd.randrange(1, R.P)
+                if R.lift_x(rx, 0) is not None:
+                    break
+            e = int.from_bytes(hashlib.sha256(th + th + b32(rx) + b32(P[0]) + m).digest(), "big") % R.N
+            sg = b32(rx) + b32(e * d % R.N)
+            ok = 0
+        pk.append(b32(P[0])); msgs.append(m); sigs.append(sg); exp.append(ok)
+    got = eng.schnorr_verify_batch(pk, msgs, sigs)
+    assert list(got) == exp
+    for i in range(0, n, 97):
+        assert (oracle.schnorr_verify(pk[i], msgs[i], sigs[i]) == 1) == bool(exp[i])
+    # recovery: Q = infinity when s*k == e for R = k*G
+    dig, rr, ss, rid, want = [], [], [], [], []
+    for i in range(n):
+        k = rnd.randrange(1, R.N)
+        Rp = R.mul(k, R.G)
+        r = Rp[0] % R.N
+        if r == 0 or Rp[0] >= R.N:
+            continue
+        s = rnd.randrange(1, R.N)
+        if i % 3 == 0:          # ordinary recoverable signature of a random key
+            d = rnd.randrange(1, R.N)
+            digest = rnd.randbytes(32)
+            e = int.from_bytes(digest, "big") % R.N
+            s = pow(k, -1, R.N) * (e + r * d) % R.N
+            want.append(R.enc65(R.mul(d, R.G)))
+        else:
+            e = s * k % R.N
+            digest = b32(e)
+            want.append(None)
+        dig.append(digest); rr.append(b32(r)); ss.append(b32(s)); rid.append(Rp[1] & 1)
+    pub, ok = eng.ecdsa_recover_batch(dig, rr, ss, rid)
+    for i, w in enumerate(want):
+        if w is None:
+            assert ok[i] == 0 and bytes(pub[i]) == bytes(65)
+        else:
+            assert ok[i] == 1 and bytes(pub[i]) == w
+    for i in range(0, len(want), 101):
+        assert oracle.ecdsa_recover(dig[i], rr[i], ss[i], rid[i]) == want[i]
