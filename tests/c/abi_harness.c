@@ -1,0 +1,137 @@
+/* abi_harness.c — the C-ABI used the way a cgo shim uses it: plain C, no Python, no torch.
+ *
+ *   gcc -O2 -I include tests/c/abi_harness.c -o /tmp/abi_harness -L secp256k1_voi_amd -lsecp256k1_voi_amd \
+ *       -Wl,-rpath,$PWD/secp256k1_voi_amd
+ *   /tmp/abi_harness cpu      host-only entry points (parsers, constant-time twins): runs anywhere
+ *   /tmp/abi_harness gpu      context + batch verification of signatures made with the CT signer
+ *
+ * Exit code 0 = every check passed.  tests/test_c_harness.py builds and runs it. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "secp256k1_voi_amd.h"
+
+static int failures = 0;
+#define CHECK(cond, msg)                                        \
+  do {                                                          \
+    if (!(cond)) {                                              \
+      fprintf(stderr, "FAIL %s (line %d)\n", msg, __LINE__);    \
+      ++failures;                                               \
+    }                                                           \
+  } while (0)
+
+static void hex(uint8_t* out, const char* s) {
+  for (size_t i = 0; s[2 * i]; ++i) {
+    unsigned v;
+    sscanf(s + 2 * i, "%2x", &v);
+    out[i] = (uint8_t)v;
+  }
+}
+
+/* generator (point.go:18-21) and 2G, 3G */
+static const char* GX = "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798";
+static const char* GY = "483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8";
+static const char* G2X = "c6047f9441ed7d6d3045406e95c07cd85c778e4b8cef3ca7abac09b95c709ee5";
+static const char* G3X = "f9308a019258c31049344f85f89d5229b531c845836f99b08601f113bce036f9";
+
+static int cpu_part(void) {
+  uint8_t k[32] = {0}, out[65], g[65], x[32];
+  g[0] = 4;
+  hex(g + 1, GX);
+  hex(g + 33, GY);
+  k[31] = 2;
+  CHECK(s2k_ct_scalar_base_mult(k, out) == S2K_OK, "ct base mult");
+  hex(x, G2X);
+  CHECK(out[0] == 4 && memcmp(out + 1, x, 32) == 0, "2*G (ScalarBaseMult)");
+  k[31] = 3;
+  CHECK(s2k_ct_scalar_mult(k, g, out) == S2K_OK, "ct scalar mult");
+  hex(x, G3X);
+  CHECK(out[0] == 4 && memcmp(out + 1, x, 32) == 0, "3*G (ScalarMult)");
+  /* ECDH is symmetric: x(a * (b G)) == x(b * (a G)) */
+  uint8_t a[32], b[32], A[65], B[65], s1[32], s2[32];
+  for (int i = 0; i < 32; ++i) {
+    a[i] = (uint8_t)(17 * i + 3);
+    b[i] = (uint8_t)(29 * i + 5);
+  }
+  a[0] &= 0x7f;
+  b[0] &= 0x7f;
+  CHECK(s2k_ct_scalar_base_mult(a, A) == S2K_OK && s2k_ct_scalar_base_mult(b, B) == S2K_OK, "keys");
+  CHECK(s2k_ct_ecdh(a, B, s1) == S2K_OK && s2k_ct_ecdh(b, A, s2) == S2K_OK && memcmp(s1, s2, 32) == 0, "ECDH symmetry");
+  /* malformed point is refused */
+  uint8_t bad[65];
+  memcpy(bad, g, 65);
+  bad[64] ^= 1;
+  CHECK(s2k_ct_scalar_mult(k, bad, out) == S2K_ERR_ARG, "off-curve point refused");
+  /* DER: 30 06 02 01 01 02 01 01 is (r, s) = (1, 1) */
+  const uint8_t der[8] = {0x30, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01};
+  uint8_t r[32], s[32];
+  CHECK(s2k_parse_asn1_signature(der, sizeof der, r, s) == 0 && r[31] == 1 && s[31] == 1, "ParseASN1Signature");
+  const uint8_t der_bad[9] = {0x30, 0x07, 0x02, 0x02, 0x00, 0x01, 0x02, 0x01, 0x01}; /* non-minimal INTEGER */
+  CHECK(s2k_parse_asn1_signature(der_bad, sizeof der_bad, r, s) != 0, "non-minimal DER refused");
+  printf("cpu: %s\n", failures ? "FAILED" : "ok");
+  return failures;
+}
+
+static int gpu_part(void) {
+  s2k_ctx* ctx = NULL;
+  int rc = s2k_ctx_create(0, &ctx);
+  if (rc != S2K_OK) {
+    fprintf(stderr, "s2k_ctx_create: %d %s\n", rc, s2k_last_error(NULL));
+    return 1;
+  }
+  enum { N = 4096 };
+  uint8_t *pub = malloc(N * 64), *dig = malloc(N * 32), *r = malloc(N * 32), *s = malloc(N * 32), *valid = malloc(N);
+  uint8_t d[32], k[32], Q[65];
+  for (int i = 0; i < N; ++i) {
+    for (int j = 0; j < 32; ++j) {
+      d[j] = (uint8_t)(i * 131 + j * 7 + 1);
+      k[j] = (uint8_t)(i * 17 + j * 23 + 9);
+      dig[i * 32 + j] = (uint8_t)(i * 5 + j * 3);
+    }
+    d[0] &= 0x7f;
+    k[0] &= 0x7f;
+    uint8_t rid;
+    s2k_ct_scalar_base_mult(d, Q);
+    memcpy(pub + i * 64, Q + 1, 64);
+    CHECK(s2k_ct_ecdsa_sign_raw(d, dig + i * 32, k, r + i * 32, s + i * 32, &rid) == S2K_OK, "sign");
+  }
+  /* corrupt every 8th digest */
+  for (int i = 0; i < N; i += 8) dig[i * 32 + 5] ^= 0x40;
+  rc = s2k_ecdsa_verify_batch(ctx, N, pub, dig, r, s, S2K_ECDSA_REJECT_MALLEABLE, valid);
+  CHECK(rc == S2K_OK, "s2k_ecdsa_verify_batch");
+  int good = 0, wrong = 0;
+  for (int i = 0; i < N; ++i) {
+    int expect = (i % 8) != 0;
+    good += valid[i];
+    wrong += valid[i] != expect;
+  }
+  CHECK(wrong == 0 && good == N - N / 8, "verdicts");
+  /* recovery gives the signer's key back */
+  uint8_t* rec = malloc(N * 65), *ok = malloc(N), *rids = calloc(N, 1);
+  for (int i = 0; i < N; i += 8) dig[i * 32 + 5] ^= 0x40; /* undo */
+  for (int i = 0; i < N; ++i) { /* recovery ids again (cheap) */
+    for (int j = 0; j < 32; ++j) {
+      d[j] = (uint8_t)(i * 131 + j * 7 + 1);
+      k[j] = (uint8_t)(i * 17 + j * 23 + 9);
+    }
+    d[0] &= 0x7f;
+    k[0] &= 0x7f;
+    uint8_t r2[32], s2[32];
+    s2k_ct_ecdsa_sign_raw(d, dig + i * 32, k, r2, s2, rids + i);
+  }
+  rc = s2k_ecdsa_recover_batch(ctx, N, dig, r, s, rids, 0, rec, ok);
+  CHECK(rc == S2K_OK, "s2k_ecdsa_recover_batch");
+  int rec_bad = 0;
+  for (int i = 0; i < N; ++i) rec_bad += !(ok[i] && memcmp(rec + i * 65 + 1, pub + i * 64, 64) == 0);
+  CHECK(rec_bad == 0, "recovered keys");
+  printf("gpu: %s (%d/%d valid, build: %s)\n", failures ? "FAILED" : "ok", good, N, s2k_build_config());
+  s2k_ctx_destroy(ctx);
+  return failures;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && strcmp(argv[1], "gpu") == 0) return gpu_part() ? 1 : 0;
+  return cpu_part() ? 1 : 0;
+}
