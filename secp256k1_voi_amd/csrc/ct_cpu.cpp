@@ -27,8 +27,16 @@ typedef unsigned __int128 u128;
 typedef uint64_t u64;
 
 // ---- masks -----------------------------------------------------------------------------------
-inline u64 mask_nonzero(u64 x) { return 0 - ((x | (0 - x)) >> 63); }   // all ones iff x != 0
-inline u64 mask_eq(u64 a, u64 b) { return ~mask_nonzero(a ^ b); }
+// Every mask passes through an empty asm statement: the optimiser must not learn that it is 0 or
+// all ones, or it turns the masked moves back into compares, branches and secret-indexed loads
+// (clang did exactly that to the table scans before the barrier was added; tests/test_ct_cpu.py
+// now counts the conditional branches of the compiled constant-time functions).
+inline u64 value_barrier(u64 x) {
+  asm volatile("" : "+r"(x));
+  return x;
+}
+inline u64 mask_nonzero(u64 x) { return value_barrier(0 - ((x | (0 - x)) >> 63)); }   // all ones iff x != 0
+inline u64 mask_eq(u64 a, u64 b) { return value_barrier(~mask_nonzero(a ^ b)); }
 
 struct u256 {
   u64 v[4];   // little-endian limbs
@@ -55,9 +63,10 @@ inline u64 sub256(u256& r, const u256& a, const u256& b) {
   return bw;
 }
 inline void cmov256(u256& r, const u256& a, u64 mask) {   // r = mask ? a : r
+  mask = value_barrier(mask);
   for (int i = 0; i < 4; ++i) r.v[i] ^= (r.v[i] ^ a.v[i]) & mask;
 }
-inline u64 is_zero256(const u256& a) { return ~mask_nonzero(a.v[0] | a.v[1] | a.v[2] | a.v[3]); }
+inline u64 is_zero256(const u256& a) { return value_barrier(~mask_nonzero(a.v[0] | a.v[1] | a.v[2] | a.v[3])); }
 inline void from_be(u256& r, const uint8_t* b) {
   for (int i = 0; i < 4; ++i) {
     u64 w = 0;

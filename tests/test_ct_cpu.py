@@ -124,3 +124,38 @@ def test_ct_operation_count_is_scalar_independent(S):
         assert S.ct_ecdsa_sign_raw(b32(v % R.N or 1), bytes(range(32)), b32((v * 7 + 1) % R.N or 1)) is not None
         counts.add(lib.s2k_ct_debug_fe_mul_count())
     assert len(counts) == 1, counts
+
+
+def test_ct_machine_code_has_no_data_dependent_branches(S):
+    """The constant-time claim at the level that matters: the COMPILED functions.  Optimisers turn
+    `mask = (w == j)` scans back into compare-and-branch chains and secret-indexed loads (clang did, before
+    the masks were routed through value_barrier()); this disassembles the object the library was linked
+    from and bounds the conditional branches of every secret-handling function by its loop counters and
+    argument checks."""
+    import re
+    import shutil
+    import subprocess
+    obj = os.path.join(os.path.dirname(S.LIB_PATH), "build", "ct_cpu.o")
+    objdump = shutil.which("objdump")
+    if not (os.path.exists(obj) and objdump):
+        pytest.skip("object file or objdump not available")
+    asm = subprocess.run([objdump, "-d", "--no-show-raw-insn", "-C", obj], capture_output=True, text=True).stdout
+    counts, fn = {}, None
+    for line in asm.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            fn = re.sub(r"\(anonymous namespace\)::", "", m.group(1)).split("(")[0]
+            counts.setdefault(fn, 0)
+        elif fn and re.search(r"\tj[a-z]+\s", line) and "\tjmp" not in line:
+            counts[fn] += 1
+    assert "ct_scalar_mult" in counts and "ct_scalar_base_mult" in counts, sorted(counts)
+    # allowed: loop back-edges (fixed trip counts), the call_once flag, NULL / range checks of the arguments, the
+    # bits of the PUBLIC exponent n - 2 in the scalar inversion
+    limits = {"ct_scalar_mult": 2, "ct_scalar_base_mult": 4, "lookup_projective": 1, "make_table": 1, "pt_add": 0, "pt_add_mixed": 0,
+              "pt_double": 0, "pt_to_record": 0, "sc_split_glv": 0, "fe_inv": 2, "fe_sqr_n": 1, "sc_inv": 3, "sc_reduce_wide": 0,
+              "s2k_ct_scalar_mult": 3, "s2k_ct_scalar_base_mult": 2, "s2k_ct_ecdh": 6, "s2k_ct_ecdsa_sign_raw": 6}
+    for name, lim in limits.items():
+        assert counts.get(name, 0) <= lim, (name, counts.get(name))
+    # nothing that looks like a switch over a 4-bit window value
+    for name in ("ct_scalar_mult", "ct_scalar_base_mult", "lookup_projective"):
+        assert counts.get(name, 0) < 8
