@@ -51,3 +51,28 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "import oracle" not in txt and "secp256k1_oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_hot_kernel_register_budget():
+    """The occupancy DESIGN.md states is a property of the compiled code objects: the ladder kernel must fit three
+    waves per SIMD (<= 168 VGPRs) without spills or scratch, the bucket pass four (<= 128)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objdir = os.path.join(root, "secp256k1_voi_amd", "build")
+    tool = os.path.join(root, "tools", "kernel_regs.sh")
+    if not (os.path.exists(os.path.join(objdir, "engine.o")) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")):
+        import pytest
+        pytest.skip("objects or llvm tools not available")
+    out = subprocess.run(["bash", tool, objdir], capture_output=True, text=True).stdout
+    info = {}
+    for line in out.splitlines():
+        m = re.match(r"\S+\s+(\S+)\s+vgpr=(\d+)\s+sgpr=(\d+)\s+spill=(\d+)\s+scratch=(\d+)", line)
+        if m:
+            info[m.group(1)] = tuple(int(x) for x in m.groups()[1:])
+    fast = [v for k, v in info.items() if k.startswith("_Z13k_verify_fastILi0E")]
+    assert fast, sorted(info)[:5]
+    vgpr, _, spill, scratch = fast[0]
+    assert vgpr <= 168 and spill == 0 and scratch == 0, fast[0]
+    acc = [v for k, v in info.items() if "k_msm_accumulate" in k]
+    assert acc and acc[0][0] <= 128 and acc[0][2] == 0, acc
