@@ -279,3 +279,27 @@ def test_schnorr_and_recovery_worklists(eng, oracle):
             assert ok[i] == 1 and bytes(pub[i]) == w
     for i in range(0, len(want), 101):
         assert oracle.ecdsa_recover(dig[i], rr[i], ss[i], rid[i]) == want[i]
+
+
+def test_host_chunked_path_matches_single_launch(eng):
+    """s2k_ecdsa_verify_batch cuts large batches into round-sized chunks with overlapped copies (first chunk
+    one round, merged tail): for a size that is not a multiple of anything, its verdicts equal those of one
+    launch over device-resident inputs, corrupted items included."""
+    import torch
+    from secp256k1_voi_amd.synth import synth_batch
+    n = 3 * 196608 + 4 * 196608 // 3 + 12345          # > 3 rounds, ragged
+    pub, dig, r, s = synth_batch(eng, n, 4096, seed=91)
+    rng = np.random.default_rng(92)
+    bad = rng.choice(n, size=5000, replace=False)
+    s[bad, rng.integers(0, 32, size=bad.size)] ^= 0x20
+    host = eng.ecdsa_verify_batch(pub, dig, r, s)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (pub, dig, r, s)]
+    out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.ecdsa_verify_batch_device(n, *(x.data_ptr() for x in d), out.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    single = out.cpu().numpy()
+    assert np.array_equal(host, single)
+    exp = np.ones(n, dtype=np.uint8)
+    exp[bad] = 0
+    assert np.array_equal(host, exp)
