@@ -268,8 +268,9 @@ def worker(args):
         cnts[k:k + 1].copy_(cnt)
     sync()
     dt = time.perf_counter() - t0
-    prof = eng.profile_read(cap=max(args.steps, 1))
+    prof = eng.profile_read_stages(cap=max(args.steps, 1))
     eng.profile(False)
+    grouping = eng.key_grouping_stats()                  # of the last timed step
     assert prof["calls"] == min(args.steps, 1024)
     assert bool((cnts == n * world).all().item()), "a timed step lost verdicts"
     assert bitmap.numel() == n * world // 8 and bool((bitmap == 0xFF).all().item())
@@ -283,19 +284,33 @@ def worker(args):
     if rank == 0:
         fast_ms = prof["fast_ms"] / prof["calls"]         # dominant kernel, HIP events on its stream
         fast_med = median(prof["fast_each"])
-        prep_ms = prof["prep_ms"] / prof["calls"]
+        calls = prof["calls"]
+        keyed = grouping["keyed"] * 2 >= n                # which ladder is the dominant kernel of this run
         clock_hz = prof["shader_mhz"] * 1e6
         value = n * world * args.steps / dt
         counts, counts_src = committed_counts()
-        traffic, traffic_src = committed_traffic()
-        roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA>", "kernel_ms": fast_ms, "kernel_ms_median": fast_med,
-                "scalar_prep_ms": prep_ms, "fallback_ms": prof["fallback_ms"] / prof["calls"],
+        kname = "k_verify_fast_keyed" if keyed else "k_verify_fast"
+        traffic, traffic_src = committed_traffic(kname)
+        stages = {"grouping_by_key_ms": prof["group_ms"] / calls, "key_tables_ms": None, "ladder_ms": fast_ms,
+                  "general_ladder_ms": prof["left_ms"] / calls, "complete_worklist_ms": prof["fallback_ms"] / calls}
+        if keyed:
+            # stage [0] is the grouping, stage [1] the per-key tables; the scalar preparation and the generator
+            # part u1*G run beside both on a second stream (secp256k1_voi_amd.h: s2k_ctx_profile_read_stages)
+            stages["grouping_by_key_ms"], stages["key_tables_ms"] = prof["prep_ms"] / calls, prof["group_ms"] / calls
+        else:
+            stages["scalar_prep_ms"] = prof["prep_ms"] / calls
+            stages.pop("grouping_by_key_ms")
+            stages.pop("key_tables_ms")
+        roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>",
+                "kernel_ms": fast_ms, "kernel_ms_median": fast_med, "stages_ms": stages,
                 "shader_clock_mhz": prof["shader_mhz"], "shader_clock_mhz_first_wave": prof["shader_mhz_first_wave"],
                 "shader_clock_mhz_last_round": prof["shader_mhz_last_round"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
                 "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
+        if counts and kname not in counts:
+            counts = None
         if counts:
-            ipv = counts["k_verify_fast"]["valu_instr_per_signature"]
-            st_ = counts.get("static", {})
+            ipv = counts[kname]["valu_instr_per_signature"]
+            st_ = counts.get("static_keyed" if keyed else "static", {})
             lane_ops = ipv * n / (fast_ms * 1e-3)
             roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
                          "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src,
@@ -334,6 +349,10 @@ def worker(args):
                        "inputs": "resident in HBM", "collective": "all-gather bitmap + all-reduce count per step",
                        "build": eng._lib.s2k_build_config().decode()},
             "roofline": roof,
+            "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)", "signatures_on_key_tables": grouping["keyed"],
+                             "tables_built_per_step": grouping["tables"], "signatures_on_general_ladder": grouping["general"],
+                             "note": "signatures are grouped by public key inside every step; keys with >= 6 signatures get a "
+                                     "precomputed table (built inside the step) and their signatures a 12-doubling ladder"},
         }
         extras = world == 1 and not args.no_extras
         if extras:
@@ -391,6 +410,32 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
     def verify_on(inputs):
         p, d, rr, ss = inputs
         eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(), d_valid.data_ptr(), 0, st)
+
+    # ---- the same batch with key grouping off: every signature as if its key were new (the reference's way) ----
+    from secp256k1_voi_amd import KEYS_AUTO, KEYS_OFF
+    if n_keys < n:
+        eng.set_key_grouping(KEYS_OFF)
+        try:
+            step()
+            eng.profile(True)
+            d_valid.zero_()
+            ms = timed(step, 5)
+            pr = eng.profile_read_stages(cap=8)
+            _, cnt = step()
+            assert int(cnt.item()) == n, "general path lost verdicts"
+        finally:
+            eng.profile(False)
+            eng.set_key_grouping(KEYS_AUTO)
+        out["general_path_same_batch"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
+                                          "kernel": "k_verify_fast<ECDSA>", "kernel_ms": pr["fast_ms"] / pr["calls"],
+                                          "shader_clock_mhz": pr["shader_mhz"],
+                                          "note": "s2k_ctx_set_key_grouping(S2K_KEYS_OFF): per-signature table and 128 doublings "
+                                                  "for every signature, step includes the same bitmap exchange"}
+        counts, _ = committed_counts()
+        if counts and "k_verify_fast" in counts and pr["shader_mhz"] > 0:
+            wave_instr = counts["k_verify_fast"]["valu_instr_per_signature"] * n / 64.0
+            out["general_path_same_batch"]["frac_at_measured_clock"] = wave_instr * 4.0 / (SIMDS * pr["fast_ms"] / pr["calls"] * 1e-3 * pr["shader_mhz"] * 1e6)
+            out["general_path_same_batch"]["frac"] = counts["k_verify_fast"]["valu_instr_per_signature"] * n / (pr["fast_ms"] / pr["calls"] * 1e-3) / VALU_PEAK_LANE_OPS
 
     # ---- K = N: every signature under its own key (SURVEY 8d "also report K = N") ----
     if n_keys < n:

@@ -89,6 +89,12 @@ const char *s2k_build_config(void);
 int s2k_ctx_profile(s2k_ctx *ctx, int enable);
 int s2k_ctx_profile_read(s2k_ctx *ctx, double ms_sum3[3], double *ms_fast_each, size_t cap, size_t *calls,
                          double shader_mhz[2]);
+/* The same with the stages apart.  Grouping off: ms_sum5[0] scalar preparation, [2] ladder, [4]
+ * complete-formula worklist.  Grouping on: [0] grouping by key, [1] per-key tables with the scalar
+ * preparation running beside them, [2] ladder over the per-key tables, [3] general ladder over the
+ * remaining signatures, [4] worklist.  ms_fast_each is stage [2]. */
+int s2k_ctx_profile_read_stages(s2k_ctx *ctx, double ms_sum5[5], double *ms_fast_each, size_t cap, size_t *calls,
+                                double shader_mhz[2]);
 
 /* ---- hot path: batch ECDSA verification ------------------------------------------- */
 /* For each i < n: secec.PublicKey.VerifyRaw(digest, r, s) (ecdsa.go:234 -> verify :392)
@@ -107,6 +113,28 @@ int s2k_ecdsa_verify_batch(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy /* n*64
 int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, const void *d_digest32,
                                   const void *d_r, const void *d_s, uint32_t flags, void *d_valid,
                                   void *hip_stream);
+/* ---- signatures that share public keys ---------------------------------------------------- */
+/* The reference keeps nothing per key (secec.PublicKey holds the point and its encoding, secec.go:150;
+ * every Verify starts DoubleScalarMultBasepointVartime from Q, point_mul_glv.go:307).  Here a batch
+ * is first grouped by public key on the device (exact: a hash table keyed by the 64 key bytes, full
+ * comparison on every hit); a key with at least `min_group` signatures gets one precomputed table,
+ * built inside the call, after which each of its signatures costs 12 point doublings instead of 128;
+ * the other signatures take the general kernel.  Verdicts are the same either way.
+ *   mode        S2K_KEYS_OFF: every signature through the general kernel (the round-1/2 path)
+ *               S2K_KEYS_AUTO (default): as described
+ *               S2K_KEYS_ALWAYS: tables even for keys with a single signature (tests)
+ *   min_group   0 = default (6): a table costs about as much as four signatures save on it
+ *   hash_bits   0 = default (slots >= 2n); smaller values force probe chains (tests)
+ *   max_tables  0 = default (2^18 tables of 9 KiB); keys beyond it take the general kernel */
+#define S2K_KEYS_OFF 0
+#define S2K_KEYS_AUTO 1
+#define S2K_KEYS_ALWAYS 2
+int s2k_ctx_set_key_grouping(s2k_ctx *ctx, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables);
+/* After the last s2k_ecdsa_verify_batch_device call has finished (synchronises the device):
+ * stats[0] signatures verified from per-key tables, [1] tables built, [2] signatures through the
+ * general kernel, [3] signatures re-done by the complete-formula kernel. */
+int s2k_ctx_key_grouping_stats(s2k_ctx *ctx, uint32_t stats[4]);
+
 /* ---- batch public-key recovery ------------------------------------------------------------ */
 /* For each i < n: secec.RecoverPublicKey(digest, r, s, recovery_id) (ecdsa.go:244-282):
  * R = RecoverPoint(r, id) (point_s11n.go:245-282), Q = (-e/r) G + (s/r) R.  ok[i] = 1 and

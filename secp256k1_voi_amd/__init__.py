@@ -30,6 +30,7 @@ ENCODING_ASN1, ENCODING_COMPACT = 0, 1
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 IMPL_COMPLETE, IMPL_FAST = 0, 1
+KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS = 0, 1, 2     # s2k_ctx_set_key_grouping
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
  HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
  HP_PT29_ADD_MIXED) = range(21)
@@ -133,6 +134,9 @@ def load_library() -> C.CDLL:
     lib.s2k_build_config.restype = C.c_char_p
     lib.s2k_ctx_profile.argtypes = [vp, ci]
     lib.s2k_ctx_profile_read.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.s2k_ctx_profile_read_stages.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.s2k_ctx_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
+    lib.s2k_ctx_key_grouping_stats.argtypes = [vp, vp]
     lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
@@ -176,7 +180,8 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version", "s2k_build_config",
-    "s2k_ctx_profile", "s2k_ctx_profile_read",
+    "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages",
+    "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
     "s2k_pack_valid_device", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
@@ -443,6 +448,33 @@ class Engine:
         return {"calls": k, "prep_ms": sums[0], "fast_ms": sums[1], "fallback_ms": sums[2],
                 "fast_each": [each[i] for i in range(min(k, cap))], "shader_mhz": sum(both) / len(both) if both else 0.0,
                 "shader_mhz_first_wave": float(mhz[0]), "shader_mhz_last_round": float(mhz[1])}
+
+    def profile_read_stages(self, cap: int = 1024):
+        """-> dict(calls, prep_ms, group_ms (grouping by key + per-key tables), fast_ms (ladder over the per-key
+        tables; the general ladder when grouping is off), left_ms (general ladder over the ungrouped rest),
+        fallback_ms: sums; fast_each; shader_mhz...) (s2k_ctx_profile_read_stages)."""
+        sums = (C.c_double * 5)()
+        each = (C.c_double * cap)()
+        calls, mhz = C.c_size_t(0), (C.c_double * 2)()
+        self._check(self._lib.s2k_ctx_profile_read_stages(self._h, sums, each, cap, C.byref(calls), mhz))
+        k = int(calls.value)
+        both = [m for m in (mhz[0], mhz[1]) if m > 0]
+        return {"calls": k, "prep_ms": sums[0], "group_ms": sums[1], "fast_ms": sums[2], "left_ms": sums[3],
+                "fallback_ms": sums[4], "fast_each": [each[i] for i in range(min(k, cap))],
+                "shader_mhz": sum(both) / len(both) if both else 0.0,
+                "shader_mhz_first_wave": float(mhz[0]), "shader_mhz_last_round": float(mhz[1])}
+
+    def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
+        """How ecdsa_verify_batch[_device] treats signatures that share a public key (s2k_ctx_set_key_grouping):
+        KEYS_OFF = every signature through the general kernel, KEYS_AUTO (default) = keys with at least
+        `min_group` (default 4) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does."""
+        self._check(self._lib.s2k_ctx_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
+
+    def key_grouping_stats(self):
+        """Of the last ecdsa_verify_batch_device call -> dict(keyed, tables, general, complete)."""
+        st = (C.c_uint32 * 4)()
+        self._check(self._lib.s2k_ctx_key_grouping_stats(self._h, st))
+        return {"keyed": int(st[0]), "tables": int(st[1]), "general": int(st[2]), "complete": int(st[3])}
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))

@@ -7,12 +7,16 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+
+#include <sys/random.h>
 
 #include "engine_internal.h"
 #include "fe.h"
 #include "jacobian29.h"
+#include "lane_tables.h"
 #include "pt29.h"
 #include "complete_path.h"
 #include "point.h"
@@ -241,7 +245,11 @@ S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe
 
 S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
                                   const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride, size_t lane) {
+  // idx: the signature; lane: the table column this thread may use (the worklist kernel passes the worklist
+  // POSITION, not the signature: the keyed ladder queues signatures in key order, and columns picked by
+  // signature would scatter a wave's table accesses over 64 cache lines: 47 ms instead of 20 for a batch
+  // that is queued whole)
   sc r, s;
   uint32_t e_raw[8];
   apt q;
@@ -272,7 +280,7 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, c
   sc e = sc_reduce_once(e_raw);
   sc26 s_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(s)));   // s^-1 * R (safegcd, modinv30.h)
   sc u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m)), u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
-  pt29 acc = dsm_complete29(u1, u2, qx, qy, gt, qt, stride, idx);
+  pt29 acc = dsm_complete29(u1, u2, qx, qy, gt, qt, stride, lane);
   ok = ok && !fe29_is_zero(acc.z);                   // ecdsa.go:450
   // x(R) mod n == r  <=>  X == r*Z  or  (r + n < p and X == (r + n)*Z)   (ecdsa.go:459-465)
   bool match = fe29_eq(acc.x, fe29_mul(fe29_from_words(r.v), acc.z));
@@ -293,7 +301,7 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
     size_t idx = wl[w];
-    out[idx] = verify_complete29(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
+    out[idx] = verify_complete29(idx, pub, dig, rsig, ssig, flags, gt, qt, stride, w);
   }
 }
 
@@ -403,82 +411,42 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // on the curve isomorphic by C = Z(2Q), remember H_j (Z_j = Z_{j-1} H_j), then scale entry j
 // by (H_{j+1}...H_7)^{2,3}.  The ladder then only ever adds affine points (8 M + 3 S); its
 // result has the true Z = Z_ladder * Z_7 * C.
-// Table storage: tb_* below.  Z_7 * C and the results handed to k_affine_finish go to the lane's
+// Table storage: tb_* (lane_tables.h).  Z_7 * C and the results handed to k_affine_finish go to the lane's
 // "fin" elements.
 // ---------------------------------------------------------------------------------------
-// Small per-lane scratch elements ("fin" region, 4 elements): 16-byte planes [quad][lane], three quads
-// per field element (limbs 0-3 | 4-7 | 8,-,-,-).  Element 0-2: (X, Y, Z) handed to k_affine_finish,
-// element 3: Z_7 * C during the ladder, then the prefix products of the shared inversion.
-constexpr int FQT_FE_WORDS = 12;
-constexpr int FIN_ELEMS = 4, FIN_WORDS = FIN_ELEMS * FQT_FE_WORDS;
-constexpr int TBL_WORDS = 8 * 8 * 4;          // per-lane table: 8 entries x 8 quads (7 used)
-S2K_DEV void fq_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int elem, const fe29& v) {
-  uint4* q = reinterpret_cast<uint4*>(base) + (size_t)(elem * 3) * stride + lane;
-  q[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
-  q[stride] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
-  q[2 * stride] = make_uint4(v.n[8], 0u, 0u, 0u);
-}
-S2K_DEV fe29 fq_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t elem) {
-  fe29 r;
-  const uint4* q = reinterpret_cast<const uint4*>(base) + (size_t)(elem * 3) * stride + lane;
-  uint4 a = q[0], b = q[stride];
-  r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
-  r.n[8] = reinterpret_cast<const uint32_t*>(q + 2 * stride)[0];
-  return r;
-}
-// Per-signature table.  Entry j (of 8 odd multiples) is seven quads of 16 bytes,
-//   [x limbs 0-3][x 4-7][y 0-3][y 4-7][beta*x 0-3][beta*x 4-7][x8, y8, (beta*x)8, -]
-// so that a ladder lookup (x or beta*x, and y) is five 16-byte loads.  During the table build the
-// beta*x slot of entry j holds H_j.  Where the quads live (S2K_QT_PACK):
-//   2 (default)  the quads of one (entry, lane) pair are CONTIGUOUS: 128 bytes = one cache line per
-//                lookup, [entry][lane][8 quads]
-//   1            planes [entry * 7 + quad][lane] (a wave's access to one quad is contiguous, but every
-//                lane of a lookup lands in a different line of five different planes)
-// Measured on MI355X, 2^20 signatures, same box (tools/ab_libs.sh; profiles/r02_table_layouts.md): the
-// round-1 layout (three 16-byte planes per element, separate beta*x column: six loads per lookup,
-// 1200 bytes per signature) 7.93-8.04 ms and 16.2 GB of L2-miss reads per launch (FETCH_SIZE, raw);
-// planes of packed entries 7.76-7.86 ms, 12.4 GB; contiguous entries 7.61-7.66 ms, 4.7 GB.
-#ifndef S2K_QT_PACK
-#define S2K_QT_PACK 2
-#endif
-enum { TB_X = 0, TB_Y = 1, TB_BX = 2 };
-constexpr int TB_ZC_ELEM = 3;   // in the fin region
-#if S2K_QT_PACK == 2
-#define TB_ENTRY(base4, stride, lane, entry) ((base4) + ((size_t)(entry) * (stride) + (lane)) * 8)
-#define TB_Q(stride, q) ((size_t)(q))
-#else
-#define TB_ENTRY(base4, stride, lane, entry) ((base4) + (size_t)((entry) * 7) * (stride) + (lane))
-#define TB_Q(stride, q) ((size_t)(q) * (stride))
-#endif
-S2K_DEV void tb_store(uint32_t* __restrict__ base, size_t stride, size_t lane, int entry, int which, const fe29& v) {
-  uint4* e = TB_ENTRY(reinterpret_cast<uint4*>(base), stride, lane, entry);
-  uint4* q = e + TB_Q(stride, which * 2);
-  q[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
-  q[TB_Q(stride, 1)] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
-  reinterpret_cast<uint32_t*>(e + TB_Q(stride, 6))[which] = v.n[8];
-}
-S2K_DEV fe29 tb_load(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t entry, int which) {
-  const uint4* e = TB_ENTRY(reinterpret_cast<const uint4*>(base), stride, lane, entry);
-  const uint4* q = e + TB_Q(stride, which * 2);
-  uint4 a = q[0], b = q[TB_Q(stride, 1)];
-  fe29 r;
-  r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
-  r.n[8] = reinterpret_cast<const uint32_t*>(e + TB_Q(stride, 6))[which];
-  return r;
-}
-// the ladder's lookup: x (lam: beta*x) and y of one entry
-S2K_DEV void tb_load_xy(const uint32_t* __restrict__ base, size_t stride, size_t lane, uint32_t entry, bool lam, fe29& x, fe29& y) {
-  const uint4* e = TB_ENTRY(reinterpret_cast<const uint4*>(base), stride, lane, entry);
-  const uint4* qx = e + TB_Q(stride, lam ? 4 : 0);
-  uint4 a = qx[0], b = qx[TB_Q(stride, 1)], c = e[TB_Q(stride, 2)], d = e[TB_Q(stride, 3)], t = e[TB_Q(stride, 6)];
-  x.n[0] = a.x; x.n[1] = a.y; x.n[2] = a.z; x.n[3] = a.w; x.n[4] = b.x; x.n[5] = b.y; x.n[6] = b.z; x.n[7] = b.w;
-  y.n[0] = c.x; y.n[1] = c.y; y.n[2] = c.z; y.n[3] = c.w; y.n[4] = d.x; y.n[5] = d.y; y.n[6] = d.z; y.n[7] = d.w;
-  x.n[8] = lam ? t.z : t.x;
-  y.n[8] = t.y;
-}
 
-enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3 };
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
+
+// Digits of an odd half scalar k < 2^129 in the order the per-key ladder consumes them.  As in
+// ds_init, digit i is nib_i = bits 4i+1 .. 4i+4 of k (signed value 2 nib_i - 15); digit i = 4c + j
+// belongs to chunk c = 2^(16c) Q and round j, and the ladder runs round 3 first, chunks upwards: its
+// nibble goes to place (3 - j) * 8 + c from the top of a 128-bit stream.
+struct digit_stream4 {
+  uint32_t w[4];
+};
+S2K_DEV digit_stream4 ds4_init_chunked(const sc& k_odd) {
+  digit_stream4 d;
+  d.w[0] = d.w[1] = d.w[2] = d.w[3] = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int bit = 4 * i + 1, limb = bit >> 5, sh = bit & 31;
+    uint32_t nib = k_odd.v[limb] >> sh;
+    if (sh > 28) nib |= k_odd.v[limb + 1] << (32 - sh);
+    nib &= 15u;
+    const int c = i >> 2, j = i & 3, pos = 124 - 4 * ((3 - j) * 8 + c);
+    d.w[pos >> 5] |= nib << (pos & 31);
+  }
+  return d;
+}
+S2K_DEV uint32_t ds4_next(digit_stream4& d) {
+  uint32_t nib = d.w[3] >> 28;
+  d.w[3] = (d.w[3] << 4) | (d.w[2] >> 28);
+  d.w[2] = (d.w[2] << 4) | (d.w[1] >> 28);
+  d.w[1] = (d.w[1] << 4) | (d.w[0] >> 28);
+  d.w[0] <<= 4;
+  return nib;
+}
 
 // MODE_ECDSA:   pub = n x 64 (X||Y), rsig = n x 32 (r);      accept iff x(R) mod n == r
 // MODE_SCHNORR: pub = n x 32 (x-only key, BIP-340), rsig = n x 64 signatures (r at offset 0);
@@ -490,34 +458,85 @@ constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 // MODE_POINT:   pub = n x 64 (X||Y), rsig unused; out_pts = n x 65 records of u1*G + u2*P with
 //               u1 and the split u2 taken from the prep planes as they are
 //               (DoubleScalarMultBasepointVartime, point_mul_glv.go:307; k_hot_prep)
+// MODE_ECDSA_KEYED / MODE_ECDSA_LEFT: MODE_ECDSA after the batch has been grouped by public key
+//               (keyed.hip).  Lane idx < *kg.counters[...] handles signature perm[idx]: inputs, prep
+//               planes and the verdict are the signature's, workspace columns are the lane's.
+//               KEYED lanes take their points from the key's precomputed affine table (table ptab[idx],
+//               no per-lane table, 12 doublings); LEFT lanes are the general path for the rest.
 // Waves per SIMD the register allocator must leave room for.  Measured (2^20 signatures):
 // unbounded (240 VGPRs, 2 waves) 11.08 ms; 3 waves (168 VGPRs, no spills) 10.89 ms; 4 waves
 // (128 VGPRs, 96 spilled) 11.45 ms.
 #ifndef S2K_FAST_WAVES
 #define S2K_FAST_WAVES 3
 #endif
+// ---------------------------------------------------------------------------------------
+// Grouped flow only: the generator part u1*G of every signature, on its own.  It needs nothing but
+// the prepared u1, so it runs on the second stream, after the scalar preparation and beside the
+// grouping and per-key table kernels (which are latency or memory bound and leave the multipliers
+// idle); the ladders then finish with one Jacobian + Jacobian addition instead of GT_WINDOWS mixed ones.
+// Out: (X, Y, Z) in three "fin"-format elements per SIGNATURE (gp planes).  A degenerate addition
+// on the way (or u1 = 0) leaves Z = 0, which the ladder's final addition passes on to the worklist.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_generator_part(uint32_t first, uint32_t n, const uint32_t* __restrict__ prep, const uint32_t* __restrict__ gt,
+                 uint32_t* __restrict__ gp, size_t stride) {
+  size_t idx = (size_t)first + (size_t)blockIdx.x * 256 + threadIdx.x;   // signatures [first, n)
+  if (idx >= n) return;
+  uint32_t u[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + idx];
+  apt g = gt_load(gt, 0, gt_next_digit(u));
+  jpt29 acc;
+  acc.x = fe29_from_words(g.x.v);
+  acc.y = fe29_from_words(g.y.v);
+  acc.z = fe29_one();
+  g = gt_load(gt, 1, gt_next_digit(u));
+#pragma unroll 1
+  for (uint32_t w = 1; w < GT_WINDOWS; ++w) {
+    const fe29 gx = fe29_from_words(g.x.v), gy = fe29_from_words(g.y.v);
+    if (w + 1 < GT_WINDOWS) g = gt_load(gt, w + 1, gt_next_digit(u));   // in flight during this addition
+    acc = jpt29_add_affine(acc, gx, gy);
+  }
+  fq_store(gp, stride, idx, 0, acc.x);
+  fq_store(gp, stride, idx, 1, acc.y);
+  fq_store(gp, stride, idx, 2, acc.z);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256, S2K_FAST_WAVES)
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
-              uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk) {
-  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
+              uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
+              key_groups kg) {
+  constexpr bool GROUPED = MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT;
+  constexpr bool ECDSA = MODE == MODE_ECDSA || GROUPED;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // lane: workspace column
+  size_t sig = idx;                                            // signature: input / prep / verdict column
+  uint32_t lanes = n;
+  if constexpr (GROUPED) {
+    lanes = kg.counters[MODE == MODE_ECDSA_KEYED ? KG_NKEYED : KG_NLEFT];
+    if (idx >= lanes) return;
+    sig = (MODE == MODE_ECDSA_KEYED ? kg.perm : kg.left)[idx];
+  } else {
+    if (idx >= n) return;
+  }
   // effective shader clock of this launch (bench.py roofline): wave 0 of workgroup 0 stamps the
   // shader cycle counter and the constant-rate wall clock when it starts and when it ends
   // (and wave 0 of the LAST workgroup, which runs in the launch's final round: the clock sags under power
   // over the 8 ms of a launch)
-  const bool stamp = clk != nullptr && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x < 64;
+  const bool stamp = clk != nullptr && (blockIdx.x == 0 || blockIdx.x == (lanes - 1) / 256) && threadIdx.x < 64;
   uint64_t t0c = 0, t0w = 0;
   if (stamp) {
     t0c = __builtin_readcyclecounter();
     t0w = __builtin_amdgcn_s_memrealtime();
   }
-  uint32_t pf = prep[(size_t)16 * stride + idx];
+  uint32_t pf = prep[(size_t)16 * stride + sig];
   bool ok;
   fe29 qx, qy;
-  if constexpr (MODE == MODE_RECOVER) {
+  if constexpr (MODE == MODE_ECDSA_KEYED) {
+    ok = (pf & PF_OK) && kg.tinfo[kg.ptab[idx]];      // the key was validated when its table was built
+  } else if constexpr (MODE == MODE_RECOVER) {
     uint32_t xw[8];
     load_be32(xw, rsig + idx * 32);
     ok = (pf & PF_OK) != 0;
@@ -538,10 +557,10 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     qy = fe29_normalize(qy);
     bool want_odd = (pf & 0x100u) != 0;
     qy = fe29_select(((qy.n[0] & 1u) != 0) != want_odd, qy, fe29_normalize_weak(fe29_negate(qy, 1)));
-  } else if constexpr (MODE == MODE_ECDSA || MODE == MODE_POINT) {
+  } else if constexpr (ECDSA || MODE == MODE_POINT) {
     apt q;
-    load_be32(q.x.v, pub + idx * 64);
-    load_be32(q.y.v, pub + idx * 64 + 32);
+    load_be32(q.x.v, pub + sig * 64);
+    load_be32(q.y.v, pub + sig * 64 + 32);
     ok = (pf & PF_OK) && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
     if (!ok) {   // keep the arithmetic on the curve; the verdict is already "invalid"
       q.x = fe_from_limbs(FE_GX);
@@ -581,7 +600,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
 
   // ---- table ----
-  {
+  if constexpr (MODE != MODE_ECDSA_KEYED) {
     jpt29 a0;
     a0.x = qx;
     a0.y = qy;
@@ -626,42 +645,85 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   sc k1 = sc_zero(), k2 = sc_zero();
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    k1.v[w] = prep[(size_t)(8 + w) * stride + idx];
-    k2.v[w] = prep[(size_t)(12 + w) * stride + idx];
+    k1.v[w] = prep[(size_t)(8 + w) * stride + sig];
+    k2.v[w] = prep[(size_t)(12 + w) * stride + sig];
   }
   k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;   // odd by construction (sc_split_glv_odd): the signed
   k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;   // odd-digit recoding is exact, no final correction
-  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
   jpt29 acc;
-  {
-    fe29 t0x = tb_load(qt, stride, idx, 0, TB_X), t0y = tb_load(qt, stride, idx, 0, TB_Y), t0bx = tb_load(qt, stride, idx, 0, TB_BX);
-    acc.x = t0x;
-    acc.y = fe29_cond_negate1(t0y, neg1);
-    acc.z = fe29_one();
-    acc = jpt29_add_affine(acc, t0bx, fe29_cond_negate1(t0y, neg2));
-  }
-#pragma unroll 1
-  for (int i = 31; i >= 0; --i) {
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) acc = jpt29_double(acc);
-    uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-      uint32_t w = t ? w2 : w1;
-      bool neg = (t ? neg2 : neg1) != (w < 8u);
-      uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
-      fe29 x, y;
-      tb_load_xy(qt, stride, idx, entry, t != 0, x, y);
-      acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
+  if constexpr (MODE == MODE_ECDSA_KEYED) {
+    // k = 16^32 + sum_i d_i 16^i with d_i = 2 nib_i - 15, i = 4c + j: round j (3 down to 0) adds
+    // d_(4c+j) * 2^(16c) Q for the eight chunks c, with four doublings between rounds; the leading
+    // 16^32 Q = 16^3 * 2^116 Q goes in first.
+    const uint4* kt = kg.ktab + (size_t)kg.ptab[idx] * (KT_SLOTS * 8);
+    digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);
+    {
+      fe29 lx, ly, lbx, ly2;
+      ke_load_xy(kt + (size_t)KT_LEAD * 8, false, lx, ly);
+      ke_load_xy(kt + (size_t)KT_LEAD * 8, true, lbx, ly2);
+      acc.x = lx;
+      acc.y = fe29_cond_negate1(ly, neg1);
+      acc.z = fe29_one();
+      acc = jpt29_add_affine(acc, lbx, fe29_cond_negate1(ly2, neg2));
     }
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+      if (round) {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) acc = jpt29_double(acc);
+      }
+#pragma unroll 1
+      for (int c = 0; c < KT_CHUNKS; ++c) {
+        uint32_t w1 = ds4_next(d1), w2 = ds4_next(d2);
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+          uint32_t w = t ? w2 : w1;
+          bool neg = (t ? neg2 : neg1) != (w < 8u);
+          uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+          fe29 x, y;
+          ke_load_xy(kt + (size_t)(c * 8 + entry) * 8, t != 0, x, y);
+          acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
+        }
+      }
+    }
+  } else {
+    digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+    {
+      fe29 t0x = tb_load(qt, stride, idx, 0, TB_X), t0y = tb_load(qt, stride, idx, 0, TB_Y), t0bx = tb_load(qt, stride, idx, 0, TB_BX);
+      acc.x = t0x;
+      acc.y = fe29_cond_negate1(t0y, neg1);
+      acc.z = fe29_one();
+      acc = jpt29_add_affine(acc, t0bx, fe29_cond_negate1(t0y, neg2));
+    }
+#pragma unroll 1
+    for (int i = 31; i >= 0; --i) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = jpt29_double(acc);
+      uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) {
+        uint32_t w = t ? w2 : w1;
+        bool neg = (t ? neg2 : neg1) != (w < 8u);
+        uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+        fe29 x, y;
+        tb_load_xy(qt, stride, idx, entry, t != 0, x, y);
+        acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
+      }
+    }
+    acc.z = fe29_mul(acc.z, fq_load(fin, stride, idx, TB_ZC_ELEM));   // times Z_7 * C: back on secp256k1 itself
   }
-  acc.z = fe29_mul(acc.z, fq_load(fin, stride, idx, TB_ZC_ELEM));   // times Z_7 * C: back on secp256k1 itself
 
   // ---- generator part: u1*G from the resident tables ----
-  {
+  if constexpr (GROUPED) {
+    jpt29 q;                                            // computed by k_generator_part
+    q.x = fq_load(kg.gp, stride, sig, 0);
+    q.y = fq_load(kg.gp, stride, sig, 1);
+    q.z = fq_load(kg.gp, stride, sig, 2);
+    acc = jpt29_add(acc, q);
+  } else {
     uint32_t u[8];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + idx];
+    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
 #pragma unroll 1
     for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
       apt g = gt_load(gt, w, gt_next_digit(u));
@@ -679,18 +741,18 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     if (fe29_is_zero(acc.z)) {
       // infinity or an exceptional case along the way: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
-      wl[pos] = (uint32_t)idx;
-    } else if constexpr (MODE != MODE_ECDSA) {
+      wl[pos] = (uint32_t)sig;
+    } else if constexpr (!ECDSA) {
       // affine epilogue (key bytes / even-y test) needs 1/Z: leave (X, Y, Z) in the lane's table
       // column and let k_affine_finish share one inversion between 16 lanes
       fq_store(fin, stride, idx, 0, acc.x);
       fq_store(fin, stride, idx, 1, acc.y);
       fq_store(fin, stride, idx, 2, acc.z);
       verdict = VERDICT_PENDING;
-    } else if constexpr (MODE == MODE_ECDSA) {
+    } else {
       // x(R) mod n == r  (ecdsa.go:450-465)
       uint32_t rw[8];
-      load_be32(rw, rsig + idx * 32);
+      load_be32(rw, rsig + sig * 32);
       fe29 zz = fe29_sqr(acc.z);
       bool match = fe29_eq(acc.x, fe29_mul(fe29_from_words(rw), zz));
       if (u256_lt(rw, FE_P_MINUS_N)) {
@@ -701,7 +763,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       verdict = match ? 1 : 0;
     }
   }
-  out[idx] = verdict;
+  out[sig] = verdict;
   if (stamp && threadIdx.x == 0) {
     uint64_t* c = clk + (blockIdx.x == 0 ? 0 : 4);
     c[0] = t0c;
@@ -1139,12 +1201,12 @@ const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; 
 //   [0,256)    per-lane point table of the fast path: 8 entries x 8 quads (tb_*); the complete path
 //              uses the first 192 words for its projective table
 //   [256,304)  four scratch field elements ("fin": X, Y, Z for k_affine_finish; Z_7*C / prefix products)
-//   then       17 words of scalar-prep output.  The prep kernel's own scratch (prefix products and
+//   then       17 words of scalar-prep output, 36 words for the generator part (grouped flow).  The prep kernel's own scratch (prefix products and
 //              s in Montgomery form, 10 words each) borrows the start of the table region,
 //              which is only written after the prep kernel has finished.
 //   then       worklist: 1 counter + n indices
 constexpr size_t WS_QT = 0, WS_FIN = TBL_WORDS, WS_PREP = TBL_WORDS + FIN_WORDS, WS_PREF = WS_QT, WS_SMONT = WS_QT + 10,
-                 WS_LANE_WORDS = WS_PREP + PREP_WORDS;
+                 WS_GP = WS_PREP + PREP_WORDS, WS_LANE_WORDS = WS_GP + 3 * FQT_FE_WORDS;
 static_assert(TBL_WORDS >= QT_WORDS, "the complete path's table must fit in the fast path's region");
 
 size_t s2k_ecdsa_workspace_bytes(size_t n) {
@@ -1176,6 +1238,11 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   s2k_ctx* ctx = new (std::nothrow) s2k_ctx();
   if (!ctx) return fail(nullptr, S2K_ERR_NOMEM, "out of host memory");
   ctx->device = device_index;
+  if (getrandom(&ctx->kg_seed, sizeof ctx->kg_seed, 0) != (ssize_t)sizeof ctx->kg_seed) ctx->kg_seed = 0x5ec9u;   // hash seed of the key grouping
+  if (const char* v = getenv("S2K_GP_FIRST_PERCENT")) {   // measurement knob (tools/keyed_probe.py)
+    int pc = atoi(v);
+    if (pc >= 0 && pc <= 100) ctx->gp_first_percent = (uint32_t)pc;
+  }
   hipError_t e = hipSetDevice(device_index);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_index);
@@ -1215,6 +1282,12 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->io) (void)hipFree(ctx->io);
   if (ctx->clk) (void)hipFree(ctx->clk);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+  if (ctx->kg) (void)hipFree(ctx->kg);
+  if (ctx->ktab) (void)hipFree(ctx->ktab);
   for (size_t i = 0; i < ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
   delete[] ctx->prof_ev;
   for (hipEvent_t e : ctx->ev_copied)
@@ -1224,18 +1297,21 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   delete ctx;
 }
 
-// per-kernel timing (s2k_ctx_profile): one event before and after each of the three kernels
+// per-stage timing (s2k_ctx_profile): six events per call, around scalar preparation | grouping and
+// per-key tables | ladder (keyed, or the general one when grouping is off) | general ladder over the
+// ungrouped rest | complete-formula worklist
+constexpr int PROF_EV = 6;
 static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
-  if (!ctx->prof_on || ctx->prof_used + 4 > ctx->prof_cap) return;
+  if (!ctx->prof_on || ctx->prof_used + PROF_EV > ctx->prof_cap) return;
   (void)hipEventRecord(ctx->prof_ev[ctx->prof_used + slot], st);
-  if (slot == 3) ctx->prof_used += 4;
+  if (slot == PROF_EV - 1) ctx->prof_used += PROF_EV;
 }
 
 int s2k_ctx_profile(s2k_ctx* ctx, int enable) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (enable && !ctx->prof_ev) {
-    const size_t cap = 4 * 1024;   // 1024 verification calls between two reads
+    const size_t cap = PROF_EV * 1024;   // 1024 verification calls between two reads
     ctx->prof_ev = new (std::nothrow) hipEvent_t[cap];
     if (!ctx->prof_ev) return fail(ctx, S2K_ERR_NOMEM, "out of host memory");
     for (size_t i = 0; i < cap; ++i) {
@@ -1254,19 +1330,19 @@ int s2k_ctx_profile(s2k_ctx* ctx, int enable) {
   return S2K_OK;
 }
 
-int s2k_ctx_profile_read(s2k_ctx* ctx, double* ms_sum3, double* ms_fast_each, size_t cap, size_t* calls,
-                         double* shader_mhz) {
-  if (!ctx || !ms_sum3 || !calls) return fail(ctx, S2K_ERR_ARG, "null argument");
+int s2k_ctx_profile_read_stages(s2k_ctx* ctx, double* ms_sum5, double* ms_fast_each, size_t cap, size_t* calls,
+                                double* shader_mhz) {
+  if (!ctx || !ms_sum5 || !calls) return fail(ctx, S2K_ERR_ARG, "null argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
-  ms_sum3[0] = ms_sum3[1] = ms_sum3[2] = 0.0;
-  const size_t k = ctx->prof_used / 4;
+  for (int j = 0; j < PROF_EV - 1; ++j) ms_sum5[j] = 0.0;
+  const size_t k = ctx->prof_used / PROF_EV;
   for (size_t i = 0; i < k; ++i) {
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < PROF_EV - 1; ++j) {
       float ms = 0.f;
-      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[4 * i + j], ctx->prof_ev[4 * i + j + 1]));
-      ms_sum3[j] += ms;
-      if (j == 1 && ms_fast_each && i < cap) ms_fast_each[i] = ms;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[PROF_EV * i + j], ctx->prof_ev[PROF_EV * i + j + 1]));
+      ms_sum5[j] += ms;
+      if (j == 2 && ms_fast_each && i < cap) ms_fast_each[i] = ms;
     }
   }
   *calls = k;
@@ -1281,6 +1357,19 @@ int s2k_ctx_profile_read(s2k_ctx* ctx, double* ms_sum3, double* ms_fast_each, si
       shader_mhz[j] = (c[3] > c[2] && wall_khz > 0) ? (double)(c[1] - c[0]) / (double)(c[3] - c[2]) * (wall_khz * 1e-3) : 0.0;
     }
   }
+  return S2K_OK;
+}
+
+// the three-stage view: preparation (with grouping and tables) | ladder | everything after it
+int s2k_ctx_profile_read(s2k_ctx* ctx, double* ms_sum3, double* ms_fast_each, size_t cap, size_t* calls,
+                         double* shader_mhz) {
+  if (!ctx || !ms_sum3 || !calls) return fail(ctx, S2K_ERR_ARG, "null argument");
+  double s5[5];
+  int rc = s2k_ctx_profile_read_stages(ctx, s5, ms_fast_each, cap, calls, shader_mhz);
+  if (rc) return rc;
+  ms_sum3[0] = s5[0] + s5[1];
+  ms_sum3[1] = s5[2];
+  ms_sum3[2] = s5[3] + s5[4];
   return S2K_OK;
 }
 
@@ -1299,6 +1388,8 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   const size_t stride = lane_stride(n);
   uint32_t* ws = (uint32_t*)ctx->ws;
   uint32_t* qt = ws + WS_QT * stride;
+  ctx->kg_counters = nullptr;
+  ctx->last_wl_count = nullptr;
   if (flags & S2K_ECDSA_FORCE_COMPLETE) {
     k_ecdsa_verify<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                                   (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
@@ -1308,28 +1399,115 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   }
   uint32_t* fin = ws + WS_FIN * stride;
   uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* gp = ws + WS_GP * stride;
   uint32_t* pref = ws + WS_PREF * stride;
   uint32_t* smont = ws + WS_SMONT * stride;
   uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
   uint32_t* wl = wl_count + 64;
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
+  const bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  ctx->last_wl_count = wl_count;
   prof_mark(ctx, st, 0);
-  k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
-                                              (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
-  HIP_TRY(ctx, hipGetLastError());
-  prof_mark(ctx, st, 1);
-  k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
-                                               ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr,
-                                               ctx->prof_on ? ctx->clk : nullptr);
-  HIP_TRY(ctx, hipGetLastError());
-  prof_mark(ctx, st, 2);
+  if (grouped) {
+    // Signatures of keys that occur often enough: per-key tables (keyed.hip) and the short ladder; the
+    // rest: the general kernel over the list `left`.  Scalar preparation and the generator part u1*G have
+    // nothing to do with the keys and run on a second stream beside the grouping and table kernels, which
+    // are short of work for the multipliers on their own (the doubling chain of the tables is one lane per
+    // KEY, the scaling pass is memory bound).  Stage times (s2k_ctx_profile_read_stages): [0] grouping,
+    // [1] tables and whatever is left of the second stream's work.
+    if (!ctx->s_aux) {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+    k_scalar_prep<<<(T + 63) / 64, 64, 0, ctx->s_aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                        (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    // the generator part in two pieces: the first beside the tables' doubling chain (latency bound), the
+    // second once k_key_odd (which does keep the multipliers busy) is through, beside the inversion and
+    // the memory-bound scaling pass
+    const uint32_t n_first = (uint32_t)((n * (size_t)ctx->gp_first_percent / 100) & ~(size_t)255);
+    if (n_first) {
+      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gtable, gp, stride);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    key_groups kg;
+    rc = s2k_internal_key_group(ctx, n, (const uint8_t*)d_pub, st, &kg);
+    if (rc) return rc;
+    kg.gp = gp;
+    prof_mark(ctx, st, 1);
+    rc = s2k_internal_key_tables(ctx, (const uint8_t*)d_pub, st, &kg, ctx->ev_mid);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
+    if (n_first < n) {
+      k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gtable, gp, stride);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->s_aux));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    prof_mark(ctx, st, 2);
+    k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+                                                                   qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
+                                                                   stride, nullptr, clk, kg);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    k_verify_fast<MODE_ECDSA_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+                                                                  qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
+                                                                  stride, nullptr, nullptr, kg);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 4);
+  } else {
+    k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
+                                                             ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk,
+                                                             key_groups{});
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    prof_mark(ctx, st, 4);
+  }
   k_verify_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                         ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
-  prof_mark(ctx, st, 3);
+  prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
+}
+
+int s2k_ctx_set_key_grouping(s2k_ctx* ctx, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (mode != S2K_KEYS_OFF && mode != S2K_KEYS_AUTO && mode != S2K_KEYS_ALWAYS)
+    return fail(ctx, S2K_ERR_ARG, "key grouping mode %d", mode);
+  if (hash_bits > 30) return fail(ctx, S2K_ERR_ARG, "hash_bits %u > 30", hash_bits);
+  ctx->kg_mode = mode;
+  ctx->kg_min_group = min_group;
+  ctx->kg_hash_bits = hash_bits;
+  ctx->kg_max_tables = max_tables ? max_tables : (1u << 18);
+  return S2K_OK;
+}
+
+int s2k_ctx_key_grouping_stats(s2k_ctx* ctx, uint32_t* stats) {
+  if (!ctx || !stats) return fail(ctx, S2K_ERR_ARG, "null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  if (ctx->kg_counters) {
+    uint32_t c[KG_COUNTERS];
+    HIP_TRY(ctx, hipMemcpy(c, ctx->kg_counters, sizeof c, hipMemcpyDeviceToHost));
+    stats[0] = c[KG_NKEYED];
+    stats[1] = c[KG_NTAB];
+    stats[2] = c[KG_NLEFT];
+  }
+  if (ctx->last_wl_count) HIP_TRY(ctx, hipMemcpy(&stats[3], ctx->last_wl_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return S2K_OK;
 }
 
 int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, const void* d_r, const void* d_s,
@@ -1366,7 +1544,8 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, ctx->gtable,
-                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, nullptr);
+                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, nullptr,
+                                                             key_groups{});
   HIP_TRY(ctx, hipGetLastError());
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
@@ -1444,7 +1623,8 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
-                                                             (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr);
+                                                             (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr,
+                                                             key_groups{});
   HIP_TRY(ctx, hipGetLastError());
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
@@ -1481,9 +1661,12 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   // chunks are whole rounds of the ladder kernel; the first one is a single round, because its copy is
   // the only one nothing hides (63 -> 31 MB up front at 256 CUs), the others two rounds
   const bool chunked = n > 3 * round;                      // small batches: one shot
+  // with key grouping on, every chunk groups (and builds tables) on its own, so fewer and larger chunks:
+  // two halves, the second copy hidden behind the first half's kernels
+  const bool halves = chunked && ctx->kg_mode != S2K_KEYS_OFF;
   int k = 0;
   for (size_t lo = 0, chunk = 0; lo < n; lo += chunk, ++k) {
-    chunk = !chunked ? n : (lo == 0 ? round : 2 * round);
+    chunk = !chunked ? n : halves ? ((n / 2 + 255) & ~(size_t)255) : (lo == 0 ? round : 2 * round);
     if (n - lo < chunk + round) chunk = n - lo;            // no launch of less than a round at the end
     const size_t cnt = chunk;
     // the event of two chunks ago has been waited on by s_comp (in stream order) before it is re-recorded
@@ -1584,7 +1767,7 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
                                               status);
     HIP_TRY(ctx, hipGetLastError());
     k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, fin, ctx->gtable,
-                                                             io + o_ok, wl_count, wl, stride, io + o_out, nullptr);
+                                                             io + o_ok, wl_count, wl, stride, io + o_out, nullptr, key_groups{});
     HIP_TRY(ctx, hipGetLastError());
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, fin, io + o_ok, stride, io + o_out);

@@ -60,4 +60,19 @@ S2K_DEV jpt29 jpt29_add_affine(const jpt29& p, const fe29& bx, const fe29& by, f
   return r;
 }
 
+// P + Q, both Jacobian.  (X2, Y2) is an affine point of the curve isomorphic by Z2 (neither formula here
+// contains the curve constant), on which P reads (X1 Z2^2, Y1 Z2^3, Z1): one mixed addition there, and
+// the result's Z times Z2 is back on secp256k1.  12 M + 4 S.  Z1 = 0 or Z2 = 0 gives Z3 = 0.
+S2K_DEV jpt29 jpt29_add(const jpt29& p, const jpt29& q) {
+  fe29 zz = fe29_sqr(q.z);                                       // [1]
+  fe29 zzz = fe29_mul(zz, q.z);                                  // [1]
+  jpt29 a;
+  a.x = fe29_mul(p.x, zz);                                       // [1]
+  a.y = fe29_mul(p.y, zzz);                                      // [2]*[1] -> [1]
+  a.z = p.z;
+  jpt29 r = jpt29_add_affine(a, q.x, q.y);
+  r.z = fe29_mul(r.z, q.z);
+  return r;
+}
+
 }  // namespace s2k

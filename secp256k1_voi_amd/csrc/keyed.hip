@@ -1,0 +1,425 @@
+// keyed.hip — signatures that share public keys: grouping by key and the per-key tables.
+//
+// The reference's verify (secec/ecdsa.go:392-470) computes u1*G + u2*Q from Q alone every time
+// (DoubleScalarMultBasepointVartime, point_mul_glv.go:307): a table of Q's small multiples, then 128
+// doublings interleaved with the table additions.  When a batch holds several signatures of one
+// key, the doublings can be done once per KEY instead: with 2^(16c) Q (c = 0..7) at hand, the 32
+// signed 4-bit digits of a half scalar are consumed four rounds of eight, 12 doublings in all.
+// This file does what has to happen before that ladder (k_verify_fast<MODE_ECDSA_KEYED>, engine.hip):
+//
+//   k_key_insert   one lane per signature: its key goes into an open-addressing hash table whose
+//                  slots hold the index of the first signature seen with that key; a hit compares
+//                  all 64 key bytes, so a group is exactly the set of signatures with identical key
+//                  bytes (whatever the hash does), and the lane takes a rank inside its group
+//   k_key_alloc    over the slots: groups of at least `min_group` signatures get a table index and
+//                  a contiguous range of keyed lanes (one atomic per workgroup and counter, no scan)
+//   k_key_place    one lane per signature: writes itself into its group's range (perm / ptab) or
+//                  appends itself to the list of the general kernel (left)
+//   k_key_chain / k_key_odd / k_key_invert / k_key_scale   the tables: key validation as NewPublicKey
+//                  (secec.go:188-216, point_s11n.go:298-307), the chain of 116 doublings per key, the eight
+//                  8-entry tables of odd multiples, ONE inversion for the key's 65 points, beta*x column
+//
+// Nothing here touches the host between the launches; the counts stay on the device and the
+// ladder kernels read them.
+#include <hip/hip_runtime.h>
+
+#include "engine_internal.h"
+#include "jacobian29.h"
+#include "lane_tables.h"
+
+namespace {
+
+// Every thread of the (256-thread) workgroup calls this, threads with nothing to take with want = 0;
+// returns the start of this thread's range in what the workgroup took from *counter with ONE atomic
+// (same-address atomics cost ~12 ns each on MI355X: one per wave made k_key_alloc 0.65 ms).
+S2K_DEV uint32_t block_alloc(uint32_t* counter, uint32_t want, uint32_t* sh /* 8 words of LDS */) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t incl = want;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t v = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += v;
+  }
+  if (lane == 63u) sh[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = sh[0] + sh[1] + sh[2] + sh[3];
+    sh[4] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t off = sh[4];
+  for (uint32_t w = 0; w < wave; ++w) off += sh[w];
+  __syncthreads();
+  return off + incl - want;
+}
+
+S2K_DEV uint32_t mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
+}
+
+constexpr uint32_t KG_MAX_PROBES = 64;
+
+// slot_of[i]: the hash slot = group of signature i (KG_NONE: probe chain too long, general kernel);
+// pos_of[i]: its rank in the group.  rep[] starts as KG_NONE, cnt[] as 0.
+__global__ void __launch_bounds__(256)
+k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32_t seed, uint32_t* __restrict__ rep,
+             uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ pos_of) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4* k = reinterpret_cast<const uint4*>(pub + (size_t)i * 64);
+  const uint4 k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+  uint32_t h = seed;
+  h = mix32(h ^ k0.x) + k0.y;
+  h = mix32(h ^ k0.z) + k0.w;
+  h = mix32(h ^ k1.x) + k1.y;
+  h = mix32(h ^ k1.z) + k1.w;
+  h = mix32(h ^ k3.z) + k3.w;   // the low words of y tell a key from its negative
+  uint32_t s = mix32(h) & hmask;
+  uint32_t found = KG_NONE;
+#pragma unroll 1
+  for (uint32_t probe = 0; probe < KG_MAX_PROBES; ++probe) {
+    uint32_t old = atomicCAS(&rep[s], KG_NONE, i);
+    if (old == KG_NONE) {
+      found = s;
+      break;
+    }
+    const uint4* o = reinterpret_cast<const uint4*>(pub + (size_t)old * 64);
+    const uint4 o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+    uint32_t diff = (o0.x ^ k0.x) | (o0.y ^ k0.y) | (o0.z ^ k0.z) | (o0.w ^ k0.w) | (o1.x ^ k1.x) | (o1.y ^ k1.y) |
+                    (o1.z ^ k1.z) | (o1.w ^ k1.w) | (o2.x ^ k2.x) | (o2.y ^ k2.y) | (o2.z ^ k2.z) | (o2.w ^ k2.w) |
+                    (o3.x ^ k3.x) | (o3.y ^ k3.y) | (o3.z ^ k3.z) | (o3.w ^ k3.w);
+    if (diff == 0) {
+      found = s;
+      break;
+    }
+    s = (s + 1) & hmask;
+  }
+  slot_of[i] = found;
+  pos_of[i] = found != KG_NONE ? atomicAdd(&cnt[found], 1u) : 0u;
+}
+
+// Each workgroup takes ALLOC_ITEMS * 256 slots (PLACE_ITEMS * 256 signatures), strided by 256 per thread.
+constexpr int ALLOC_ITEMS = 16, PLACE_ITEMS = 4;
+
+__global__ void __launch_bounds__(256)
+k_key_alloc(uint32_t slots, uint32_t min_group, uint32_t max_tables, const uint32_t* __restrict__ rep,
+            const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base, uint32_t* __restrict__ tix,
+            uint32_t* __restrict__ trep, uint32_t* __restrict__ counters) {
+  __shared__ uint32_t sh[8];
+  const uint32_t s0 = blockIdx.x * (256 * ALLOC_ITEMS) + threadIdx.x;
+  uint32_t c[ALLOC_ITEMS];
+  uint32_t ntab = 0;
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    const uint32_t s = s0 + k * 256;
+    c[k] = s < slots ? cnt[s] : 0u;
+    if (c[k] < min_group) c[k] = 0;          // (min_group >= 1: empty slots drop out too)
+    ntab += c[k] ? 1u : 0u;
+  }
+  uint32_t t = block_alloc(&counters[KG_NTAB], ntab, sh);
+  uint32_t nsig = 0;
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    if (!c[k]) continue;
+    if (t >= max_tables) c[k] = 0;           // out of tables (the counter itself is clamped by its readers)
+    nsig += c[k];
+    ++t;
+  }
+  t -= ntab;
+  uint32_t b = block_alloc(&counters[KG_NKEYED], nsig, sh);
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    const uint32_t s = s0 + k * 256;
+    if (s >= slots) continue;
+    const bool had = cnt[s] >= min_group && cnt[s] > 0;
+    if (c[k]) {
+      base[s] = b;
+      tix[s] = t;
+      trep[t] = rep[s];
+      b += c[k];
+    } else {
+      tix[s] = KG_NONE;
+    }
+    if (had) ++t;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ pos_of,
+            const uint32_t* __restrict__ base, const uint32_t* __restrict__ tix, uint32_t* __restrict__ perm,
+            uint32_t* __restrict__ ptab, uint32_t* __restrict__ left, uint32_t* __restrict__ counters) {
+  __shared__ uint32_t sh[8];
+  const uint32_t i0 = blockIdx.x * (256 * PLACE_ITEMS) + threadIdx.x;
+  uint32_t t[PLACE_ITEMS];
+  uint32_t nleft = 0;
+#pragma unroll
+  for (int k = 0; k < PLACE_ITEMS; ++k) {
+    const uint32_t i = i0 + k * 256;
+    t[k] = KG_NONE;
+    if (i < n) {
+      const uint32_t s = slot_of[i];
+      if (s != KG_NONE) t[k] = tix[s];
+      if (t[k] == KG_NONE) ++nleft;
+      else {
+        const uint32_t p = base[s] + pos_of[i];
+        perm[p] = i;
+        ptab[p] = t[k];
+      }
+    }
+  }
+  uint32_t q = block_alloc(&counters[KG_NLEFT], nleft, sh);
+#pragma unroll
+  for (int k = 0; k < PLACE_ITEMS; ++k) {
+    const uint32_t i = i0 + k * 256;
+    if (i < n && t[k] == KG_NONE) left[q++] = i;
+  }
+}
+
+// ---- per-key tables ----
+// Entry layout: lane_tables.h (x, y, beta*x in eight quads).  Entries 8c + j (c < 8, j < 8) hold
+// (2j + 1) * 2^(16c) Q, entry 64 holds 2^116 Q.  Four launches (only the first is a serial chain per key;
+// one lane doing everything took 1.5 ms for 2^16 keys, latency bound at one wave per SIMD):
+//   k_key_chain  lane per key: key validation, doubling chain from Q; the Jacobian 2^(16c) Q (c = 1..7)
+//                and 2^116 Q are parked in the entries 8c and 64 (X, Y, and Z in the beta*x slot)
+//   k_key_odd    lane per (key, chunk): the common-Z table of odd multiples exactly as k_verify_fast
+//                builds its per-signature table, started from the base's JACOBIAN X, Y as if they were
+//                affine: neither the doubling nor the addition formula contains the curve constant b,
+//                so this computes on the curve isomorphic by the base's Z, and the chunk's points end
+//                up with the common Z_total = Z_7 * C * Z_base (scratch slot c)
+//   k_key_invert lane per key: the nine Z_total (eight chunks and the lead point) inverted together
+//                (Montgomery's trick, prefix products in scratch slots 9..16); the lead point made affine
+//   k_key_scale  lane per (key, chunk): the scaling pass of k_key_odd's table starts from 1 / Z_total
+//                instead of 1: the points come out affine on secp256k1 itself; beta*x column
+// Cost per key: 116 doublings, 8 * (1 doubling + 7 additions), 1 inversion, ~7 products per point.
+constexpr int KT_SCR = KT_ENTRIES;   // first scratch entry
+S2K_DEV uint4* kt_scratch(uint4* kt, int slot, int& which) {   // 21 field elements in the 7 scratch entries
+  which = slot % 3;
+  return kt + (size_t)(KT_SCR + slot / 3) * 8;
+}
+S2K_DEV void scr_store(uint4* kt, int slot, const fe29& v) {
+  int which;
+  uint4* e = kt_scratch(kt, slot, which);
+  ke_store(e, which, v);
+}
+S2K_DEV fe29 scr_load(uint4* kt, int slot) {
+  int which;
+  uint4* e = kt_scratch(kt, slot, which);
+  return ke_load(e, which);
+}
+S2K_DEV uint32_t table_count(const uint32_t* __restrict__ counters, uint32_t max_tables) {
+  uint32_t ntab = counters[KG_NTAB];
+  return ntab > max_tables ? max_tables : ntab;
+}
+
+__global__ void __launch_bounds__(64)
+k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const uint32_t* __restrict__ trep,
+            const uint8_t* __restrict__ pub, uint4* __restrict__ ktab, uint8_t* __restrict__ tinfo) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= table_count(counters, max_tables)) return;
+  const size_t sig = trep[t];
+  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+
+  // NewPublicKey: canonical coordinates, on the curve (the identity has no 64-byte encoding)
+  apt q;
+  load_be32(q.x.v, pub + sig * 64);
+  load_be32(q.y.v, pub + sig * 64 + 32);
+  bool ok = fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
+  if (!ok) {
+    q.x = fe_from_limbs(FE_GX);
+    q.y = fe_from_limbs(FE_GY);
+  }
+  fe29 qx = fe29_from_words(q.x.v), qy = fe29_from_words(q.y.v);
+  {
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
+    rhs.n[0] += 7;
+    if (!fe29_eq(fe29_sqr(qy), rhs)) {
+      ok = false;
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
+    }
+  }
+  tinfo[t] = ok ? 1 : 0;
+
+  jpt29 cur;
+  cur.x = qx;
+  cur.y = qy;
+  cur.z = fe29_one();
+  ke_store(kt, TB_X, cur.x);
+  ke_store(kt, TB_Y, cur.y);
+  ke_store(kt, TB_BX, cur.z);
+#pragma unroll 1
+  for (int c = 1; c <= KT_CHUNKS; ++c) {
+    const int nd = c < KT_CHUNKS ? 16 : 4;
+#pragma unroll 1
+    for (int j = 0; j < nd; ++j) cur = jpt29_double(cur);
+    uint4* e = kt + (size_t)(c * 8) * 8;     // c == 8: the lead entry
+    ke_store(e, TB_X, cur.x);
+    ke_store(e, TB_Y, cur.y);
+    ke_store(e, TB_BX, cur.z);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __restrict__ ktab) {
+  uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t t = id / KT_CHUNKS, c = id % KT_CHUNKS;
+  if (t >= table_count(counters, max_tables)) return;
+  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+  uint4* e0 = kt + (size_t)(c * 8) * 8;
+  jpt29 a0;
+  a0.x = ke_load(e0, TB_X);
+  a0.y = ke_load(e0, TB_Y);
+  a0.z = fe29_one();
+  const fe29 zb = ke_load(e0, TB_BX);
+  jpt29 d = jpt29_double(a0);
+  fe29 c2 = fe29_sqr(d.z);
+  fe29 c3 = fe29_mul(c2, d.z);
+  const fe29 dx = d.x, dy = d.y;
+  jpt29 cur;
+  cur.x = fe29_mul(a0.x, c2);
+  cur.y = fe29_mul(a0.y, c3);
+  cur.z = fe29_one();
+  ke_store(e0, TB_X, cur.x);
+  ke_store(e0, TB_Y, cur.y);
+#pragma unroll 1
+  for (int j = 1; j < 8; ++j) {
+    fe29 h;
+    cur = jpt29_add_affine(cur, dx, dy, &h);
+    ke_store3(e0 + (size_t)j * 8, cur.x, cur.y, h);
+  }
+  scr_store(kt, (int)c, fe29_mul(fe29_mul(cur.z, d.z), zb));
+}
+
+__global__ void __launch_bounds__(64)
+k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __restrict__ ktab) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= table_count(counters, max_tables)) return;
+  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+  fe29 prefix = scr_load(kt, 0);
+  scr_store(kt, 9, prefix);
+#pragma unroll 1
+  for (int c = 1; c < KT_CHUNKS; ++c) {
+    prefix = fe29_mul(prefix, scr_load(kt, c));
+    scr_store(kt, 9 + c, prefix);
+  }
+  uint4* el = kt + (size_t)KT_LEAD * 8;
+  const fe29 zl = ke_load(el, TB_BX);
+  fe29 inv = fe29_inv(fe29_mul(prefix, zl));
+  {
+    fe29 zi = fe29_mul(inv, prefix);
+    inv = fe29_mul(inv, zl);
+    fe29 zi2 = fe29_sqr(zi);
+    fe29 x = fe29_mul(ke_load(el, TB_X), zi2);
+    fe29 y = fe29_mul(fe29_mul(ke_load(el, TB_Y), zi2), zi);
+    ke_store(el, TB_X, x);
+    ke_store(el, TB_Y, y);
+    ke_store(el, TB_BX, fe29_mul(x, fe29_from_words(FE_BETA)));
+  }
+#pragma unroll 1
+  for (int c = KT_CHUNKS - 1; c >= 0; --c) {
+    fe29 zi = c > 0 ? fe29_mul(inv, scr_load(kt, 9 + c - 1)) : inv;   // 1 / Z_total of chunk c
+    if (c > 0) inv = fe29_mul(inv, scr_load(kt, c));
+    scr_store(kt, c, zi);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __restrict__ ktab) {
+  uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t t = id / KT_CHUNKS, c = id % KT_CHUNKS;
+  if (t >= table_count(counters, max_tables)) return;
+  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+  uint4* e0 = kt + (size_t)(c * 8) * 8;
+  const fe29 beta = fe29_from_words(FE_BETA);
+  fe29 rr = scr_load(kt, (int)c);
+#pragma unroll 1
+  for (int j = 7; j >= 0; --j) {
+    uint4* e = e0 + (size_t)j * 8;
+    fe29 r2 = fe29_sqr(rr);
+    fe29 r3 = fe29_mul(r2, rr);
+    fe29 x = fe29_mul(ke_load(e, TB_X), r2);
+    fe29 y = fe29_mul(ke_load(e, TB_Y), r3);
+    if (j > 0) rr = fe29_mul(rr, ke_load(e, TB_BX));   // H_j: entry j - 1 sits one addition lower
+    ke_store3(e, x, y, fe29_mul(x, beta));
+  }
+}
+
+static uint32_t pow2_at_least(size_t v) {
+  uint32_t b = 0;
+  while (((size_t)1 << b) < v) ++b;
+  return b;
+}
+
+}  // namespace
+
+__attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub,
+                                                                 hipStream_t st, key_groups* out) {
+  const uint32_t min_group = ctx->kg_mode == S2K_KEYS_ALWAYS ? 1u : (ctx->kg_min_group ? ctx->kg_min_group : KG_MIN_GROUP);
+  uint32_t bits = ctx->kg_hash_bits ? ctx->kg_hash_bits : pow2_at_least(2 * n);
+  if (bits < 4) bits = 4;
+  if (bits > 30) bits = 30;
+  const size_t slots = (size_t)1 << bits;
+  size_t max_tables = n / min_group;
+  if (max_tables > ctx->kg_max_tables) max_tables = ctx->kg_max_tables;
+  if (max_tables == 0) max_tables = 1;
+  // grouping arrays: counters | rep, cnt, base, tix [slots] | slot_of, pos_of, perm, ptab, left [n] | trep [tables] | tinfo
+  const size_t np = (n + 63) & ~(size_t)63, tp = (max_tables + 63) & ~(size_t)63;
+  const size_t words = KG_COUNTERS + 4 * slots + 5 * np + tp;
+  int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t) + tp);
+  if (rc) return rc;
+  rc = ctx_reserve(ctx, &ctx->ktab, &ctx->ktab_bytes, max_tables * (size_t)KT_SLOTS * 128);
+  if (rc) return rc;
+  uint32_t* w = (uint32_t*)ctx->kg;
+  uint32_t* counters = w;
+  uint32_t* rep = w + KG_COUNTERS;
+  uint32_t* cnt = rep + slots;
+  uint32_t* base = cnt + slots;
+  uint32_t* tix = base + slots;
+  uint32_t* slot_of = tix + slots;
+  uint32_t* pos_of = slot_of + np;
+  uint32_t* perm = pos_of + np;
+  uint32_t* ptab = perm + np;
+  uint32_t* left = ptab + np;
+  uint32_t* trep = left + np;
+  uint8_t* tinfo = (uint8_t*)(trep + tp);
+  ctx->kg_counters = counters;
+  HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
+  k_key_insert<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_alloc<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, min_group, (uint32_t)max_tables, rep, cnt, base, tix, trep, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, base, tix, perm, ptab, left, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  out->counters = counters;
+  out->perm = perm;
+  out->ptab = ptab;
+  out->left = left;
+  out->ktab = (const uint4*)ctx->ktab;
+  out->tinfo = tinfo;
+  out->trep = trep;
+  out->max_tables = (uint32_t)max_tables;
+  return S2K_OK;
+}
+
+__attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st,
+                                                                  const key_groups* g, hipEvent_t ev_after_odd) {
+  uint4* ktab = (uint4*)ctx->ktab;
+  const size_t max_tables = g->max_tables;
+  k_key_chain<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, ktab);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
+  k_key_invert<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, ktab);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, ktab);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}

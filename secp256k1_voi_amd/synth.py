@@ -18,9 +18,10 @@ def be_gt(a, b):
     return anyd & (a[rows, first] > b[first])
 
 
-def synth_batch(eng, n, n_keys, seed):
+def synth_batch(eng, n, n_keys, seed, key_idx=None):
     """Valid low-s ECDSA signatures built with the engine's own batched primitives
-    (scalar_base_mult, Fn inverse/mul/add); returns uint8 arrays pub (n,64), digest, r, s."""
+    (scalar_base_mult, Fn inverse/mul/add); returns uint8 arrays pub (n,64), digest, r, s.
+    Signature i is made with key key_idx[i] (default i mod n_keys)."""
     rng = np.random.default_rng(seed)
 
     def rand_scalars(m):
@@ -31,7 +32,7 @@ def synth_batch(eng, n, n_keys, seed):
 
     d = rand_scalars(n_keys)
     Q = eng.scalar_base_mult_batch(d)[:, 1:]
-    key_idx = np.arange(n) % n_keys
+    key_idx = np.arange(n) % n_keys if key_idx is None else np.asarray(key_idx)
     k = rand_scalars(n)
     digest = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     Rp = eng.scalar_base_mult_batch(k)

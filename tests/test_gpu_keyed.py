@@ -1,0 +1,230 @@
+"""Signatures that share public keys (keyed.hip, k_verify_fast<MODE_ECDSA_KEYED>): the verdicts must not
+depend on how the batch is grouped.  Every case runs the same inputs with grouping off, automatic and
+forced, compares all three with the CPU oracle (the reference's algorithm, oracle/), and checks through
+s2k_ctx_key_grouping_stats that the path under test actually ran."""
+import os
+
+import numpy as np
+import pytest
+
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+P_FIELD = 2**256 - 2**32 - 977
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.init()
+    import secp256k1_voi_amd as S
+    e = S.Engine(0)
+    yield e
+    e.set_key_grouping(S.KEYS_AUTO)
+
+
+def _device_run(eng, pub, dig, r, s, flags=0):
+    import torch
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (pub, dig, r, s)]
+    out = torch.empty(len(pub), dtype=torch.uint8, device=dev)
+    eng.ecdsa_verify_batch_device(len(pub), *(x.data_ptr() for x in t), out.data_ptr(), flags=flags)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), eng.key_grouping_stats()
+
+
+def _ragged_batch(eng, seed, sizes):
+    """Signatures of len(sizes) keys, key j signing sizes[j] of them, shuffled."""
+    from secp256k1_voi_amd.synth import synth_batch
+    key_idx = np.random.default_rng(seed).permutation(np.repeat(np.arange(len(sizes)), sizes))
+    return synth_batch(eng, len(key_idx), len(sizes), seed=seed, key_idx=key_idx)
+
+
+def _damage(pub, dig, r, s, seed):
+    from secp256k1_voi_amd.synth import N_ORDER
+    n = len(pub)
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 24, size=n)
+    idx = lambda k: np.nonzero(kind == k)[0]
+    i = idx(0); r[i, rng.integers(0, 32, size=i.size)] ^= (1 << rng.integers(0, 8, size=i.size)).astype(np.uint8)
+    i = idx(1); s[i, rng.integers(0, 32, size=i.size)] ^= (1 << rng.integers(0, 8, size=i.size)).astype(np.uint8)
+    i = idx(2); dig[i, rng.integers(0, 32, size=i.size)] ^= (1 << rng.integers(0, 8, size=i.size)).astype(np.uint8)
+    i = idx(3); r[i] = 0
+    i = idx(4); s[i] = 0
+    i = idx(5); r[i] = np.frombuffer(N_ORDER.to_bytes(32, "big"), np.uint8)
+    i = idx(6); pub[i] = pub[(i + 1) % n]                      # somebody else's key
+    return kind
+
+
+def _check_all_modes(eng, oracle, pub, dig, r, s, expect_keyed=None, **grouping):
+    import secp256k1_voi_amd as S
+    exp = oracle.ecdsa_verify_batch(pub, dig, r, s, nthreads=os.cpu_count() or 1)
+    n = len(pub)
+    eng.set_key_grouping(S.KEYS_OFF)
+    got, st = _device_run(eng, pub, dig, r, s)
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
+    assert st["keyed"] == 0 and st["tables"] == 0
+    eng.set_key_grouping(S.KEYS_AUTO, **grouping)
+    got, st_auto = _device_run(eng, pub, dig, r, s)
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
+    assert st_auto["keyed"] + st_auto["general"] == n
+    if expect_keyed is not None:
+        assert st_auto["keyed"] == expect_keyed, st_auto
+    eng.set_key_grouping(S.KEYS_ALWAYS, **{k: v for k, v in grouping.items() if k != "min_group"})
+    got, st_all = _device_run(eng, pub, dig, r, s)
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
+    assert st_all["keyed"] + st_all["general"] == n
+    eng.set_key_grouping(S.KEYS_AUTO)
+    return exp, st_auto, st_all
+
+
+def test_ragged_groups_match_oracle(eng, oracle):
+    """Keys with 1 .. 70 signatures each, shuffled, a quarter of the signatures damaged: identical verdicts
+    with grouping off / automatic / forced; automatic grouping puts exactly the groups of >= 6 (the default
+    threshold), or of >= 3 when asked, on the tables."""
+    sizes = np.array([1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 15, 16, 17, 33, 64, 70] * 6 + [1] * 100)
+    pub, dig, r, s = _ragged_batch(eng, 11, sizes)
+    _damage(pub, dig, r, s, 12)
+    # damage kind 6 copies other keys around, so recount the groups from the bytes
+    _, counts = np.unique(pub, axis=0, return_counts=True)
+    exp, st_auto, st_all = _check_all_modes(eng, oracle, pub, dig, r, s, expect_keyed=int(counts[counts >= 6].sum()))
+    assert st_auto["tables"] == int((counts >= 6).sum())
+    _, st3, _ = _check_all_modes(eng, oracle, pub, dig, r, s, expect_keyed=int(counts[counts >= 3].sum()), min_group=3)
+    assert st3["tables"] == int((counts >= 3).sum())
+    assert st_all["keyed"] == len(pub) and st_all["tables"] == len(counts)
+    assert 0 < exp.sum() < len(pub)
+
+
+def test_invalid_keys_in_groups(eng, oracle):
+    """Groups whose key is not a public key (off the curve, coordinate >= p, all zero): every member is
+    rejected, exactly as NewPublicKey would refuse the key (secec.go:188-216), on the table path too."""
+    sizes = np.array([8] * 40 + [1] * 30)
+    pub, dig, r, s = _ragged_batch(eng, 21, sizes)
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    bad_off = inv == 0
+    pub[bad_off, 63] ^= 1                                         # y off the curve
+    big = np.frombuffer((P_FIELD + 5).to_bytes(32, "big"), np.uint8)
+    pub[inv == 1, :32] = big                                      # x >= p
+    pub[inv == 2, 32:] = np.frombuffer(P_FIELD.to_bytes(32, "big"), np.uint8)   # y = p
+    pub[inv == 3] = 0
+    # a valid point that is not the signer's: x = G.x with -G.y
+    gx = np.frombuffer(R.GX.to_bytes(32, "big"), np.uint8)
+    gyn = np.frombuffer((P_FIELD - R.GY).to_bytes(32, "big"), np.uint8)
+    pub[inv == 4, :32] = gx
+    pub[inv == 4, 32:] = gyn
+    exp, st_auto, _ = _check_all_modes(eng, oracle, pub, dig, r, s)
+    for k in range(5):
+        assert exp[inv == k].sum() == 0
+    assert exp[inv >= 5].all()
+    assert st_auto["keyed"] >= 8 * 35
+
+
+def test_hash_table_pressure(eng, oracle):
+    """The grouping must stay exact whatever the hash table does: 64 slots for 600 keys (probe chains hit their
+    limit, those signatures take the general kernel), 1024 slots (long chains), and a cap of 5 tables."""
+    sizes = np.array([8] * 500 + [1] * 100)
+    pub, dig, r, s = _ragged_batch(eng, 31, sizes)
+    _damage(pub, dig, r, s, 32)
+    _, st, _ = _check_all_modes(eng, oracle, pub, dig, r, s, hash_bits=6)
+    assert 0 < st["keyed"] <= 64 * 12 and st["general"] > 0
+    _, st, _ = _check_all_modes(eng, oracle, pub, dig, r, s, hash_bits=10)
+    assert st["keyed"] > 3000
+    _, st, st_all = _check_all_modes(eng, oracle, pub, dig, r, s, max_tables=5)
+    assert st["tables"] >= 5 and 0 < st["keyed"] <= 5 * 12
+    assert 0 < st_all["keyed"] <= 5 * 12
+
+
+def test_exceptional_ladders_with_shared_keys(eng, oracle):
+    """Signatures built so that the incomplete formulas break down (synth_all_fallback_batch), many per key:
+    the table ladder must notice (Z = 0) and hand every one of them to the complete kernel."""
+    from secp256k1_voi_amd.synth import synth_all_fallback_batch
+    n = 4096
+    pub, e, r, s = synth_all_fallback_batch(eng, n, 64, seed=41)
+    exp, st_auto, _ = _check_all_modes(eng, oracle, pub, e, r, s, expect_keyed=n)
+    assert st_auto["complete"] == n
+    assert not exp.any()                                          # R = infinity: the reference says false
+
+
+def test_chosen_scalars_on_tables(eng, oracle):
+    """VALID signatures with chosen u2 = r/s (and random u1): for a key with known d, R = (u1 + u2 d) G,
+    r = x(R) mod n, s = r / u2, e = u1 s.  The u2 are the values around which a windowed ladder over
+    2^(16c) Q has its corner cases: tiny values, powers of two at the chunk borders, lambda and its
+    neighbours (one GLV half collapses), n - small.  Whatever happens inside the ladder (an addition
+    that degenerates sends the lane to the complete kernel), every signature must verify."""
+    from secp256k1_voi_amd.synth import N_ORDER
+    n_keys, per_key = 8, 64
+    rng = np.random.default_rng(81)
+    lam = R.LAMBDA
+    base = [1, 2, 3, 15, 16, 17, 255, 2**16 - 1, 2**16, 2**16 + 1, 2**32, 2**48 + 2**16, 2**64, 2**112, 2**116, 2**116 + 1,
+            2**127, 2**128 - 1, 2**128, 2**128 + 1, 2**129, lam, lam + 1, lam - 1, 2 * lam % N_ORDER, (lam * 2**16) % N_ORDER,
+            (lam + 2**16) % N_ORDER, N_ORDER - lam, N_ORDER - 1, N_ORDER - 2, N_ORDER - 2**16, (N_ORDER - 1) // 2, (N_ORDER + 1) // 2,
+            (1 + lam) * 2**116 % N_ORDER, sum(2**(16 * c) for c in range(8)), sum(15 * 2**(4 * i + 1) for i in range(32)) + 1]
+    u2 = [base[i % len(base)] if i % 2 == 0 else (base[(i // 2) % len(base)] * int(rng.integers(1, 1 << 20)) + int(rng.integers(0, 3))) % N_ORDER or 1
+          for i in range(n_keys * per_key)]
+    d = [int.from_bytes(rng.bytes(32), "big") % (N_ORDER - 1) + 1 for _ in range(n_keys)]
+    u1 = [int.from_bytes(rng.bytes(32), "big") % N_ORDER for _ in u2]
+    key = [i % n_keys for i in range(len(u2))]
+    kR = [(a + b * d[k]) % N_ORDER or 1 for a, b, k in zip(u1, u2, key)]
+    as_rows = lambda v: np.frombuffer(b"".join(int(x).to_bytes(32, "big") for x in v), np.uint8).reshape(-1, 32).copy()
+    Rp = eng.scalar_base_mult_batch(as_rows(kR))
+    Q = eng.scalar_base_mult_batch(as_rows(d))[:, 1:]
+    rr = [int.from_bytes(bytes(Rp[i, 1:33]), "big") % N_ORDER for i in range(len(u2))]
+    ss = [x * pow(b, -1, N_ORDER) % N_ORDER for x, b in zip(rr, u2)]
+    ee = [a * x % N_ORDER for a, x in zip(u1, ss)]
+    pub = np.ascontiguousarray(Q[key])
+    exp, st_auto, _ = _check_all_modes(eng, oracle, pub, as_rows(ee), as_rows(rr), as_rows(ss), expect_keyed=len(u2))
+    fixed = [i for i in range(len(u2)) if (u1[i] + u2[i] * d[key[i]]) % N_ORDER]
+    assert exp[fixed].all()
+
+
+def test_small_and_odd_batches(eng, oracle):
+    """Batch sizes around the wave / workgroup / grouping thresholds, one key for everything."""
+    from secp256k1_voi_amd.synth import synth_batch
+    import secp256k1_voi_amd as S
+    pub, dig, r, s = synth_batch(eng, 1500, 1, seed=51)
+    r[::7, 5] ^= 1
+    exp = oracle.ecdsa_verify_batch(pub, dig, r, s, nthreads=os.cpu_count() or 1)
+    eng.set_key_grouping(S.KEYS_AUTO)
+    for n in (1, 63, 255, 256, 257, 511, 1025, 1500):
+        got, st = _device_run(eng, pub[:n], dig[:n], r[:n], s[:n])
+        assert np.array_equal(got, exp[:n]), n
+        assert st["keyed"] == (n if n >= 256 else 0), (n, st)
+        assert st["tables"] == (1 if n >= 256 else 0)
+
+
+def test_reject_malleable_on_tables(eng, oracle):
+    from secp256k1_voi_amd.synth import N_ORDER, synth_batch
+    import secp256k1_voi_amd as S
+    n = 2048
+    pub, dig, r, s = synth_batch(eng, n, 16, seed=61)
+    flip = np.arange(n) % 3 == 0                                  # s -> n - s
+    for i in np.nonzero(flip)[0]:
+        s[i] = np.frombuffer((N_ORDER - int.from_bytes(bytes(s[i]), "big")).to_bytes(32, "big"), np.uint8)
+    eng.set_key_grouping(S.KEYS_AUTO)
+    for rm in (False, True):
+        exp = oracle.ecdsa_verify_batch(pub, dig, r, s, reject_malleable=rm, nthreads=os.cpu_count() or 1)
+        got, st = _device_run(eng, pub, dig, r, s, flags=S.REJECT_MALLEABLE if rm else 0)
+        assert np.array_equal(got, exp)
+        assert st["keyed"] == n
+    assert exp.sum() == n - flip.sum()
+
+
+def test_full_size_tables_vs_general(eng):
+    """2^20 signatures of 2^16 keys (the bench's workload) with seeded damage: the table path and the general
+    path give the same 2^20 verdicts (the general path is compared with the oracle at this size in
+    test_gpu_round2.test_full_size_differential_vs_oracle, which since the grouping is on by default also
+    exercises the tables)."""
+    from secp256k1_voi_amd.synth import synth_batch
+    import secp256k1_voi_amd as S
+    n = 1 << 20
+    pub, dig, r, s = synth_batch(eng, n, 1 << 16, seed=71)
+    kind = _damage(pub, dig, r, s, 72)
+    eng.set_key_grouping(S.KEYS_OFF)
+    a, st0 = _device_run(eng, pub, dig, r, s)
+    eng.set_key_grouping(S.KEYS_AUTO)
+    b, st1 = _device_run(eng, pub, dig, r, s)
+    assert np.array_equal(a, b)
+    assert st0["keyed"] == 0 and st1["keyed"] > n * 0.9 and st1["tables"] >= (1 << 16) * 0.99
+    assert a[kind >= 7].all() and a[kind <= 5].sum() == 0

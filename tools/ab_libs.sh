@@ -12,7 +12,7 @@ for v in "$@"; do
   echo "[$v] $T"
   case "$T" in *failed*|*error*|"") echo "[$v] parity failed: variant skipped"; continue;; esac
   for rep in 1 2 3; do
-    timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --no-extras 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('[$v]', 'ms_per_step=%.3f kernel_ms=%.3f median=%.3f clock=%.0f prep=%.3f build=%s' % (d['ms_per_step'], r['kernel_ms'], r['kernel_ms_median'], r['shader_clock_mhz'], r['scalar_prep_ms'], d['config']['build']))"
+    timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --no-extras 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('[$v]', 'ms_per_step=%.3f kernel_ms=%.3f median=%.3f clock=%.0f build=%s' % (d['ms_per_step'], r['kernel_ms'], r['kernel_ms_median'], r['shader_clock_mhz'], d['config']['build']))"
   done
   (cd /tmp && export TMPDIR=/tmp && cd $REPO && \
    timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$v -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --no-extras > /dev/null 2>&1; \

@@ -7,6 +7,7 @@ python - <<'PY'
 import json
 d=json.load(open("gpurun_out/check/bench_n1.json"))
 print({k:d[k] for k in ("value","ms_per_step")}); r=d["roofline"]; print({k:r.get(k) for k in ("kernel_ms","frac","frac_at_measured_clock","shader_clock_mhz_first_wave","shader_clock_mhz_last_round")})
-for k in ("distinct_keys","worst_case_all_fallback","msm_2p20","schnorr_rlc_2p20","pcie_inclusive","extras_error"):
+print("stages", r.get("stages_ms")); print("grouping", d.get("key_grouping"))
+for k in ("general_path_same_batch","distinct_keys","worst_case_all_fallback","msm_2p20","schnorr_rlc_2p20","pcie_inclusive","extras_error"):
     print(k, d.get(k))
 PY
