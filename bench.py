@@ -322,11 +322,18 @@ def worker(args):
                 wave_instr = ipv * n / 64.0
                 cyc_avail = SIMDS * fast_ms * 1e-3 * clock_hz
                 roof["frac_at_measured_clock"] = wave_instr * 4.0 / cyc_avail
-                if st_:
+                if "mad_u64_u32_per_verify" in st_:
                     roof["mad_issue_frac_at_measured_clock"] = st_["mad_u64_u32_per_verify"] * n / 64.0 * 4.0 / cyc_avail
-            if st_:
-                roof.update({"fp_products_per_verify": st_["fp_products_per_verify"],
-                             "mad_u64_u32_per_verify": st_["mad_u64_u32_per_verify"],
+                if "valu_instr_whole_step_per_verify" in st_:
+                    # every kernel of the step (grouping, tables, preparation, generator part, ladder) against the
+                    # issue slots of the whole step
+                    roof["whole_step_issue_frac_at_measured_clock"] = (st_["valu_instr_whole_step_per_verify"] * n / 64.0 * 4.0 /
+                                                                       (SIMDS * dt / args.steps * clock_hz))
+                    roof["valu_instr_whole_step_per_verify"] = st_["valu_instr_whole_step_per_verify"]
+            if "fp_products_per_verify" in st_:
+                roof["fp_products_per_verify"] = st_["fp_products_per_verify"]
+            if "mad_u64_u32_per_verify" in st_:
+                roof.update({"mad_u64_u32_per_verify": st_["mad_u64_u32_per_verify"],
                              "mad_u64_u32_per_s": st_["mad_u64_u32_per_verify"] * n / (fast_ms * 1e-3)})
             # the guide's nominal VALU rate (one wave64 instruction per 2 cycles per SIMD) is reached by pure
             # VOP2 / f32 streams only; against it the kernel sits at half the figure above

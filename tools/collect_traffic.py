@@ -24,7 +24,9 @@ def per_kernel(dirname, counter):
         for row in csv.DictReader(open(fn)):
             if row["Counter_Name"] == counter:
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
-                name = name.split("<")[0]          # template instances (k_verify_fast<0>) share an entry
+                # ladder instances: <0> general, <4> over per-key tables, <5> general over the ungrouped rest
+                name = name.replace("k_verify_fast<4>", "k_verify_fast_keyed").replace("k_verify_fast<5>", "k_verify_fast_left")
+                name = name.split("<")[0]          # the other template instances (k_verify_fast<0>) share an entry
                 acc[name].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 

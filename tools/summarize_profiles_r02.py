@@ -18,7 +18,7 @@ TIMED = 20
 
 
 def short(name):
-    n = name.replace("void ", "").split("(")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     return n
 
 
@@ -54,20 +54,27 @@ def main():
         v = acc.get((k, c), [])
         v = v[-last:] if len(v) >= last else v
         return sum(v) / len(v) if v else None
-    fast = next((k for k in set(k for k, _ in acc) if k.startswith("k_verify_fast<0>")), None)
     res = {"source": "rocprofv3 --pmc (tools/collect_profiles_r02.sh), averages over the last %d dispatches, 2^20 signatures per dispatch" % TIMED}
-    if fast:
+    # the ladder kernels: template instance <0> = general, <4> = over per-key tables (all 2^20 lanes live in the bench)
+    for inst, key in (("k_verify_fast<0>", "k_verify_fast"), ("k_verify_fast<4>", "k_verify_fast_keyed")):
+        fast = next((k for k in set(k for k, _ in acc) if k.startswith(inst)), None)
+        if not fast:
+            continue
         valu, waves, gui = avg(fast, "SQ_INSTS_VALU"), avg(fast, "SQ_WAVES"), avg(fast, "GRBM_GUI_ACTIVE")
         sec = span[fast][-TIMED:]
         sec = sum(sec) / len(sec)
-        res["k_verify_fast"] = {"valu_instr_per_signature": valu / waves, "waves": waves,
-                                "salu_instr_per_wave": avg(fast, "SQ_INSTS_SALU") / waves, "vmem_instr_per_wave": avg(fast, "SQ_INSTS_VMEM") / waves,
-                                "grbm_gui_active": gui, "dispatch_seconds_under_pmc": sec,
-                                # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
-                                "clock_mhz_from_gui_active": gui / 8 / sec / 1e6}
-    prep = "k_scalar_prep"
-    if avg(prep, "SQ_INSTS_VALU"):
-        res["k_scalar_prep"] = {"valu_instr_per_signature": avg(prep, "SQ_INSTS_VALU") * 64 / (1 << 20)}
+        res[key] = {"valu_instr_per_signature": valu / waves, "waves": waves,
+                    "salu_instr_per_wave": avg(fast, "SQ_INSTS_SALU") / waves, "vmem_instr_per_wave": avg(fast, "SQ_INSTS_VMEM") / waves,
+                    "grbm_gui_active": gui, "dispatch_seconds_under_pmc": sec,
+                    # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
+                    "clock_mhz_from_gui_active": gui / 8 / sec / 1e6}
+    # the other kernels of a step: VALU instructions per signature of the batch (wave counts differ per kernel)
+    for k in sorted(set(k for k, _ in acc)):
+        if k.startswith("k_verify_fast") or not k.startswith("k_"):
+            continue
+        v = avg(k, "SQ_INSTS_VALU")
+        if v:
+            res[k] = {"valu_instr_per_signature": v * 64 / (1 << 20), "launches_averaged": min(TIMED, len(acc[(k, "SQ_INSTS_VALU")]))}
     json.dump(res, open(out + "/valu_counts.json", "w"), indent=1)
 
 
