@@ -328,7 +328,9 @@ enum {
   S2K_HP_MUL = 0, S2K_HP_SQR, S2K_HP_MUL_PLUS, S2K_HP_SQR_PLUS, S2K_HP_MUL_ADD_MUL, S2K_HP_MUL_ADD_SQR,
   S2K_HP_ADD, S2K_HP_NEGATE, S2K_HP_HALF, S2K_HP_NORMALIZE, S2K_HP_COND_NEGATE1, S2K_HP_INV, S2K_HP_SQRT,
   S2K_HP_EQ, S2K_HP_MUL_SMALL21, S2K_HP_NORMALIZE_WEAK, S2K_HP_JDBL, S2K_HP_JADD, S2K_HP_PT29_DBL,
-  S2K_HP_PT29_ADD, S2K_HP_PT29_ADD_MIXED
+  S2K_HP_PT29_ADD, S2K_HP_PT29_ADD_MIXED,
+  S2K_HP_INV_GCD,   /* fe29_inv_gcd: the safegcd inversion mod p of the per-key tables (same values as S2K_HP_INV) */
+  S2K_HP_JADD_FULL  /* jpt29_add: P as for JADD, Q = (d, e) lifted to Z2 = c^2 */
 };
 int s2k_fp_op_batch_ex(s2k_ctx *ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t *const in[5],
                        uint8_t *out, uint8_t *out2, uint8_t *flag);

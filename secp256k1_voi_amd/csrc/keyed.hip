@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "engine_internal.h"
+#include "fe29_inv.h"
 #include "jacobian29.h"
 #include "lane_tables.h"
 
@@ -63,6 +64,7 @@ S2K_DEV uint32_t mix32(uint32_t h) {
 }
 
 constexpr uint32_t KG_MAX_PROBES = 64;
+constexpr int KG_SHARE_ROUNDS = 4;
 
 // slot_of[i]: the hash slot = group of signature i (KG_NONE: probe chain too long, general kernel);
 // pos_of[i]: its rank in the group.  rep[] starts as KG_NONE, cnt[] as 0.
@@ -83,7 +85,11 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32
   uint32_t found = KG_NONE;
 #pragma unroll 1
   for (uint32_t probe = 0; probe < KG_MAX_PROBES; ++probe) {
-    uint32_t old = atomicCAS(&rep[s], KG_NONE, i);
+    // a slot never changes once it is taken, so a plain load that sees it taken is final; only a slot
+    // seen empty needs the atomic (2^20 compare-and-swaps on ONE address, a batch under a single key,
+    // cost 6 ms)
+    uint32_t old = __atomic_load_n(&rep[s], __ATOMIC_RELAXED);
+    if (old == KG_NONE) old = atomicCAS(&rep[s], KG_NONE, i);
     if (old == KG_NONE) {
       found = s;
       break;
@@ -100,7 +106,31 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32
     s = (s + 1) & hmask;
   }
   slot_of[i] = found;
-  pos_of[i] = found != KG_NONE ? atomicAdd(&cnt[found], 1u) : 0u;
+  // Rank in the group: one atomic per lane, except that lanes of this wave which share a slot go together.
+  // Up to KG_SHARE_ROUNDS times the first unserved lane collects everyone with its slot (a batch under one
+  // key, or four: 1 or 4 atomics per wave instead of 64 on the same address, 13 ms -> 0.2 ms); with
+  // many keys per wave the rounds serve one lane each and the rest go alone, as before.
+  const uint32_t lane = threadIdx.x & 63u;
+  bool pending = found != KG_NONE;
+  uint32_t pos = 0;
+#pragma unroll 1
+  for (int round = 0; round < KG_SHARE_ROUNDS; ++round) {
+    const unsigned long long act = __ballot(pending);
+    if (!act) break;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t s0 = __shfl(found, leader, 64);
+    const bool mine = pending && found == s0;
+    const unsigned long long m = __ballot(mine);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cnt[s0], (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (mine) {
+      pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      pending = false;
+    }
+  }
+  if (pending) pos = atomicAdd(&cnt[found], 1u);
+  pos_of[i] = pos;
 }
 
 // Each workgroup takes ALLOC_ITEMS * 256 slots (PLACE_ITEMS * 256 signatures), strided by 256 per thread.
@@ -309,7 +339,7 @@ k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* 
   }
   uint4* el = kt + (size_t)KT_LEAD * 8;
   const fe29 zl = ke_load(el, TB_BX);
-  fe29 inv = fe29_inv(fe29_mul(prefix, zl));
+  fe29 inv = fe29_inv_gcd(fe29_mul(prefix, zl));   // safegcd (fe29_inv.h): a third of the Fermat chain, and this kernel is one serial lane per key
   {
     fe29 zi = fe29_mul(inv, prefix);
     inv = fe29_mul(inv, zl);

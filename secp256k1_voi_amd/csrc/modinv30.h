@@ -1,4 +1,4 @@
-// modinv30.h — x^-1 mod n by the Bernstein–Yang "safegcd" division steps (eprint 2019/266), on
+// modinv30.h — x^-1 mod n (and mod p) by the Bernstein–Yang "safegcd" division steps (eprint 2019/266), on
 // 9 signed limbs of 30 bits, one inversion per lane, constant instruction flow (no lane diverges).
 //
 // Replaces the Fermat chain of Scalar.Invert (scalar_invert.go:11-303: 253 squarings + 40
@@ -21,6 +21,10 @@ constexpr int32_t MI_M30 = 0x3FFFFFFF;
 __device__ static const int32_t MI_N[9] = {0x10364141, 0x3f497a33, 0x348a03bb, 0x2bb739ab, 0x3ffffeba,
                                            0x3fffffff, 0x3fffffff, 0x3fffffff, 0xffff};
 constexpr uint32_t MI_NINV30 = 0x2a774ec1u;   // n^-1 mod 2^30
+// the same for the field prime p = 2^256 - 2^32 - 977 (k_key_chain / k_key_finish: per-key tables, keyed.hip)
+__device__ static const int32_t MI_P[9] = {0x3ffffc2f, 0x3ffffffb, 0x3fffffff, 0x3fffffff, 0x3fffffff,
+                                           0x3fffffff, 0x3fffffff, 0x3fffffff, 0xffff};
+constexpr uint32_t MI_PINV30 = 0x2ddacacfu;   // p^-1 mod 2^30
 
 // acc += a * b (signed 32 x 32 -> 64), as one v_mad_i64_i32 (inline asm: see pt29.h on why no
 // C-level 64-bit multiply is left to the compiler)
@@ -80,8 +84,11 @@ S2K_DEV void mi_update_fg(s30& f, s30& g, const int32_t t[4]) {
   g.v[8] = (int32_t)cg;
 }
 
-// (d, e) <- (u d + v e, q d + r e) / 2^30 mod n, kept in (-2n, n)
+// (d, e) <- (u d + v e, q d + r e) / 2^30 mod m, kept in (-2m, m); m = p (FP) or n
+template <bool FP>
 S2K_DEV void mi_update_de(s30& d, s30& e, const int32_t t[4]) {
+  const int32_t* MI_N = FP ? MI_P : s2k::MI_N;
+  const uint32_t MI_NINV30 = FP ? MI_PINV30 : s2k::MI_NINV30;
   const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
   const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
   int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
@@ -115,8 +122,10 @@ S2K_DEV void mi_update_de(s30& d, s30& e, const int32_t t[4]) {
   e.v[8] = (int32_t)ce;
 }
 
-// r in (-2n, n) -> (+-r) in [0, n); sign < 0 negates
+// r in (-2m, m) -> (+-r) in [0, m); sign < 0 negates
+template <bool FP>
 S2K_DEV void mi_normalize(s30& r, int32_t sign) {
+  const int32_t* MI_N = FP ? MI_P : s2k::MI_N;
   int32_t c = r.v[8] >> 31;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.v[i] += MI_N[i] & c;
@@ -138,21 +147,23 @@ S2K_DEV void mi_normalize(s30& r, int32_t sign) {
   }
 }
 
-// x^-1 mod n for a canonical x (Scalar.Invert, scalar_invert.go:11; 0 -> 0)
-__device__ __noinline__ sc sc_modinv(sc x) {
+// x^-1 mod m for a canonical x held in 8 words (0 -> 0)
+template <bool FP>
+S2K_DEV void mi_modinv_words(uint32_t out[8], const uint32_t x[8]) {
+  const int32_t* M = FP ? MI_P : MI_N;
   s30 d, e, f, g;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     d.v[i] = 0;
     e.v[i] = i == 0 ? 1 : 0;
-    f.v[i] = MI_N[i];
+    f.v[i] = M[i];
   }
   // 8 x 32 -> 9 x 30
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int lo = 30 * i, w = lo >> 5, sh = lo & 31;
-    uint32_t limb = x.v[w] >> sh;
-    if (sh > 2 && w + 1 < 8) limb |= x.v[w + 1] << (32 - sh);
+    uint32_t limb = x[w] >> sh;
+    if (sh > 2 && w + 1 < 8) limb |= x[w + 1] << (32 - sh);
     g.v[i] = (int32_t)(limb & (uint32_t)MI_M30);
   }
   int32_t zeta = -1;
@@ -160,20 +171,25 @@ __device__ __noinline__ sc sc_modinv(sc x) {
   for (int it = 0; it < 20; ++it) {
     int32_t t[4];
     zeta = mi_divsteps30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
-    mi_update_de(d, e, t);
+    mi_update_de<FP>(d, e, t);
     mi_update_fg(f, g, t);
   }
-  mi_normalize(d, f.v[8]);
+  mi_normalize<FP>(d, f.v[8]);
   // 9 x 30 -> 8 x 32
-  sc r;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int lo = 32 * j, i = lo / 30, sh = lo - 30 * i;      // word j starts at bit `sh` of limb i
     uint32_t wv = (uint32_t)d.v[i] >> sh;
     wv |= (uint32_t)d.v[i + 1] << (30 - sh);
     if (30 - sh + 30 < 32 && i + 2 < 9) wv |= (uint32_t)d.v[i + 2] << (60 - sh);
-    r.v[j] = wv;
+    out[j] = wv;
   }
+}
+
+// x^-1 mod n for a canonical x (Scalar.Invert, scalar_invert.go:11; 0 -> 0)
+__device__ __noinline__ sc sc_modinv(sc x) {
+  sc r;
+  mi_modinv_words<false>(r.v, x.v);
   return r;
 }
 

@@ -9,6 +9,7 @@
 
 #include "complete_path.h"
 #include "engine_internal.h"
+#include "fe29_inv.h"
 #include "jacobian29.h"
 #include "pt29.h"
 #include "sc26.h"
@@ -250,11 +251,13 @@ k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__
     case S2K_HP_NORMALIZE: r = a; f = fe29_is_zero(a) ? 1 : 0; break;
     case S2K_HP_COND_NEGATE1: r = fe29_cond_negate1(a, (b.n[0] & 1u) != 0); break;
     case S2K_HP_INV: r = fe29_inv(a); break;
+    case S2K_HP_INV_GCD: r = fe29_inv_gcd(a); break;
     case S2K_HP_SQRT: f = fe29_sqrt(r, a) ? 1 : 0; if (!f) r = fe29_zero(); break;
     case S2K_HP_EQ: f = fe29_eq(a, b) ? 1 : 0; break;
     case S2K_HP_MUL_SMALL21: r = fe29_mul_small_norm(a, 21); break;
     case S2K_HP_NORMALIZE_WEAK: r = fe29_normalize_weak(a); break;
     case S2K_HP_JDBL:
+    case S2K_HP_JADD_FULL:
     case S2K_HP_JADD: {
       // P = (a, b) affine, lifted to Jacobian with Z = c (any non-zero value): X = a c^2, Y = b c^3
       // (lazy code of c with bit 3 set: no lift, P = (a, b, 1) with a, b in their lazy forms: x [1], y [<= 2])
@@ -268,7 +271,17 @@ k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__
         p.y = b;
         p.z = fe29_one();
       }
-      jpt29 q = op == S2K_HP_JDBL ? jpt29_double(p) : jpt29_add_affine(p, d, e);
+      jpt29 q;
+      if (op == S2K_HP_JADD_FULL) {
+        jpt29 t;
+        fe29 z2 = fe29_sqr(c), z4 = fe29_sqr(z2);
+        t.x = fe29_mul(d, z4);
+        t.y = fe29_mul(e, fe29_mul(z4, z2));
+        t.z = z2;
+        q = jpt29_add(p, t);
+      } else {
+        q = op == S2K_HP_JDBL ? jpt29_double(p) : jpt29_add_affine(p, d, e);
+      }
       if (fe29_is_zero(q.z)) {   // exceptional input of the incomplete formulas (or a true infinity)
         f = 0;
       } else {
@@ -484,7 +497,7 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
                        uint8_t* out, uint8_t* out2, uint8_t* flag) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fp_op_batch_ex serves S2K_IMPL_FAST only (8x32: s2k_fp_op_batch)");
-  if (op < 0 || op > S2K_HP_PT29_ADD_MIXED) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (op < 0 || op > S2K_HP_JADD_FULL) return fail(ctx, S2K_ERR_ARG, "bad op");
   if (n == 0) return S2K_OK;
   if (!in || !in[0] || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");

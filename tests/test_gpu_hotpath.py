@@ -177,6 +177,10 @@ def test_fe29_linear_and_predicates(eng, oracle):
     sub = a[:len(FP_EDGE) + 600]
     out, _, _ = eng.fp_op_batch_ex(S.HP_INV, [[b32(v) for v in sub]], 0)
     assert rows(out) == [oracle.fp_inv(b32(x % P)) for x in sub]
+    # the safegcd inversion mod p (per-key tables) gives the same values, lazy inputs included
+    for code in (0, 1, 4):
+        out, _, _ = eng.fp_op_batch_ex(S.HP_INV_GCD, [[b32(v) for v in sub]], lazy(code))
+        assert rows(out) == [oracle.fp_inv(b32(x % P)) for x in sub]
     sq = [x * x % P for x in sub[:300]] + sub[300:]
     out, _, flag = eng.fp_op_batch_ex(S.HP_SQRT, [[b32(v) for v in sq]], 0)
     for x, o, f in zip(sq, ints(out), flag):
@@ -219,12 +223,13 @@ def test_jacobian_double_and_add_random_z(eng, oracle, codes):
     x, y, flag = eng.fp_op_batch_ex(S.HP_JDBL, cols[:3], lazy(*codes[:3]))
     assert flag.all()
     assert list(zip(ints(x), ints(y))) == [R.add(p, p) for p in pts]
-    x, y, flag = eng.fp_op_batch_ex(S.HP_JADD, cols, lazy(*codes))
-    for p, q, xi, yi, f in zip(pts, qs, ints(x), ints(y), flag):
-        if p[0] == q[0]:
-            assert f == 0
-        else:
-            assert f == 1 and (xi, yi) == R.add(p, q)
+    for op in (S.HP_JADD, S.HP_JADD_FULL):      # mixed addition; Jacobian + Jacobian (jpt29_add, Q at Z2 = Z^2)
+        x, y, flag = eng.fp_op_batch_ex(op, cols, lazy(*codes))
+        for p, q, xi, yi, f in zip(pts, qs, ints(x), ints(y), flag):
+            if p[0] == q[0]:
+                assert f == 0
+            else:
+                assert f == 1 and (xi, yi) == R.add(p, q)
 
 
 @pytest.mark.parametrize("codes", [(0, 0, 0, 0, 0), (0, 0, 4, 0, 0), (0, 0, 1, 0, 0)])
