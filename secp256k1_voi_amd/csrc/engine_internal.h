@@ -217,6 +217,18 @@ int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, hipStre
 // (ev_after_odd is recorded on st between k_key_odd and k_key_invert)
 int s2k_internal_key_tables(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st, const key_groups* g, hipEvent_t ev_after_odd);
 
+// grouping of x-only keys for the BIP-340 whole-batch check (msm.hip): every key a group, long groups cut
+// into virtual groups of KG_VGROUP signatures
+constexpr uint32_t KG_VGROUP = 1024;
+struct key_groups32 {
+  const uint32_t *rep, *cnt, *base, *tix;   // per hash slot: first signature, size, first sorted position, first virtual group
+  const uint32_t* perm;                     // sorted position -> signature
+  const uint32_t* left;                     // signatures whose key found no slot (each is its own group)
+  const uint32_t* vslot;                    // virtual group -> slot
+  uint32_t ngroups, nleft;                  // (host values)
+};
+int s2k_internal_key_group32(s2k_ctx* ctx, size_t n, const uint8_t* d_pk32, hipStream_t st, key_groups32* out);
+
 struct dev_buf {
   void* p = nullptr;
   ~dev_buf() {

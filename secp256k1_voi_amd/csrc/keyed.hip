@@ -68,13 +68,17 @@ constexpr int KG_SHARE_ROUNDS = 4;
 
 // slot_of[i]: the hash slot = group of signature i (KG_NONE: probe chain too long, general kernel);
 // pos_of[i]: its rank in the group.  rep[] starts as KG_NONE, cnt[] as 0.
+// KEYBYTES: 64 (X || Y, ECDSA) or 32 (x-only BIP-340 keys: the whole-batch check sums the coefficients of
+// each distinct key, msm.hip)
+template <int KEYBYTES>
 __global__ void __launch_bounds__(256)
 k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32_t seed, uint32_t* __restrict__ rep,
              uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ pos_of) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint4* k = reinterpret_cast<const uint4*>(pub + (size_t)i * 64);
-  const uint4 k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+  const uint4* k = reinterpret_cast<const uint4*>(pub + (size_t)i * KEYBYTES);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  const uint4 k0 = k[0], k1 = k[1], k2 = KEYBYTES == 64 ? k[2] : zero4, k3 = KEYBYTES == 64 ? k[3] : zero4;
   uint32_t h = seed;
   h = mix32(h ^ k0.x) + k0.y;
   h = mix32(h ^ k0.z) + k0.w;
@@ -94,8 +98,8 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32
       found = s;
       break;
     }
-    const uint4* o = reinterpret_cast<const uint4*>(pub + (size_t)old * 64);
-    const uint4 o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+    const uint4* o = reinterpret_cast<const uint4*>(pub + (size_t)old * KEYBYTES);
+    const uint4 o0 = o[0], o1 = o[1], o2 = KEYBYTES == 64 ? o[2] : zero4, o3 = KEYBYTES == 64 ? o[3] : zero4;
     uint32_t diff = (o0.x ^ k0.x) | (o0.y ^ k0.y) | (o0.z ^ k0.z) | (o0.w ^ k0.w) | (o1.x ^ k1.x) | (o1.y ^ k1.y) |
                     (o1.z ^ k1.z) | (o1.w ^ k1.w) | (o2.x ^ k2.x) | (o2.y ^ k2.y) | (o2.z ^ k2.z) | (o2.w ^ k2.w) |
                     (o3.x ^ k3.x) | (o3.y ^ k3.y) | (o3.z ^ k3.z) | (o3.w ^ k3.w);
@@ -379,6 +383,44 @@ k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* _
   }
 }
 
+// Grouping for the BIP-340 whole-batch check: EVERY key forms a group; groups of more than
+// KG_VGROUP signatures are cut into virtual groups of that size (each gets its own term: the lane that
+// sums a group's coefficients walks its members one by one).  vslot[t]: slot of virtual group t,
+// tix[s]: first virtual group of slot s.
+__global__ void __launch_bounds__(256)
+k_key_alloc_all(uint32_t slots, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base, uint32_t* __restrict__ tix,
+                uint32_t* __restrict__ vslot, uint32_t* __restrict__ counters) {
+  __shared__ uint32_t sh[8];
+  const uint32_t s0 = blockIdx.x * (256 * ALLOC_ITEMS) + threadIdx.x;
+  uint32_t c[ALLOC_ITEMS];
+  uint32_t ntab = 0, nsig = 0;
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    const uint32_t s = s0 + k * 256;
+    c[k] = s < slots ? cnt[s] : 0u;
+    ntab += (c[k] + KG_VGROUP - 1) / KG_VGROUP;
+    nsig += c[k];
+  }
+  uint32_t t = block_alloc(&counters[KG_NTAB], ntab, sh);
+  uint32_t b = block_alloc(&counters[KG_NKEYED], nsig, sh);
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    const uint32_t s = s0 + k * 256;
+    if (s >= slots) continue;
+    if (!c[k]) {
+      tix[s] = KG_NONE;
+      continue;
+    }
+    base[s] = b;
+    tix[s] = t;
+    const uint32_t nv = (c[k] + KG_VGROUP - 1) / KG_VGROUP;
+#pragma unroll 1
+    for (uint32_t v = 0; v < nv; ++v) vslot[t + v] = s;
+    t += nv;
+    b += c[k];
+  }
+}
+
 static uint32_t pow2_at_least(size_t v) {
   uint32_t b = 0;
   while (((size_t)1 << b) < v) ++b;
@@ -421,7 +463,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
-  k_key_insert<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
+  k_key_insert<64><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
   HIP_TRY(ctx, hipGetLastError());
   k_key_alloc<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, min_group, (uint32_t)max_tables, rep, cnt, base, tix, trep, counters);
   HIP_TRY(ctx, hipGetLastError());
@@ -451,5 +493,55 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
   HIP_TRY(ctx, hipGetLastError());
   k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, ktab);
   HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+// BIP-340 whole-batch check (msm.hip): all n x-only keys grouped, every group gets (virtual) group indices.
+// Synchronises the stream to hand the counts to the host (they size the multiscalar multiplication).
+__attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx, size_t n, const uint8_t* d_pk32,
+                                                                   hipStream_t st, key_groups32* out) {
+  uint32_t bits = ctx->kg_hash_bits ? ctx->kg_hash_bits : pow2_at_least(2 * n);
+  if (bits < 4) bits = 4;
+  if (bits > 30) bits = 30;
+  const size_t slots = (size_t)1 << bits;
+  // counters | rep, cnt, base, tix [slots] | slot_of, pos_of, perm, ptab, left, vslot [n]
+  const size_t np = (n + 63) & ~(size_t)63;
+  const size_t words = KG_COUNTERS + 4 * slots + 6 * np;
+  int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t));
+  if (rc) return rc;
+  uint32_t* w = (uint32_t*)ctx->kg;
+  uint32_t* counters = w;
+  uint32_t* rep = w + KG_COUNTERS;
+  uint32_t* cnt = rep + slots;
+  uint32_t* base = cnt + slots;
+  uint32_t* tix = base + slots;
+  uint32_t* slot_of = tix + slots;
+  uint32_t* pos_of = slot_of + np;
+  uint32_t* perm = pos_of + np;
+  uint32_t* ptab = perm + np;
+  uint32_t* left = ptab + np;
+  uint32_t* vslot = left + np;
+  HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
+  k_key_insert<32><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pk32, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_alloc_all<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, cnt, base, tix, vslot, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, base, tix, perm, ptab, left, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t hc[KG_COUNTERS];
+  HIP_TRY(ctx, hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  out->rep = rep;
+  out->cnt = cnt;
+  out->base = base;
+  out->tix = tix;
+  out->perm = perm;
+  out->left = left;
+  out->vslot = vslot;
+  out->ngroups = hc[KG_NTAB];
+  out->nleft = hc[KG_NLEFT];
+  if ((size_t)hc[KG_NKEYED] + hc[KG_NLEFT] != n) return fail(ctx, S2K_ERR_HIP, "internal: key grouping lost signatures");
   return S2K_OK;
 }

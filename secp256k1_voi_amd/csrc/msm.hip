@@ -632,8 +632,13 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
 // (SHA-256(seed || i)); the seed is caller-supplied secret randomness.  The reference has
 // only the single-signature Verify (schnorr.go:221-253); the contract is
 // "batch accepts <=> every single Verify accepts", up to 2^-128.
-// Terms: [0, n) = a_i * (-R_i); [n, 2n) and [2n, 3n) = the two halves of (a_i e_i) * (-P_i);
+// Terms, plain form: [0, n) = a_i * (-R_i); [n, 2n) and [2n, 3n) = the two halves of (a_i e_i) * (-P_i);
 // 3n, 3n + 1 = the two halves of (sum a_i s_i) * G.
+// Aggregated form (the whole-batch verdict; keys repeat in real batches): the signatures are grouped by key
+// (keyed.hip) and each distinct key P contributes ONE term pair (sum over its signatures of a_i e_i) * (-P):
+// [0, n) as before, n + 2t, n + 2t + 1 for group t, then the generator's pair.  One square root per distinct
+// key instead of one per signature, n + 2 K + 2 terms instead of 3 n + 2.  The sum is the same group
+// element, so the error point of a rejected batch can seed the bisection, which works on the plain form.
 // ---------------------------------------------------------------------------------------
 S2K_DEV bool lift_x_words(uint32_t yw[8], const uint32_t xw[8]) {
   if (!fe_is_canonical_raw(xw)) return false;
@@ -651,14 +656,18 @@ S2K_DEV bool lift_x_words(uint32_t yw[8], const uint32_t xw[8]) {
 struct rlc_key {   // PRF key of the coefficients, passed by value as a kernel argument
   uint32_t w[8];
 };
+// AGG: the key terms are left to k_rlc_key_terms (one term pair per DISTINCT key, its coefficient the sum of
+// a_i e_i over the key's signatures): this kernel stores a_i e_i in ae_out instead, and neither lifts nor
+// judges the key.  N: plane stride of the term arrays (3n + 2 plain, n + 2 (groups) + 2 aggregated).
+template <bool AGG>
 __global__ void __launch_bounds__(256)
-k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
+k_schnorr_rlc_prep(uint32_t n, size_t N, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
                    const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs, uint32_t msg_len,
                    rlc_key seed_be, uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw,
-                   uint8_t* __restrict__ flag, uint32_t* __restrict__ as_out, uint32_t* __restrict__ status) {
+                   uint8_t* __restrict__ flag, uint32_t* __restrict__ as_out, uint32_t* __restrict__ ae_out,
+                   uint32_t* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const size_t N = 3 * (size_t)n + 2;   // plane stride of the term arrays
   uint32_t r_le[8], pk_le[8];
   sc s;
   load_be32(r_le, sig + i * 64);
@@ -667,7 +676,7 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
   bool ok = sc_is_canonical_raw(s.v);
   uint32_t ry[8], py[8];
   ok = lift_x_words(ry, r_le) && ok;      // r < p and on the curve (BIP-340 batch: fail if lift fails)
-  ok = lift_x_words(py, pk_le) && ok;
+  if constexpr (!AGG) ok = lift_x_words(py, pk_le) && ok;
   if (!ok) atomicOr(status, 2u);
   // e_i
   uint32_t r_be[8], pk_be[8], dg[8];
@@ -707,18 +716,81 @@ k_schnorr_rlc_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __
   // -a_i * R_i and -(a_i e_i) * P_i are entered as a_i * (-R_i) and (a_i e_i) * (-P_i): negating the
   // point is free, whereas n - a_i (a_i < 2^128) would put every R term into the same 0xFFFF
   // buckets of the upper windows and serialise them on single lanes.
-  uint32_t npy[8];
-  u256_sub(npy, FE_P, py);
-  if (ok) {
-    msm_store_term(scw, ptw, N, i, a, r_le, ry, true);                          // a_i < 2^128 already
-    msm_store_split(scw, ptw, N, (size_t)n + i, 2 * (size_t)n + i, ae, pk_le, npy);
+  if (ok) msm_store_term(scw, ptw, N, i, a, r_le, ry, true);                          // a_i < 2^128 already
+  if constexpr (AGG) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) ae_out[(size_t)w * n + i] = ae.v[w];
+  } else {
+    uint32_t npy[8];
+    u256_sub(npy, FE_P, py);
+    if (ok) msm_store_split(scw, ptw, N, (size_t)n + i, 2 * (size_t)n + i, ae, pk_le, npy);
+    flag[(size_t)n + i] = ok ? 1 : 0;
+    flag[2 * (size_t)n + i] = ok ? 1 : 0;
   }
   // a signature whose r or key does not lift is invalid on its own; it takes no part in the combination
 #pragma unroll
   for (int w = 0; w < 8; ++w) as_out[(size_t)w * n + i] = ok ? as.v[w] : 0u;
   flag[i] = ok ? 1 : 0;
-  flag[(size_t)n + i] = ok ? 1 : 0;
-  flag[2 * (size_t)n + i] = ok ? 1 : 0;
+}
+
+// Aggregated key terms.  Lane t < ngroups: virtual group t (the signatures perm[first .. first + count) of
+// one key); lane ngroups + q: the signature left[q] on its own.  The group's coefficient is the sum of
+// a_i e_i over its members that are still in the combination (flag); the key is lifted ONCE.  A key that
+// does not lift takes its signatures out of the combination (flag, a_i s_i) and fails the batch (status).
+// Terms n + 2t, n + 2t + 1.
+__global__ void __launch_bounds__(64)
+k_rlc_key_terms(uint32_t n, size_t N, uint32_t ngroups, uint32_t nleft, const uint32_t* __restrict__ vslot,
+                const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ base,
+                const uint32_t* __restrict__ tix, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ left,
+                const uint8_t* __restrict__ pk, const uint32_t* __restrict__ ae, uint32_t* __restrict__ as_io,
+                uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag,
+                uint32_t* __restrict__ status) {
+  uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= ngroups + nleft) return;
+  uint32_t first = 0, count = 1, key_sig;
+  const uint32_t* members;
+  if (t < ngroups) {
+    const uint32_t s = vslot[t], v = t - tix[s];
+    first = base[s] + v * KG_VGROUP;
+    const uint32_t rest = cnt[s] - v * KG_VGROUP;
+    count = rest < KG_VGROUP ? rest : KG_VGROUP;
+    key_sig = rep[s];
+    members = perm;
+  } else {
+    first = t - ngroups;
+    key_sig = left[first];
+    members = left;
+  }
+  uint32_t pk_le[8], py[8];
+  load_be32(pk_le, pk + (size_t)key_sig * 32);
+  const bool key_ok = lift_x_words(py, pk_le);
+  sc sum = sc_zero();
+  bool any = false;
+#pragma unroll 1
+  for (uint32_t j = 0; j < count; ++j) {
+    const size_t i = members[first + j];
+    if (!flag[i]) continue;
+    if (!key_ok) {   // out of the combination
+      flag[i] = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) as_io[(size_t)w * n + i] = 0u;
+      continue;
+    }
+    sc v;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v.v[w] = ae[(size_t)w * n + i];
+    sum = sc_add(sum, v);
+    any = true;
+  }
+  if (!key_ok) atomicOr(status, 2u);
+  const size_t t1 = (size_t)n + 2 * (size_t)t, t2 = t1 + 1;
+  if (key_ok && any) {
+    uint32_t npy[8];
+    u256_sub(npy, FE_P, py);
+    msm_store_split(scw, ptw, N, t1, t2, sum, pk_le, npy);
+    flag[t1] = 1;
+    flag[t2] = 1;
+  }
 }
 
 // sum of n scalars mod n in two launches: RLC_SUM_BLOCKS workgroups leave one partial sum each in
@@ -728,7 +800,7 @@ constexpr uint32_t RLC_SUM_BLOCKS = 256;
 // (`as` has plane stride `stride`; a sub-range of a saved batch passes as + lo with the batch's stride)
 __global__ void __launch_bounds__(256)
 k_schnorr_rlc_sum(uint32_t n, size_t stride, const uint32_t* __restrict__ as, uint32_t* __restrict__ part,
-                  uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag) {
+                  uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag, size_t N) {
   __shared__ uint32_t sh[256][8];
   sc acc = sc_zero();
   if (as) {
@@ -764,13 +836,12 @@ k_schnorr_rlc_sum(uint32_t n, size_t stride, const uint32_t* __restrict__ as, ui
 #pragma unroll
     for (int w = 0; w < 8; ++w) part[blockIdx.x * 8 + w] = sh[0][w];
   } else {
-    const size_t N = 3 * (size_t)n + 2;
-    sc tot;
+    sc tot;                                   // the generator's terms are the last two of the N
 #pragma unroll
     for (int w = 0; w < 8; ++w) tot.v[w] = sh[0][w];
-    msm_store_split(scw, ptw, N, 3 * (size_t)n, 3 * (size_t)n + 1, tot, FE_GX, FE_GY);
-    flag[3 * (size_t)n] = 1;
-    flag[3 * (size_t)n + 1] = 1;
+    msm_store_split(scw, ptw, N, N - 2, N - 1, tot, FE_GX, FE_GY);
+    flag[N - 2] = 1;
+    flag[N - 1] = 1;
   }
 }
 
@@ -933,28 +1004,58 @@ static int stage_schnorr(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_
 // [status word .. 64: error point record] in h.  The caller's seed is mixed with 32 bytes from the
 // operating system's CSPRNG, so a reused or predictable seed does not weaken the check (the
 // coefficients have to be unpredictable to whoever chose the signatures).
+enum rlc_mode {
+  RLC_AGGREGATED,        // one term pair per distinct key; combination evaluated
+  RLC_PLAIN_TERMS_ONLY   // one term pair per signature (the layout the bisection gathers from); terms only
+};
+// `seed_be`: the coefficient key; derived here from seed32 and OS randomness when `fresh`, otherwise taken
+// as it is (a second pass over the same batch must use the coefficients of the first).
 static int rlc_run_full(s2k_ctx* ctx, hipStream_t st, size_t n, const void* d_pk, const void* d_msgs,
                         const void* d_msg_offsets, size_t msg_len, const void* d_sig, const uint8_t* seed32, msm_ws& m,
-                        uint32_t** as_out, uint8_t h[192]) {
-  const size_t N = 3 * n + 2;
-  int rc = msm_setup(ctx, N, n * 8 * 4 + 256 + RLC_SUM_BLOCKS * 32, m);
+                        uint32_t** as_out, uint8_t h[192], rlc_mode mode, rlc_key& seed_be, bool fresh) {
+  if (fresh) {
+    uint8_t mix[64], key[32];
+    memcpy(mix, seed32, 32);
+    if (getrandom(mix + 32, 32, 0) != 32) return fail(ctx, S2K_ERR_HIP, "getrandom failed: no randomness for the batch coefficients");
+    host_sha256(key, mix, 64);
+    for (int j = 0; j < 8; ++j)
+      seed_be.w[j] = ((uint32_t)key[4 * j] << 24) | ((uint32_t)key[4 * j + 1] << 16) | ((uint32_t)key[4 * j + 2] << 8) | key[4 * j + 3];
+  }
+  key_groups32 kg;
+  size_t N = 3 * n + 2;
+  if (mode == RLC_AGGREGATED) {
+    int rc = s2k_internal_key_group32(ctx, n, (const uint8_t*)d_pk, st, &kg);
+    if (rc) return rc;
+    N = n + 2 * ((size_t)kg.ngroups + kg.nleft) + 2;
+  }
+  // aux: 256 bytes | partial sums of the generator's coefficient | a_i s_i planes | a_i e_i planes (aggregated)
+  const size_t as_bytes = n * 8 * 4;
+  int rc = msm_setup(ctx, N, 256 + RLC_SUM_BLOCKS * 32 + as_bytes + (mode == RLC_AGGREGATED ? as_bytes : 0), m);
   if (rc) return rc;
-  uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
   uint32_t* sum_part = (uint32_t*)(m.aux + 256);
-  uint8_t mix[64], key[32];
-  memcpy(mix, seed32, 32);
-  if (getrandom(mix + 32, 32, 0) != 32) return fail(ctx, S2K_ERR_HIP, "getrandom failed: no randomness for the batch coefficients");
-  host_sha256(key, mix, 64);
-  rlc_key seed_be;
-  for (int j = 0; j < 8; ++j)
-    seed_be.w[j] = ((uint32_t)key[4 * j] << 24) | ((uint32_t)key[4 * j + 1] << 16) | ((uint32_t)key[4 * j + 2] << 8) | key[4 * j + 3];
+  uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
+  uint32_t* ae = as + n * 8;
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
-  k_schnorr_rlc_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
-                                                    (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
-                                                    (uint32_t)msg_len, seed_be, m.scw, m.ptw, m.flag, as, m.status);
-  HIP_TRY(ctx, hipGetLastError());
-  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, n, as, sum_part, m.scw, m.ptw, m.flag);
-  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, n, nullptr, sum_part, m.scw, m.ptw, m.flag);
+  if (mode == RLC_AGGREGATED) {
+    HIP_TRY(ctx, hipMemsetAsync(m.flag, 0, N, st));     // the key terms set their own flags
+    k_schnorr_rlc_prep<true><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, N, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
+                                                            (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
+                                                            (uint32_t)msg_len, seed_be, m.scw, m.ptw, m.flag, as, ae, m.status);
+    HIP_TRY(ctx, hipGetLastError());
+    const uint32_t lanes = kg.ngroups + kg.nleft;
+    k_rlc_key_terms<<<(lanes + 63) / 64, 64, 0, st>>>((uint32_t)n, N, kg.ngroups, kg.nleft, kg.vslot, kg.rep, kg.cnt, kg.base, kg.tix,
+                                                      kg.perm, kg.left, (const uint8_t*)d_pk, ae, as, m.scw, m.ptw, m.flag, m.status);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    k_schnorr_rlc_prep<false><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, N, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
+                                                             (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
+                                                             (uint32_t)msg_len, seed_be, m.scw, m.ptw, m.flag, as, nullptr, m.status);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (as_out) *as_out = as;
+  if (mode == RLC_PLAIN_TERMS_ONLY) return S2K_OK;
+  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, n, as, sum_part, m.scw, m.ptw, m.flag, N);
+  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, n, nullptr, sum_part, m.scw, m.ptw, m.flag, N);
   HIP_TRY(ctx, hipGetLastError());
   uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
   rc = msm_core(ctx, st, N, m, d_out);
@@ -962,7 +1063,6 @@ static int rlc_run_full(s2k_ctx* ctx, hipStream_t st, size_t n, const void* d_pk
   HIP_TRY(ctx, hipMemcpyAsync(h, m.status, 64 + 65, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   ctx->have_last = false;
-  if (as_out) *as_out = as;
   return S2K_OK;
 }
 
@@ -984,7 +1084,8 @@ int s2k_schnorr_batch_verify_rlc_device(s2k_ctx* ctx, size_t n, const void* d_pk
   if (rc) return rc;
   msm_ws m;
   uint8_t h[192];
-  rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, nullptr, h);
+  rlc_key coeff;
+  rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, nullptr, h, RLC_AGGREGATED, coeff, true);
   if (rc) return rc;
   uint32_t h_status;
   memcpy(&h_status, h, 4);
@@ -1027,12 +1128,20 @@ int s2k_schnorr_verify_batch_bisect_device(s2k_ctx* ctx, size_t n, const void* d
   msm_ws m;
   uint32_t* as = nullptr;
   uint8_t h[192];
-  rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, &as, h);
+  rlc_key coeff;
+  rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, &as, h, RLC_AGGREGATED, coeff, true);
   if (rc) return rc;
   if (h[64] == 0x00) {   // the combination of every liftable signature vanishes: those are all valid
     k_rlc_mark_valid<<<blocks_for(n), 256, 0, st>>>(0u, (uint32_t)n, m.flag, valid);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
+  }
+  // Rejected.  The bisection gathers per-signature terms, so the plain form is prepared now, with the
+  // coefficients of the pass that has just failed: its error point h + 64 is the plain form's as well.
+  {
+    uint8_t h2[192];
+    rc = rlc_run_full(ctx, st, n, d_pk, d_msgs, d_msg_offsets, msg_len, d_sig, seed32, m, &as, h2, RLC_PLAIN_TERMS_ONLY, coeff, false);
+    if (rc) return rc;
   }
   // keep the terms: the sub-range runs re-carve the multiscalar workspace
   const size_t NS = 3 * n;
@@ -1057,8 +1166,8 @@ int s2k_schnorr_verify_batch_bisect_device(s2k_ctx* ctx, size_t n, const void* d
     uint32_t* sum_part = (uint32_t*)w.aux;
     HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, w.zero_bytes, st));
     k_rlc_gather<<<blocks_for(3 * (size_t)cnt), 256, 0, st>>>(lo, cnt, (uint32_t)n, s_scw, s_ptw, s_flag, w.scw, w.ptw, w.flag);
-    k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>(cnt, n, s_as + lo, sum_part, w.scw, w.ptw, w.flag);
-    k_schnorr_rlc_sum<<<1, 256, 0, st>>>(cnt, n, nullptr, sum_part, w.scw, w.ptw, w.flag);
+    k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>(cnt, n, s_as + lo, sum_part, w.scw, w.ptw, w.flag, N);
+    k_schnorr_rlc_sum<<<1, 256, 0, st>>>(cnt, n, nullptr, sum_part, w.scw, w.ptw, w.flag, N);
     HIP_TRY(ctx, hipGetLastError());
     uint8_t* d_out = (uint8_t*)w.status + 64;
     r = msm_core(ctx, st, N, w, d_out);

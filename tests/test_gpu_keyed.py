@@ -228,3 +228,56 @@ def test_full_size_tables_vs_general(eng):
     assert np.array_equal(a, b)
     assert st0["keyed"] == 0 and st1["keyed"] > n * 0.9 and st1["tables"] >= (1 << 16) * 0.99
     assert a[kind >= 7].all() and a[kind <= 5].sum() == 0
+
+
+# ---- BIP-340 whole-batch check with one term pair per DISTINCT key (msm.hip, aggregated form) ----
+def test_schnorr_batch_aggregates_keys(eng, oracle):
+    """s2k_schnorr_batch_verify_rlc / the bisecting entry point on batches whose keys repeat: group sizes from
+    1 to 3000 (more than one virtual group of 1024), an invalid key shared by several signatures, hash tables
+    too small for the keys (signatures that find no slot form their own groups), damaged signatures.
+    Whole-batch verdict == all per-signature verdicts; per-signature verdicts == the oracle's."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    n = 1 << 18                                                   # above the bisection's leaf size: combinations run
+    seed = bytes(range(32))
+    # keys: i mod 5000 for the first half, then a block of 3000 signatures under key 7, then distinct keys
+    pk, msgs, sig = synth_schnorr_batch(eng, n, n, seed=91)       # n distinct keys, valid signatures
+    half = n // 2
+    pk2, msgs2, sig2 = synth_schnorr_batch(eng, half + 3000, 5000, seed=92)
+    pk[:half], msgs[:half], sig[:half] = pk2[:half], msgs2[:half], sig2[:half]
+    big = np.nonzero(np.arange(half + 3000) % 5000 == 7)[0]
+    pkb, mb, sb = synth_schnorr_batch(eng, 3000, 1, seed=93)
+    pk[half:half + 3000], msgs[half:half + 3000], sig[half:half + 3000] = pkb, mb, sb
+    perm = np.random.default_rng(94).permutation(n)
+    pk, msgs, sig = pk[perm].copy(), msgs[perm].copy(), sig[perm].copy()
+
+    def check(pk, msgs, sig, expect_bad):
+        ok = eng.schnorr_batch_verify_rlc(pk, msgs, sig, seed)
+        assert ok == (len(expect_bad) == 0)
+        v, st = eng.schnorr_verify_batch_auto(pk, msgs, sig, seed, return_stats=True)
+        exp = np.ones(n, dtype=np.uint8)
+        exp[list(expect_bad)] = 0
+        assert np.array_equal(v, exp), (np.nonzero(v != exp)[0][:10], st)
+        for i in list(expect_bad)[:8]:
+            assert oracle.schnorr_verify(bytes(pk[i]), bytes(msgs[i]), bytes(sig[i])) != 1
+        return st
+
+    for bits in (0, 12):                                           # default table; 4096 slots for ~136 000 keys
+        eng.set_key_grouping(S.KEYS_AUTO, hash_bits=bits)
+        check(pk, msgs, sig, [])
+        # one bad signature inside the 3000-signature group, one in a singleton group
+        bad = sig.copy()
+        i_big = int(np.nonzero((pk == pkb[0]).all(axis=1))[0][1500])
+        i_one = int(np.nonzero(perm >= half + 3000)[0][17])
+        bad[i_big, 40] ^= 1
+        bad[i_one, 63] ^= 0x80
+        check(pk, msgs, bad, [i_big, i_one])
+        # a key that is no x-coordinate, shared by every signature of one 5000-cycle key: all of them invalid
+        not_x = next(x for x in range(2, 100) if R.lift_x(x, 0) is None)
+        victim = pk[int(np.nonzero(perm < half)[0][3])].copy()
+        members = np.nonzero((pk == victim).all(axis=1))[0]
+        assert len(members) >= 20
+        pk_bad = pk.copy()
+        pk_bad[members] = np.frombuffer(R.b32(not_x), np.uint8)
+        check(pk_bad, msgs, sig, list(members))
+    eng.set_key_grouping(S.KEYS_AUTO)
