@@ -193,9 +193,10 @@ int s2k_schnorr_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pk, co
                                     const void *d_msg_offsets, size_t msg_len, const void *d_sig, uint32_t flags,
                                     void *d_valid, void *hip_stream);
 
-/* Whole-batch BIP-340 verification as ONE multi-scalar multiplication of 2n+1 terms
- * ((sum a_i s_i) G - sum a_i R_i - sum a_i e_i P_i == infinity, a_0 = 1, a_i = 128 bits of
- * SHA-256(key || i), key = SHA-256(seed32 || 32 bytes of getrandom(2))).  *all_valid = 1 iff every
+/* Whole-batch BIP-340 verification as ONE multi-scalar multiplication of n + K + 1 points
+ * ((sum a_i s_i) G - sum a_i R_i - sum over the K distinct keys P of (sum of a_i e_i over P's signatures) P
+ * == infinity, a_0 = 1, a_i = 128 bits of SHA-256(key || i), key = SHA-256(seed32 || 32 bytes of
+ * getrandom(2)); the signatures are grouped by key on the device).  *all_valid = 1 iff every
  * signature of the batch verifies (false accept probability 2^-128).  seed32 should be fresh CSPRNG
  * output; because the library mixes in operating-system randomness of its own, a reused or
  * predictable seed does not make the coefficients predictable.  It does not say which signature

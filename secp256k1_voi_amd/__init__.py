@@ -358,7 +358,8 @@ class Engine:
         return out
 
     def schnorr_batch_verify_rlc(self, pk32, msgs, sig64, seed32: bytes | None = None) -> bool:
-        """True iff every (key, message, signature) triple verifies — one MSM of 3n+2 terms."""
+        """True iff every (key, message, signature) triple verifies — one MSM of n + 2K + 2 terms
+        (K distinct keys: the coefficients of a key's signatures are summed first)."""
         pk32 = _arr(pk32, 32)
         n = pk32.shape[0]
         sig64 = _arr(sig64, 64, n)
