@@ -1,3 +1,8 @@
 #!/bin/bash
-# same-box sweep of the generator-part split (S2K_GP_FIRST_PERCENT), 2^20 signatures of 2^16 keys
-for rep in 1 2; do for pc in 45 60 80 100; do S2K_GP_FIRST_PERCENT=$pc PROBE_MODES=auto timeout 300 python tools/keyed_probe.py 20 16 2>/dev/null | tail -1 | cut -c1-200 | sed "s/^/pc=$pc /"; done; done
+# same-box A/B of library variants on the 2^16-key batch: S2K_LIB=<path> per variant, default library last
+for rep in 1 2; do
+  for lib in libsecp256k1_voi_amd.gp1.so default; do
+    if [ "$lib" = default ]; then unset S2K_LIB; else export S2K_LIB=$PWD/secp256k1_voi_amd/$lib; fi
+    PROBE_MODES=auto timeout 300 python tools/keyed_probe.py 20 16 2>/dev/null | tail -1 | cut -c1-200 | sed "s|^|$lib |"
+  done
+done
