@@ -415,7 +415,8 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // "fin" elements.
 // ---------------------------------------------------------------------------------------
 
-enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5 };
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
+       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 
 // Digits of an odd half scalar k < 2^129 in the order the per-key ladder consumes them.  As in
@@ -463,6 +464,8 @@ S2K_DEV uint32_t ds4_next(digit_stream4& d) {
 //               planes and the verdict are the signature's, workspace columns are the lane's.
 //               KEYED lanes take their points from the key's precomputed affine table (table ptab[idx],
 //               no per-lane table, 12 doublings); LEFT lanes are the general path for the rest.
+// MODE_SCHNORR_KEYED / MODE_SCHNORR_LEFT: the same for BIP-340 (tables of the lifted x-only keys); results go
+//               to k_affine_finish in the SIGNATURE's fin column.
 // Waves per SIMD the register allocator must leave room for.  Measured (2^20 signatures):
 // unbounded (240 VGPRs, 2 waves) 11.08 ms; 3 waves (168 VGPRs, no spills) 10.89 ms; 4 waves
 // (128 VGPRs, 96 spilled) 11.45 ms.
@@ -509,15 +512,16 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
               key_groups kg) {
-  constexpr bool GROUPED = MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT;
-  constexpr bool ECDSA = MODE == MODE_ECDSA || GROUPED;
+  constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED;
+  constexpr bool GROUPED = KEYED || MODE == MODE_ECDSA_LEFT || MODE == MODE_SCHNORR_LEFT;
+  constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // lane: workspace column
   size_t sig = idx;                                            // signature: input / prep / verdict column
   uint32_t lanes = n;
   if constexpr (GROUPED) {
-    lanes = kg.counters[MODE == MODE_ECDSA_KEYED ? KG_NKEYED : KG_NLEFT];
+    lanes = kg.counters[KEYED ? KG_NKEYED : KG_NLEFT];
     if (idx >= lanes) return;
-    sig = (MODE == MODE_ECDSA_KEYED ? kg.perm : kg.left)[idx];
+    sig = (KEYED ? kg.perm : kg.left)[idx];
   } else {
     if (idx >= n) return;
   }
@@ -534,7 +538,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   uint32_t pf = prep[(size_t)16 * stride + sig];
   bool ok;
   fe29 qx, qy;
-  if constexpr (MODE == MODE_ECDSA_KEYED) {
+  if constexpr (KEYED) {
     ok = (pf & PF_OK) && kg.tinfo[kg.ptab[idx]];      // the key was validated when its table was built
   } else if constexpr (MODE == MODE_RECOVER) {
     uint32_t xw[8];
@@ -579,7 +583,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     }
   } else {
     uint32_t xw[8];
-    load_be32(xw, pub + idx * 32);
+    load_be32(xw, pub + sig * 32);
     ok = (pf & PF_OK) && fe_is_canonical_raw(xw);
     if (!ok) {
 #pragma unroll
@@ -600,7 +604,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
 
   // ---- table ----
-  if constexpr (MODE != MODE_ECDSA_KEYED) {
+  if constexpr (!KEYED) {
     jpt29 a0;
     a0.x = qx;
     a0.y = qy;
@@ -651,7 +655,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;   // odd by construction (sc_split_glv_odd): the signed
   k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;   // odd-digit recoding is exact, no final correction
   jpt29 acc;
-  if constexpr (MODE == MODE_ECDSA_KEYED) {
+  if constexpr (KEYED) {
     // k = 16^32 + sum_i d_i 16^i with d_i = 2 nib_i - 15, i = 4c + j: round j (3 down to 0) adds
     // d_(4c+j) * 2^(16c) Q for the eight chunks c, with four doublings between rounds; the leading
     // 16^32 Q = 16^3 * 2^116 Q goes in first.
@@ -743,11 +747,11 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       uint32_t pos = atomicAdd(wl_count, 1u);
       wl[pos] = (uint32_t)sig;
     } else if constexpr (!ECDSA) {
-      // affine epilogue (key bytes / even-y test) needs 1/Z: leave (X, Y, Z) in the lane's table
-      // column and let k_affine_finish share one inversion between 16 lanes
-      fq_store(fin, stride, idx, 0, acc.x);
-      fq_store(fin, stride, idx, 1, acc.y);
-      fq_store(fin, stride, idx, 2, acc.z);
+      // affine epilogue (key bytes / even-y test) needs 1/Z: leave (X, Y, Z) in the SIGNATURE's fin
+      // column (its own lane's when not grouped) and let k_affine_finish share one inversion between 16
+      fq_store(fin, stride, sig, 0, acc.x);
+      fq_store(fin, stride, sig, 1, acc.y);
+      fq_store(fin, stride, sig, 2, acc.z);
       verdict = VERDICT_PENDING;
     } else {
       // x(R) mod n == r  (ecdsa.go:450-465)
@@ -1029,7 +1033,7 @@ k_schnorr_worklist(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
       px = fe29_from_words(FE_GX);
       py = fe29_from_words(FE_GY);
     }
-    pt29 R = dsm_complete29(s, sc_neg(e), px, py, gt, qt, stride, idx);   // s*G - e*P (schnorr.go:244)
+    pt29 R = dsm_complete29(s, sc_neg(e), px, py, gt, qt, stride, w);   // s*G - e*P (schnorr.go:244); table column = worklist position
     uint32_t rx[8], ry[8], r_le[8];
     bool finite = p29_to_affine_words(rx, ry, R);
     load_be32(r_le, sig + idx * 64);
@@ -1182,6 +1186,59 @@ k_point_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restri
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+// per-stage timing (s2k_ctx_profile): six events per call, around scalar preparation | grouping and
+// per-key tables | ladder (keyed, or the general one when grouping is off) | general ladder over the
+// ungrouped rest | complete-formula worklist
+constexpr int PROF_EV = 6;
+static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
+  if (!ctx->prof_on || ctx->prof_used + PROF_EV > ctx->prof_cap) return;
+  (void)hipEventRecord(ctx->prof_ev[ctx->prof_used + slot], st);
+  if (slot == PROF_EV - 1) ctx->prof_used += PROF_EV;
+}
+
+// Front end of the grouped flows (ECDSA and BIP-340 verification): everything up to the ladders.
+// Caller's stream: grouping by key (k_key_insert / k_key_alloc / k_key_place), then the per-key tables.
+// Second stream: the scalar preparation (`launch_prep`), then the generator part u1*G in two pieces.  These
+// have nothing to do with the keys and the grouping / table kernels are short of work for the multipliers
+// on their own (the doubling chain of the tables is one lane per KEY, the scaling pass is memory bound).
+// The first piece of the generator part runs beside the chain, the second once k_key_odd (which does keep
+// the multipliers busy) is through.  Returns with the caller's stream waiting for the second.
+// Stage times (s2k_ctx_profile_read_stages): [0] grouping, [1] tables and whatever is left of the second
+// stream's work.
+template <class PrepFn>
+static int grouped_front(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* d_keys, int key_bytes, uint32_t* prep,
+                         uint32_t* gp, size_t stride, PrepFn launch_prep, key_groups* kg) {
+  if (!ctx->s_aux) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+  launch_prep(ctx->s_aux);
+  HIP_TRY(ctx, hipGetLastError());
+  const uint32_t n_first = (uint32_t)((n * (size_t)ctx->gp_first_percent / 100) & ~(size_t)255);
+  if (n_first) {
+    k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gtable, gp, stride);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  int rc = s2k_internal_key_group(ctx, n, d_keys, key_bytes, st, kg);
+  if (rc) return rc;
+  kg->gp = gp;
+  prof_mark(ctx, st, 1);
+  rc = s2k_internal_key_tables(ctx, d_keys, st, kg, ctx->ev_mid);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
+  if (n_first < n) {
+    k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gtable, gp, stride);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->s_aux));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  return S2K_OK;
+}
+
 extern "C" {
 
 const char* s2k_version(void) { return "secp256k1_voi_amd 0.2 (gfx950)"; }
@@ -1297,16 +1354,6 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   delete ctx;
 }
 
-// per-stage timing (s2k_ctx_profile): six events per call, around scalar preparation | grouping and
-// per-key tables | ladder (keyed, or the general one when grouping is off) | general ladder over the
-// ungrouped rest | complete-formula worklist
-constexpr int PROF_EV = 6;
-static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
-  if (!ctx->prof_on || ctx->prof_used + PROF_EV > ctx->prof_cap) return;
-  (void)hipEventRecord(ctx->prof_ev[ctx->prof_used + slot], st);
-  if (slot == PROF_EV - 1) ctx->prof_used += PROF_EV;
-}
-
 int s2k_ctx_profile(s2k_ctx* ctx, int enable) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1412,44 +1459,15 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, con
   prof_mark(ctx, st, 0);
   if (grouped) {
     // Signatures of keys that occur often enough: per-key tables (keyed.hip) and the short ladder; the
-    // rest: the general kernel over the list `left`.  Scalar preparation and the generator part u1*G have
-    // nothing to do with the keys and run on a second stream beside the grouping and table kernels, which
-    // are short of work for the multipliers on their own (the doubling chain of the tables is one lane per
-    // KEY, the scaling pass is memory bound).  Stage times (s2k_ctx_profile_read_stages): [0] grouping,
-    // [1] tables and whatever is left of the second stream's work.
-    if (!ctx->s_aux) {
-      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
-    }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
-    k_scalar_prep<<<(T + 63) / 64, 64, 0, ctx->s_aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
-                                                        (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
-    HIP_TRY(ctx, hipGetLastError());
-    // the generator part in two pieces: the first beside the tables' doubling chain (latency bound), the
-    // second once k_key_odd (which does keep the multipliers busy) is through, beside the inversion and
-    // the memory-bound scaling pass
-    const uint32_t n_first = (uint32_t)((n * (size_t)ctx->gp_first_percent / 100) & ~(size_t)255);
-    if (n_first) {
-      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gtable, gp, stride);
-      HIP_TRY(ctx, hipGetLastError());
-    }
+    // rest: the general kernel over the list `left`.
     key_groups kg;
-    rc = s2k_internal_key_group(ctx, n, (const uint8_t*)d_pub, st, &kg);
+    rc = grouped_front(ctx, st, n, (const uint8_t*)d_pub, 64, prep, gp, stride,
+                       [&](hipStream_t aux) {
+                         k_scalar_prep<<<(T + 63) / 64, 64, 0, aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                                      (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
+                       },
+                       &kg);
     if (rc) return rc;
-    kg.gp = gp;
-    prof_mark(ctx, st, 1);
-    rc = s2k_internal_key_tables(ctx, (const uint8_t*)d_pub, st, &kg, ctx->ev_mid);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
-    if (n_first < n) {
-      k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gtable, gp, stride);
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->s_aux));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
                                                                    qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
@@ -1620,12 +1638,32 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     return ctx_leave(ctx, st);
   }
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
-  k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
-  HIP_TRY(ctx, hipGetLastError());
-  k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
-                                                             (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr,
-                                                             key_groups{});
-  HIP_TRY(ctx, hipGetLastError());
+  ctx->kg_counters = nullptr;
+  ctx->last_wl_count = wl_count;
+  if (ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH) {
+    // signatures that share an x-only key: the grouped flow of the ECDSA path (s2k_ctx_set_key_grouping)
+    uint32_t* gp = ws + WS_GP * stride;
+    key_groups kg;
+    rc = grouped_front(ctx, st, n, pk, 32, prep, gp, stride,
+                       [&](hipStream_t aux) {
+                         k_schnorr_prep<<<blocks_for(n), 256, 0, aux>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+                       },
+                       &kg);
+    if (rc) return rc;
+    k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
+                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
+    HIP_TRY(ctx, hipGetLastError());
+    k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
+                                                                    (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
+                                                               (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr,
+                                                               key_groups{});
+    HIP_TRY(ctx, hipGetLastError());
+  }
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, fin, (uint8_t*)d_valid, stride, nullptr);

@@ -211,9 +211,10 @@ struct key_groups {        // device pointers of one call
   const uint32_t* trep;    // per table: a signature that carries the key
   const uint32_t* gp;      // per signature: u1*G (Jacobian, three fin-format elements; k_generator_part)
   uint32_t max_tables;
+  int key_bytes;           // 64: X || Y (ECDSA), 32: x-only (BIP-340)
 };
 // groups the batch's signatures by public key, then builds the tables (enqueue only, no host sync)
-int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, hipStream_t st, key_groups* out);
+int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes, hipStream_t st, key_groups* out);
 // (ev_after_odd is recorded on st between k_key_odd and k_key_invert)
 int s2k_internal_key_tables(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st, const key_groups* g, hipEvent_t ev_after_odd);
 

@@ -250,6 +250,9 @@ S2K_DEV uint32_t table_count(const uint32_t* __restrict__ counters, uint32_t max
   return ntab > max_tables ? max_tables : ntab;
 }
 
+// XONLY: the keys are 32-byte BIP-340 x-only keys, validated and lifted to the even-y point as
+// NewSchnorrPublicKey does (schnorr.go:257-275); otherwise 64-byte X || Y.
+template <bool XONLY>
 __global__ void __launch_bounds__(64)
 k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const uint32_t* __restrict__ trep,
             const uint8_t* __restrict__ pub, uint4* __restrict__ ktab, uint8_t* __restrict__ tinfo) {
@@ -257,18 +260,38 @@ k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const ui
   if (t >= table_count(counters, max_tables)) return;
   const size_t sig = trep[t];
   uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
-
-  // NewPublicKey: canonical coordinates, on the curve (the identity has no 64-byte encoding)
-  apt q;
-  load_be32(q.x.v, pub + sig * 64);
-  load_be32(q.y.v, pub + sig * 64 + 32);
-  bool ok = fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
-  if (!ok) {
-    q.x = fe_from_limbs(FE_GX);
-    q.y = fe_from_limbs(FE_GY);
-  }
-  fe29 qx = fe29_from_words(q.x.v), qy = fe29_from_words(q.y.v);
-  {
+  bool ok;
+  fe29 qx, qy;
+  if constexpr (XONLY) {
+    uint32_t xw[8];
+    load_be32(xw, pub + sig * 32);
+    ok = fe_is_canonical_raw(xw);
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xw[i] = FE_GX[i];
+    }
+    qx = fe29_from_words(xw);
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
+    rhs.n[0] += 7;
+    if (!fe29_sqrt(qy, rhs)) {   // not an x-coordinate of the curve
+      ok = false;
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
+    }
+    qy = fe29_normalize(qy);
+    qy = fe29_select((qy.n[0] & 1u) != 0, qy, fe29_normalize_weak(fe29_negate(qy, 1)));   // even y
+  } else {
+    // NewPublicKey: canonical coordinates, on the curve (the identity has no 64-byte encoding)
+    apt q;
+    load_be32(q.x.v, pub + sig * 64);
+    load_be32(q.y.v, pub + sig * 64 + 32);
+    ok = fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
+    if (!ok) {
+      q.x = fe_from_limbs(FE_GX);
+      q.y = fe_from_limbs(FE_GY);
+    }
+    qx = fe29_from_words(q.x.v);
+    qy = fe29_from_words(q.y.v);
     fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
     rhs.n[0] += 7;
     if (!fe29_eq(fe29_sqr(qy), rhs)) {
@@ -429,7 +452,7 @@ static uint32_t pow2_at_least(size_t v) {
 
 }  // namespace
 
-__attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub,
+__attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes,
                                                                  hipStream_t st, key_groups* out) {
   const uint32_t min_group = ctx->kg_mode == S2K_KEYS_ALWAYS ? 1u : (ctx->kg_min_group ? ctx->kg_min_group : KG_MIN_GROUP);
   uint32_t bits = ctx->kg_hash_bits ? ctx->kg_hash_bits : pow2_at_least(2 * n);
@@ -463,7 +486,10 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
-  k_key_insert<64><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
+  if (key_bytes == 64)
+    k_key_insert<64><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
+  else
+    k_key_insert<32><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
   HIP_TRY(ctx, hipGetLastError());
   k_key_alloc<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, min_group, (uint32_t)max_tables, rep, cnt, base, tix, trep, counters);
   HIP_TRY(ctx, hipGetLastError());
@@ -477,6 +503,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   out->tinfo = tinfo;
   out->trep = trep;
   out->max_tables = (uint32_t)max_tables;
+  out->key_bytes = key_bytes;
   return S2K_OK;
 }
 
@@ -484,7 +511,10 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
                                                                   const key_groups* g, hipEvent_t ev_after_odd) {
   uint4* ktab = (uint4*)ctx->ktab;
   const size_t max_tables = g->max_tables;
-  k_key_chain<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
+  if (g->key_bytes == 64)
+    k_key_chain<false><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
+  else
+    k_key_chain<true><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
   HIP_TRY(ctx, hipGetLastError());
   k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, ktab);
   HIP_TRY(ctx, hipGetLastError());

@@ -281,3 +281,77 @@ def test_schnorr_batch_aggregates_keys(eng, oracle):
         pk_bad[members] = np.frombuffer(R.b32(not_x), np.uint8)
         check(pk_bad, msgs, sig, list(members))
     eng.set_key_grouping(S.KEYS_AUTO)
+
+
+# ---- BIP-340 per-signature verification with per-key tables (MODE_SCHNORR_KEYED / _LEFT) ----
+def test_schnorr_per_signature_on_tables(eng, oracle):
+    """s2k_schnorr_verify_batch with grouping off / automatic / forced: ragged groups of x-only keys, damaged
+    r / s / message, keys that are no x-coordinate or >= p (shared by whole groups), r = a non-residue;
+    all three modes give the oracle's verdicts (SchnorrPublicKey.Verify, schnorr.go:221-253)."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    n_keys, n = 300, 6000
+    pk, msgs, sig = synth_schnorr_batch(eng, n, n_keys, seed=101)          # key i mod 300: 20 signatures each
+    pk2, msgs2, sig2 = synth_schnorr_batch(eng, 500, 500, seed=102)        # 500 singletons
+    pk, msgs, sig = np.concatenate([pk, pk2]), np.concatenate([msgs, msgs2]), np.concatenate([sig, sig2])
+    n = len(pk)
+    perm = np.random.default_rng(103).permutation(n)
+    pk, msgs, sig = pk[perm].copy(), msgs[perm].copy(), sig[perm].copy()
+    rng = np.random.default_rng(104)
+    kind = rng.integers(0, 20, size=n)
+    i = np.nonzero(kind == 0)[0]; sig[i, rng.integers(0, 32, size=i.size)] ^= 1          # r
+    i = np.nonzero(kind == 1)[0]; sig[i, 32 + rng.integers(0, 32, size=i.size)] ^= 0x10  # s
+    i = np.nonzero(kind == 2)[0]; msgs[i, 0] ^= 0x80
+    i = np.nonzero(kind == 3)[0]; sig[i, 32:] = 0xFF                                     # s >= n
+    not_x = next(x for x in range(2, 100) if R.lift_x(x, 0) is None)
+    keys = np.unique(pk, axis=0)
+    for j, bad in ((0, R.b32(not_x)), (1, R.b32(R.P + 1)), (2, bytes(32))):
+        pk[(pk == keys[j]).all(axis=1)] = np.frombuffer(bad, np.uint8)
+    exp = np.array([1 if oracle.schnorr_verify(bytes(pk[j]), bytes(msgs[j]), bytes(sig[j])) == 1 else 0 for j in range(n)], dtype=np.uint8)
+    assert 0 < exp.sum() < n
+    for mode in (S.KEYS_OFF, S.KEYS_AUTO, S.KEYS_ALWAYS):
+        eng.set_key_grouping(mode)
+        got = eng.schnorr_verify_batch(pk, msgs, sig)
+        assert np.array_equal(got, exp), (mode, np.nonzero(got != exp)[0][:10])
+        st = eng.key_grouping_stats()
+        if mode == S.KEYS_OFF:
+            assert st["keyed"] == 0
+        elif mode == S.KEYS_AUTO:
+            assert st["keyed"] >= 5000 and st["general"] >= 400 and st["keyed"] + st["general"] == n
+        else:
+            assert st["keyed"] == n
+    eng.set_key_grouping(S.KEYS_AUTO)
+
+
+def test_schnorr_exceptional_ladders_on_tables(eng, oracle):
+    """BIP-340 signatures with s*G - e*P = infinity (R' has no x: invalid), many per key: the table ladder ends
+    with Z = 0 and the worklist kernel decides, as on the general path."""
+    import hashlib
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import N_ORDER
+    rng = np.random.default_rng(111)
+    n_keys, per = 16, 64
+    d = [int.from_bytes(rng.bytes(32), "big") % (N_ORDER - 1) + 1 for _ in range(n_keys)]
+    P = eng.scalar_base_mult_batch(np.frombuffer(b"".join(R.b32(x) for x in d), np.uint8).reshape(-1, 32))
+    d = [N_ORDER - x if P[j, 64] & 1 else x for j, x in enumerate(d)]          # even-y keys
+    pks, msgs, sigs = [], [], []
+    th = hashlib.sha256(b"BIP0340/challenge").digest()
+    for j in range(n_keys * per):
+        k = j % n_keys
+        pkb = bytes(P[k, 1:33])
+        r = rng.bytes(32)                         # any r: e is fixed by (r, pk, m), then s = e d makes s G - e P vanish
+        m = rng.bytes(32)
+        e = int.from_bytes(hashlib.sha256(th + th + r + pkb + m).digest(), "big") % N_ORDER
+        pks.append(pkb); msgs.append(m); sigs.append(r + R.b32(e * d[k] % N_ORDER))
+    pk = np.frombuffer(b"".join(pks), np.uint8).reshape(-1, 32)
+    mm = np.frombuffer(b"".join(msgs), np.uint8).reshape(-1, 32)
+    sg = np.frombuffer(b"".join(sigs), np.uint8).reshape(-1, 64)
+    for mode in (S.KEYS_OFF, S.KEYS_AUTO):
+        eng.set_key_grouping(mode)
+        got = eng.schnorr_verify_batch(pk, mm, sg)
+        assert not got.any()
+        st = eng.key_grouping_stats()
+        assert st["complete"] >= len(pk) - 8       # (a random r that is no x-coordinate is rejected before the ladder matters)
+    for j in range(0, len(pk), 97):
+        assert oracle.schnorr_verify(bytes(pk[j]), bytes(mm[j]), bytes(sg[j])) != 1
+    eng.set_key_grouping(S.KEYS_AUTO)
