@@ -15,6 +15,7 @@
 
 #include "engine_internal.h"
 #include "fe.h"
+#include "fe29_inv.h"
 #include "jacobian29.h"
 #include "lane_tables.h"
 #include "pt29.h"
@@ -802,7 +803,7 @@ k_affine_finish(uint32_t n, uint32_t T, const uint8_t* __restrict__ rsig, uint32
     if (out[i] == VERDICT_PENDING) acc = fe29_mul(acc, fq_load(fin, stride, i, 2));
     fq_store(fin, stride, i, 3, acc);
   }
-  fe29 inv = fe29_inv(acc);
+  fe29 inv = fe29_inv_gcd(acc);   // safegcd mod p (fe29_inv.h): a quarter of the Fermat chain's instructions, and this kernel is latency bound
 #pragma unroll 1
   for (int j = FIN_M - 1; j >= 0; --j) {
     size_t i = (size_t)t + (size_t)j * T;
@@ -992,7 +993,7 @@ k_recover_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
 // x/Z, y/Z of a projective 9x29 point (canonical words); false for the identity
 S2K_DEV bool p29_to_affine_words(uint32_t xw[8], uint32_t yw[8], const pt29& p) {
   if (fe29_is_zero(p.z)) return false;
-  fe29 zi = fe29_inv(fe29_normalize_weak(p.z));
+  fe29 zi = fe29_inv_gcd(fe29_normalize_weak(p.z));
   fe29_to_words(xw, fe29_normalize(fe29_mul(p.x, zi)));
   fe29_to_words(yw, fe29_normalize(fe29_mul(p.y, zi)));
   return true;
