@@ -1279,6 +1279,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_ensure_ws(s2k_ctx* ctx, s
     HIP_TRY(ctx, hipFree(ctx->ws));
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
+    ctx->last_wl_count = nullptr;   // pointed into the old workspace (s2k_ctx_key_grouping_stats)
   }
   HIP_TRY(ctx, hipMalloc(&ctx->ws, need));
   ctx->ws_bytes = need;

@@ -537,6 +537,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx,
   // counters | rep, cnt, base, tix [slots] | slot_of, pos_of, perm, ptab, left, vslot [n]
   const size_t np = (n + 63) & ~(size_t)63;
   const size_t words = KG_COUNTERS + 4 * slots + 6 * np;
+  ctx->kg_counters = nullptr;   // (of an earlier verification call: the buffer may move)
   int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t));
   if (rc) return rc;
   uint32_t* w = (uint32_t*)ctx->kg;

@@ -23,7 +23,9 @@ def per_kernel(dirname, counter):
     for fn in glob.glob(dirname + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
             if row["Counter_Name"] == counter:
-                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+                name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+                if name.startswith("k_key_"):
+                    name = name.split("<")[0]
                 # ladder instances: <0> general, <4> over per-key tables, <5> general over the ungrouped rest
                 name = name.replace("k_verify_fast<4>", "k_verify_fast_keyed").replace("k_verify_fast<5>", "k_verify_fast_left")
                 name = name.split("<")[0]          # the other template instances (k_verify_fast<0>) share an entry
