@@ -125,7 +125,9 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
  *               S2K_KEYS_ALWAYS: tables even for keys with a single signature (tests)
  *   min_group   0 = default (6): a table costs about as much as four signatures save on it
  *   hash_bits   0 = default (slots >= 2n); smaller values force probe chains (tests)
- *   max_tables  0 = default (2^18 tables of 9 KiB); keys beyond it take the general kernel */
+ *   max_tables  0 = default (2^18 tables of 9 KiB).  The threshold is raised until n / threshold tables
+ *               fit: a batch of n signatures builds tables for keys with at least
+ *               max(min_group, ceil(n / max_tables)) signatures */
 #define S2K_KEYS_OFF 0
 #define S2K_KEYS_AUTO 1
 #define S2K_KEYS_ALWAYS 2

@@ -94,13 +94,16 @@ struct s2k_ctx {
   int kg_mode = S2K_KEYS_AUTO;
   uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = 1u << 18, kg_seed = 0;
   hipStream_t s_aux = nullptr;       // scalar preparation runs here, beside the grouping and the table kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_part0 = nullptr, ev_part1 = nullptr;
+  hipStream_t s_aux2 = nullptr;      // two-part flow: the second half of the tables is built here, beside the first half's ladder
+  uint32_t kg_parts = 1;             // 1: all tables, then all ladders; 2: the two-part flow (S2K_KEYED_PARTS; measured slower)
   uint32_t gp_first_percent = 60;    // share of k_generator_part launched beside k_key_chain (the rest: after k_key_odd)
   void* kg = nullptr;
   size_t kg_bytes = 0;
   void* ktab = nullptr;
   size_t ktab_bytes = 0;
   uint32_t* kg_counters = nullptr;   // device, KG_COUNTERS words (of the last call; null: it did not group)
+  uint32_t kg_last_max_tables = 0;   // table cap of that call (the device counter of tables is not clamped)
   uint32_t* last_wl_count = nullptr; // device: the last verification call's complete-formula worklist length
   char err[512] = {0};
 };
@@ -195,7 +198,7 @@ constexpr int KT_CHUNKS = 8;
 constexpr int KT_LEAD = KT_CHUNKS * 8;          // entry of 2^116 Q
 constexpr int KT_ENTRIES = KT_LEAD + 1;
 constexpr int KT_SLOTS = 72;                    // entries of 128 bytes reserved per key: 65 + 7 of build scratch
-enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_COUNTERS = 16 };
+enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
 constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grouping
 // Signatures per key from which a table pays: a table costs ~15 ns, a signature saves ~3.6 ns on it
@@ -212,11 +215,16 @@ struct key_groups {        // device pointers of one call
   const uint32_t* gp;      // per signature: u1*G (Jacobian, three fin-format elements; k_generator_part)
   uint32_t max_tables;
   int key_bytes;           // 64: X || Y (ECDSA), 32: x-only (BIP-340)
+  // two-part flow: part 0 = tables [0, counters[KG_SPLIT_T]) and lanes [0, counters[KG_SPLIT_LANE]), part 1 the
+  // rest; nparts == 1: everything (kernels take these from the copy of the struct they are launched with)
+  uint32_t part, nparts;
 };
 // groups the batch's signatures by public key, then builds the tables (enqueue only, no host sync)
 int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes, hipStream_t st, key_groups* out);
-// (ev_after_odd is recorded on st between k_key_odd and k_key_invert)
-int s2k_internal_key_tables(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st, const key_groups* g, hipEvent_t ev_after_odd);
+int s2k_internal_key_chains(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st, const key_groups* g);
+// (ev_after_odd, if any, is recorded on st between k_key_odd and k_key_invert)
+int s2k_internal_key_tables(s2k_ctx* ctx, hipStream_t st, const key_groups* g, uint32_t part, uint32_t nparts,
+                            hipEvent_t ev_after_odd);
 
 // grouping of x-only keys for the BIP-340 whole-batch check (msm.hip): every key a group, long groups cut
 // into virtual groups of KG_VGROUP signatures

@@ -11,9 +11,10 @@
 //                  slots hold the index of the first signature seen with that key; a hit compares
 //                  all 64 key bytes, so a group is exactly the set of signatures with identical key
 //                  bytes (whatever the hash does), and the lane takes a rank inside its group
-//   k_key_alloc    over the slots: groups of at least `min_group` signatures get a table index and
-//                  a contiguous range of keyed lanes (one atomic per workgroup and counter, no scan)
-//   k_key_place    one lane per signature: writes itself into its group's range (perm / ptab) or
+//   k_key_alloc    over the slots: groups of at least `min_group` signatures get a table index and a
+//                  contiguous range of ladder lanes, both from ONE 64-bit atomic per workgroup, so that
+//                  lane order is table order; k_key_counts then fixes the split of the two-part flow
+//   k_key_place    one lane per signature: writes itself into its table's lane range (perm / ptab) or
 //                  appends itself to the list of the general kernel (left)
 //   k_key_chain / k_key_odd / k_key_invert / k_key_scale   the tables: key validation as NewPublicKey
 //                  (secec.go:188-216, point_s11n.go:298-307), the chain of 116 doublings per key, the eight
@@ -140,53 +141,99 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32
 // Each workgroup takes ALLOC_ITEMS * 256 slots (PLACE_ITEMS * 256 signatures), strided by 256 per thread.
 constexpr int ALLOC_ITEMS = 16, PLACE_ITEMS = 4;
 
+// Two counts per thread, ONE 64-bit atomic per workgroup (tables in the high word, signatures in the low):
+// table indices and ladder-lane ranges are handed out in the same order, so lane order is table order and
+// the tables of the first k lanes are the first tables (the two-part flow splits both at one point).
+S2K_DEV void block_alloc2(unsigned long long* counter, uint32_t want_hi, uint32_t want_lo, uint32_t* sh /* 16 words */,
+                          uint32_t& off_hi, uint32_t& off_lo) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t ih = want_hi, il = want_lo;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t vh = __shfl_up(ih, d, 64), vl = __shfl_up(il, d, 64);
+    if (lane >= (uint32_t)d) {
+      ih += vh;
+      il += vl;
+    }
+  }
+  if (lane == 63u) {
+    sh[wave] = ih;
+    sh[4 + wave] = il;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t th = sh[0] + sh[1] + sh[2] + sh[3], tl = sh[4] + sh[5] + sh[6] + sh[7];
+    unsigned long long old = (th | tl) ? atomicAdd(counter, ((unsigned long long)th << 32) | tl) : 0ull;
+    sh[8] = (uint32_t)(old >> 32);
+    sh[9] = (uint32_t)old;
+  }
+  __syncthreads();
+  off_hi = sh[8];
+  off_lo = sh[9];
+  for (uint32_t w = 0; w < wave; ++w) {
+    off_hi += sh[w];
+    off_lo += sh[4 + w];
+  }
+  off_hi += ih - want_hi;
+  off_lo += il - want_lo;
+  __syncthreads();
+}
+
+// (every table holds at least min_group signatures and the host keeps n / min_group <= max_tables, so the
+// table count cannot pass max_tables)
 __global__ void __launch_bounds__(256)
-k_key_alloc(uint32_t slots, uint32_t min_group, uint32_t max_tables, const uint32_t* __restrict__ rep,
-            const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base, uint32_t* __restrict__ tix,
-            uint32_t* __restrict__ trep, uint32_t* __restrict__ counters) {
-  __shared__ uint32_t sh[8];
+k_key_alloc(uint32_t slots, uint32_t min_group, const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cnt,
+            uint32_t* __restrict__ tix, uint32_t* __restrict__ trep, uint32_t* __restrict__ tbase,
+            uint32_t* __restrict__ counters) {
+  __shared__ uint32_t sh[16];
   const uint32_t s0 = blockIdx.x * (256 * ALLOC_ITEMS) + threadIdx.x;
   uint32_t c[ALLOC_ITEMS];
-  uint32_t ntab = 0;
+  uint32_t ntab = 0, nsig = 0;
 #pragma unroll
   for (int k = 0; k < ALLOC_ITEMS; ++k) {
     const uint32_t s = s0 + k * 256;
     c[k] = s < slots ? cnt[s] : 0u;
     if (c[k] < min_group) c[k] = 0;          // (min_group >= 1: empty slots drop out too)
     ntab += c[k] ? 1u : 0u;
-  }
-  uint32_t t = block_alloc(&counters[KG_NTAB], ntab, sh);
-  uint32_t nsig = 0;
-#pragma unroll
-  for (int k = 0; k < ALLOC_ITEMS; ++k) {
-    if (!c[k]) continue;
-    if (t >= max_tables) c[k] = 0;           // out of tables (the counter itself is clamped by its readers)
     nsig += c[k];
-    ++t;
   }
-  t -= ntab;
-  uint32_t b = block_alloc(&counters[KG_NKEYED], nsig, sh);
+  uint32_t t, b;
+  block_alloc2(reinterpret_cast<unsigned long long*>(&counters[KG_ALLOC64]), ntab, nsig, sh, t, b);
 #pragma unroll
   for (int k = 0; k < ALLOC_ITEMS; ++k) {
     const uint32_t s = s0 + k * 256;
     if (s >= slots) continue;
-    const bool had = cnt[s] >= min_group && cnt[s] > 0;
     if (c[k]) {
-      base[s] = b;
       tix[s] = t;
       trep[t] = rep[s];
+      tbase[t] = b;
+      ++t;
       b += c[k];
     } else {
       tix[s] = KG_NONE;
     }
-    if (had) ++t;
   }
+}
+
+// the counts where their readers expect them, and the split of the two-part flow: tables [0, split) are
+// built first and their signatures verified while the rest of the tables is being built.  Few tables: no split.
+constexpr uint32_t KG_SPLIT_MIN_TABLES = 4096;
+__global__ void k_key_counts(uint32_t* __restrict__ tbase, uint32_t* __restrict__ counters) {
+  const unsigned long long both = *reinterpret_cast<const unsigned long long*>(&counters[KG_ALLOC64]);
+  const uint32_t T = (uint32_t)(both >> 32), nk = (uint32_t)both;
+  counters[KG_NTAB] = T;
+  counters[KG_NKEYED] = nk;
+  tbase[T] = nk;
+  const uint32_t split = T < KG_SPLIT_MIN_TABLES ? T : T / 2;
+  counters[KG_SPLIT_T] = split;
+  counters[KG_SPLIT_LANE] = split == T ? nk : tbase[split];
 }
 
 __global__ void __launch_bounds__(256)
 k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ pos_of,
-            const uint32_t* __restrict__ base, const uint32_t* __restrict__ tix, uint32_t* __restrict__ perm,
-            uint32_t* __restrict__ ptab, uint32_t* __restrict__ left, uint32_t* __restrict__ counters) {
+            const uint32_t* __restrict__ base, bool base_by_table, const uint32_t* __restrict__ tix,
+            uint32_t* __restrict__ perm, uint32_t* __restrict__ ptab, uint32_t* __restrict__ left,
+            uint32_t* __restrict__ counters) {
   __shared__ uint32_t sh[8];
   const uint32_t i0 = blockIdx.x * (256 * PLACE_ITEMS) + threadIdx.x;
   uint32_t t[PLACE_ITEMS];
@@ -200,7 +247,7 @@ k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __
       if (s != KG_NONE) t[k] = tix[s];
       if (t[k] == KG_NONE) ++nleft;
       else {
-        const uint32_t p = base[s] + pos_of[i];
+        const uint32_t p = base[base_by_table ? t[k] : s] + pos_of[i];   // (tbase[table] or base[slot])
         perm[p] = i;
         ptab[p] = t[k];
       }
@@ -248,6 +295,18 @@ S2K_DEV fe29 scr_load(uint4* kt, int slot) {
 S2K_DEV uint32_t table_count(const uint32_t* __restrict__ counters, uint32_t max_tables) {
   uint32_t ntab = counters[KG_NTAB];
   return ntab > max_tables ? max_tables : ntab;
+}
+// tables [lo, hi) of part `part` of `nparts` (1: all of them; 2: split at counters[KG_SPLIT_T], k_key_scan)
+S2K_DEV void table_range(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts,
+                         uint32_t& lo, uint32_t& hi) {
+  const uint32_t T = table_count(counters, max_tables);
+  lo = 0;
+  hi = T;
+  if (nparts > 1) {
+    const uint32_t sp = counters[KG_SPLIT_T];
+    if (part) lo = sp;
+    else hi = sp;
+  }
 }
 
 // XONLY: the keys are 32-byte BIP-340 x-only keys, validated and lifted to the even-y point as
@@ -322,10 +381,11 @@ k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const ui
 }
 
 __global__ void __launch_bounds__(256)
-k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __restrict__ ktab) {
-  uint32_t id = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t t = id / KT_CHUNKS, c = id % KT_CHUNKS;
-  if (t >= table_count(counters, max_tables)) return;
+k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
+  uint32_t id = blockIdx.x * 256 + threadIdx.x, lo, hi;
+  table_range(counters, max_tables, part, nparts, lo, hi);
+  const uint32_t t = lo + id / KT_CHUNKS, c = id % KT_CHUNKS;
+  if (t >= hi) return;
   uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
   uint4* e0 = kt + (size_t)(c * 8) * 8;
   jpt29 a0;
@@ -353,9 +413,11 @@ k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __r
 }
 
 __global__ void __launch_bounds__(64)
-k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __restrict__ ktab) {
-  uint32_t t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= table_count(counters, max_tables)) return;
+k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
+  uint32_t lo, hi;
+  table_range(counters, max_tables, part, nparts, lo, hi);
+  const uint32_t t = lo + blockIdx.x * 64 + threadIdx.x;
+  if (t >= hi) return;
   uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
   fe29 prefix = scr_load(kt, 0);
   scr_store(kt, 9, prefix);
@@ -386,10 +448,11 @@ k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* 
 }
 
 __global__ void __launch_bounds__(256)
-k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint4* __restrict__ ktab) {
-  uint32_t id = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t t = id / KT_CHUNKS, c = id % KT_CHUNKS;
-  if (t >= table_count(counters, max_tables)) return;
+k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
+  uint32_t id = blockIdx.x * 256 + threadIdx.x, lo, hi;
+  table_range(counters, max_tables, part, nparts, lo, hi);
+  const uint32_t t = lo + id / KT_CHUNKS, c = id % KT_CHUNKS;
+  if (t >= hi) return;
   uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
   uint4* e0 = kt + (size_t)(c * 8) * 8;
   const fe29 beta = fe29_from_words(FE_BETA);
@@ -454,17 +517,19 @@ static uint32_t pow2_at_least(size_t v) {
 
 __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes,
                                                                  hipStream_t st, key_groups* out) {
-  const uint32_t min_group = ctx->kg_mode == S2K_KEYS_ALWAYS ? 1u : (ctx->kg_min_group ? ctx->kg_min_group : KG_MIN_GROUP);
+  const uint32_t min_group_asked = ctx->kg_mode == S2K_KEYS_ALWAYS ? 1u : (ctx->kg_min_group ? ctx->kg_min_group : KG_MIN_GROUP);
   uint32_t bits = ctx->kg_hash_bits ? ctx->kg_hash_bits : pow2_at_least(2 * n);
   if (bits < 4) bits = 4;
   if (bits > 30) bits = 30;
   const size_t slots = (size_t)1 << bits;
+  // tables are never refused on the device: the threshold is raised until n / threshold of them fit the cap
+  uint32_t min_group = min_group_asked;
+  if (n / min_group > ctx->kg_max_tables) min_group = (uint32_t)((n + ctx->kg_max_tables - 1) / ctx->kg_max_tables);
   size_t max_tables = n / min_group;
-  if (max_tables > ctx->kg_max_tables) max_tables = ctx->kg_max_tables;
   if (max_tables == 0) max_tables = 1;
-  // grouping arrays: counters | rep, cnt, base, tix [slots] | slot_of, pos_of, perm, ptab, left [n] | trep [tables] | tinfo
-  const size_t np = (n + 63) & ~(size_t)63, tp = (max_tables + 63) & ~(size_t)63;
-  const size_t words = KG_COUNTERS + 4 * slots + 5 * np + tp;
+  // grouping arrays: counters | rep, cnt, tix [slots] | slot_of, pos_of, perm, ptab, left [n] | trep, tbase [tables] | tinfo
+  const size_t np = (n + 63) & ~(size_t)63, tp = ((max_tables + 63) & ~(size_t)63) + 64;
+  const size_t words = KG_COUNTERS + 3 * slots + 5 * np + 2 * tp;
   int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t) + tp);
   if (rc) return rc;
   rc = ctx_reserve(ctx, &ctx->ktab, &ctx->ktab_bytes, max_tables * (size_t)KT_SLOTS * 128);
@@ -473,16 +538,17 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   uint32_t* counters = w;
   uint32_t* rep = w + KG_COUNTERS;
   uint32_t* cnt = rep + slots;
-  uint32_t* base = cnt + slots;
-  uint32_t* tix = base + slots;
+  uint32_t* tix = cnt + slots;
   uint32_t* slot_of = tix + slots;
   uint32_t* pos_of = slot_of + np;
   uint32_t* perm = pos_of + np;
   uint32_t* ptab = perm + np;
   uint32_t* left = ptab + np;
   uint32_t* trep = left + np;
-  uint8_t* tinfo = (uint8_t*)(trep + tp);
+  uint32_t* tbase = trep + tp;
+  uint8_t* tinfo = (uint8_t*)(tbase + tp);
   ctx->kg_counters = counters;
+  ctx->kg_last_max_tables = (uint32_t)max_tables;
   HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
@@ -491,9 +557,11 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   else
     k_key_insert<32><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_alloc<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, min_group, (uint32_t)max_tables, rep, cnt, base, tix, trep, counters);
+  k_key_alloc<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, min_group, rep, cnt, tix, trep, tbase, counters);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, base, tix, perm, ptab, left, counters);
+  k_key_counts<<<1, 1, 0, st>>>(tbase, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, tbase, true, tix, perm, ptab, left, counters);
   HIP_TRY(ctx, hipGetLastError());
   out->counters = counters;
   out->perm = perm;
@@ -507,8 +575,9 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   return S2K_OK;
 }
 
-__attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st,
-                                                                  const key_groups* g, hipEvent_t ev_after_odd) {
+// the doubling chains of ALL tables (one launch: its duration is one lane's latency whatever the count)
+__attribute__((visibility("hidden"))) int s2k_internal_key_chains(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st,
+                                                                  const key_groups* g) {
   uint4* ktab = (uint4*)ctx->ktab;
   const size_t max_tables = g->max_tables;
   if (g->key_bytes == 64)
@@ -516,12 +585,20 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
   else
     k_key_chain<true><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, ktab);
+  return S2K_OK;
+}
+
+// odd multiples, inversion, scaling for the tables of part `part` of `nparts`
+__attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, hipStream_t st, const key_groups* g, uint32_t part,
+                                                                  uint32_t nparts, hipEvent_t ev_after_odd) {
+  uint4* ktab = (uint4*)ctx->ktab;
+  const size_t max_tables = g->max_tables;
+  k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
-  k_key_invert<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, ktab);
+  k_key_invert<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, ktab);
+  k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
@@ -559,7 +636,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx,
   HIP_TRY(ctx, hipGetLastError());
   k_key_alloc_all<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, cnt, base, tix, vslot, counters);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, base, tix, perm, ptab, left, counters);
+  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, base, false, tix, perm, ptab, left, counters);
   HIP_TRY(ctx, hipGetLastError());
   uint32_t hc[KG_COUNTERS];
   HIP_TRY(ctx, hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, st));

@@ -123,7 +123,7 @@ def test_invalid_keys_in_groups(eng, oracle):
 
 def test_hash_table_pressure(eng, oracle):
     """The grouping must stay exact whatever the hash table does: 64 slots for 600 keys (probe chains hit their
-    limit, those signatures take the general kernel), 1024 slots (long chains), and a cap of 5 tables."""
+    limit, those signatures take the general kernel), 1024 slots (long chains), and caps on the number of tables."""
     sizes = np.array([8] * 500 + [1] * 100)
     pub, dig, r, s = _ragged_batch(eng, 31, sizes)
     _damage(pub, dig, r, s, 32)
@@ -131,9 +131,15 @@ def test_hash_table_pressure(eng, oracle):
     assert 0 < st["keyed"] <= 64 * 12 and st["general"] > 0
     _, st, _ = _check_all_modes(eng, oracle, pub, dig, r, s, hash_bits=10)
     assert st["keyed"] > 3000
+    # a cap of 5 tables for 4100 signatures raises the threshold to 820 signatures per key: nothing qualifies
     _, st, st_all = _check_all_modes(eng, oracle, pub, dig, r, s, max_tables=5)
-    assert st["tables"] >= 5 and 0 < st["keyed"] <= 5 * 12
-    assert 0 < st_all["keyed"] <= 5 * 12
+    assert st["tables"] == 0 and st["keyed"] == 0 and st["general"] == len(pub)
+    assert st_all["keyed"] == 0
+    # a cap of 300: threshold 14, still nothing; 600: threshold 7, the groups of 8 and more get tables
+    _, st, _ = _check_all_modes(eng, oracle, pub, dig, r, s, max_tables=300)
+    assert st["keyed"] == 0
+    _, st, _ = _check_all_modes(eng, oracle, pub, dig, r, s, max_tables=600)
+    assert 0 < st["tables"] <= 600 and st["keyed"] >= 7 * st["tables"]
 
 
 def test_exceptional_ladders_with_shared_keys(eng, oracle):
