@@ -361,3 +361,15 @@ def test_schnorr_exceptional_ladders_on_tables(eng, oracle):
     for j in range(0, len(pk), 97):
         assert oracle.schnorr_verify(bytes(pk[j]), bytes(mm[j]), bytes(sg[j])) != 1
     eng.set_key_grouping(S.KEYS_AUTO)
+
+
+def test_randomised_grouping_stress():
+    """tools/stress_keyed.py: random batch sizes, key reuse patterns, damage and grouping settings; ECDSA, BIP-340
+    per-signature and whole-batch verdicts against the oracle (25 iterations here; the tool runs any number)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_keyed.py"), "25", "7"], capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "stress ok" in res.stdout
