@@ -284,27 +284,36 @@ def test_schnorr_and_recovery_worklists(eng, oracle):
 
 
 def test_host_chunked_path_matches_single_launch(eng):
-    """s2k_ecdsa_verify_batch cuts large batches into round-sized chunks with overlapped copies (first chunk
-    one round, merged tail): for a size that is not a multiple of anything, its verdicts equal those of one
-    launch over device-resident inputs, corrupted items included."""
+    """s2k_ecdsa_verify_batch from host buffers.  Key grouping off: the batch is cut into round-sized chunks with
+    overlapped copies (first chunk one round, merged tail).  Key grouping on (default): one call, the keys copied
+    first and the digests / signatures while the tables are being built.  For a size that is not a multiple of
+    anything, both give the verdicts of one launch over device-resident inputs, corrupted items included."""
     import torch
+    import secp256k1_voi_amd as S
     from secp256k1_voi_amd.synth import synth_batch
     n = 3 * 196608 + 4 * 196608 // 3 + 12345          # > 3 rounds, ragged
     pub, dig, r, s = synth_batch(eng, n, 4096, seed=91)
     rng = np.random.default_rng(92)
     bad = rng.choice(n, size=5000, replace=False)
     s[bad, rng.integers(0, 32, size=bad.size)] ^= 0x20
-    host = eng.ecdsa_verify_batch(pub, dig, r, s)
     dev = torch.device("cuda", 0)
     d = [torch.from_numpy(x).to(dev) for x in (pub, dig, r, s)]
     out = torch.zeros(n, dtype=torch.uint8, device=dev)
     eng.ecdsa_verify_batch_device(n, *(x.data_ptr() for x in d), out.data_ptr(), 0, 0)
     torch.cuda.synchronize()
     single = out.cpu().numpy()
-    assert np.array_equal(host, single)
     exp = np.ones(n, dtype=np.uint8)
     exp[bad] = 0
-    assert np.array_equal(host, exp)
+    assert np.array_equal(single, exp)
+    try:
+        for mode in (S.KEYS_OFF, S.KEYS_AUTO):
+            eng.set_key_grouping(mode)
+            host = eng.ecdsa_verify_batch(pub, dig, r, s)
+            assert np.array_equal(host, exp), mode
+            host = eng.ecdsa_verify_batch(pub, dig, r, s, force_complete=True)      # the reference-shaped path, host buffers
+            assert np.array_equal(host, exp), mode
+    finally:
+        eng.set_key_grouping(S.KEYS_AUTO)
 
 
 def test_full_size_differential_vs_oracle(eng, oracle):
