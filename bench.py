@@ -372,13 +372,15 @@ def worker(args):
         # One untimed call first: it creates the context's staging buffers and streams.
         if not args.no_pcie and world == 1:
             eng.ecdsa_verify_batch(pub, digest, r, s)
-            t1 = time.perf_counter()
-            hv = eng.ecdsa_verify_batch(pub, digest, r, s)
-            dt_host = time.perf_counter() - t1
-            assert int(hv.sum()) == n
-            line["pcie_inclusive"] = {"value": n / dt_host, "unit": "verifications/s",
-                                      "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch, "
-                                              "second call (staging buffers exist)" % batch_log2}
+            host_ms = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                hv = eng.ecdsa_verify_batch(pub, digest, r, s)
+                host_ms.append((time.perf_counter() - t1) * 1e3)
+                assert int(hv.sum()) == n
+            line["pcie_inclusive"] = {"value": n / (median(host_ms) * 1e-3), "unit": "verifications/s", "ms_each": host_ms,
+                                      "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch per call, "
+                                              "median of 3 calls after one that creates the staging buffers" % batch_log2}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(pub, digest, r, s)
         print(json.dumps(line), flush=True)
