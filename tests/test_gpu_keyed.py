@@ -373,3 +373,32 @@ def test_randomised_grouping_stress():
                          text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "stress ok" in res.stdout
+
+
+def test_two_part_flow(oracle):
+    """S2K_KEYED_PARTS=2 (off by default): tables of the second half of the keys are built beside the
+    first half's ladder.  Enough keys for the split to happen (>= 4096 tables), damaged signatures, ECDSA and
+    BIP-340 per-signature verification: the oracle's verdicts, and a context of its own for the setting."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch, synth_schnorr_batch
+    os.environ["S2K_KEYED_PARTS"] = "2"
+    try:
+        e2 = S.Engine(0)
+    finally:
+        del os.environ["S2K_KEYED_PARTS"]
+    n_keys, n = 5000, 5000 * 9
+    pub, dig, r, s = synth_batch(e2, n, n_keys, seed=121)
+    _damage(pub, dig, r, s, 122)
+    exp = oracle.ecdsa_verify_batch(pub, dig, r, s, nthreads=os.cpu_count() or 1)
+    got = e2.ecdsa_verify_batch(pub, dig, r, s)
+    st = e2.key_grouping_stats()
+    assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
+    assert st["tables"] >= 4096 and st["keyed"] > n * 0.8
+    m = 4200 * 7
+    pk, msgs, sig = synth_schnorr_batch(e2, m, 4200, seed=123)
+    sig[::11, 40] ^= 1
+    e_s = np.array([1 if oracle.schnorr_verify(bytes(pk[j]), bytes(msgs[j]), bytes(sig[j])) == 1 else 0 for j in range(m)], dtype=np.uint8)
+    g_s = e2.schnorr_verify_batch(pk, msgs, sig)
+    assert np.array_equal(g_s, e_s)
+    assert e2.key_grouping_stats()["tables"] >= 4096
+    e2.close()
