@@ -113,8 +113,8 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32
   slot_of[i] = found;
   // Rank in the group: one atomic per lane, except that lanes of this wave which share a slot go together.
   // Up to KG_SHARE_ROUNDS times the first unserved lane collects everyone with its slot (a batch under one
-  // key, or four: 1 or 4 atomics per wave instead of 64 on the same address, 13 ms -> 0.2 ms); with
-  // many keys per wave the rounds serve one lane each and the rest go alone, as before.
+  // key, or four: 1 or 4 atomics per wave instead of 64 on the same address, 13 ms -> 0.2 ms); a round
+  // that serves a single lane ends the sharing (a wave of distinct keys) and the rest go alone, as before.
   const uint32_t lane = threadIdx.x & 63u;
   bool pending = found != KG_NONE;
   uint32_t pos = 0;
@@ -133,6 +133,7 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32
       pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       pending = false;
     }
+    if (__popcll(m) == 1) break;   // nobody shared the leader's slot: a wave of distinct keys, the rest go alone
   }
   if (pending) pos = atomicAdd(&cnt[found], 1u);
   pos_of[i] = pos;
