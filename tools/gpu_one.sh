@@ -1,3 +1,6 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_keyed.py -m gpu -q -x 2>&1 | tail -2
-for rep in 1 2; do PROBE_MODES=off,auto timeout 300 python tools/keyed_probe.py 20 0,2,16,20 2>/dev/null | cut -c1-200; done
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_last.json 2> gpurun_out/bench_last.err; echo rc=$?
+python3 -c "
+import json
+d=json.load(open('gpurun_out/bench_last.json'))
+print(d['value'], d['ms_per_step'], d['distinct_keys'], d.get('extras_error'), d['pcie_inclusive']['value'])"
