@@ -108,6 +108,18 @@ static int gpu_part(void) {
     wrong += valid[i] != expect;
   }
   CHECK(wrong == 0 && good == N - N / 8, "verdicts");
+  /* the keys repeat (256 of them, 16 signatures each): the call above grouped them and went through per-key
+   * tables; the same batch with the grouping off must give the same verdicts */
+  uint32_t st[4] = {0, 0, 0, 0};
+  CHECK(s2k_ctx_key_grouping_stats(ctx, st) == S2K_OK && st[0] == N && st[1] == 256 && st[2] == 0, "grouping statistics");
+  uint8_t* valid2 = malloc(N);
+  CHECK(s2k_ctx_set_key_grouping(ctx, S2K_KEYS_OFF, 0, 0, 0) == S2K_OK, "s2k_ctx_set_key_grouping");
+  rc = s2k_ecdsa_verify_batch(ctx, N, pub, dig, r, s, S2K_ECDSA_REJECT_MALLEABLE, valid2);
+  CHECK(rc == S2K_OK && memcmp(valid, valid2, N) == 0, "same verdicts without the grouping");
+  CHECK(s2k_ctx_key_grouping_stats(ctx, st) == S2K_OK && st[0] == 0 && st[1] == 0, "grouping statistics (off)");
+  CHECK(s2k_ctx_set_key_grouping(ctx, 7, 0, 0, 0) == S2K_ERR_ARG, "bad grouping mode refused");
+  CHECK(s2k_ctx_set_key_grouping(ctx, S2K_KEYS_AUTO, 0, 0, 0) == S2K_OK, "grouping back on");
+  free(valid2);
   /* recovery gives the signer's key back */
   uint8_t* rec = malloc(N * 65), *ok = malloc(N), *rids = calloc(N, 1);
   for (int i = 0; i < N; i += 8) dig[i * 32 + 5] ^= 0x40; /* undo */
