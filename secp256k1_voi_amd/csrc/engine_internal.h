@@ -201,8 +201,9 @@ constexpr int KT_SLOTS = 72;                    // entries of 128 bytes reserved
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
 constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grouping
-// Signatures per key from which a table pays: a table costs ~15 ns, a signature saves ~3.6 ns on it
-// (MI355X, 2^20 signatures: 4 per key 8.56 ms with tables against 8.17 without, 16 per key 5.5 against 8.1)
+// Signatures per key from which a table pays, measured (MI355X, 2^20 signatures, ms with tables / without):
+// 4 per key 7.94 / 8.02, 5 per key 8.08 / 8.01 (the table kernels do not scale linearly and the clock sags),
+// 6 per key 6.65 / 7.93, 8 per key 6.02 / 7.96, 16 per key 5.1 / 8.0
 constexpr uint32_t KG_MIN_GROUP = 6;
 struct key_groups {        // device pointers of one call
   uint32_t* counters;      // [KG_NKEYED] signatures on the keyed path, [KG_NTAB] tables, [KG_NLEFT] the rest

@@ -21,9 +21,10 @@ def main():
     if os.environ.get("S2K_GP_FIRST_PERCENT"):
         print(json.dumps({"gp_first_percent": int(os.environ["S2K_GP_FIRST_PERCENT"])}), flush=True)
     for kl in keys_logs:
-        if kl > lg:
+        nkeys = 1 << kl if kl <= 30 else kl          # (values above 30: the number of keys itself)
+        if nkeys > n:
             continue
-        inp = [torch.from_numpy(x).to(dev) for x in synth_batch(eng, n, 1 << kl, seed=5)]
+        inp = [torch.from_numpy(x).to(dev) for x in synth_batch(eng, n, nkeys, seed=5)]
         out = torch.empty(n, dtype=torch.uint8, device=dev)
         ref = None
         modes = ((S.KEYS_OFF, "off"), (S.KEYS_AUTO, "auto"), (S.KEYS_ALWAYS, "always"))
