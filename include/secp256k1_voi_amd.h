@@ -333,7 +333,11 @@ enum {
   S2K_HP_EQ, S2K_HP_MUL_SMALL21, S2K_HP_NORMALIZE_WEAK, S2K_HP_JDBL, S2K_HP_JADD, S2K_HP_PT29_DBL,
   S2K_HP_PT29_ADD, S2K_HP_PT29_ADD_MIXED,
   S2K_HP_INV_GCD,   /* fe29_inv_gcd: the safegcd inversion mod p of the per-key tables (same values as S2K_HP_INV) */
-  S2K_HP_JADD_FULL  /* jpt29_add: P as for JADD, Q = (d, e) lifted to Z2 = c^2 */
+  S2K_HP_JADD_FULL, /* jpt29_add: P as for JADD, Q = (d, e) lifted to Z2 = c^2 */
+  /* pt29q.h: the complete formulas spread over the four lanes of a quad (the serial tail of the multi-scalar
+   * multiplication); inputs and outputs as PT29_DBL / PT29_ADD (Q scaled by c as well).  Bits 20.. of `lazy`: how often
+   * the operation is chained on its own result (P + Q + Q + ..., 2^k P); 0 means once. */
+  S2K_HP_PT29Q_DBL, S2K_HP_PT29Q_ADD
 };
 int s2k_fp_op_batch_ex(s2k_ctx *ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t *const in[5],
                        uint8_t *out, uint8_t *out2, uint8_t *flag);

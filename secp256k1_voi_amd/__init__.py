@@ -33,7 +33,7 @@ IMPL_COMPLETE, IMPL_FAST = 0, 1
 KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS = 0, 1, 2     # s2k_ctx_set_key_grouping
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
  HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
- HP_PT29_ADD_MIXED, HP_INV_GCD, HP_JADD_FULL) = range(23)
+ HP_PT29_ADD_MIXED, HP_INV_GCD, HP_JADD_FULL, HP_PT29Q_DBL, HP_PT29Q_ADD) = range(25)
 
 IDENTITY = bytes(65)
 
@@ -93,9 +93,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", '-DS2K_BUILD_FLAGS="%s"' % extra.replace('"', "'")]
     flags += extra.split()
 
+    # an object is reused when it is newer than its own source and every header, and was built with these flags
+    headers = [d for d in deps if d.endswith(".h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    same_flags = built_with == extra
+
     def compile_one(u):
         obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
-        cmd = ["hipcc", *flags, "-c", os.path.join(CSRC, u), "-o", obj]
+        src = os.path.join(CSRC, u)
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(src)):
+            return obj
+        cmd = ["hipcc", *flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -34,15 +34,15 @@
 #include "engine_internal.h"
 #include "fe29_inv.h"
 #include "pt29.h"
+#include "pt29q.h"
 #include "sc.h"
 #include "sha256.h"
 
 namespace {
 
 #ifndef S2K_MSM_CHUNK_LOG2
-#define S2K_MSM_CHUNK_LOG2 4   // A/B on MI355X at 2^20 terms: 2 -> 2.55, 3 -> 2.43, 4 -> 2.34, 5 -> 2.44 ms
+#define S2K_MSM_CHUNK_LOG2 3   // default of the buckets per reduction chunk (log2); S2K_MSM_CHUNK_LOG2 in the environment overrides it
 #endif
-constexpr int CHUNK_LOG2 = S2K_MSM_CHUNK_LOG2, CHUNK = 1 << CHUNK_LOG2;   // buckets per reduction chunk
 // Every input term k*P is split with the curve endomorphism (splitGLV, point_mul_glv.go:59) into
 // |k1| * (+-P) + |k2| * (+-lambda P), |k1|, |k2| < 2^128: twice the terms, half the windows.  The
 // bucket additions stay the same (2n * 8 instead of n * 16 at c = 16) but the serial tail -
@@ -53,8 +53,9 @@ constexpr uint32_t SCALAR_BITS = 128;
 struct msm_geom {
   uint32_t c;        // window bits
   uint32_t nw;       // windows = ceil(128 / c)
-  uint32_t nb;       // keys per window = 2^c (key 0 unused)
-  uint32_t nchunk;   // nb / CHUNK
+  uint32_t nb;       // keys per slot = 2^(c-1): the magnitudes 1 .. 2^(c-1) of a signed digit (key = magnitude - 1)
+  uint32_t nslot;    // nw + 1 slots of nb keys: one per window, the top window (unsigned, up to 2^c) takes two
+  uint32_t chunk_log2, nchunk;   // buckets per reduction chunk (log2), chunks per slot = nb >> chunk_log2
 };
 
 S2K_DEV uint32_t msm_digit(const uint32_t* __restrict__ scw, size_t n_stride, size_t i, uint32_t w, uint32_t c) {
@@ -63,6 +64,24 @@ S2K_DEV uint32_t msm_digit(const uint32_t* __restrict__ scw, size_t n_stride, si
   uint32_t hi = word + 1 < SCW_WORDS ? scw[(size_t)(word + 1) * n_stride + i] : 0u;
   uint64_t v = ((uint64_t)hi << 32) | lo;
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+}
+// Signed digits: k = sum_w d_w 2^(cw) with |d_w| <= 2^(c-1) below the top window (a digit above 2^(c-1) becomes
+// digit - 2^c and carries one into the next window); the top window stays unsigned, 0 .. 2^c, and its
+// magnitudes above 2^(c-1) simply continue into the extra slot.  Half the buckets of unsigned digits: the bucket
+// of magnitude m receives +P for digit m and -P for digit -m.  f(key, negative) for every non-zero digit of term i,
+// key = window * nb + magnitude - 1.
+constexpr uint32_t TERM_NEG = 0x80000000u;    // sign flag next to a term index (term counts stay below 2^30)
+template <class F>
+S2K_DEV void msm_for_digits(const uint32_t* __restrict__ scw, size_t n_stride, size_t i, const msm_geom& g, F f) {
+  uint32_t carry = 0;
+  const uint32_t half = g.nb, full = g.nb << 1;
+  for (uint32_t w = 0; w < g.nw; ++w) {
+    uint32_t v = msm_digit(scw, n_stride, i, w, g.c) + carry;
+    const bool neg = w + 1 < g.nw && v > half;
+    carry = neg ? 1u : 0u;
+    const uint32_t m = neg ? full - v : v;
+    if (m) f(w * g.nb + m - 1u, neg);
+  }
 }
 
 // pt29 in planes [word][slot], PT_WORDS words per point
@@ -92,6 +111,18 @@ S2K_DEV pt29 pt_select(bool pick_b, const pt29& a, const pt29& b) {
   r.y = fe29_select(pick_b, a.y, b.y);
   r.z = fe29_select(pick_b, a.z, b.z);
   return r;
+}
+
+// one coordinate (cc = 0, 1, 2: x, y, z) of a stored point: the quad-spread group law (pt29q.h) keeps a point in four lanes
+S2K_DEV fe29 ptq_load(const uint32_t* __restrict__ base, size_t stride, size_t slot, uint32_t cc) {
+  fe29 r;
+#pragma unroll
+  for (int w = 0; w < 9; ++w) r.n[w] = base[(size_t)(9 * cc + w) * stride + slot];
+  return r;
+}
+S2K_DEV void ptq_store(uint32_t* __restrict__ base, size_t stride, size_t slot, uint32_t cc, const fe29& v) {
+#pragma unroll
+  for (int w = 0; w < 9; ++w) base[(size_t)(9 * cc + w) * stride + slot] = v.n[w];
 }
 
 // term `t` of a term array with plane stride N: magnitude k (< 2^128), point (x, +-y)
@@ -212,12 +243,12 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* count, c
 }
 
 // ---------------------------------------------------------------------------------------
-// Two-level counting sort of the (key, term) pairs, key = window * 2^c + digit (digit 0 skipped).
+// Two-level counting sort of the (key, term) pairs, key = window * 2^(c-1) + |digit| - 1 (zero digits skipped).
 // FINE keys per coarse bucket; a sort workgroup owns SORT_TERMS consecutive terms.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t FINE_BITS = 10, FINE = 1u << FINE_BITS;
 constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = 4096;
-constexpr uint32_t MAX_COARSE = 1024;     // nkeys / FINE for c = 16 (the largest geometry)
+constexpr uint32_t MAX_COARSE = 512;      // nkeys / FINE, at most 9 * 2^15 / 2^10 (c = 16, the largest geometry)
 
 // matrix[coarse * nblk_pad + block] = pairs of this workgroup's terms falling into `coarse`
 __global__ void __launch_bounds__(SORT_THREADS)
@@ -230,15 +261,12 @@ k_msm_coarse_count(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, con
   for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
     size_t i = base + t;
     if (i >= n || flag[i] != 1) continue;
-    for (uint32_t w = 0; w < g.nw; ++w) {
-      uint32_t d = msm_digit(scw, n, i, w, g.c);
-      if (d) atomicAdd(&h[(w * g.nb + d) >> FINE_BITS], 1u);
-    }
+    msm_for_digits(scw, n, i, g, [&](uint32_t key, bool) { atomicAdd(&h[key >> FINE_BITS], 1u); });
   }
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) matrix[(size_t)t * nblk_pad + blockIdx.x] = h[t];
 }
-// pairs[pos] = (key & (FINE - 1), term), grouped by coarse bucket; `mbase` is the scanned matrix
+// pairs[pos] = (key & (FINE - 1), term | sign), grouped by coarse bucket; `mbase` is the scanned matrix
 __global__ void __launch_bounds__(SORT_THREADS)
 k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
                      uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint2* __restrict__ pairs) {
@@ -249,13 +277,10 @@ k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, c
   for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
     size_t i = base + t;
     if (i >= n || flag[i] != 1) continue;
-    for (uint32_t w = 0; w < g.nw; ++w) {
-      uint32_t d = msm_digit(scw, n, i, w, g.c);
-      if (!d) continue;
-      uint32_t key = w * g.nb + d;
+    msm_for_digits(scw, n, i, g, [&](uint32_t key, bool neg) {
       uint32_t pos = atomicAdd(&cur[key >> FINE_BITS], 1u);
-      pairs[pos] = make_uint2(key & (FINE - 1), (uint32_t)i);
-    }
+      pairs[pos] = make_uint2(key & (FINE - 1), (uint32_t)i | (neg ? TERM_NEG : 0u));
+    });
   }
 }
 // one workgroup per coarse bucket: pairs -> list (term indices grouped by key), count[key],
@@ -270,7 +295,17 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
   const uint32_t hi = b + 1 < ncoarse ? mbase[(size_t)(b + 1) * nblk_pad] : mbase[total_slot];
   h[t] = 0;
   __syncthreads();
-  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS) atomicAdd(&h[pairs[j].x], 1u);
+  // four loads in flight per thread: one pair per trip made this kernel latency bound (a global load, then an
+  // LDS atomic that waits for it, 32 times in a row)
+  constexpr uint32_t U = 4;
+  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS * U) {
+    uint32_t k[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) k[u] = j + u * SORT_THREADS < hi ? pairs[j + u * SORT_THREADS].x : FINE;
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+      if (k[u] < FINE) atomicAdd(&h[k[u]], 1u);
+  }
   __syncthreads();
   const uint32_t mine = h[t];
   part[t] = mine;
@@ -288,221 +323,261 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
   if (b + 1 == ncoarse && t == FINE - 1) offset[key + 1] = hi;
   h[t] = off;                      // running cursor of key t
   __syncthreads();
-  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS) {
-    uint2 e = pairs[j];
-    list[atomicAdd(&h[e.x], 1u)] = e.y;
+  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS * U) {
+    uint2 e[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) e[u] = j + u * SORT_THREADS < hi ? pairs[j + u * SORT_THREADS] : make_uint2(FINE, 0u);
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+      if (e[u].x < FINE) list[atomicAdd(&h[e[u].x], 1u)] = e[u].y;
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// Load balance of the bucket pass.  The unit of work is a SEGMENT: at most seg_len (512) consecutive
-// entries of one bucket (a bucket of up to seg_len points is one segment; a larger one - only
-// adversarial or degenerate inputs produce those at 2^20 terms - is cut into several, so no lane
-// ever adds more than seg_len points).  Bucket sizes are Poisson distributed (mean 32 at 2^20
-// inputs), so in bucket order a wave would wait for the largest of its 64 buckets; the segments
-// are therefore visited in order of decreasing size (a counting sort by size, SIZE_BINS bins,
-// block-aggregated so that only one global atomic per block and bin is issued): the 64 lanes of
-// a wave own (almost) equally full segments, and the big ones are scheduled first.
-// perm[slot] = key | segment << 20;  firstslot[key] = slot of the bucket's segment 0.
+// The bucket pass.  The sorted list is cut into RANGES of L consecutive entries, one lane per range, whatever
+// buckets the entries belong to: every lane does exactly L additions (the last one fewer), so all the waves of
+// the launch finish together and - L chosen so that the lanes fill the chip once - every SIMD keeps its four
+// waves from start to end.  (One lane per bucket, the buckets ordered by size, was the round-2 design: bucket sizes
+// are Poisson distributed, a SIMD's waves ran out one after the other and the longest ended alone at half the issue
+// rate: 0.79-0.85 of the issue slots.)
+// A lane walks its range; at every bucket border (offset[] of the sort) it flushes its accumulator and restarts
+// from the identity (the complete formulas take the identity as they take any point).  A bucket that lies inside one
+// range is written to its final place sums[key]; a piece of a bucket that continues from the previous range goes to
+// sums[nkeys + lane] ("left edge"), a piece that continues into the next range to sums[nkeys + nlanes + lane] ("right
+// edge"); a range that lies inside one bucket altogether is a left edge.  k_msm_stitch then completes every bucket
+// that crosses a range border: right edge of its first range + left edges of the following ones (one addition for an
+// ordinary bucket; buckets spread over more than STITCH_SERIAL ranges - only engineered inputs make those - are
+// queued for k_msm_stitch_big, one workgroup per bucket, a tree over the pieces).
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t SIZE_BINS = 256, SEG_LEN_MIN = 512, KEY_BITS = 20, SEG_BITS = 32 - KEY_BITS;   // seg_len = max(SEG_LEN_MIN, terms / 2^SEG_BITS)
-S2K_DEV uint32_t size_bin(uint32_t cnt) { return SIZE_BINS - 1 - (cnt < SIZE_BINS - 1 ? cnt : SIZE_BINS - 1); }   // bin 0 = largest
-S2K_DEV uint32_t seg_count(uint32_t cnt, uint32_t seg_len) { return cnt <= seg_len ? 1u : (cnt + seg_len - 1) / seg_len; }
+constexpr uint32_t MSM_LANES = 1u << 18;      // lanes that fill an MI355X once at four waves per SIMD (256 CU x 4 x 4 x 64)
+constexpr uint32_t MSM_L_MIN = 8;             // shortest range
+constexpr uint32_t STITCH_SERIAL = 8, STITCH_BIG_CAP = 4096;
 
-__global__ void __launch_bounds__(256)
-k_msm_size_hist(uint32_t nkeys, uint32_t seg_len, const uint32_t* __restrict__ count, uint32_t* __restrict__ sizehist) {
-  __shared__ uint32_t h[SIZE_BINS];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (key < nkeys) {
-    uint32_t cnt = count[key];
-    atomicAdd(&h[size_bin(cnt)], seg_count(cnt, seg_len));
-  }
-  __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&sizehist[threadIdx.x], h[threadIdx.x]);
-}
-// exclusive scan of the SIZE_BINS totals (one workgroup); also clears the cursors and leaves the
-// number of segments in sizecur[SIZE_BINS]
-__global__ void __launch_bounds__(256) k_msm_size_scan(const uint32_t* __restrict__ sizehist, uint32_t* __restrict__ sizebase,
-                                                       uint32_t* __restrict__ sizecur) {
-  __shared__ uint32_t part[SIZE_BINS];
-  uint32_t t = threadIdx.x, mine = sizehist[t];
-  part[t] = mine;
-  __syncthreads();
-  for (uint32_t s = 1; s < SIZE_BINS; s <<= 1) {
-    uint32_t a = t >= s ? part[t - s] : 0;
-    __syncthreads();
-    part[t] += a;
-    __syncthreads();
-  }
-  sizebase[t] = part[t] - mine;
-  sizecur[t] = 0;
-  if (t == SIZE_BINS - 1) sizecur[SIZE_BINS] = part[t];
-}
-__global__ void __launch_bounds__(256)
-k_msm_size_scatter(uint32_t nkeys, uint32_t seg_len, const uint32_t* __restrict__ count, const uint32_t* __restrict__ sizebase,
-                   uint32_t* __restrict__ sizecur, uint32_t* __restrict__ perm, uint32_t* __restrict__ firstslot) {
-  __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
-  uint32_t bin = 0, rank = 0, nseg = 0;
-  if (key < nkeys) {
-    uint32_t cnt = count[key];
-    bin = size_bin(cnt);
-    nseg = seg_count(cnt, seg_len);
-    rank = atomicAdd(&h[bin], nseg);
-  }
-  __syncthreads();
-  if (h[threadIdx.x]) base[threadIdx.x] = sizebase[threadIdx.x] + atomicAdd(&sizecur[threadIdx.x], h[threadIdx.x]);
-  __syncthreads();
-  if (key < nkeys) {
-    uint32_t slot = base[bin] + rank;
-    firstslot[key] = slot;
-    for (uint32_t sgm = 0; sgm < nseg; ++sgm) perm[slot + sgm] = (uint32_t)key | (sgm << KEY_BITS);
-  }
-}
-
-// one lane per segment: complete mixed additions of its points -> segsum[slot]
-__global__ void __launch_bounds__(256)
-k_msm_accumulate(uint32_t cap, uint32_t seg_len, const uint32_t* __restrict__ nseg_total, const uint32_t* __restrict__ perm,
-                 const uint32_t* __restrict__ offset, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
-                 uint32_t* __restrict__ segsum) {
-  size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (slot >= *nseg_total) return;
-  uint32_t pk = perm[slot];
-  size_t key = pk & ((1u << KEY_BITS) - 1u);
-  uint32_t lo = offset[key] + (pk >> KEY_BITS) * seg_len, end = offset[key + 1];
-  uint32_t hi = end - lo > seg_len ? lo + seg_len : end;
-  pt29 acc = pt29_identity();
-#pragma unroll 1
-  for (uint32_t j = lo; j < hi; ++j) {
-    size_t i = list[j];
-    const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + i * 16);
-    uint4 a = rec4[0], b = rec4[1], c = rec4[2], d = rec4[3];
-    uint32_t xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint32_t yw[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    if (j == lo) {            // the first point of a segment is the accumulator (Z = 1): no addition
-      acc.x = fe29_from_words(xw);
-      acc.y = fe29_from_words(yw);
-      acc.z = fe29_one();
-    } else {
-      acc = pt29_add_mixed(acc, fe29_from_words(xw), fe29_from_words(yw));
-    }
-  }
-  pt_store(segsum, cap, slot, acc);
-}
-// the bucket of `key`: its segment sums added up (one segment for every ordinary bucket)
-S2K_DEV pt29 bucket_load(const uint32_t* __restrict__ segsum, size_t cap, uint32_t seg_len, const uint32_t* __restrict__ count,
-                         const uint32_t* __restrict__ firstslot, size_t key) {
-  uint32_t slot = firstslot[key], nseg = seg_count(count[key], seg_len);
-  pt29 r = pt_load(segsum, cap, slot);
-#pragma unroll 1
-  for (uint32_t sgm = 1; sgm < nseg; ++sgm) r = pt29_add(r, pt_load(segsum, cap, slot + sgm));
+struct msm_rec {
+  uint4 a, b, c, d;
+};
+S2K_DEV msm_rec msm_load_rec(const uint32_t* __restrict__ ptw, uint32_t entry) {
+  const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + (size_t)(entry & ~TERM_NEG) * 16);
+  msm_rec r;
+  r.a = rec4[0]; r.b = rec4[1]; r.c = rec4[2]; r.d = rec4[3];
   return r;
 }
-
-// chunk (w, j): buckets b in [CHUNK j, CHUNK j + CHUNK) of window w -> sum_b b * B_b
-__global__ void __launch_bounds__(64)
-k_msm_reduce(msm_geom g, const uint32_t* __restrict__ segsum, size_t cap, uint32_t seg_len, const uint32_t* __restrict__ count,
-             const uint32_t* __restrict__ firstslot, uint32_t* __restrict__ partial) {
-  size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
-  size_t nslots = (size_t)g.nw * g.nchunk;
-  if (id >= nslots) return;
-  uint32_t w = (uint32_t)(id / g.nchunk), j = (uint32_t)(id % g.nchunk);
-  size_t base = (size_t)w * g.nb + (size_t)j * CHUNK;
-  pt29 run = pt29_identity(), tot = pt29_identity();
-#pragma unroll 1
-  for (int b = CHUNK - 1; b >= 1; --b) {
-    run = pt29_add(run, bucket_load(segsum, cap, seg_len, count, firstslot, base + b));
-    tot = pt29_add(tot, run);
+// A list entry is a term index with the digit's sign: a negative digit adds -P = (x, p - y), formed on the 32-bit
+// words before the limbs are cut.
+S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
+  uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+  uint32_t yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
+  // neg: p - y = ~y + p + 1 over the eight words (y in [1, p), so the result is in (0, p) and the carry out is dropped)
+  constexpr uint32_t PW[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  const uint32_t M = 0u - (entry >> 31);
+  uint64_t cy = M & 1u;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    cy += (uint64_t)(yw[w] ^ M) + (PW[w] & M);
+    yw[w] = (uint32_t)cy;
+    cy >>= 32;
   }
-  run = pt29_add(run, bucket_load(segsum, cap, seg_len, count, firstslot, base));       // S_j (bucket CHUNK*j has coefficient 0 in tot)
-  // tot += (CHUNK j) * S_j :  j * S_j by double-and-add, then CHUNK_LOG2 doublings
-  pt29 m = pt29_identity();
-#pragma unroll 1
-  for (int bit = 16 - CHUNK_LOG2 - 1; bit >= 0; --bit) {   // j < 2^(c - CHUNK_LOG2), c <= 16
-    m = pt29_double(m);
-    pt29 s = pt29_add(m, run);
-    m = pt_select((j >> bit) & 1u, m, s);
+  x = fe29_from_words(xw);
+  y = fe29_from_words(yw);
+}
+// the key whose bucket holds list position p: offset[key] <= p < offset[key + 1]  (p < offset[nkeys])
+S2K_DEV uint32_t msm_key_at(const uint32_t* __restrict__ offset, uint32_t nkeys, uint32_t p) {
+  uint32_t lo = 0, hi = nkeys;            // invariant: offset[lo] <= p < offset[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offset[mid] <= p) lo = mid; else hi = mid;
   }
-#pragma unroll 1
-  for (int t = 0; t < CHUNK_LOG2; ++t) m = pt29_double(m);
-  tot = pt29_add(tot, m);
-  pt_store(partial, nslots, id, tot);
+  return lo;
 }
 
-// tree sum of a window's chunk results, partial[w][0..nchunk) -> partial[w][0], in two launches of
-// 256-thread workgroups (a 1024-thread workgroup would cap the kernel at 128 VGPRs and spill):
-// `span` consecutive slots are folded into the first one by each workgroup
+#ifndef S2K_MSM_PREFETCH
+#define S2K_MSM_PREFETCH 1   // the next point's record is loaded before the current addition starts
+#endif
+#if S2K_MSM_PREFETCH
+__global__ void __launch_bounds__(256, 4)     // four waves per SIMD: at most 128 VGPRs
+#else
+__global__ void __launch_bounds__(256)
+#endif
+k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw, uint32_t* __restrict__ sums) {
+  const uint32_t lane = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t total = offset[nkeys];
+  const uint64_t lo64 = (uint64_t)lane * L;
+  if (lo64 >= total) return;
+  const uint32_t lo = (uint32_t)lo64, hi = total - lo > L ? lo + L : total;
+  uint32_t key = msm_key_at(offset, nkeys, lo);
+  uint32_t border = offset[key + 1];                       // > lo
+  bool open_left = offset[key] < lo;
+  pt29 acc = pt29_identity();
+  uint32_t e_cur = list[lo], e_nxt = lo + 1 < hi ? list[lo + 1] : 0u;
+  msm_rec r_cur = msm_load_rec(ptw, e_cur);
+#pragma unroll 1
+  for (uint32_t j = lo; j < hi; ++j) {
+    if (j == border) {                                     // a bucket ends here: flush, next non-empty bucket
+      pt_store(sums, stride, open_left ? (size_t)nkeys + lane : (size_t)key, acc);
+      open_left = false;
+      acc = pt29_identity();
+      do {
+        ++key;
+        border = offset[key + 1];
+      } while (border <= j);
+    }
+#if S2K_MSM_PREFETCH
+    const msm_rec r_nxt = msm_load_rec(ptw, e_nxt);        // entry 0 when past the end: a valid address
+    const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;
+#endif
+    fe29 qx, qy;
+    msm_point_of(r_cur, e_cur, qx, qy);
+    acc = pt29_add_mixed(acc, qx, qy);
+#if S2K_MSM_PREFETCH
+    r_cur = r_nxt;
+    e_cur = e_nxt;
+    e_nxt = e_nn;
+#else
+    e_cur = e_nxt;
+    e_nxt = j + 2 < hi ? list[j + 2] : 0u;
+    r_cur = msm_load_rec(ptw, e_cur);
+#endif
+  }
+  // the last piece: left edge if it came in from the previous range (then it may go on as well: a range inside one
+  // bucket), right edge if it goes on into the next range, else a whole bucket
+  const bool open_right = border > hi;
+  pt_store(sums, stride, open_left ? (size_t)nkeys + lane : (open_right ? (size_t)nkeys + nlanes + lane : (size_t)key), acc);
+}
+
+// one lane per key: the identity for an empty bucket; a bucket that crosses range borders is put together from its
+// pieces (see above); a bucket inside one range has been written by that range's lane
+__global__ void __launch_bounds__(256)
+k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+             uint32_t* __restrict__ sums, uint32_t* __restrict__ big /* [0] count, [1 ..] keys */) {
+  const uint32_t key = blockIdx.x * 256 + threadIdx.x;
+  if (key >= nkeys) return;
+  const uint32_t b = offset[key], e = offset[key + 1];
+  if (b == e) {
+    pt_store(sums, stride, key, pt29_identity());
+    return;
+  }
+  const uint32_t k_lo = b / L, k_hi = (e - 1) / L;
+  if (k_lo == k_hi) return;
+  if (k_hi - k_lo > STITCH_SERIAL) {
+    const uint32_t pos = atomicAdd(&big[0], 1u);
+    if (pos < STITCH_BIG_CAP) {
+      big[1 + pos] = key;
+      return;
+    }                                       // more oversized buckets than the queue holds: serial after all
+  }
+  // first piece: the bucket starts at a range border (then that range's piece is a right edge too, unless the bucket
+  // IS the rest of the range... it is open to the right, so: right edge) or inside the range (right edge)
+  pt29 r = pt_load(sums, stride, (size_t)nkeys + nlanes + k_lo);
+#pragma unroll 1
+  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, pt_load(sums, stride, (size_t)nkeys + k));
+  pt_store(sums, stride, key, r);
+}
+// one workgroup per queued bucket: the threads take the pieces round robin, then a tree in LDS
+__global__ void __launch_bounds__(256)
+k_msm_stitch_big(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+                 uint32_t* __restrict__ sums, const uint32_t* __restrict__ big) {
+  __shared__ uint32_t sh[PT_WORDS][128];
+  const uint32_t nbig = big[0] < STITCH_BIG_CAP ? big[0] : STITCH_BIG_CAP;
+  for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
+    const uint32_t key = big[1 + q];
+    const uint32_t k_lo = offset[key] / L, k_hi = (offset[key + 1] - 1) / L;
+    pt29 r = pt29_identity();
+#pragma unroll 1
+    for (uint32_t k = k_lo + threadIdx.x; k <= k_hi; k += 256)
+      r = pt29_add(r, pt_load(sums, stride, k == k_lo ? (size_t)nkeys + nlanes + k : (size_t)nkeys + k));
+    for (uint32_t half = 128; half >= 1; half >>= 1) {
+      __syncthreads();
+      if (threadIdx.x >= half && threadIdx.x < 2 * half) pt_store(&sh[0][0], 128, threadIdx.x - half, r);
+      __syncthreads();
+      if (threadIdx.x < half) r = pt29_add(r, pt_load(&sh[0][0], 128, threadIdx.x));
+    }
+    if (threadIdx.x == 0) pt_store(sums, stride, key, r);
+    __syncthreads();
+  }
+}
+
+// chunk (s, j): keys [CHUNK j, CHUNK j + CHUNK) of slot s, i.e. the magnitudes m = off + CHUNK j + t + 1, t = 0 .. CHUNK - 1
+// (off = nb for the extra slot of the top window, else 0)  ->  sum_t m * B_t = sum_t (t + 1) B_t + (off + CHUNK j) * S.
+// This kernel, the tree and the Horner tail below are serial chains of group operations on a chip that has nothing else
+// to do: they run the quad-spread formulas (pt29q.h), FOUR LANES PER CHUNK, each holding one coordinate.
+__global__ void __launch_bounds__(256)
+k_msm_reduce(msm_geom g, const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ partial) {
+  const size_t th = (size_t)blockIdx.x * 256 + threadIdx.x, id = th >> 2;
+  const uint32_t q = (uint32_t)th & 3u, cc = q < 2 ? q : 2u;
+  const size_t nslots = (size_t)g.nslot * g.nchunk;
+  if (id >= nslots) return;                                   // (whole quads leave together)
+  const uint32_t sl = (uint32_t)(id / g.nchunk), j = (uint32_t)(id % g.nchunk);
+  const int CHUNK_LOG2 = (int)g.chunk_log2, CHUNK = 1 << CHUNK_LOG2;
+  const size_t base = (size_t)sl * g.nb + (size_t)j * CHUNK;
+  fe29 run = pt29q_identity(q), tot = pt29q_identity(q);
+  fe29 nxt = ptq_load(sums, stride, base + CHUNK - 1, cc);
+#pragma unroll 1
+  for (int t = CHUNK - 1; t >= 0; --t) {
+    const fe29 cur = nxt;
+    if (t > 0) nxt = ptq_load(sums, stride, base + t - 1, cc);     // in flight during the two additions
+    run = pt29q_add(run, cur, q);
+    tot = pt29q_add(tot, run, q);
+  }
+  // tot += (off + CHUNK j) * S :  jj * S by double-and-add, then CHUNK_LOG2 doublings
+  const uint32_t jj = j + (sl == g.nw ? g.nchunk : 0u);
+  fe29 m = pt29q_identity(q);
+#pragma unroll 1
+  for (int bit = (int)g.c - CHUNK_LOG2 - 1; bit >= 0; --bit) {   // jj < 2 nchunk = 2^(c - CHUNK_LOG2)
+    m = pt29q_double(m, q);
+    const fe29 s = pt29q_add(m, run, q);
+    m = fe29_pick((jj >> bit) & 1u, m, s);
+  }
+#pragma unroll 1
+  for (int t = 0; t < CHUNK_LOG2; ++t) m = pt29q_double(m, q);
+  tot = pt29q_add(tot, m, q);
+  if (q < 3) ptq_store(partial, nslots, id, cc, tot);
+}
+
+// tree sum of a slot's chunk results, partial[s][0..nchunk) -> partial[s][0], in two launches of 256-thread workgroups:
+// `span` consecutive slots are folded into the first one by each workgroup, a quad per addition
 __global__ void __launch_bounds__(256) k_msm_tree(uint32_t nslots_total, uint32_t span, uint32_t stride_slots,
                                                   uint32_t* __restrict__ partial) {
   // workgroup b folds slots [b * span * stride_slots, ...) taken every stride_slots
   const size_t base = (size_t)blockIdx.x * span * stride_slots;
+  const uint32_t q = threadIdx.x & 3u, cc = q < 2 ? q : 2u, pair = threadIdx.x >> 2;
   for (uint32_t half = span >> 1; half >= 1; half >>= 1) {
-    for (uint32_t t = threadIdx.x; t < half; t += 256) {
+    for (uint32_t t = pair; t < half; t += 64) {
       const size_t ia = base + (size_t)t * stride_slots, ib = base + (size_t)(t + half) * stride_slots;
-      pt29 a = pt_load(partial, nslots_total, ia), c = pt_load(partial, nslots_total, ib);
-      pt_store(partial, nslots_total, ia, pt29_add(a, c));
+      const fe29 r = pt29q_add(ptq_load(partial, nslots_total, ia, cc), ptq_load(partial, nslots_total, ib, cc), q);
+      if (q < 3) ptq_store(partial, nslots_total, ia, cc, r);
     }
     __syncthreads();
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// Horner over the window sums, then the 65-byte record.  The 128 - c doublings are a serial
-// chain, and a lone wave issues dependent multiply-adds at half rate, so the doubling is spread
-// over the lanes of the (single) wave: all lanes hold the same point; in each of the two layers of
-// Algorithm 9 lane L (mod 4) computes a different product of it (operands selected by lane,
-// one fe29_mul / one fused multiply-add executed by the whole wave), and the results are
-// handed round with v_readlane (a lane's value as a wave-uniform scalar).  305 dependent
-// multiply-adds per doubling instead of 748.
+// Horner over the window sums, then the 65-byte record: 128 - c doublings, a serial chain on one wave (its sixteen
+// quads all run the same recurrence), lane 0 writes the result.
 // ---------------------------------------------------------------------------------------
-S2K_DEV fe29 lane_bcast(const fe29& v, int lane) {
-  fe29 r;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) r.n[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.n[i], lane);
-  return r;
-}
-S2K_DEV fe29 sel4(uint32_t id, const fe29& a0, const fe29& a1, const fe29& a2, const fe29& a3) {
-  return fe29_select(id >= 2, fe29_select(id == 1, a0, a1), fe29_select(id == 3, a2, a3));
-}
-// 2p, all lanes of the wave holding the same p (pt29_double spread over lanes 0..3 mod 4)
-S2K_DEV pt29 pt29_double_wave(const pt29& p) {
-  const uint32_t id = threadIdx.x & 3u;
-  // layer 1: Y^2 | Y Z | Z^2 | X Y
-  fe29 P = fe29_mul(sel4(id, p.y, p.y, p.z, p.x), sel4(id, p.y, p.z, p.z, p.y));
-  fe29 t0 = lane_bcast(P, 0), t1 = lane_bcast(P, 1), zz = lane_bcast(P, 2), xy = lane_bcast(P, 3);
-  fe29 z3 = fe29_mul_int(fe29_normalize_weak(fe29_mul_int(t0, 4)), 2);                  // [2]   8 Y^2
-  fe29 t2 = fe29_mul_small_norm(zz, 21);                                                // [1]   b3 Z^2
-  fe29 y3 = fe29_add(t0, t2);                                                           // [2]
-  fe29 t0m = fe29_normalize_weak(fe29_add(t0, fe29_negate(fe29_mul_small_norm(zz, 63), 1)));   // [1]   Y^2 - 3 b3 Z^2
-  // layer 2: Y3 = t2 z3 + t0m y3 | Z3 = t1 z3 | X3 = (2 t0m) (X Y)
-  const fe29 zero = fe29_zero();
-  fe29 Q = fe29_mul_add_mul(sel4(id, t2, t1, fe29_mul_int(t0m, 2), zero), sel4(id, z3, z3, xy, zero),
-                            sel4(id, t0m, zero, zero, zero), sel4(id, y3, zero, zero, zero));
-  pt29 r;
-  r.y = lane_bcast(Q, 0);
-  r.z = lane_bcast(Q, 1);
-  r.x = lane_bcast(Q, 2);
-  return r;
-}
-
-// one wave; every lane runs the same Horner recurrence, lane 0 writes the result
-__global__ void __launch_bounds__(64) k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65) {
-  // out65: the 65-byte record of the sum (all zero for the identity)
-  size_t nslots = (size_t)g.nw * g.nchunk;
-  pt29 acc = pt_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk);
+__global__ void __launch_bounds__(64) k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65, int affine) {
+  // out65: the 65-byte record of the sum (all zero for the identity); affine == 0: only identity or not is wanted
+  // (first byte 0x00 / 0x04, coordinates left zero): the whole-batch BIP-340 verdict skips the inversion
+  const uint32_t q = threadIdx.x & 3u, cc = q < 2 ? q : 2u;
+  const size_t nslots = (size_t)g.nslot * g.nchunk;
+  // the two slots of the top window carry the same weight
+  fe29 accq = pt29q_add(ptq_load(partial, nslots, (size_t)g.nw * g.nchunk, cc), ptq_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk, cc), q);
 #pragma unroll 1
   for (int w = (int)g.nw - 2; w >= 0; --w) {
+    const fe29 add = ptq_load(partial, nslots, (size_t)w * g.nchunk, cc);
 #pragma unroll 1
-    for (uint32_t t = 0; t < g.c; ++t) acc = pt29_double_wave(acc);
-    acc = pt29_add(acc, pt_load(partial, nslots, (size_t)w * g.nchunk));
+    for (uint32_t t = 0; t < g.c; ++t) accq = pt29q_double(accq, q);
+    accq = pt29q_add(accq, add, q);
   }
+  const pt29 acc = pt29q_gather(accq);
   if (threadIdx.x != 0) return;
   if (fe29_is_zero(acc.z)) {
     for (int i = 0; i < 65; ++i) out65[i] = 0;
+    return;
+  }
+  if (!affine) {
+    out65[0] = 0x04;
+    for (int i = 1; i < 65; ++i) out65[i] = 0;
     return;
   }
   fe29 zi = fe29_inv_gcd(fe29_normalize_weak(acc.z));   // one lane, serial: safegcd (fe29_inv.h) is 0.04 ms where the Fermat chain was 0.15
@@ -520,9 +595,9 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *count, *matrix, *offset, *bsum, *scw, *ptw, *list, *segsum, *partial, *perm, *firstslot, *sizes;
-  size_t segcap;       // capacity in segments: nkeys + pairs / seg_len, rounded up
-  uint32_t seg_len;
+  uint32_t *status, *count, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big;
+  uint32_t L, nlanes;  // bucket pass: entries per range, ranges (upper bound from the term count)
+  size_t sum_stride;   // slots of `sums`: nkeys buckets, then the left and the right edge piece of every range
   uint2* pairs;
   uint32_t ncoarse, nsortblk, nblk_pad;
   uint8_t* flag;
@@ -543,24 +618,41 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   }();
   g.c = n >= ((size_t)1 << c16_from_log2) ? 16 : (n >= 256 ? 12 : 8);
   g.nw = (SCALAR_BITS + g.c - 1) / g.c;
-  g.nb = 1u << g.c;
-  g.nchunk = g.nb / CHUNK;
-  m.nkeys = (size_t)g.nw * g.nb;                     // multiple of 1024 for every c used
-  m.nslots = (size_t)g.nw * g.nchunk;
+  g.nb = 1u << (g.c - 1);
+  g.nslot = g.nw + 1;
+  static const int chunk_log2 = [] {       // tuning hook
+    const char* e = getenv("S2K_MSM_CHUNK_LOG2");
+    int v = e ? atoi(e) : S2K_MSM_CHUNK_LOG2;
+    return v < 1 ? 1 : (v > 6 ? 6 : v);
+  }();
+  g.chunk_log2 = (uint32_t)chunk_log2;
+  g.nchunk = g.nb >> g.chunk_log2;
+  m.nkeys = align_up((size_t)g.nslot * g.nb, FINE);   // (c = 8: 17 slots of 128 keys, padded; the padding keys stay empty)
+  m.nslots = (size_t)g.nslot * g.nchunk;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  m.seg_len = (uint32_t)((n >> SEG_BITS) + 1 > SEG_LEN_MIN ? (n >> SEG_BITS) + 1 : SEG_LEN_MIN);   // at most 2^SEG_BITS segments per bucket
-  m.segcap = align_up(m.nkeys + (n * (size_t)g.nw) / m.seg_len + 1, 256);
-  // status word, then 3 x SIZE_BINS + 1 words (size histogram, bases, cursors, segment total), zeroed with the counters
+  {
+    static const uint32_t lanes_target = [] {   // tuning hook
+      const char* e = getenv("S2K_MSM_LANES");
+      return e ? (uint32_t)atoi(e) : MSM_LANES;
+    }();
+    const size_t pairs_max = n * (size_t)g.nw;
+    size_t L = (pairs_max + lanes_target - 1) / lanes_target;
+    if (L < MSM_L_MIN) L = MSM_L_MIN;
+    m.L = (uint32_t)L;
+    m.nlanes = (uint32_t)((pairs_max + L - 1) / L);
+    m.sum_stride = align_up(m.nkeys + 2 * (size_t)m.nlanes, 64);
+  }
+  // status word, then the queue of oversized buckets (counter + keys), zeroed with the counters
   m.ncoarse = (uint32_t)(m.nkeys >> FINE_BITS);
   m.nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);
   m.nblk_pad = (m.nsortblk + 1 + 1023) / 1024 * 1024;   // one spare column: the scan total lands in it
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
-  size_t o_status = carve(256), o_sizes = carve((3 * SIZE_BINS + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
+  size_t o_status = carve(256), o_big = carve((STITCH_BIG_CAP + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
          o_count = carve((m.nkeys + 1) * 4), o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
          o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
-         o_list = carve(n * (size_t)g.nw * 4), o_segsum = carve(m.segcap * PT_WORDS * 4),
-         o_partial = carve(m.nslots * PT_WORDS * 4), o_perm = carve(m.segcap * 4), o_firstslot = carve(m.nkeys * 4), o_aux = carve(aux_bytes);
+         o_list = carve(n * (size_t)g.nw * 4), o_sums = carve(m.sum_stride * PT_WORDS * 4),
+         o_partial = carve(m.nslots * PT_WORDS * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
@@ -574,18 +666,16 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.ptw = (uint32_t*)(ws + o_ptw);
   m.flag = ws + o_flag;
   m.list = (uint32_t*)(ws + o_list);
-  m.segsum = (uint32_t*)(ws + o_segsum);
-  m.firstslot = (uint32_t*)(ws + o_firstslot);
+  m.sums = (uint32_t*)(ws + o_sums);
   m.partial = (uint32_t*)(ws + o_partial);
-  m.perm = (uint32_t*)(ws + o_perm);
-  m.sizes = (uint32_t*)(ws + o_sizes);
+  m.big = (uint32_t*)(ws + o_big);
   m.aux = ws + o_aux;
-  m.zero_bytes = o_count;   // status, size bins and the coarse matrix
+  m.zero_bytes = o_count;   // status, the queue of oversized buckets and the coarse matrix
   return S2K_OK;
 }
 
 // buckets -> result, given scw / ptw / flag already filled and status/count/cursor zeroed
-int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65) {
+int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65, bool affine = true) {
   const msm_geom& g = m.g;
   // sort: coarse partition (counts -> scan -> scatter), then one workgroup per coarse bucket
   k_msm_coarse_count<<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix);
@@ -603,25 +693,21 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   k_msm_fine_sort<<<m.ncoarse, SORT_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, m.pairs, m.count,
                                                       m.offset, m.list);
   HIP_TRY(ctx, hipGetLastError());
-  uint32_t *sizehist = m.sizes, *sizebase = m.sizes + SIZE_BINS, *sizecur = m.sizes + 2 * SIZE_BINS;
-  k_msm_size_hist<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.seg_len, m.count, sizehist);
-  k_msm_size_scan<<<1, SIZE_BINS, 0, st>>>(sizehist, sizebase, sizecur);
-  k_msm_size_scatter<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)m.nkeys, m.seg_len, m.count, sizebase, sizecur, m.perm,
-                                                          m.firstslot);
+  k_msm_accumulate<<<blocks_for(m.nlanes), 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.list, m.ptw, m.sums);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_accumulate<<<blocks_for(m.segcap), 256, 0, st>>>((uint32_t)m.segcap, m.seg_len, sizecur + SIZE_BINS, m.perm, m.offset, m.list,
-                                                         m.ptw, m.segsum);
+  k_msm_stitch<<<blocks_for(m.nkeys), 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.sums, m.big);
+  k_msm_stitch_big<<<64, 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.sums, m.big);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_reduce<<<(unsigned)((m.nslots + 63) / 64), 64, 0, st>>>(g, m.segsum, m.segcap, m.seg_len, m.count, m.firstslot, m.partial);
+  k_msm_reduce<<<blocks_for(4 * m.nslots), 256, 0, st>>>(g, m.sums, m.sum_stride, m.partial);
   HIP_TRY(ctx, hipGetLastError());
   {
     // level 1: groups of up to 512 chunk results; level 2: the group sums of each window
     const uint32_t span1 = g.nchunk < 512 ? g.nchunk : 512, groups = g.nchunk / span1;
-    k_msm_tree<<<g.nw * groups, 256, 0, st>>>((uint32_t)m.nslots, span1, 1u, m.partial);
-    if (groups > 1) k_msm_tree<<<g.nw, 256, 0, st>>>((uint32_t)m.nslots, groups, span1, m.partial);
+    k_msm_tree<<<g.nslot * groups, 256, 0, st>>>((uint32_t)m.nslots, span1, 1u, m.partial);
+    if (groups > 1) k_msm_tree<<<g.nslot, 256, 0, st>>>((uint32_t)m.nslots, groups, span1, m.partial);
   }
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65);
+  k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
@@ -1059,7 +1145,7 @@ static int rlc_run_full(s2k_ctx* ctx, hipStream_t st, size_t n, const void* d_pk
   k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, n, nullptr, sum_part, m.scw, m.ptw, m.flag, N);
   HIP_TRY(ctx, hipGetLastError());
   uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
-  rc = msm_core(ctx, st, N, m, d_out);
+  rc = msm_core(ctx, st, N, m, d_out, /*affine=*/as_out != nullptr);   // the verdict alone needs no coordinates; the bisection does
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h, m.status, 64 + 65, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -12,6 +12,7 @@
 #include "fe29_inv.h"
 #include "jacobian29.h"
 #include "pt29.h"
+#include "pt29q.h"
 #include "sc26.h"
 
 using namespace s2k;
@@ -340,6 +341,67 @@ k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__
   if (flag) flag[idx] = f;
 }
 
+// The quad-spread group law of pt29q.h, four lanes per item: inputs as for PT29_DBL / PT29_ADD above (P = (a : b : 1)
+// scaled by Z = c, c == 0: the identity; Q = (d, e) scaled by the same c, or affine when P is the identity); `reps`
+// > 1 chains the operation (r = r + Q / r = 2 r again and again) so that outputs are fed back as inputs.
+__global__ void __launch_bounds__(256)
+k_pt29q_op(int op, uint32_t lazy, uint32_t n, uint32_t reps, hp_args args, uint8_t* __restrict__ out, uint8_t* __restrict__ out2,
+           uint8_t* __restrict__ flag) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t idx = t >> 2;
+  const uint32_t q = (uint32_t)t & 3u;
+  if (idx >= n) return;
+  fe29 v[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    v[j] = fe29_zero();
+    if (args.in[j]) {
+      uint32_t w[8];
+      load_be32(w, args.in[j] + idx * 32);
+      v[j] = fe29_lazy_form(fe29_from_words(w), (lazy >> (4 * j)) & 15u);
+    }
+  }
+  const fe29 &a = v[0], &b = v[1], &c = v[2], &d = v[3], &e = v[4];
+  pt29 p, s;
+  const bool p_inf = fe29_is_zero(c);
+  const fe29 cn = fe29_normalize_weak(c);
+  p.x = fe29_mul(a, cn);
+  p.y = fe29_mul(b, cn);
+  p.z = cn;
+  s.x = fe29_mul(d, cn);
+  s.y = fe29_mul(e, cn);
+  s.z = cn;
+  if (p_inf) {
+    p = pt29_identity();
+    s.x = fe29_normalize_weak(d);
+    s.y = fe29_normalize_weak(e);
+    s.z = fe29_one();
+  }
+  fe29 rc = pt29q_from(p, q);
+  const fe29 sc_ = pt29q_from(s, q);
+#pragma unroll 1
+  for (uint32_t i = 0; i < reps; ++i) rc = op == S2K_HP_PT29Q_DBL ? pt29q_double(rc, q) : pt29q_add(rc, sc_, q);
+  const pt29 r = pt29q_gather(rc);
+  if (q != 0) return;
+  fe29 x = fe29_zero(), y = fe29_zero();
+  uint8_t f = 1;
+  if (fe29_is_zero(r.z)) {
+    f = 0;
+  } else {
+    fe29 zi = fe29_inv(r.z);
+    x = fe29_mul(r.x, zi);
+    y = fe29_mul(r.y, zi);
+  }
+  uint32_t w[8];
+  fe29_to_words(w, fe29_normalize(x));
+  store_be32(out + idx * 32, w);
+  if (out2) {
+    fe29_to_words(w, fe29_normalize(y));
+    store_be32(out2 + idx * 32, w);
+  }
+  if (flag) flag[idx] = f;
+}
+
 // odd GLV split of the hot path (sc_split_glv_odd): magnitudes (129 bits) and sign bits
 __global__ void __launch_bounds__(256)
 k_split_glv_odd(uint32_t n, const uint8_t* __restrict__ k, uint8_t* __restrict__ k1o, uint8_t* __restrict__ k2o,
@@ -497,7 +559,9 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
                        uint8_t* out, uint8_t* out2, uint8_t* flag) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fp_op_batch_ex serves S2K_IMPL_FAST only (8x32: s2k_fp_op_batch)");
-  if (op < 0 || op > S2K_HP_JADD_FULL) return fail(ctx, S2K_ERR_ARG, "bad op");
+  const uint32_t reps = lazy >> 20;           // quad operations: bits 20.. of `lazy` = how often the operation is chained (0: once)
+  lazy &= 0xfffffu;
+  if (op < 0 || op > S2K_HP_PT29Q_ADD) return fail(ctx, S2K_ERR_ARG, "bad op");
   if (n == 0) return S2K_OK;
   if (!in || !in[0] || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
@@ -515,7 +579,10 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
   HIP_TRY(ctx, dout.alloc(n * 32));
   if (out2) HIP_TRY(ctx, dout2.alloc(n * 32));
   if (flag) HIP_TRY(ctx, dflag.alloc(n));
-  k_fp29_op<<<blocks_for(n), 256>>>(op, lazy, (uint32_t)n, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);
+  if (op == S2K_HP_PT29Q_DBL || op == S2K_HP_PT29Q_ADD)
+    k_pt29q_op<<<blocks_for(4 * n), 256>>>(op, lazy, (uint32_t)n, reps ? reps : 1u, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);
+  else
+    k_fp29_op<<<blocks_for(n), 256>>>(op, lazy, (uint32_t)n, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 32, hipMemcpyDeviceToHost));

@@ -266,6 +266,44 @@ def test_pt29_complete_formulas_random_z(eng, oracle, codes):
     check(*eng.fp_op_batch_ex(S.HP_PT29_ADD_MIXED, cols, lazy(*codes)), expect("add"))
 
 
+@pytest.mark.parametrize("codes", [(0, 0, 0, 0, 0), (0, 0, 4, 0, 0), (0, 0, 1, 0, 0)])
+def test_pt29q_quad_formulas(eng, oracle, codes):
+    """pt29q_add / pt29q_double (pt29q.h: the complete formulas spread over the four lanes of a quad, the serial tail of
+    the multi-scalar multiplication): same cases as the single-lane forms - P + P, P - P, identity + Q - and chained
+    on their own outputs (P + 5 Q, 2^7 P), against big-integer arithmetic."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(130)
+    pts = wycheproof_points(oracle)[:200] + curve_points(rnd, 600)
+    qs = shuffled(pts, 131)
+    for i in range(0, len(pts), 5):
+        qs[i] = pts[i] if (i // 5) % 2 == 0 else R.neg(pts[i])
+    z = [rnd.randrange(1, P) for _ in pts]
+    for i in range(3, len(pts), 11):
+        z[i] = 0                       # P = identity
+    cols = [[b32(p[0]) for p in pts], [b32(p[1]) for p in pts], [b32(v) for v in z],
+            [b32(q[0]) for q in qs], [b32(q[1]) for q in qs]]
+
+    def expect(op, reps):
+        out = []
+        for p, q, zz in zip(pts, qs, z):
+            r = None if zz == 0 else p
+            for _ in range(reps):
+                r = R.add(r, r) if op == "dbl" else R.add(r, q)
+            out.append(r)
+        return out
+
+    def check(x, y, flag, exp):
+        for xi, yi, f, e in zip(ints(x), ints(y), flag, exp):
+            if e is None:
+                assert f == 0
+            else:
+                assert f == 1 and (xi, yi) == e
+    for reps in (1, 5):
+        check(*eng.fp_op_batch_ex(S.HP_PT29Q_ADD, cols, lazy(*codes) | reps << 20), expect("add", reps))
+    for reps in (1, 7):
+        check(*eng.fp_op_batch_ex(S.HP_PT29Q_DBL, cols, lazy(*codes) | reps << 20), expect("dbl", reps))
+
+
 # ---- scalars: odd GLV split and safegcd inversion ----
 def test_split_glv_odd(eng):
     """sc_split_glv_odd (hot path): k == +-k1 +- k2*lambda (mod n), k1 and k2 odd and below 2^129, for the
