@@ -244,11 +244,28 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* count, c
 
 // ---------------------------------------------------------------------------------------
 // Two-level counting sort of the (key, term) pairs, key = window * 2^(c-1) + |digit| - 1 (zero digits skipped).
-// FINE keys per coarse bucket; a sort workgroup owns SORT_TERMS consecutive terms.
+// FINE keys per coarse bucket; a sort workgroup owns SORT_TERMS consecutive terms.  A pair is ONE 32-bit word while the
+// term index fits 23 bits (fine key << 24 | sign << 23 | term: up to 2^22 inputs), two words beyond (WIDE).
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t FINE_BITS = 10, FINE = 1u << FINE_BITS;
-constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = 4096;
-constexpr uint32_t MAX_COARSE = 512;      // nkeys / FINE, at most 9 * 2^15 / 2^10 (c = 16, the largest geometry)
+constexpr uint32_t FINE_BITS = 8, FINE = 1u << FINE_BITS;
+constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = 8192;
+constexpr uint32_t MAX_COARSE = 1152;     // nkeys / FINE, at most 9 * 2^15 / 2^8 (c = 16, the largest geometry)
+constexpr uint32_t NARROW_TERM_BITS = 23;
+constexpr uint32_t FS_THREADS = 512, FS_STAGE = 19456;   // fine sort: threads, list entries staged in LDS (76 KiB: two workgroups per CU)
+
+template <bool WIDE> struct msm_pair;
+template <> struct msm_pair<false> {
+  typedef uint32_t type;
+  static S2K_DEV type make(uint32_t fine, uint32_t term, bool neg) { return fine << 24 | (neg ? 1u << NARROW_TERM_BITS : 0u) | term; }
+  static S2K_DEV uint32_t fine(type p) { return p >> 24; }
+  static S2K_DEV uint32_t entry(type p) { return (p & ((1u << NARROW_TERM_BITS) - 1u)) | ((p >> NARROW_TERM_BITS & 1u) << 31); }
+};
+template <> struct msm_pair<true> {
+  typedef uint2 type;
+  static S2K_DEV type make(uint32_t fine, uint32_t term, bool neg) { return make_uint2(fine, term | (neg ? TERM_NEG : 0u)); }
+  static S2K_DEV uint32_t fine(type p) { return p.x; }
+  static S2K_DEV uint32_t entry(type p) { return p.y; }
+};
 
 // matrix[coarse * nblk_pad + block] = pairs of this workgroup's terms falling into `coarse`
 __global__ void __launch_bounds__(SORT_THREADS)
@@ -266,10 +283,12 @@ k_msm_coarse_count(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, con
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) matrix[(size_t)t * nblk_pad + blockIdx.x] = h[t];
 }
-// pairs[pos] = (key & (FINE - 1), term | sign), grouped by coarse bucket; `mbase` is the scanned matrix
+// pairs[pos] = (key & (FINE - 1), term, sign), grouped by coarse bucket; `mbase` is the scanned matrix
+template <bool WIDE>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
-                     uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint2* __restrict__ pairs) {
+                     uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase,
+                     typename msm_pair<WIDE>::type* __restrict__ pairs) {
   __shared__ uint32_t cur[MAX_COARSE];
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) cur[t] = mbase[(size_t)t * nblk_pad + blockIdx.x];
   __syncthreads();
@@ -279,58 +298,74 @@ k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, c
     if (i >= n || flag[i] != 1) continue;
     msm_for_digits(scw, n, i, g, [&](uint32_t key, bool neg) {
       uint32_t pos = atomicAdd(&cur[key >> FINE_BITS], 1u);
-      pairs[pos] = make_uint2(key & (FINE - 1), (uint32_t)i | (neg ? TERM_NEG : 0u));
+      pairs[pos] = msm_pair<WIDE>::make(key & (FINE - 1), (uint32_t)i, neg);
     });
   }
 }
-// one workgroup per coarse bucket: pairs -> list (term indices grouped by key), count[key],
-// offset[key]; the last workgroup also writes offset[nkeys] = total
-__global__ void __launch_bounds__(SORT_THREADS)
+// one workgroup per coarse bucket: pairs -> list (term index | sign << 31, grouped by key), offset[key]; the last
+// workgroup also writes offset[nkeys] = total.  The sorted piece of the list is put together in LDS and written out in
+// order (scattered 4-byte stores straight to memory cost six times the list's size in write traffic); a coarse
+// bucket too large for that - only engineered inputs - is scattered directly.
+template <bool WIDE>
+__global__ void __launch_bounds__(FS_THREADS)
 k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint32_t total_slot,
-                const uint2* __restrict__ pairs, uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
+                const typename msm_pair<WIDE>::type* __restrict__ pairs, uint32_t* __restrict__ offset,
                 uint32_t* __restrict__ list) {
-  __shared__ uint32_t h[FINE], part[FINE];
+  typedef msm_pair<WIDE> PR;
+  __shared__ uint32_t h[FINE], part[FINE], stage[FS_STAGE];
   const uint32_t b = blockIdx.x, t = threadIdx.x;
   const uint32_t lo = mbase[(size_t)b * nblk_pad];
   const uint32_t hi = b + 1 < ncoarse ? mbase[(size_t)(b + 1) * nblk_pad] : mbase[total_slot];
-  h[t] = 0;
+  if (t < FINE) h[t] = 0;
   __syncthreads();
-  // four loads in flight per thread: one pair per trip made this kernel latency bound (a global load, then an
-  // LDS atomic that waits for it, 32 times in a row)
+  // four loads in flight per thread (one pair per trip made this kernel latency bound: a global load, then an LDS
+  // atomic that waits for it, dozens of times in a row)
   constexpr uint32_t U = 4;
-  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS * U) {
+  for (uint32_t j = lo + t; j < hi; j += FS_THREADS * U) {
     uint32_t k[U];
 #pragma unroll
-    for (uint32_t u = 0; u < U; ++u) k[u] = j + u * SORT_THREADS < hi ? pairs[j + u * SORT_THREADS].x : FINE;
+    for (uint32_t u = 0; u < U; ++u) k[u] = j + u * FS_THREADS < hi ? PR::fine(pairs[j + u * FS_THREADS]) : FINE;
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u)
       if (k[u] < FINE) atomicAdd(&h[k[u]], 1u);
   }
   __syncthreads();
-  const uint32_t mine = h[t];
-  part[t] = mine;
+  const uint32_t mine = t < FINE ? h[t] : 0u;
+  if (t < FINE) part[t] = mine;
   __syncthreads();
   for (uint32_t s = 1; s < FINE; s <<= 1) {
-    uint32_t a = t >= s ? part[t - s] : 0;
+    uint32_t a = (t < FINE && t >= s) ? part[t - s] : 0;
     __syncthreads();
-    part[t] += a;
+    if (t < FINE) part[t] += a;
     __syncthreads();
   }
-  const uint32_t off = lo + part[t] - mine;
-  const size_t key = (size_t)b * FINE + t;
-  count[key] = mine;
-  offset[key] = off;
-  if (b + 1 == ncoarse && t == FINE - 1) offset[key + 1] = hi;
-  h[t] = off;                      // running cursor of key t
+  const bool staged = hi - lo <= FS_STAGE;
+  if (t < FINE) {
+    const uint32_t off = lo + part[t] - mine;
+    const size_t key = (size_t)b * FINE + t;
+    offset[key] = off;
+    if (b + 1 == ncoarse && t == FINE - 1) offset[key + 1] = hi;
+    h[t] = staged ? off - lo : off;                      // running cursor of key t
+  }
   __syncthreads();
-  for (uint32_t j = lo + t; j < hi; j += SORT_THREADS * U) {
-    uint2 e[U];
+  for (uint32_t j = lo + t; j < hi; j += FS_THREADS * U) {
+    typename PR::type e[U];
+    bool ok[U];
 #pragma unroll
-    for (uint32_t u = 0; u < U; ++u) e[u] = j + u * SORT_THREADS < hi ? pairs[j + u * SORT_THREADS] : make_uint2(FINE, 0u);
+    for (uint32_t u = 0; u < U; ++u) {
+      ok[u] = j + u * FS_THREADS < hi;
+      e[u] = pairs[ok[u] ? j + u * FS_THREADS : lo];
+    }
 #pragma unroll
-    for (uint32_t u = 0; u < U; ++u)
-      if (e[u].x < FINE) list[atomicAdd(&h[e[u].x], 1u)] = e[u].y;
+    for (uint32_t u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      const uint32_t pos = atomicAdd(&h[PR::fine(e[u])], 1u);
+      if (staged) stage[pos] = PR::entry(e[u]); else list[pos] = PR::entry(e[u]);
+    }
   }
+  if (!staged) return;
+  __syncthreads();
+  for (uint32_t j = t; j < hi - lo; j += FS_THREADS) list[lo + j] = stage[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -595,10 +630,11 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *count, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big;
+  uint32_t *status, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big;
   uint32_t L, nlanes;  // bucket pass: entries per range, ranges (upper bound from the term count)
   size_t sum_stride;   // slots of `sums`: nkeys buckets, then the left and the right edge piece of every range
-  uint2* pairs;
+  void* pairs;
+  bool wide;           // two-word pairs (term indices beyond 23 bits)
   uint32_t ncoarse, nsortblk, nblk_pad;
   uint8_t* flag;
   size_t zero_bytes;   // status + size bins + coarse matrix, contiguous from the start
@@ -649,7 +685,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.nblk_pad = (m.nsortblk + 1 + 1023) / 1024 * 1024;   // one spare column: the scan total lands in it
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
   size_t o_status = carve(256), o_big = carve((STITCH_BIG_CAP + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
-         o_count = carve((m.nkeys + 1) * 4), o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
+         o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
          o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_sums = carve(m.sum_stride * PT_WORDS * 4),
          o_partial = carve(m.nslots * PT_WORDS * 4), o_aux = carve(aux_bytes);
@@ -657,9 +693,10 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
   m.status = (uint32_t*)(ws + o_status);
-  m.count = (uint32_t*)(ws + o_count);
   m.matrix = (uint32_t*)(ws + o_matrix);
-  m.pairs = (uint2*)(ws + o_pairs);
+  m.pairs = ws + o_pairs;
+  static const bool force_wide = getenv("S2K_MSM_WIDE_PAIRS") != nullptr;   // test hook: the two-word pairs at any size
+  m.wide = force_wide || n > ((size_t)1 << NARROW_TERM_BITS);
   m.offset = (uint32_t*)(ws + o_offset);
   m.bsum = (uint32_t*)(ws + o_bsum);
   m.scw = (uint32_t*)(ws + o_scw);
@@ -670,7 +707,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.partial = (uint32_t*)(ws + o_partial);
   m.big = (uint32_t*)(ws + o_big);
   m.aux = ws + o_aux;
-  m.zero_bytes = o_count;   // status, the queue of oversized buckets and the coarse matrix
+  m.zero_bytes = o_offset;   // status, the queue of oversized buckets and the coarse matrix
   return S2K_OK;
 }
 
@@ -687,11 +724,13 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   k_msm_scan_top<<<1, 1024, 0, st>>>(m.bsum, scan_blocks, m.matrix + mat_words);
   k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_coarse_scatter<<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix,
-                                                            m.pairs);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_fine_sort<<<m.ncoarse, SORT_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, m.pairs, m.count,
-                                                      m.offset, m.list);
+  if (m.wide) {
+    k_msm_coarse_scatter<true><<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs);
+    k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list);
+  } else {
+    k_msm_coarse_scatter<false><<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs);
+    k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list);
+  }
   HIP_TRY(ctx, hipGetLastError());
   k_msm_accumulate<<<blocks_for(m.nlanes), 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.list, m.ptw, m.sums);
   HIP_TRY(ctx, hipGetLastError());
