@@ -155,8 +155,16 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx *ctx, size_t n, const void *d_digest3
  * the payload of the multi-GPU bitmap all-gather / count all-reduce. */
 int s2k_pack_valid_device(s2k_ctx *ctx, size_t n, const void *d_valid, void *d_bitmap, void *d_count,
                           void *hip_stream);
-/* Bytes of device workspace the context holds for batches of up to n signatures. */
+/* Bytes of the per-signature device workspace (tables, scratch, worklist) for batches of up to n signatures.  It is
+ * ONE of the context's buffers: see s2k_ctx_device_bytes for everything a verification call of n signatures holds. */
 size_t s2k_ecdsa_workspace_bytes(size_t n);
+/* Device memory the context holds once it has verified a batch of n signatures with its current key-grouping
+ * settings (s2k_ctx_set_key_grouping): the resident generator tables (3 GiB), the per-signature workspace above, and -
+ * with the grouping on, the default, for n >= 256 - the grouping arrays and the per-key table buffer (n / min_group
+ * tables of 9 KiB, at most max_tables: 1.6 GB at n = 2^20, whether or not keys repeat).  The multi-scalar and BIP-340
+ * batch entry points keep a workspace of their own on top (about 1.4 KB per term).  Size HBM by this, not by
+ * s2k_ecdsa_workspace_bytes alone, when several contexts share a device. */
+size_t s2k_ctx_device_bytes(const s2k_ctx *ctx, size_t n);
 
 /* ---- host-side ingest: the reference's byte-level parsing, in batch --------------------- */
 /* ParseASN1Signature (secec/s11n.go:83): strict DER SEQUENCE { r INTEGER, s INTEGER }, r, s in

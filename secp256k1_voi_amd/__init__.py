@@ -152,6 +152,8 @@ def load_library() -> C.CDLL:
     lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
     lib.s2k_ecdsa_workspace_bytes.restype = sz
+    lib.s2k_ctx_device_bytes.argtypes = [vp, sz]
+    lib.s2k_ctx_device_bytes.restype = sz
     lib.s2k_parse_asn1_signature.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_char_p]
     lib.s2k_parse_compact_signature.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_char_p]
     lib.s2k_is_valid_signature_encoding_bip0066.argtypes = [C.c_char_p, sz]
@@ -190,7 +192,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version", "s2k_build_config",
     "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages",
     "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
-    "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes",
+    "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
     "s2k_pack_valid_device", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
@@ -476,7 +478,7 @@ class Engine:
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         """How ecdsa_verify_batch[_device] treats signatures that share a public key (s2k_ctx_set_key_grouping):
         KEYS_OFF = every signature through the general kernel, KEYS_AUTO (default) = keys with at least
-        `min_group` (default 4) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does."""
+        `min_group` (default 6, the measured break-even) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does."""
         self._check(self._lib.s2k_ctx_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
 
     def key_grouping_stats(self):
@@ -487,6 +489,11 @@ class Engine:
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))
+
+    def device_bytes(self, n):
+        """Device memory this engine holds after a verification call of n signatures with the current grouping settings
+        (generator tables + per-signature workspace + grouping arrays and per-key table buffer)."""
+        return self._lib.s2k_ctx_device_bytes(self._h, int(n))
 
     # ---- group ----------------------------------------------------------------------
     def _points_out(self, n):

@@ -1214,19 +1214,8 @@ static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
 // Stage times (s2k_ctx_profile_read_stages): [0] grouping, [1] tables and whatever is left of the second
 // stream's work.
 template <class PrepFn>
-static int grouped_front(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* d_keys, int key_bytes, uint32_t* prep,
-                         uint32_t* gp, size_t stride, PrepFn launch_prep, key_groups* kg) {
-  if (!ctx->s_aux) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux2, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_part0, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_part1, hipEventDisableTiming));
-  }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* d_keys, int key_bytes, uint32_t* prep,
+                                uint32_t* gp, size_t stride, PrepFn launch_prep, key_groups* kg) {
   launch_prep(ctx->s_aux);
   HIP_TRY(ctx, hipGetLastError());
   const uint32_t n_first = (uint32_t)((n * (size_t)ctx->gp_first_percent / 100) & ~(size_t)255);
@@ -1261,9 +1250,32 @@ static int grouped_front(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* 
     k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gtable, gp, stride);
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->s_aux));
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   return S2K_OK;
+}
+template <class PrepFn>
+static int grouped_front(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* d_keys, int key_bytes, uint32_t* prep,
+                         uint32_t* gp, size_t stride, PrepFn launch_prep, key_groups* kg) {
+  int rc = ctx_aux_streams(ctx);
+  if (rc) return rc;
+  // the buffers the grouping needs are reserved BEFORE the fork: growing one is a device-wide synchronisation
+  // (hipFree), which must not meet work of this call in flight on the second stream
+  rc = s2k_internal_key_reserve(ctx, n, key_bytes);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+  rc = grouped_front_forked(ctx, st, n, d_keys, key_bytes, prep, gp, stride, launch_prep, kg);
+  // error or not, the caller's stream waits for the second one again, and the context's next call for this one: an
+  // error return leaves nothing of this call in flight behind the context's back
+  ctx_aux_join(ctx, st);
+  if (kg->nparts > 1 && rc == S2K_OK) { /* (ev_part1 is waited for by the caller, before the second ladder) */ }
+  if (rc) {
+    if (ctx->s_aux2) {
+      (void)hipEventRecord(ctx->ev_part1, ctx->s_aux2);
+      (void)hipStreamWaitEvent(st, ctx->ev_part1, 0);
+    }
+    (void)ctx_leave(ctx, st);
+  }
+  return rc;
 }
 
 extern "C" {
@@ -1295,6 +1307,12 @@ static_assert(TBL_WORDS >= QT_WORDS, "the complete path's table must fit in the 
 
 size_t s2k_ecdsa_workspace_bytes(size_t n) {
   return (lane_stride(n) * WS_LANE_WORDS + 64 + lane_stride(n)) * sizeof(uint32_t);
+}
+size_t s2k_ctx_device_bytes(const s2k_ctx* ctx, size_t n) {
+  if (!ctx) return 0;
+  size_t total = GT_ENTRIES * 64 + s2k_ecdsa_workspace_bytes(n);
+  if (ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH) total += s2k_internal_key_bytes(ctx, n);
+  return total;
 }
 
 // (shared with ops.hip; not part of the ABI)

@@ -92,7 +92,8 @@ struct s2k_ctx {
   uint64_t* clk = nullptr;      // device: s_memtime / s_memrealtime stamps of one wave of k_verify_fast
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
   int kg_mode = S2K_KEYS_AUTO;
-  uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = 1u << 18, kg_seed = 0;
+  uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = 1u << 18;
+  uint64_t kg_seed = 0;              // hash seed of the key grouping (operating-system randomness, per context)
   hipStream_t s_aux = nullptr;       // scalar preparation runs here, beside the grouping and the table kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_part0 = nullptr, ev_part1 = nullptr;
   hipStream_t s_aux2 = nullptr;      // two-part flow: the second half of the tables is built here, beside the first half's ladder
@@ -165,6 +166,26 @@ static inline unsigned fallback_blocks(const s2k_ctx* ctx, size_t n) {
   return (unsigned)(want < cap ? want : cap);
 }
 
+// second / third stream of the grouped flows and of the BIP-340 whole-batch check, with the events that fork and join them
+inline int ctx_aux_streams(s2k_ctx* ctx) {
+  if (ctx->s_aux) return S2K_OK;
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux2, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_part0, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_part1, hipEventDisableTiming));
+  return S2K_OK;
+}
+// after a fork: whatever happened, the caller's stream waits for the second one again (an error return must not leave
+// work of this call in flight on a stream the next call does not wait for)
+inline void ctx_aux_join(s2k_ctx* ctx, hipStream_t st) {
+  if (!ctx->s_aux) return;
+  (void)hipEventRecord(ctx->ev_join, ctx->s_aux);
+  (void)hipStreamWaitEvent(st, ctx->ev_join, 0);
+}
+
 // copy / compute streams and the events chaining them, for the host-buffer entry points
 inline int ctx_streams(s2k_ctx* ctx) {
   if (ctx->s_copy) return S2K_OK;
@@ -222,6 +243,8 @@ struct key_groups {        // device pointers of one call
 };
 // groups the batch's signatures by public key, then builds the tables (enqueue only, no host sync)
 int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes, hipStream_t st, key_groups* out);
+int s2k_internal_key_reserve(s2k_ctx* ctx, size_t n, int key_bytes);   // grow the grouping arrays / table buffer (before any fork)
+size_t s2k_internal_key_bytes(const s2k_ctx* ctx, size_t n);            // what those hold for a batch of n
 int s2k_internal_key_chains(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st, const key_groups* g);
 // (ev_after_odd, if any, is recorded on st between k_key_odd and k_key_invert)
 int s2k_internal_key_tables(s2k_ctx* ctx, hipStream_t st, const key_groups* g, uint32_t part, uint32_t nparts,
@@ -238,6 +261,7 @@ struct key_groups32 {
   uint32_t ngroups, nleft;                  // (host values)
 };
 int s2k_internal_key_group32(s2k_ctx* ctx, size_t n, const uint8_t* d_pk32, hipStream_t st, key_groups32* out);
+int s2k_internal_key_reserve32(s2k_ctx* ctx, size_t n);
 
 struct dev_buf {
   void* p = nullptr;

@@ -73,19 +73,26 @@ constexpr int KG_SHARE_ROUNDS = 4;
 // each distinct key, msm.hip)
 template <int KEYBYTES>
 __global__ void __launch_bounds__(256)
-k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint32_t seed, uint32_t* __restrict__ rep,
+k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint64_t seed, uint32_t* __restrict__ rep,
              uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ pos_of) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint4* k = reinterpret_cast<const uint4*>(pub + (size_t)i * KEYBYTES);
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   const uint4 k0 = k[0], k1 = k[1], k2 = KEYBYTES == 64 ? k[2] : zero4, k3 = KEYBYTES == 64 ? k[3] : zero4;
-  uint32_t h = seed;
-  h = mix32(h ^ k0.x) + k0.y;
-  h = mix32(h ^ k0.z) + k0.w;
-  h = mix32(h ^ k1.x) + k1.y;
-  h = mix32(h ^ k1.z) + k1.w;
-  h = mix32(h ^ k3.z) + k3.w;   // the low words of y tell a key from its negative
+  // every word of the key goes through the mixer, chained: h = mix(h ^ word).  The difference two keys leave in the
+  // state after a word depends on the state before it, i.e. on the seed, so no pair of byte strings collides for every
+  // seed (the round-2 hash took X and the last 8 bytes of Y, some words by plain addition: keys differing elsewhere in Y,
+  // or by a cancelling add / xor pair, met in one slot whatever the seed, and an engineered batch could walk every lane
+  // through all 64 probes).  The 64-bit seed is drawn per context from the operating system.
+  uint32_t h = (uint32_t)seed;
+  h = mix32(h ^ k0.x); h = mix32(h ^ k0.y); h = mix32(h ^ k0.z); h = mix32(h ^ k0.w);
+  h = mix32(h ^ k1.x); h = mix32(h ^ k1.y); h = mix32(h ^ k1.z); h = mix32(h ^ k1.w);
+  h ^= (uint32_t)(seed >> 32);
+  if (KEYBYTES == 64) {
+    h = mix32(h ^ k2.x); h = mix32(h ^ k2.y); h = mix32(h ^ k2.z); h = mix32(h ^ k2.w);
+    h = mix32(h ^ k3.x); h = mix32(h ^ k3.y); h = mix32(h ^ k3.z); h = mix32(h ^ k3.w);
+  }
   uint32_t s = mix32(h) & hmask;
   uint32_t found = KG_NONE;
 #pragma unroll 1
@@ -516,24 +523,52 @@ static uint32_t pow2_at_least(size_t v) {
 
 }  // namespace
 
-__attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes,
-                                                                 hipStream_t st, key_groups* out) {
+// sizes of one call's grouping arrays and table buffer
+struct key_group_sizes {
+  uint32_t min_group;
+  size_t slots, max_tables, np, tp, kg_bytes, ktab_bytes;
+};
+static key_group_sizes key_group_plan(const s2k_ctx* ctx, size_t n) {
+  key_group_sizes z;
   const uint32_t min_group_asked = ctx->kg_mode == S2K_KEYS_ALWAYS ? 1u : (ctx->kg_min_group ? ctx->kg_min_group : KG_MIN_GROUP);
   uint32_t bits = ctx->kg_hash_bits ? ctx->kg_hash_bits : pow2_at_least(2 * n);
   if (bits < 4) bits = 4;
   if (bits > 30) bits = 30;
-  const size_t slots = (size_t)1 << bits;
+  z.slots = (size_t)1 << bits;
   // tables are never refused on the device: the threshold is raised until n / threshold of them fit the cap
-  uint32_t min_group = min_group_asked;
-  if (n / min_group > ctx->kg_max_tables) min_group = (uint32_t)((n + ctx->kg_max_tables - 1) / ctx->kg_max_tables);
-  size_t max_tables = n / min_group;
-  if (max_tables == 0) max_tables = 1;
+  z.min_group = min_group_asked;
+  if (n / z.min_group > ctx->kg_max_tables) z.min_group = (uint32_t)((n + ctx->kg_max_tables - 1) / ctx->kg_max_tables);
+  z.max_tables = n / z.min_group;
+  if (z.max_tables == 0) z.max_tables = 1;
   // grouping arrays: counters | rep, cnt, tix [slots] | slot_of, pos_of, perm, ptab, left [n] | trep, tbase [tables] | tinfo
-  const size_t np = (n + 63) & ~(size_t)63, tp = ((max_tables + 63) & ~(size_t)63) + 64;
-  const size_t words = KG_COUNTERS + 3 * slots + 5 * np + 2 * tp;
-  int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t) + tp);
+  z.np = (n + 63) & ~(size_t)63;
+  z.tp = ((z.max_tables + 63) & ~(size_t)63) + 64;
+  const size_t words = KG_COUNTERS + 3 * z.slots + 5 * z.np + 2 * z.tp;
+  z.kg_bytes = words * sizeof(uint32_t) + z.tp;
+  z.ktab_bytes = z.max_tables * (size_t)KT_SLOTS * 128;
+  return z;
+}
+// device memory the grouped flow of a batch of n holds on top of the verification workspace (grouping arrays + per-key tables)
+__attribute__((visibility("hidden"))) size_t s2k_internal_key_bytes(const s2k_ctx* ctx, size_t n) {
+  const key_group_sizes z = key_group_plan(ctx, n);
+  return z.kg_bytes + z.ktab_bytes;
+}
+// grows the context's grouping arrays and table buffer for a batch of n: to be called BEFORE work of the call is put on a
+// second stream (growing frees and allocates, which synchronises the device)
+__attribute__((visibility("hidden"))) int s2k_internal_key_reserve(s2k_ctx* ctx, size_t n, int key_bytes) {
+  (void)key_bytes;
+  const key_group_sizes z = key_group_plan(ctx, n);
+  int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, z.kg_bytes);
   if (rc) return rc;
-  rc = ctx_reserve(ctx, &ctx->ktab, &ctx->ktab_bytes, max_tables * (size_t)KT_SLOTS * 128);
+  return ctx_reserve(ctx, &ctx->ktab, &ctx->ktab_bytes, z.ktab_bytes);
+}
+
+__attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes,
+                                                                 hipStream_t st, key_groups* out) {
+  const key_group_sizes z = key_group_plan(ctx, n);
+  const size_t slots = z.slots, max_tables = z.max_tables, np = z.np, tp = z.tp;
+  const uint32_t min_group = z.min_group;
+  int rc = s2k_internal_key_reserve(ctx, n, key_bytes);   // (a no-op when the caller has reserved already)
   if (rc) return rc;
   uint32_t* w = (uint32_t*)ctx->kg;
   uint32_t* counters = w;
@@ -604,6 +639,17 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
   return S2K_OK;
 }
 
+// grows the grouping arrays for s2k_internal_key_group32 on n keys (before any work of the call is on a second stream)
+__attribute__((visibility("hidden"))) int s2k_internal_key_reserve32(s2k_ctx* ctx, size_t n) {
+  uint32_t bits = ctx->kg_hash_bits ? ctx->kg_hash_bits : pow2_at_least(2 * n);
+  if (bits < 4) bits = 4;
+  if (bits > 30) bits = 30;
+  const size_t slots = (size_t)1 << bits, np = (n + 63) & ~(size_t)63;
+  const size_t words = KG_COUNTERS + 4 * slots + 6 * np;
+  if (words * sizeof(uint32_t) > ctx->kg_bytes) ctx->kg_counters = nullptr;   // (of an earlier verification call: the buffer moves)
+  return ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t));
+}
+
 // BIP-340 whole-batch check (msm.hip): all n x-only keys grouped, every group gets (virtual) group indices.
 // Synchronises the stream to hand the counts to the host (they size the multiscalar multiplication).
 __attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx, size_t n, const uint8_t* d_pk32,
@@ -614,9 +660,8 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx,
   const size_t slots = (size_t)1 << bits;
   // counters | rep, cnt, base, tix [slots] | slot_of, pos_of, perm, ptab, left, vslot [n]
   const size_t np = (n + 63) & ~(size_t)63;
-  const size_t words = KG_COUNTERS + 4 * slots + 6 * np;
-  ctx->kg_counters = nullptr;   // (of an earlier verification call: the buffer may move)
-  int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t));
+  ctx->kg_counters = nullptr;   // (of an earlier verification call: these arrays overwrite its counters)
+  int rc = s2k_internal_key_reserve32(ctx, n);   // (a no-op when the caller has reserved already)
   if (rc) return rc;
   uint32_t* w = (uint32_t*)ctx->kg;
   uint32_t* counters = w;

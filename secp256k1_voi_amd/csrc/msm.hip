@@ -269,7 +269,7 @@ template <> struct msm_pair<true> {
 
 // matrix[coarse * nblk_pad + block] = pairs of this workgroup's terms falling into `coarse`
 __global__ void __launch_bounds__(SORT_THREADS)
-k_msm_coarse_count(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
+k_msm_coarse_count(uint32_t n, size_t nstride, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
                    uint32_t ncoarse, uint32_t nblk_pad, uint32_t* __restrict__ matrix) {
   __shared__ uint32_t h[MAX_COARSE];
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) h[t] = 0;
@@ -278,7 +278,7 @@ k_msm_coarse_count(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, con
   for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
     size_t i = base + t;
     if (i >= n || flag[i] != 1) continue;
-    msm_for_digits(scw, n, i, g, [&](uint32_t key, bool) { atomicAdd(&h[key >> FINE_BITS], 1u); });
+    msm_for_digits(scw, nstride, i, g, [&](uint32_t key, bool) { atomicAdd(&h[key >> FINE_BITS], 1u); });
   }
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) matrix[(size_t)t * nblk_pad + blockIdx.x] = h[t];
@@ -286,7 +286,7 @@ k_msm_coarse_count(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, con
 // pairs[pos] = (key & (FINE - 1), term, sign), grouped by coarse bucket; `mbase` is the scanned matrix
 template <bool WIDE>
 __global__ void __launch_bounds__(SORT_THREADS)
-k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
+k_msm_coarse_scatter(uint32_t n, size_t nstride, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
                      uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase,
                      typename msm_pair<WIDE>::type* __restrict__ pairs) {
   __shared__ uint32_t cur[MAX_COARSE];
@@ -296,7 +296,7 @@ k_msm_coarse_scatter(uint32_t n, msm_geom g, const uint32_t* __restrict__ scw, c
   for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
     size_t i = base + t;
     if (i >= n || flag[i] != 1) continue;
-    msm_for_digits(scw, n, i, g, [&](uint32_t key, bool neg) {
+    msm_for_digits(scw, nstride, i, g, [&](uint32_t key, bool neg) {
       uint32_t pos = atomicAdd(&cur[key >> FINE_BITS], 1u);
       pairs[pos] = msm_pair<WIDE>::make(key & (FINE - 1), (uint32_t)i, neg);
     });
@@ -388,20 +388,24 @@ constexpr uint32_t MSM_LANES = 1u << 18;      // lanes that fill an MI355X once 
 constexpr uint32_t MSM_L_MIN = 8;             // shortest range
 constexpr uint32_t STITCH_SERIAL = 8, STITCH_BIG_CAP = 4096;
 
-struct msm_rec {
-  uint4 a, b, c, d;
+// A list entry is a term index with the digit's sign: a negative digit adds -P = (x, p - y), formed on the 32-bit
+// words before the limbs are cut.  The record's x half is fetched one addition ahead (a random 64-byte read from the
+// term array); its y half - the other half of the line the x half has brought in - when the addition starts.
+struct msm_half {
+  uint4 a, b;
 };
-S2K_DEV msm_rec msm_load_rec(const uint32_t* __restrict__ ptw, uint32_t entry) {
-  const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + (size_t)(entry & ~TERM_NEG) * 16);
-  msm_rec r;
-  r.a = rec4[0]; r.b = rec4[1]; r.c = rec4[2]; r.d = rec4[3];
+S2K_DEV msm_half msm_load_half(const uint32_t* __restrict__ ptw, uint32_t entry, int half) {
+  const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + (size_t)(entry & ~TERM_NEG) * 16) + 2 * half;
+  msm_half r;
+  r.a = rec4[0]; r.b = rec4[1];
   return r;
 }
-// A list entry is a term index with the digit's sign: a negative digit adds -P = (x, p - y), formed on the 32-bit
-// words before the limbs are cut.
-S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
+S2K_DEV fe29 msm_x_of(const msm_half& r) {
   uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
-  uint32_t yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
+  return fe29_from_words(xw);
+}
+S2K_DEV fe29 msm_y_of(const msm_half& r, uint32_t entry) {
+  uint32_t yw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
   // neg: p - y = ~y + p + 1 over the eight words (y in [1, p), so the result is in (0, p) and the carry out is dropped)
   constexpr uint32_t PW[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   const uint32_t M = 0u - (entry >> 31);
@@ -412,8 +416,7 @@ S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
     yw[w] = (uint32_t)cy;
     cy >>= 32;
   }
-  x = fe29_from_words(xw);
-  y = fe29_from_words(yw);
+  return fe29_from_words(yw);
 }
 // the key whose bucket holds list position p: offset[key] <= p < offset[key + 1]  (p < offset[nkeys])
 S2K_DEV uint32_t msm_key_at(const uint32_t* __restrict__ offset, uint32_t nkeys, uint32_t p) {
@@ -425,14 +428,7 @@ S2K_DEV uint32_t msm_key_at(const uint32_t* __restrict__ offset, uint32_t nkeys,
   return lo;
 }
 
-#ifndef S2K_MSM_PREFETCH
-#define S2K_MSM_PREFETCH 1   // the next point's record is loaded before the current addition starts
-#endif
-#if S2K_MSM_PREFETCH
 __global__ void __launch_bounds__(256, 4)     // four waves per SIMD: at most 128 VGPRs
-#else
-__global__ void __launch_bounds__(256)
-#endif
 k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
                  const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw, uint32_t* __restrict__ sums) {
   const uint32_t lane = blockIdx.x * 256 + threadIdx.x;
@@ -445,7 +441,7 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
   bool open_left = offset[key] < lo;
   pt29 acc = pt29_identity();
   uint32_t e_cur = list[lo], e_nxt = lo + 1 < hi ? list[lo + 1] : 0u;
-  msm_rec r_cur = msm_load_rec(ptw, e_cur);
+  msm_half x_cur = msm_load_half(ptw, e_cur, 0);
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
     if (j == border) {                                     // a bucket ends here: flush, next non-empty bucket
@@ -457,22 +453,13 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
         border = offset[key + 1];
       } while (border <= j);
     }
-#if S2K_MSM_PREFETCH
-    const msm_rec r_nxt = msm_load_rec(ptw, e_nxt);        // entry 0 when past the end: a valid address
+    const msm_half y_cur = msm_load_half(ptw, e_cur, 1);
+    const msm_half x_nxt = msm_load_half(ptw, e_nxt, 0);   // entry 0 when past the end: a valid address
     const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;
-#endif
-    fe29 qx, qy;
-    msm_point_of(r_cur, e_cur, qx, qy);
-    acc = pt29_add_mixed(acc, qx, qy);
-#if S2K_MSM_PREFETCH
-    r_cur = r_nxt;
+    acc = pt29_add_mixed(acc, msm_x_of(x_cur), msm_y_of(y_cur, e_cur));
+    x_cur = x_nxt;
     e_cur = e_nxt;
     e_nxt = e_nn;
-#else
-    e_cur = e_nxt;
-    e_nxt = j + 2 < hi ? list[j + 2] : 0u;
-    r_cur = msm_load_rec(ptw, e_cur);
-#endif
   }
   // the last piece: left edge if it came in from the previous range (then it may go on as well: a range inside one
   // bucket), right edge if it goes on into the next range, else a whole bucket
@@ -631,7 +618,8 @@ struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
   uint32_t *status, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big;
-  uint32_t L, nlanes;  // bucket pass: entries per range, ranges (upper bound from the term count)
+  size_t cap;          // term capacity the workspace was carved for = plane stride of scw (a call may run on fewer terms)
+  uint32_t lanes_cap;  // bucket pass: most ranges any term count up to cap can make
   size_t sum_stride;   // slots of `sums`: nkeys buckets, then the left and the right edge piece of every range
   void* pairs;
   bool wide;           // two-word pairs (term indices beyond 23 bits)
@@ -641,7 +629,14 @@ struct msm_ws {
   uint8_t* aux;        // extra caller-requested scratch
 };
 
-// carve the MSM workspace for n terms (+ aux_bytes of scratch for the caller)
+static uint32_t msm_lanes_target() {   // tuning hook: S2K_MSM_LANES overrides the lanes that fill the chip once
+  static const uint32_t v = [] {
+    const char* e = getenv("S2K_MSM_LANES");
+    return e && atoi(e) > 0 ? (uint32_t)atoi(e) : MSM_LANES;
+  }();
+  return v;
+}
+// carve the MSM workspace for up to n terms (+ aux_bytes of scratch for the caller)
 int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   msm_geom& g = m.g;
   // window width: measured (tools/msm_sweep.py, MI355X, ms for 2^11 .. 2^20 inputs = twice as many terms):
@@ -667,17 +662,11 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.nslots = (size_t)g.nslot * g.nchunk;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  m.cap = n;
   {
-    static const uint32_t lanes_target = [] {   // tuning hook
-      const char* e = getenv("S2K_MSM_LANES");
-      return e ? (uint32_t)atoi(e) : MSM_LANES;
-    }();
-    const size_t pairs_max = n * (size_t)g.nw;
-    size_t L = (pairs_max + lanes_target - 1) / lanes_target;
-    if (L < MSM_L_MIN) L = MSM_L_MIN;
-    m.L = (uint32_t)L;
-    m.nlanes = (uint32_t)((pairs_max + L - 1) / L);
-    m.sum_stride = align_up(m.nkeys + 2 * (size_t)m.nlanes, 64);
+    const size_t pairs_max = n * (size_t)g.nw, by_len = (pairs_max + MSM_L_MIN - 1) / MSM_L_MIN;
+    m.lanes_cap = (uint32_t)(by_len < msm_lanes_target() ? by_len : msm_lanes_target()) + 1;
+    m.sum_stride = align_up(m.nkeys + 2 * (size_t)m.lanes_cap, 64);
   }
   // status word, then the queue of oversized buckets (counter + keys), zeroed with the counters
   m.ncoarse = (uint32_t)(m.nkeys >> FINE_BITS);
@@ -714,8 +703,15 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
 // buckets -> result, given scw / ptw / flag already filled and status/count/cursor zeroed
 int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65, bool affine = true) {
   const msm_geom& g = m.g;
+  if (n > m.cap) return fail(ctx, S2K_ERR_ARG, "internal: more terms than the multiscalar workspace was carved for");
+  const uint32_t nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);      // <= m.nsortblk: the matrix columns beyond stay zero
+  // ranges of the bucket pass: as long as it takes for the lanes to fill the chip once
+  const size_t pairs_max = n * (size_t)g.nw;
+  size_t L = (pairs_max + msm_lanes_target() - 1) / msm_lanes_target();
+  if (L < MSM_L_MIN) L = MSM_L_MIN;
+  const uint32_t nlanes = (uint32_t)((pairs_max + L - 1) / L);                   // <= m.lanes_cap
   // sort: coarse partition (counts -> scan -> scatter), then one workgroup per coarse bucket
-  k_msm_coarse_count<<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix);
+  k_msm_coarse_count<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
   const unsigned scan_blocks = (unsigned)(mat_words / 1024);
@@ -725,17 +721,17 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
   if (m.wide) {
-    k_msm_coarse_scatter<true><<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs);
+    k_msm_coarse_scatter<true><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs);
     k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list);
   } else {
-    k_msm_coarse_scatter<false><<<m.nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs);
+    k_msm_coarse_scatter<false><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs);
     k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list);
   }
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_accumulate<<<blocks_for(m.nlanes), 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.list, m.ptw, m.sums);
+  k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.list, m.ptw, m.sums);
   HIP_TRY(ctx, hipGetLastError());
-  k_msm_stitch<<<blocks_for(m.nkeys), 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.sums, m.big);
-  k_msm_stitch_big<<<64, 256, 0, st>>>(m.L, (uint32_t)m.nkeys, m.nlanes, m.sum_stride, m.offset, m.sums, m.big);
+  k_msm_stitch<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
+  k_msm_stitch_big<<<64, 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
   HIP_TRY(ctx, hipGetLastError());
   k_msm_reduce<<<blocks_for(4 * m.nslots), 256, 0, st>>>(g, m.sums, m.sum_stride, m.partial);
   HIP_TRY(ctx, hipGetLastError());
@@ -859,16 +855,32 @@ k_schnorr_rlc_prep(uint32_t n, size_t N, const uint8_t* __restrict__ pk, const u
   flag[i] = ok ? 1 : 0;
 }
 
-// Aggregated key terms.  Lane t < ngroups: virtual group t (the signatures perm[first .. first + count) of
-// one key); lane ngroups + q: the signature left[q] on its own.  The group's coefficient is the sum of
-// a_i e_i over its members that are still in the combination (flag); the key is lifted ONCE.  A key that
-// does not lift takes its signatures out of the combination (flag, a_i s_i) and fails the batch (status).
-// Terms n + 2t, n + 2t + 1.
+// Aggregated key terms, in two kernels.  Lane t < ngroups: virtual group t (the signatures perm[first .. first + count)
+// of one key); lane ngroups + q: the signature left[q] on its own.
+// k_rlc_key_lift lifts the group's key ONCE (a square root: the expensive part; it needs the grouping only, so it runs on
+// the second stream beside k_schnorr_rlc_prep): ky[w][t] = the even y, kok[t] = 1 if the key lifts.
+__global__ void __launch_bounds__(64)
+k_rlc_key_lift(uint32_t ngroups, uint32_t nleft, size_t kstride, const uint32_t* __restrict__ vslot, const uint32_t* __restrict__ rep,
+               const uint32_t* __restrict__ left, const uint8_t* __restrict__ pk, uint32_t* __restrict__ ky, uint8_t* __restrict__ kok) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= ngroups + nleft) return;
+  const uint32_t key_sig = t < ngroups ? rep[vslot[t]] : left[t - ngroups];
+  uint32_t pk_le[8], py[8];
+  load_be32(pk_le, pk + (size_t)key_sig * 32);
+  const bool key_ok = lift_x_words(py, pk_le);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) ky[(size_t)w * kstride + t] = key_ok ? py[w] : 0u;
+  kok[t] = key_ok ? 1 : 0;
+}
+// k_rlc_key_terms: the group's coefficient is the sum of a_i e_i over its members that are still in the combination
+// (flag).  A key that does not lift takes its signatures out of the combination (flag, a_i s_i) and fails the batch
+// (status).  Terms n + 2t, n + 2t + 1 (N: plane stride of the term arrays).
 __global__ void __launch_bounds__(64)
 k_rlc_key_terms(uint32_t n, size_t N, uint32_t ngroups, uint32_t nleft, const uint32_t* __restrict__ vslot,
                 const uint32_t* __restrict__ rep, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ base,
                 const uint32_t* __restrict__ tix, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ left,
-                const uint8_t* __restrict__ pk, const uint32_t* __restrict__ ae, uint32_t* __restrict__ as_io,
+                const uint8_t* __restrict__ pk, size_t kstride, const uint32_t* __restrict__ ky, const uint8_t* __restrict__ kok,
+                const uint32_t* __restrict__ ae, uint32_t* __restrict__ as_io,
                 uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag,
                 uint32_t* __restrict__ status) {
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
@@ -887,9 +899,7 @@ k_rlc_key_terms(uint32_t n, size_t N, uint32_t ngroups, uint32_t nleft, const ui
     key_sig = left[first];
     members = left;
   }
-  uint32_t pk_le[8], py[8];
-  load_be32(pk_le, pk + (size_t)key_sig * 32);
-  const bool key_ok = lift_x_words(py, pk_le);
+  const bool key_ok = kok[t] != 0;
   sc sum = sc_zero();
   bool any = false;
 #pragma unroll 1
@@ -911,7 +921,10 @@ k_rlc_key_terms(uint32_t n, size_t N, uint32_t ngroups, uint32_t nleft, const ui
   if (!key_ok) atomicOr(status, 2u);
   const size_t t1 = (size_t)n + 2 * (size_t)t, t2 = t1 + 1;
   if (key_ok && any) {
-    uint32_t npy[8];
+    uint32_t pk_le[8], py[8], npy[8];
+    load_be32(pk_le, pk + (size_t)key_sig * 32);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) py[w] = ky[(size_t)w * kstride + t];
     u256_sub(npy, FE_P, py);
     msm_store_split(scw, ptw, N, t1, t2, sum, pk_le, npy);
     flag[t1] = 1;
@@ -921,12 +934,12 @@ k_rlc_key_terms(uint32_t n, size_t N, uint32_t ngroups, uint32_t nleft, const ui
 
 // sum of n scalars mod n in two launches: RLC_SUM_BLOCKS workgroups leave one partial sum each in
 // `part` (8 words each), then one workgroup folds those and writes the result as terms 3n, 3n + 1
-// with the point G (as == nullptr selects the second stage)
+// with the point G (as == nullptr selects the second stage); N terms in arrays of plane stride tstride
 constexpr uint32_t RLC_SUM_BLOCKS = 256;
 // (`as` has plane stride `stride`; a sub-range of a saved batch passes as + lo with the batch's stride)
 __global__ void __launch_bounds__(256)
 k_schnorr_rlc_sum(uint32_t n, size_t stride, const uint32_t* __restrict__ as, uint32_t* __restrict__ part,
-                  uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag, size_t N) {
+                  uint32_t* __restrict__ scw, uint32_t* __restrict__ ptw, uint8_t* __restrict__ flag, size_t N, size_t tstride) {
   __shared__ uint32_t sh[256][8];
   sc acc = sc_zero();
   if (as) {
@@ -965,7 +978,7 @@ k_schnorr_rlc_sum(uint32_t n, size_t stride, const uint32_t* __restrict__ as, ui
     sc tot;                                   // the generator's terms are the last two of the N
 #pragma unroll
     for (int w = 0; w < 8; ++w) tot.v[w] = sh[0][w];
-    msm_store_split(scw, ptw, N, N - 2, N - 1, tot, FE_GX, FE_GY);
+    msm_store_split(scw, ptw, tstride, N - 2, N - 1, tot, FE_GX, FE_GY);
     flag[N - 2] = 1;
     flag[N - 1] = 1;
   }
@@ -1147,41 +1160,62 @@ static int rlc_run_full(s2k_ctx* ctx, hipStream_t st, size_t n, const void* d_pk
     for (int j = 0; j < 8; ++j)
       seed_be.w[j] = ((uint32_t)key[4 * j] << 24) | ((uint32_t)key[4 * j + 1] << 16) | ((uint32_t)key[4 * j + 2] << 8) | key[4 * j + 3];
   }
-  key_groups32 kg;
-  size_t N = 3 * n + 2;
-  if (mode == RLC_AGGREGATED) {
-    int rc = s2k_internal_key_group32(ctx, n, (const uint8_t*)d_pk, st, &kg);
-    if (rc) return rc;
-    N = n + 2 * ((size_t)kg.ngroups + kg.nleft) + 2;
-  }
-  // aux: 256 bytes | partial sums of the generator's coefficient | a_i s_i planes | a_i e_i planes (aggregated)
-  const size_t as_bytes = n * 8 * 4;
-  int rc = msm_setup(ctx, N, 256 + RLC_SUM_BLOCKS * 32 + as_bytes + (mode == RLC_AGGREGATED ? as_bytes : 0), m);
+  // The workspace is carved for the plain form's 3n + 2 terms in both modes (the aggregated form has fewer, but how many
+  // is known only once the keys are grouped, and the preparation must not wait for that): `cap` is the plane stride.
+  const size_t cap = 3 * n + 2;
+  size_t N = cap;
+  // aux: 256 bytes | partial sums of the generator's coefficient | a_i s_i planes | a_i e_i planes, lifted keys (aggregated)
+  const size_t as_bytes = n * 8 * 4, kstride = (n + 63) & ~(size_t)63;
+  int rc = msm_setup(ctx, cap, 256 + RLC_SUM_BLOCKS * 32 + as_bytes + (mode == RLC_AGGREGATED ? as_bytes + kstride * 36 : 0), m);
   if (rc) return rc;
   uint32_t* sum_part = (uint32_t*)(m.aux + 256);
   uint32_t* as = (uint32_t*)(m.aux + 256 + RLC_SUM_BLOCKS * 32);
   uint32_t* ae = as + n * 8;
+  uint32_t* ky = ae + n * 8;
+  uint8_t* kok = (uint8_t*)(ky + kstride * 8);
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
   if (mode == RLC_AGGREGATED) {
-    HIP_TRY(ctx, hipMemsetAsync(m.flag, 0, N, st));     // the key terms set their own flags
-    k_schnorr_rlc_prep<true><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, N, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
+    // Two streams.  Caller's: the per-signature preparation (challenge hash, square root of r, coefficients: 1.2 ms of
+    // multiplier time for 2^20 signatures).  Second: the grouping of the keys (hash table, latency bound; it ends with
+    // the one host read of the call, the group count) and one square root per DISTINCT key.  They meet at the key terms.
+    rc = ctx_aux_streams(ctx);
+    if (rc) return rc;
+    rc = s2k_internal_key_reserve32(ctx, n);   // the grouping arrays are grown before the fork (growing synchronises the device)
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(m.flag, 0, cap, st));     // the key terms set their own flags
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+    k_schnorr_rlc_prep<true><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, cap, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
                                                             (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
                                                             (uint32_t)msg_len, seed_be, m.scw, m.ptw, m.flag, as, ae, m.status);
-    HIP_TRY(ctx, hipGetLastError());
-    const uint32_t lanes = kg.ngroups + kg.nleft;
-    k_rlc_key_terms<<<(lanes + 63) / 64, 64, 0, st>>>((uint32_t)n, N, kg.ngroups, kg.nleft, kg.vslot, kg.rep, kg.cnt, kg.base, kg.tix,
-                                                      kg.perm, kg.left, (const uint8_t*)d_pk, ae, as, m.scw, m.ptw, m.flag, m.status);
+    key_groups32 kg;
+    rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "k_schnorr_rlc_prep launch failed");
+    if (rc == S2K_OK) rc = s2k_internal_key_group32(ctx, n, (const uint8_t*)d_pk, ctx->s_aux, &kg);   // (synchronises the second stream)
+    uint32_t lanes = 0;
+    if (rc == S2K_OK) {
+      lanes = kg.ngroups + kg.nleft;
+      N = n + 2 * (size_t)lanes + 2;
+      k_rlc_key_lift<<<(lanes + 63) / 64, 64, 0, ctx->s_aux>>>(kg.ngroups, kg.nleft, kstride, kg.vslot, kg.rep, kg.left, (const uint8_t*)d_pk, ky, kok);
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "k_rlc_key_lift launch failed");
+    }
+    ctx_aux_join(ctx, st);            // error or not: nothing stays in flight on the second stream alone
+    if (rc) {
+      (void)ctx_leave(ctx, st);
+      return rc;
+    }
+    k_rlc_key_terms<<<(lanes + 63) / 64, 64, 0, st>>>((uint32_t)n, cap, kg.ngroups, kg.nleft, kg.vslot, kg.rep, kg.cnt, kg.base, kg.tix,
+                                                      kg.perm, kg.left, (const uint8_t*)d_pk, kstride, ky, kok, ae, as, m.scw, m.ptw, m.flag, m.status);
     HIP_TRY(ctx, hipGetLastError());
   } else {
-    k_schnorr_rlc_prep<false><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, N, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
+    k_schnorr_rlc_prep<false><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, cap, (const uint8_t*)d_pk, (const uint8_t*)d_sig,
                                                              (const uint8_t*)d_msgs, (const uint64_t*)d_msg_offsets,
                                                              (uint32_t)msg_len, seed_be, m.scw, m.ptw, m.flag, as, nullptr, m.status);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (as_out) *as_out = as;
   if (mode == RLC_PLAIN_TERMS_ONLY) return S2K_OK;
-  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, n, as, sum_part, m.scw, m.ptw, m.flag, N);
-  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, n, nullptr, sum_part, m.scw, m.ptw, m.flag, N);
+  k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>((uint32_t)n, n, as, sum_part, m.scw, m.ptw, m.flag, N, cap);
+  k_schnorr_rlc_sum<<<1, 256, 0, st>>>((uint32_t)n, n, nullptr, sum_part, m.scw, m.ptw, m.flag, N, cap);
   HIP_TRY(ctx, hipGetLastError());
   uint8_t* d_out = (uint8_t*)m.status + 64;   // 65-byte record inside the 256-byte status slot
   rc = msm_core(ctx, st, N, m, d_out, /*affine=*/as_out != nullptr);   // the verdict alone needs no coordinates; the bisection does
@@ -1292,8 +1326,8 @@ int s2k_schnorr_verify_batch_bisect_device(s2k_ctx* ctx, size_t n, const void* d
     uint32_t* sum_part = (uint32_t*)w.aux;
     HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, w.zero_bytes, st));
     k_rlc_gather<<<blocks_for(3 * (size_t)cnt), 256, 0, st>>>(lo, cnt, (uint32_t)n, s_scw, s_ptw, s_flag, w.scw, w.ptw, w.flag);
-    k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>(cnt, n, s_as + lo, sum_part, w.scw, w.ptw, w.flag, N);
-    k_schnorr_rlc_sum<<<1, 256, 0, st>>>(cnt, n, nullptr, sum_part, w.scw, w.ptw, w.flag, N);
+    k_schnorr_rlc_sum<<<RLC_SUM_BLOCKS, 256, 0, st>>>(cnt, n, s_as + lo, sum_part, w.scw, w.ptw, w.flag, N, N);
+    k_schnorr_rlc_sum<<<1, 256, 0, st>>>(cnt, n, nullptr, sum_part, w.scw, w.ptw, w.flag, N, N);
     HIP_TRY(ctx, hipGetLastError());
     uint8_t* d_out = (uint8_t*)w.status + 64;
     r = msm_core(ctx, st, N, w, d_out);
