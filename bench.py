@@ -390,6 +390,39 @@ def worker(args):
     return rc
 
 
+def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_stage):
+    """`roofline` object of BASELINE config 3 / 4: the dominant kernel's VALU instructions (PMC, committed profile of the
+    same entry point at the same size, tools/collect_msm_profiles.sh) over its live duration (HIP events on the call's
+    stream, s2k_ctx_profile_msm) against the 4-cycle issue peak; the whole call the same way; algorithmic work per
+    unit; fetched + written bytes of the dominant kernel next to the algorithmic ones."""
+    prof = None
+    src = None
+    for name in ("r03_%s_profile_2p20.json" % which,):
+        prof = load_profile_json(name)
+        if prof:
+            src = name
+            break
+    k = stages["calls"]
+    st_ms = {a: stages[a] / k for a in ("front_ms", "sort_ms", "bucket_pass_ms", "reduce_ms", "tail_ms")}
+    kernel_ms = st_ms[dominant_stage]
+    roof = {"bound": "valu", "kernel": dominant, "kernel_ms": kernel_ms, "stages_ms": st_ms, "unit": "Tlane-op/s",
+            "peak": VALU_PEAK_LANE_OPS / 1e12, "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
+    if prof and dominant in prof["kernels"]:
+        kk = prof["kernels"][dominant]
+        wave_instr = kk["valu_wave_instr_per_call"]
+        lane_ops = wave_instr * 64 / (kernel_ms * 1e-3)
+        total = prof["valu_wave_instr_per_call"]
+        roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                     "valu_wave_instr_dominant_kernel": wave_instr, "valu_wave_instr_whole_call": total,
+                     "whole_call_frac": total * 64 / (call_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                     "counts_from": "profiles/" + src,
+                     "frac_def": "VALU wave-instructions of the kernel (PMC, committed profile of this entry point at this size) x 64 / "
+                                 "its live duration / peak; whole_call_frac: all kernels of the call over the call's duration",
+                     "traffic": (kk.get("fetch_bytes_per_call") or 0) + (kk.get("write_bytes_per_call") or 0)})
+    roof.update(units)
+    return roof
+
+
 def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
     """The other BASELINE configurations and side figures on one GPU; every number is guarded by a
     check of the full result."""
@@ -480,11 +513,23 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
     k, pts, tot = synth_msm_terms(eng, m, seed=7)
     dk, dp = torch.from_numpy(k).to(dev), torch.from_numpy(pts).to(dev)
     dout = torch.zeros(80, dtype=torch.uint8, device=dev)
+    eng.multi_scalar_mult_device(m, dk.data_ptr(), dp.data_ptr(), dout.data_ptr(), st)      # (allocates the workspace)
+    eng.profile_msm(True)
     ms = timed(lambda: eng.multi_scalar_mult_device(m, dk.data_ptr(), dp.data_ptr(), dout.data_ptr(), st), 5)
+    stages = eng.profile_read_msm()
     want = eng.scalar_base_mult_batch([tot.to_bytes(32, "big")])[0].tobytes()
     assert dout[:65].cpu().numpy().tobytes() == want, "2^20-term MSM differs from (sum k_i d_i) G"
     out["msm_2p20"] = {"terms": m, "ms": ms, "terms_per_s": m / (ms * 1e-3),
-                       "check": "full sum == (sum k_i d_i mod n) * G (big-int on the host, base mult on the device)"}
+                       "check": "full sum == (sum k_i d_i mod n) * G (big-int on the host, base mult on the device)",
+                       "roofline": multiscalar_roofline(eng, "msm", ms, stages, {
+                           # every input is two 128-bit terms (endomorphism), 8 signed 16-bit windows each: one bucket
+                           # addition per non-zero digit (complete mixed addition: 11 field products), + one per bucket
+                           # crossing a range border and the reduction's ~3 complete additions per bucket (12 products)
+                           "point_adds_per_term": 2 * 8 * (1 - 2.0 ** -16) + (9 * 32768 * 4.0) / m,
+                           "fp_products_per_term": 2 * 8 * 11 + (9 * 32768 * 4.0 * 12) / m + 4,
+                           "algorithmic_bytes_per_term": 32 + 65,
+                           "hbm": {"bound": "hbm", "achieved": (32 + 65) * m / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": (32 + 65) * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}, "k_msm_accumulate", "bucket_pass_ms")}
     del dk, dp
 
     # ---- config 4: 2^20 BIP-340 signatures as one random-linear-combination MSM ----
@@ -497,7 +542,11 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
         rc_ = lib.s2k_schnorr_batch_verify_rlc_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32, dsig.data_ptr(),
                                                       seed.ctypes.data, ctypes.byref(res), st)
         assert rc_ == 0
+    rlc()
+    eng.profile_read_msm()
     ms = timed(rlc, 5)
+    stages = eng.profile_read_msm()
+    eng.profile_msm(False)
     assert res.value == 1, "valid BIP-340 batch rejected"
     bad = int(np.random.default_rng(5).integers(0, m))
     dsig[bad, 63] ^= 1                       # one bad signature anywhere must reject the batch
@@ -525,7 +574,16 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
                                "locate_stats": {"sub_combinations": int(stats[0]), "verified_one_by_one": int(stats[1]),
                                                 "levels": int(stats[2])},
                                "check": "accepts the valid batch, rejects it with one flipped bit at index %d; "
-                                        "per-signature verification accepts all" % bad}
+                                        "per-signature verification accepts all" % bad,
+                               "roofline": multiscalar_roofline(eng, "rlc", ms, stages, {
+                                   # per signature: one square root (lift_x of r: 253 squarings + 13 products), the
+                                   # challenge hash (2 SHA-256 compressions) and the coefficient (1), 3 scalar products; one
+                                   # 128-bit term (8 bucket additions); per distinct key one more square root and two terms
+                                   "fp_products_per_sig": 266 + 8 * 11 + (16 * 11 + 266) / 16.0,
+                                   "point_adds_per_sig": 8 + 16 / 16.0,
+                                   "algorithmic_bytes_per_sig": 32 + 32 + 64,
+                                   "hbm": {"bound": "hbm", "achieved": 128 * m / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": 128 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}, "k_schnorr_rlc_prep<true>", "front_ms")}
     return out
 
 

@@ -96,6 +96,15 @@ int s2k_ctx_profile_read(s2k_ctx *ctx, double ms_sum3[3], double *ms_fast_each, 
 int s2k_ctx_profile_read_stages(s2k_ctx *ctx, double ms_sum5[5], double *ms_fast_each, size_t cap, size_t *calls,
                                 double shader_mhz[2]);
 
+/* The same for the multi-scalar path (s2k_multi_scalar_mult_device, s2k_schnorr_batch_verify_rlc_device and the
+ * bisection's sub-range runs): while enabled every call records HIP events on its stream between its stages;
+ * s2k_ctx_profile_read_msm synchronises the device and returns the summed durations: ms_sum5[0] front end (parsing of
+ * the terms; for BIP-340 the per-signature preparation with the key grouping, key lifts and key terms), [1] sort of the
+ * (window, digit) keys, [2] bucket pass (k_msm_accumulate: the dominant kernel), [3] stitching of the buckets, bucket
+ * reduction and tree, [4] Horner tail and affine result; and the number of calls since the last read. */
+int s2k_ctx_profile_msm(s2k_ctx *ctx, int enable);
+int s2k_ctx_profile_read_msm(s2k_ctx *ctx, double ms_sum5[5], size_t *calls);
+
 /* ---- hot path: batch ECDSA verification ------------------------------------------- */
 /* For each i < n: secec.PublicKey.VerifyRaw(digest, r, s) (ecdsa.go:234 -> verify :392)
  * after ParseCompactSignature's range checks (s11n.go:129-144) and NewPublicKey's point

@@ -143,6 +143,8 @@ def load_library() -> C.CDLL:
     lib.s2k_ctx_profile.argtypes = [vp, ci]
     lib.s2k_ctx_profile_read.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.s2k_ctx_profile_read_stages.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.s2k_ctx_profile_msm.argtypes = [vp, ci]
+    lib.s2k_ctx_profile_read_msm.argtypes = [vp, vp, vp]
     lib.s2k_ctx_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
     lib.s2k_ctx_key_grouping_stats.argtypes = [vp, vp]
     lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
@@ -190,7 +192,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version", "s2k_build_config",
-    "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages",
+    "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages", "s2k_ctx_profile_msm", "s2k_ctx_profile_read_msm",
     "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
     "s2k_pack_valid_device", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
@@ -474,6 +476,18 @@ class Engine:
                 "fallback_ms": sums[4], "fast_each": [each[i] for i in range(min(k, cap))],
                 "shader_mhz": sum(both) / len(both) if both else 0.0,
                 "shader_mhz_first_wave": float(mhz[0]), "shader_mhz_last_round": float(mhz[1])}
+
+    def profile_msm(self, enable: bool = True):
+        """Stage timing of the multi-scalar path (s2k_ctx_profile_msm)."""
+        self._check(self._lib.s2k_ctx_profile_msm(self._h, 1 if enable else 0))
+
+    def profile_read_msm(self):
+        """-> dict(calls, front_ms, sort_ms, bucket_pass_ms, reduce_ms, tail_ms): sums over the calls since the last read."""
+        sums = (C.c_double * 5)()
+        calls = C.c_size_t(0)
+        self._check(self._lib.s2k_ctx_profile_read_msm(self._h, sums, C.byref(calls)))
+        return {"calls": int(calls.value), "front_ms": sums[0], "sort_ms": sums[1], "bucket_pass_ms": sums[2],
+                "reduce_ms": sums[3], "tail_ms": sums[4]}
 
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         """How ecdsa_verify_batch[_device] treats signatures that share a public key (s2k_ctx_set_key_grouping):

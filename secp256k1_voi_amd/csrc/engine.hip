@@ -1399,6 +1399,8 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->kg) (void)hipFree(ctx->kg);
   if (ctx->ktab) (void)hipFree(ctx->ktab);
   for (size_t i = 0; i < ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+  for (size_t i = 0; i < ctx->msm_prof_cap; ++i) (void)hipEventDestroy(ctx->msm_prof_ev[i]);
+  delete[] ctx->msm_prof_ev;
   delete[] ctx->prof_ev;
   for (hipEvent_t e : ctx->ev_copied)
     if (e) (void)hipEventDestroy(e);

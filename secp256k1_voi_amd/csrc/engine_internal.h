@@ -90,6 +90,10 @@ struct s2k_ctx {
   hipEvent_t* prof_ev = nullptr;
   size_t prof_cap = 0, prof_used = 0;
   uint64_t* clk = nullptr;      // device: s_memtime / s_memrealtime stamps of one wave of k_verify_fast
+  // the same for the multi-scalar path (s2k_ctx_profile_msm): MSM_PROF_EV events per call, see msm_prof_mark
+  hipEvent_t* msm_prof_ev = nullptr;
+  size_t msm_prof_cap = 0, msm_prof_used = 0;
+  bool msm_prof_on = false;
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
   int kg_mode = S2K_KEYS_AUTO;
   uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = 1u << 18;
@@ -184,6 +188,16 @@ inline void ctx_aux_join(s2k_ctx* ctx, hipStream_t st) {
   if (!ctx->s_aux) return;
   (void)hipEventRecord(ctx->ev_join, ctx->s_aux);
   (void)hipStreamWaitEvent(st, ctx->ev_join, 0);
+}
+
+// stage timing of the multi-scalar path (s2k_ctx_profile_msm): events before the front end (parsing, or the BIP-340
+// preparation with grouping and key terms) | the sort | the bucket pass | stitching, reduction and tree | the Horner
+// tail | the end
+constexpr int MSM_PROF_EV = 6;
+inline void msm_prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
+  if (!ctx->msm_prof_on || ctx->msm_prof_used + MSM_PROF_EV > ctx->msm_prof_cap) return;
+  (void)hipEventRecord(ctx->msm_prof_ev[ctx->msm_prof_used + slot], st);
+  if (slot == MSM_PROF_EV - 1) ctx->msm_prof_used += MSM_PROF_EV;
 }
 
 // copy / compute streams and the events chaining them, for the host-buffer entry points

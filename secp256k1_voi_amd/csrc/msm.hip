@@ -711,6 +711,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   if (L < MSM_L_MIN) L = MSM_L_MIN;
   const uint32_t nlanes = (uint32_t)((pairs_max + L - 1) / L);                   // <= m.lanes_cap
   // sort: coarse partition (counts -> scan -> scatter), then one workgroup per coarse bucket
+  msm_prof_mark(ctx, st, 1);
   k_msm_coarse_count<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
@@ -728,8 +729,10 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list);
   }
   HIP_TRY(ctx, hipGetLastError());
+  msm_prof_mark(ctx, st, 2);
   k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.list, m.ptw, m.sums);
   HIP_TRY(ctx, hipGetLastError());
+  msm_prof_mark(ctx, st, 3);
   k_msm_stitch<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
   k_msm_stitch_big<<<64, 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
   HIP_TRY(ctx, hipGetLastError());
@@ -742,8 +745,10 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     if (groups > 1) k_msm_tree<<<g.nslot, 256, 0, st>>>((uint32_t)m.nslots, groups, span1, m.partial);
   }
   HIP_TRY(ctx, hipGetLastError());
+  msm_prof_mark(ctx, st, 4);
   k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());
+  msm_prof_mark(ctx, st, 5);
   return S2K_OK;
 }
 
@@ -1035,6 +1040,45 @@ k_rlc_mark_valid(uint32_t lo, uint32_t m, const uint8_t* __restrict__ s_flag, ui
 
 extern "C" {
 
+int s2k_ctx_profile_msm(s2k_ctx* ctx, int enable) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (enable && !ctx->msm_prof_ev) {
+    const size_t cap = MSM_PROF_EV * 256;   // 256 calls between two reads
+    ctx->msm_prof_ev = new (std::nothrow) hipEvent_t[cap];
+    if (!ctx->msm_prof_ev) return fail(ctx, S2K_ERR_NOMEM, "out of host memory");
+    for (size_t i = 0; i < cap; ++i) {
+      hipError_t e = hipEventCreate(&ctx->msm_prof_ev[i]);
+      if (e != hipSuccess) {
+        for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(ctx->msm_prof_ev[j]);
+        delete[] ctx->msm_prof_ev;
+        ctx->msm_prof_ev = nullptr;
+        return fail(ctx, S2K_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+      }
+    }
+    ctx->msm_prof_cap = cap;
+  }
+  ctx->msm_prof_on = enable != 0;
+  ctx->msm_prof_used = 0;
+  return S2K_OK;
+}
+int s2k_ctx_profile_read_msm(s2k_ctx* ctx, double ms_sum5[5], size_t* calls) {
+  if (!ctx || !ms_sum5 || !calls) return fail(ctx, S2K_ERR_ARG, "null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  for (int j = 0; j < MSM_PROF_EV - 1; ++j) ms_sum5[j] = 0.0;
+  const size_t k = ctx->msm_prof_used / MSM_PROF_EV;
+  for (size_t i = 0; i < k; ++i)
+    for (int j = 0; j < MSM_PROF_EV - 1; ++j) {
+      float ms = 0.f;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->msm_prof_ev[MSM_PROF_EV * i + j], ctx->msm_prof_ev[MSM_PROF_EV * i + j + 1]));
+      ms_sum5[j] += ms;
+    }
+  *calls = k;
+  ctx->msm_prof_used = 0;
+  return S2K_OK;
+}
+
 int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, const void* d_points, void* d_out65,
                                  void* hip_stream) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
@@ -1052,6 +1096,7 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
   msm_ws m;
   rc = msm_setup(ctx, 2 * n, 0, m);   // every input is two terms (endomorphism split)
   if (rc) return rc;
+  msm_prof_mark(ctx, st, 0);
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
   k_msm_parse<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, m.scw,
                                              m.ptw, m.flag, m.status);
@@ -1173,6 +1218,7 @@ static int rlc_run_full(s2k_ctx* ctx, hipStream_t st, size_t n, const void* d_pk
   uint32_t* ae = as + n * 8;
   uint32_t* ky = ae + n * 8;
   uint8_t* kok = (uint8_t*)(ky + kstride * 8);
+  msm_prof_mark(ctx, st, 0);
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
   if (mode == RLC_AGGREGATED) {
     // Two streams.  Caller's: the per-signature preparation (challenge hash, square root of r, coefficients: 1.2 ms of

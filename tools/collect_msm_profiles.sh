@@ -22,8 +22,8 @@ for W in msm rlc; do
   python3 - <<PY
 import json
 d = json.load(open("$P/${W}_profile_2p20.json"))
-print("$W: call %.3f ms kernels" % d["sum_kernel_ms_per_call"])
+print("$W: call %.3f ms kernels, %.3f ms span" % (d["sum_kernel_ms_per_call"], d["span_ms_per_call"]))
 for k, v in d["kernels"].items():
-    print("  %-28s %5.1f launches/call %8.3f ms/call  valu %8.1f M  fetch %7.1f MB write %7.1f MB" % (k, v["launches_per_call"], v["ms_per_call"], (v.get("valu_wave_instr_per_call") or 0) / 1e6, (v.get("fetch_bytes_per_call") or 0) / 1e6, (v.get("write_bytes_per_call") or 0) / 1e6))
+    print("  %-28s %5.1f launches/call %8.3f ms/call  valu %8.1f M  issue %.2f  fetch %7.1f MB write %7.1f MB" % (k, v["launches_per_call"], v["ms_per_call"], (v.get("valu_wave_instr_per_call") or 0) / 1e6, v.get("issue_frac") or 0, (v.get("fetch_bytes_per_call") or 0) / 1e6, (v.get("write_bytes_per_call") or 0) / 1e6))
 PY
 done

@@ -7,7 +7,7 @@ Per kernel and per CALL of the entry point (the first call of the run, which all
 launches, milliseconds (kernel trace), VALU wave-instructions (SQ_INSTS_VALU), fetched / written bytes
 (FETCH_SIZE / WRITE_SIZE, KiB -> bytes; fetch doubled per the gfx950 note of MI355X_MICROARCH.md), and the issue
 fraction = wave-instructions x 4 cycles / (1024 SIMDs x kernel time x clock), clock from GRBM_GUI_ACTIVE of the
-counter pass."""
+counter pass (the counter sums the 8 XCDs)."""
 import csv
 import glob
 import json
@@ -35,13 +35,16 @@ def main():
     # kernel trace: time order; the marker of a call is the first kernel of the path
     tr = [r for r in rows(f"{base}/{what}_trace") if "Start_Timestamp" in r and "Counter_Name" not in r]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ks = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in tr]
-    ks = [(k, d) for k, d in ks if k.startswith("k_") and not k.startswith(SKIP)]
-    first = "k_msm_parse" if what == "msm" else ("k_key_insert" if any(k.startswith("k_key_insert") for k, _ in ks) else "k_schnorr_rlc_prep")
-    starts = [i for i, (k, _) in enumerate(ks) if k.startswith(first)]
-    starts = starts[-calls:]
-    timed = ks[starts[1]:]          # drop the first call
-    ncall = len(starts) - 1
+    ks3 = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in tr]
+    ks3 = [x for x in ks3 if x[0].startswith("k_") and not x[0].startswith(SKIP)]
+    ks = [(k, (e - b) / 1e6) for k, b, e in ks3]
+    # a call ends with k_msm_final: call i = the kernels after the previous k_msm_final up to and including this one
+    ends = [i for i, (k, _) in enumerate(ks) if k.startswith("k_msm_final")]
+    ends = ends[-calls:]
+    timed = ks[ends[0] + 1:ends[-1] + 1]          # drop the first call (it allocates and warms up)
+    ncall = len(ends) - 1
+    # wall span of a call: first kernel start to k_msm_final end (kernels of two streams overlap in the BIP-340 flow)
+    spans = [(ks3[ends[i + 1]][2] - min(b for _, b, _ in ks3[ends[i] + 1:ends[i + 1] + 1])) / 1e6 for i in range(ncall)]
     ms = defaultdict(float)
     cnt = defaultdict(int)
     order = []
@@ -81,6 +84,7 @@ def main():
                    "rlc": "s2k_schnorr_batch_verify_rlc_device, 2^20 signatures of 2^16 keys (BASELINE config 4)"}[what]
     out["calls_averaged"] = ncall
     out["sum_kernel_ms_per_call"] = sum(ms.values()) / ncall
+    out["span_ms_per_call"] = sum(spans) / ncall
     kern = OrderedDict()
     tot_valu = 0.0
     for k in order:
@@ -91,7 +95,7 @@ def main():
             e["valu_wave_instr_per_call"] = valu[k]
             tot_valu += valu[k]
             big = dur_pmc.get(k, 0) > 0 and gui_sum.get(k, 0) > 0
-            clock = gui_sum[k] / dur_pmc[k] if big else None
+            clock = gui_sum[k] / dur_pmc[k] / 8.0 if big else None      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
             if clock and clock > 5e8:
                 e["clock_ghz_counter_pass"] = clock / 1e9
             ghz = (clock if clock and clock > 1.5e9 else 2.2e9)
@@ -102,7 +106,7 @@ def main():
             e["write_bytes_per_call"] = write[k] * 1024
         kern[k] = e
     out["valu_wave_instr_per_call"] = tot_valu
-    out["whole_call_issue_frac_at_2p2ghz"] = tot_valu * 4 / (1024 * out["sum_kernel_ms_per_call"] * 1e-3 * 2.2e9)
+    out["whole_call_issue_frac_at_2p2ghz"] = tot_valu * 4 / (1024 * out["span_ms_per_call"] * 1e-3 * 2.2e9)
     out["kernels"] = kern
     json.dump(out, sys.stdout, indent=1)
     print()
