@@ -5,26 +5,25 @@
 // algorithm for large batches (point_mul_multi.go:16-18, README.md:91); this is that method,
 // laid out for a GPU.  Parity is on the resulting group element (canonical bytes).
 //
-//   1. k_msm_parse     one lane per term: reduce the scalar, parse and check the point
-//   2. sort of the (window, digit) keys, two levels, all counting done in LDS:
-//      k_msm_coarse_count / scan / k_msm_coarse_scatter  partition the n*nw (key, term) pairs by
-//                      the key's upper bits (1024 keys per coarse bucket): each workgroup counts
-//                      its slice of terms in LDS and publishes one row of a [coarse][workgroup]
-//                      matrix, whose exclusive scan gives every workgroup a private output range
-//                      per coarse bucket (no global atomics)
-//      k_msm_fine_sort one workgroup per coarse bucket: LDS histogram of the 1024 keys, scan,
-//                      scatter of the term indices; emits the per-key counts and offsets
-//   3. k_msm_size_*    order the buckets by decreasing size (load balance, see below)
-//   4. k_msm_accumulate one lane per bucket: complete mixed additions of its points
-//   5. k_msm_reduce    one lane per chunk of 32 buckets: sum_b b*B_b by running sums, plus the
-//                      chunk offset by double-and-add
-//   6. k_msm_tree      tree-sum of the chunk results per window (two launches of 256-thread workgroups)
-//   7. k_msm_final     Horner over the windows, affine result
-// All additions use the complete formulas (pt29.h): buckets receive arbitrary points
-// (duplicates, inverses, the same point many times), so there is no exceptional case to
-// detect and no fallback.  Every term is first split with the curve endomorphism into two
-// 128-bit terms (below).  Window width c is 8 bits for small inputs and 16 bits for large ones
-// (2^20 inputs: 2^21 terms, 8 windows x 65535 buckets, ~32 points per bucket).
+//   1. k_msm_parse     one lane per term: reduce the scalar, parse and check the point, split with the endomorphism
+//   2. sort of the (window, signed digit) keys, two levels, all counting done in LDS:
+//      k_msm_coarse_count / scan / k_msm_coarse_scatter  partition the (key, term) pairs by the key's upper bits
+//                      (256 keys per coarse bucket): each workgroup counts its slice of terms in LDS and publishes
+//                      one row of a [coarse][workgroup] matrix, whose exclusive scan gives every workgroup a private
+//                      output range per coarse bucket (no global atomics)
+//      k_msm_fine_sort one workgroup per coarse bucket: LDS histogram of its 256 keys, scan, the sorted piece of the
+//                      list assembled in LDS and written out in order; emits the per-key offsets
+//   3. k_msm_accumulate the bucket pass: the sorted list cut into equal ranges, one lane per range, complete mixed
+//                      additions; k_msm_stitch puts together the buckets that cross range borders
+//   4. k_msm_reduce    four lanes per chunk of 8 buckets (pt29q.h): sum_b b*B_b by running sums, plus the chunk offset
+//                      by double-and-add
+//   5. k_msm_tree      tree-sum of the chunk results per window (two launches, a quad per addition)
+//   6. k_msm_final     Horner over the windows, affine result
+// All additions use the complete formulas (pt29.h, pt29q.h): buckets receive arbitrary points (duplicates, inverses,
+// the same point many times), so there is no exceptional case to detect and no fallback.  Every term is first split
+// with the curve endomorphism into two 128-bit terms (below); the digits are signed (half the buckets).  Window width
+// c is 8 bits for small inputs and 16 bits for large ones (2^20 inputs: 2^21 terms, 9 slots x 32768 buckets, ~57
+// points per bucket).
 #include <sys/random.h>
 
 #include <cstdlib>
@@ -40,6 +39,9 @@
 
 namespace {
 
+#ifndef S2K_MSM_WAVES
+#define S2K_MSM_WAVES 3   // waves per SIMD the bucket pass is built for (register budget 168) and sized to fill once
+#endif
 #ifndef S2K_MSM_CHUNK_LOG2
 #define S2K_MSM_CHUNK_LOG2 3   // default of the buckets per reduction chunk (log2); S2K_MSM_CHUNK_LOG2 in the environment overrides it
 #endif
@@ -58,11 +60,16 @@ struct msm_geom {
   uint32_t chunk_log2, nchunk;   // buckets per reduction chunk (log2), chunks per slot = nb >> chunk_log2
 };
 
-S2K_DEV uint32_t msm_digit(const uint32_t* __restrict__ scw, size_t n_stride, size_t i, uint32_t w, uint32_t c) {
-  uint32_t bit = w * c, word = bit >> 5, sh = bit & 31;
-  uint32_t lo = scw[(size_t)word * n_stride + i];
-  uint32_t hi = word + 1 < SCW_WORDS ? scw[(size_t)(word + 1) * n_stride + i] : 0u;
-  uint64_t v = ((uint64_t)hi << 32) | lo;
+// window w (c bits) of a 128-bit magnitude held in k[0..3] (k[4] = 0)
+S2K_DEV uint32_t msm_digit(const uint32_t k[SCW_WORDS], uint32_t w, uint32_t c) {
+  const uint32_t bit = w * c, word = bit >> 5, sh = bit & 31;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < SCW_WORDS; ++j) {      // (selects, not indexed loads: k[] stays in registers)
+    lo = word == (uint32_t)j ? k[j] : lo;
+    hi = word + 1 == (uint32_t)j ? k[j] : hi;
+  }
+  const uint64_t v = ((uint64_t)hi << 32) | lo;
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 // Signed digits: k = sum_w d_w 2^(cw) with |d_w| <= 2^(c-1) below the top window (a digit above 2^(c-1) becomes
@@ -73,10 +80,14 @@ S2K_DEV uint32_t msm_digit(const uint32_t* __restrict__ scw, size_t n_stride, si
 constexpr uint32_t TERM_NEG = 0x80000000u;    // sign flag next to a term index (term counts stay below 2^30)
 template <class F>
 S2K_DEV void msm_for_digits(const uint32_t* __restrict__ scw, size_t n_stride, size_t i, const msm_geom& g, F f) {
+  uint32_t k[SCW_WORDS];
+#pragma unroll
+  for (int j = 0; j < SCW_WORDS - 1; ++j) k[j] = scw[(size_t)j * n_stride + i];     // the magnitude, loaded once
+  k[SCW_WORDS - 1] = 0;
   uint32_t carry = 0;
   const uint32_t half = g.nb, full = g.nb << 1;
   for (uint32_t w = 0; w < g.nw; ++w) {
-    uint32_t v = msm_digit(scw, n_stride, i, w, g.c) + carry;
+    uint32_t v = msm_digit(k, w, g.c) + carry;
     const bool neg = w + 1 < g.nw && v > half;
     carry = neg ? 1u : 0u;
     const uint32_t m = neg ? full - v : v;
@@ -248,7 +259,10 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* count, c
 // term index fits 23 bits (fine key << 24 | sign << 23 | term: up to 2^22 inputs), two words beyond (WIDE).
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t FINE_BITS = 8, FINE = 1u << FINE_BITS;
-constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = 8192;
+#ifndef S2K_MSM_SORT_TERMS
+#define S2K_MSM_SORT_TERMS 8192
+#endif
+constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = S2K_MSM_SORT_TERMS;
 constexpr uint32_t MAX_COARSE = 1152;     // nkeys / FINE, at most 9 * 2^15 / 2^8 (c = 16, the largest geometry)
 constexpr uint32_t NARROW_TERM_BITS = 23;
 constexpr uint32_t FS_THREADS = 512, FS_STAGE = 19456;   // fine sort: threads, list entries staged in LDS (76 KiB: two workgroups per CU)
@@ -302,15 +316,15 @@ k_msm_coarse_scatter(uint32_t n, size_t nstride, msm_geom g, const uint32_t* __r
     });
   }
 }
-// one workgroup per coarse bucket: pairs -> list (term index | sign << 31, grouped by key), offset[key]; the last
-// workgroup also writes offset[nkeys] = total.  The sorted piece of the list is put together in LDS and written out in
+// one workgroup per coarse bucket: pairs -> list (term index | sign << 31, grouped by key), offset[key], lanekey[range];
+// the last workgroup also writes offset[nkeys] = total.  The sorted piece of the list is put together in LDS and written out in
 // order (scattered 4-byte stores straight to memory cost six times the list's size in write traffic); a coarse
 // bucket too large for that - only engineered inputs - is scattered directly.
 template <bool WIDE>
 __global__ void __launch_bounds__(FS_THREADS)
 k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint32_t total_slot,
                 const typename msm_pair<WIDE>::type* __restrict__ pairs, uint32_t* __restrict__ offset,
-                uint32_t* __restrict__ list) {
+                uint32_t* __restrict__ list, uint32_t L, uint32_t* __restrict__ lanekey) {
   typedef msm_pair<WIDE> PR;
   __shared__ uint32_t h[FINE], part[FINE], stage[FS_STAGE];
   const uint32_t b = blockIdx.x, t = threadIdx.x;
@@ -346,6 +360,9 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
     offset[key] = off;
     if (b + 1 == ncoarse && t == FINE - 1) offset[key + 1] = hi;
     h[t] = staged ? off - lo : off;                      // running cursor of key t
+    // the bucket pass cuts the list into ranges of L entries: the key of every range start that falls into this bucket
+    // (saves each of its lanes a binary search of offset[], 19 dependent loads with the whole chip waiting)
+    for (uint32_t k = (off + L - 1) / L; (uint64_t)k * L < (uint64_t)off + mine; ++k) lanekey[k] = (uint32_t)key;
   }
   __syncthreads();
   for (uint32_t j = lo + t; j < hi; j += FS_THREADS * U) {
@@ -371,7 +388,7 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
 // ---------------------------------------------------------------------------------------
 // The bucket pass.  The sorted list is cut into RANGES of L consecutive entries, one lane per range, whatever
 // buckets the entries belong to: every lane does exactly L additions (the last one fewer), so all the waves of
-// the launch finish together and - L chosen so that the lanes fill the chip once - every SIMD keeps its four
+// the launch finish together and - L chosen so that the lanes fill the chip once - every SIMD keeps its
 // waves from start to end.  (One lane per bucket, the buckets ordered by size, was the round-2 design: bucket sizes
 // are Poisson distributed, a SIMD's waves ran out one after the other and the longest ended alone at half the issue
 // rate: 0.79-0.85 of the issue slots.)
@@ -384,28 +401,27 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
 // ordinary bucket; buckets spread over more than STITCH_SERIAL ranges - only engineered inputs make those - are
 // queued for k_msm_stitch_big, one workgroup per bucket, a tree over the pieces).
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t MSM_LANES = 1u << 18;      // lanes that fill an MI355X once at four waves per SIMD (256 CU x 4 x 4 x 64)
+constexpr uint32_t MSM_LANES = 256u * 4u * 64u * S2K_MSM_WAVES;      // lanes that fill an MI355X once (256 CU x 4 SIMD x waves x 64)
 constexpr uint32_t MSM_L_MIN = 8;             // shortest range
 constexpr uint32_t STITCH_SERIAL = 8, STITCH_BIG_CAP = 4096;
 
 // A list entry is a term index with the digit's sign: a negative digit adds -P = (x, p - y), formed on the 32-bit
-// words before the limbs are cut.  The record's x half is fetched one addition ahead (a random 64-byte read from the
-// term array); its y half - the other half of the line the x half has brought in - when the addition starts.
-struct msm_half {
-  uint4 a, b;
+// words before the limbs are cut.  The record (a random 64-byte read from the term array) is fetched one addition
+// ahead, into registers: 16 of them, which is why the kernel is built for three waves per SIMD (with four the record
+// had to be fetched in two halves, and the second half's line had left the L2 by the time it was asked for: 5.4 GB
+// fetched per 2^20-term call instead of 3.5).
+struct msm_rec {
+  uint4 a, b, c, d;
 };
-S2K_DEV msm_half msm_load_half(const uint32_t* __restrict__ ptw, uint32_t entry, int half) {
-  const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + (size_t)(entry & ~TERM_NEG) * 16) + 2 * half;
-  msm_half r;
-  r.a = rec4[0]; r.b = rec4[1];
+S2K_DEV msm_rec msm_load_rec(const uint32_t* __restrict__ ptw, uint32_t entry) {
+  const uint4* rec4 = reinterpret_cast<const uint4*>(ptw + (size_t)(entry & ~TERM_NEG) * 16);
+  msm_rec r;
+  r.a = rec4[0]; r.b = rec4[1]; r.c = rec4[2]; r.d = rec4[3];
   return r;
 }
-S2K_DEV fe29 msm_x_of(const msm_half& r) {
+S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
   uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
-  return fe29_from_words(xw);
-}
-S2K_DEV fe29 msm_y_of(const msm_half& r, uint32_t entry) {
-  uint32_t yw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+  uint32_t yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
   // neg: p - y = ~y + p + 1 over the eight words (y in [1, p), so the result is in (0, p) and the carry out is dropped)
   constexpr uint32_t PW[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   const uint32_t M = 0u - (entry >> 31);
@@ -416,32 +432,24 @@ S2K_DEV fe29 msm_y_of(const msm_half& r, uint32_t entry) {
     yw[w] = (uint32_t)cy;
     cy >>= 32;
   }
-  return fe29_from_words(yw);
+  x = fe29_from_words(xw);
+  y = fe29_from_words(yw);
 }
-// the key whose bucket holds list position p: offset[key] <= p < offset[key + 1]  (p < offset[nkeys])
-S2K_DEV uint32_t msm_key_at(const uint32_t* __restrict__ offset, uint32_t nkeys, uint32_t p) {
-  uint32_t lo = 0, hi = nkeys;            // invariant: offset[lo] <= p < offset[hi]
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (offset[mid] <= p) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
-__global__ void __launch_bounds__(256, 4)     // four waves per SIMD: at most 128 VGPRs
+__global__ void __launch_bounds__(256, S2K_MSM_WAVES)
 k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
-                 const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw, uint32_t* __restrict__ sums) {
+                 const uint32_t* __restrict__ lanekey, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
+                 uint32_t* __restrict__ sums) {
   const uint32_t lane = blockIdx.x * 256 + threadIdx.x;
   const uint32_t total = offset[nkeys];
   const uint64_t lo64 = (uint64_t)lane * L;
   if (lo64 >= total) return;
   const uint32_t lo = (uint32_t)lo64, hi = total - lo > L ? lo + L : total;
-  uint32_t key = msm_key_at(offset, nkeys, lo);
+  uint32_t key = lanekey[lane];                            // offset[key] <= lo < offset[key + 1] (k_msm_fine_sort)
   uint32_t border = offset[key + 1];                       // > lo
   bool open_left = offset[key] < lo;
   pt29 acc = pt29_identity();
   uint32_t e_cur = list[lo], e_nxt = lo + 1 < hi ? list[lo + 1] : 0u;
-  msm_half x_cur = msm_load_half(ptw, e_cur, 0);
+  msm_rec r_cur = msm_load_rec(ptw, e_cur);
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
     if (j == border) {                                     // a bucket ends here: flush, next non-empty bucket
@@ -453,11 +461,12 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
         border = offset[key + 1];
       } while (border <= j);
     }
-    const msm_half y_cur = msm_load_half(ptw, e_cur, 1);
-    const msm_half x_nxt = msm_load_half(ptw, e_nxt, 0);   // entry 0 when past the end: a valid address
+    const msm_rec r_nxt = msm_load_rec(ptw, e_nxt);        // entry 0 when past the end: a valid address
     const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;
-    acc = pt29_add_mixed(acc, msm_x_of(x_cur), msm_y_of(y_cur, e_cur));
-    x_cur = x_nxt;
+    fe29 qx, qy;
+    msm_point_of(r_cur, e_cur, qx, qy);
+    acc = pt29_add_mixed(acc, qx, qy);
+    r_cur = r_nxt;
     e_cur = e_nxt;
     e_nxt = e_nn;
   }
@@ -617,7 +626,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big;
+  uint32_t *status, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big, *lanekey;
   size_t cap;          // term capacity the workspace was carved for = plane stride of scw (a call may run on fewer terms)
   uint32_t lanes_cap;  // bucket pass: most ranges any term count up to cap can make
   size_t sum_stride;   // slots of `sums`: nkeys buckets, then the left and the right edge piece of every range
@@ -677,7 +686,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
          o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
          o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_sums = carve(m.sum_stride * PT_WORDS * 4),
-         o_partial = carve(m.nslots * PT_WORDS * 4), o_aux = carve(aux_bytes);
+         o_partial = carve(m.nslots * PT_WORDS * 4), o_lanekey = carve((size_t)m.lanes_cap * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
@@ -695,6 +704,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.sums = (uint32_t*)(ws + o_sums);
   m.partial = (uint32_t*)(ws + o_partial);
   m.big = (uint32_t*)(ws + o_big);
+  m.lanekey = (uint32_t*)(ws + o_lanekey);
   m.aux = ws + o_aux;
   m.zero_bytes = o_offset;   // status, the queue of oversized buckets and the coarse matrix
   return S2K_OK;
@@ -723,14 +733,14 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   HIP_TRY(ctx, hipGetLastError());
   if (m.wide) {
     k_msm_coarse_scatter<true><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs);
-    k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list);
+    k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list, (uint32_t)L, m.lanekey);
   } else {
     k_msm_coarse_scatter<false><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs);
-    k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list);
+    k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list, (uint32_t)L, m.lanekey);
   }
   HIP_TRY(ctx, hipGetLastError());
   msm_prof_mark(ctx, st, 2);
-  k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.list, m.ptw, m.sums);
+  k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums);
   HIP_TRY(ctx, hipGetLastError());
   msm_prof_mark(ctx, st, 3);
   k_msm_stitch<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
