@@ -159,6 +159,19 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx *ctx, size_t n, const void *d_digest3
                                    const void *d_recovery_id, uint32_t flags, void *d_pub65, void *d_ok,
                                    void *hip_stream);
 
+/* Page-locked host buffers for the host-pointer entry points (no reference counterpart: the reference never leaves the
+ * host; this is the price of the boundary, cf. secec.PublicKey.Verify, ecdsa.go:171-228, which a cgo shim batches into
+ * s2k_ecdsa_verify_batch).  From pageable memory every copy is staged by the runtime and 2^20 verifications cost
+ * 8.4-9.5 ms against 5.2-5.7 resident; from pinned memory the copies are asynchronous and the batch is processed in one
+ * grouped call whose table phase overlaps the transfer of the digests and signatures.  s2k_host_alloc / s2k_host_free:
+ * hipHostMalloc / hipHostFree (NULL on failure).  s2k_host_register / s2k_host_unregister: pin memory the caller
+ * already owns (e.g. a Go slice held for the call: pass &slice[0]); unregister before the memory is freed or moved.
+ * s2k_ecdsa_verify_batch detects pinned buffers by itself (all four inputs must be pinned). */
+void *s2k_host_alloc(size_t bytes);
+void s2k_host_free(void *p);
+int s2k_host_register(void *p, size_t bytes);
+int s2k_host_unregister(void *p);
+
 /* Packs valid[n] (0/1 bytes, device) into a bitmap (bit i of byte i/8, LSB first; (n+7)/8
  * bytes, device) and writes the number of valid items to *d_count (uint64, device).  This is
  * the payload of the multi-GPU bitmap all-gather / count all-reduce. */

@@ -38,6 +38,34 @@ KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS = 0, 1, 2     # s2k_ctx_set_key_grouping
 IDENTITY = bytes(65)
 
 
+def pinned_array(shape, dtype=np.uint8) -> np.ndarray:
+    """A numpy array in page-locked host memory (s2k_host_alloc): host-buffer calls copy from it asynchronously.
+    The memory is released when the array (and every view of it) is gone."""
+    import weakref
+    lib = load_library()
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib.s2k_host_alloc(max(nbytes, 1))
+    if not p:
+        raise EngineError("s2k_host_alloc failed")
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(p)
+    weakref.finalize(buf, lib.s2k_host_free, p)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def host_register(a: np.ndarray) -> None:
+    """Pin an existing (contiguous) array for asynchronous copies (s2k_host_register); undo with host_unregister
+    before the array is released."""
+    lib = load_library()
+    if lib.s2k_host_register(a.ctypes.data, a.nbytes) != 0:
+        raise EngineError(lib.s2k_last_error(None).decode())
+
+
+def host_unregister(a: np.ndarray) -> None:
+    lib = load_library()
+    if lib.s2k_host_unregister(a.ctypes.data) != 0:
+        raise EngineError(lib.s2k_last_error(None).decode())
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -152,6 +180,12 @@ def load_library() -> C.CDLL:
     lib.s2k_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_ecdsa_recover_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp, vp]
     lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.s2k_host_alloc.argtypes = [sz]
+    lib.s2k_host_alloc.restype = vp
+    lib.s2k_host_free.argtypes = [vp]
+    lib.s2k_host_free.restype = None
+    lib.s2k_host_register.argtypes = [vp, sz]
+    lib.s2k_host_unregister.argtypes = [vp]
     lib.s2k_ecdsa_workspace_bytes.argtypes = [sz]
     lib.s2k_ecdsa_workspace_bytes.restype = sz
     lib.s2k_ctx_device_bytes.argtypes = [vp, sz]
@@ -195,7 +229,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages", "s2k_ctx_profile_msm", "s2k_ctx_profile_read_msm",
     "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
-    "s2k_pack_valid_device", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
+    "s2k_pack_valid_device", "s2k_host_alloc", "s2k_host_free", "s2k_host_register", "s2k_host_unregister", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",

@@ -77,6 +77,7 @@ struct s2k_ctx {
   size_t io_bytes = 0;
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr};
+  hipEvent_t ev_arrival[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pieces of a pinned batch on their way in
   int cu_count = 0;
   // Calls on one context share its workspaces.  Every enqueue ends by recording ev_done on its
   // stream, and an enqueue on a different stream than the previous one first waits for it, so
@@ -206,6 +207,12 @@ inline int ctx_streams(s2k_ctx* ctx) {
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
   for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return S2K_OK;
+}
+
+inline int ctx_arrival_events(s2k_ctx* ctx) {
+  for (hipEvent_t& e : ctx->ev_arrival)
+    if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return S2K_OK;
 }
 
