@@ -146,7 +146,10 @@ int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, 
   HIP_TRY(ctx, hipMemcpyAsync(io + o_do, dig_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_copy));
   HIP_TRY(ctx, hipMemcpyAsync(io + o_so, sig_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_copy));
   const size_t round = (size_t)3 * 4 * (size_t)ctx->cu_count * 64;
-  const size_t chunk = n > 3 * round ? 2 * round : n;
+  // with key grouping on, every chunk groups (and builds tables) on its own, so fewer and larger chunks: two halves
+  // (s2k_ecdsa_verify_batch does the same; three chunks of a 2^20 batch left under 6 signatures per key and chunk,
+  // below the table threshold: the whole batch went through the general ladder)
+  const size_t chunk = n <= 3 * round ? n : (ctx->kg_mode != S2K_KEYS_OFF ? ((n / 2 + 255) & ~(size_t)255) : 2 * round);
   int k = 0;
   for (size_t lo = 0; lo < n; lo += chunk, ++k) {
     const size_t cnt = n - lo < chunk ? n - lo : chunk, hi = lo + cnt;

@@ -89,16 +89,19 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
         return bitmap, count
     world = dist.get_world_size()
     assert n * world == n_total, "gather_valid_device needs equal shards"
-    if dist.get_backend() == "gloo":       # CPU collectives (tests on a box without RCCL peers)
-        parts = [torch.empty(bitmap.numel(), dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(parts, bitmap.cpu())
-        c = count.cpu()
-        dist.all_reduce(c)
-        return torch.cat(parts).to(valid.device), c.to(valid.device)
-    full = torch.empty(bitmap.numel() * world, dtype=torch.uint8, device=valid.device)
-    dist.all_gather_into_tensor(full, bitmap)
-    dist.all_reduce(count)
-    return full, count
+    # One code path for both backends: the same two collectives on the same shapes; the only difference is where the
+    # tensors live (gloo moves bytes between host buffers, nccl = RCCL between device buffers over xGMI).  What the
+    # 2-rank tests exercise on one GPU with gloo is therefore the logic an 8-GPU RCCL run executes.
+    on_host = dist.get_backend() == "gloo"
+    mine = bitmap.cpu() if on_host else bitmap
+    cnt = count.cpu() if on_host else count
+    full = torch.empty(mine.numel() * world, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(full, mine)
+    dist.all_reduce(cnt)
+    if on_host:
+        full, cnt = full.to(valid.device), cnt.to(valid.device)
+        count.copy_(cnt)
+    return full, cnt
 
 
 def msm_sharded(engine, scalars, points, dist=None):
@@ -116,9 +119,10 @@ def msm_sharded(engine, scalars, points, dist=None):
     mine = torch.tensor(list(part), dtype=torch.uint8)
     if dist.get_backend() != "gloo":
         mine = mine.to(torch.device("cuda", engine.device))   # the engine's GPU, not torch's current device
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
-    recs = [bytes(p.cpu().numpy().tobytes()) for p in parts]
+    full = torch.empty(65 * world, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(full, mine)
+    raw = full.cpu().numpy().tobytes()
+    recs = [raw[65 * r:65 * r + 65] for r in range(world)]
     one = (1).to_bytes(32, "big")
     return engine.multi_scalar_mult([one] * world, recs)
 

@@ -75,3 +75,50 @@ def test_device_bytes_counts_grouping_buffers(eng):
     assert off >= ws + (3 << 30)
     assert auto - off >= (n // 6) * 72 * 128          # the per-key table buffer alone
     assert eng.device_bytes(100) == eng.workspace_bytes(100) + off - ws   # below 256 signatures nothing is grouped
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_entry_points_two_ranks_real_engine():
+    """msm_sharded, schnorr_batch_verify_sharded and the device-resident verification flow (gather_valid_device with the
+    engine's bitmap packing) in TWO rank processes that share GPU 0 (gloo collectives; fresh children, started before they
+    touch a GPU): the multi-scalar sum over 2^16 known-discrete-log terms equals (sum k_i d_i) G on every rank, the BIP-340
+    batch is accepted, rejected by both ranks when one signature in the last rank's shard is damaged, and the gathered
+    bitmap / count of the verification shards match the seeded damage pattern of BOTH ranks."""
+    port = _free_port()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), "2", str(port), "16"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+    assert sorted(o["rank"] for o in outs) == [0, 1]
+    for o in outs:
+        assert o["msm_ok"] and o["schnorr_all_valid"] and not o["schnorr_one_bad"], o
+        assert o["ecdsa_bitmap_ok"] and o["ecdsa_count_ok"] and o["keyed"] > 0, o
+    assert outs[0]["msm_sum"] == outs[1]["msm_sum"]
+
+
+def test_bench_two_ranks_full_per_rank_size():
+    """`bench.py --gpus 2 --oversubscribe` at the REAL per-rank size of BASELINE config 5 (2^21 verifications per rank), two
+    ranks sharing GPU 0: the corrupted-bitmap guard on the gathered bitmap must pass and the line must describe 2^22 in
+    total."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "2^22 in total" in d["config"]["workload"], d["config"]
