@@ -13,6 +13,8 @@
 
 #include <sys/random.h>
 
+#include <mutex>
+
 #include "engine_internal.h"
 #include "fe.h"
 #include "fe29_inv.h"
@@ -1331,6 +1333,52 @@ __attribute__((visibility("hidden"))) int s2k_internal_ensure_ws(s2k_ctx* ctx, s
   return S2K_OK;
 }
 
+// The resident generator tables (3 GiB, read-only once built) are shared by the contexts of a device: a second context
+// - one per goroutine / thread is the intended use, INTEGRATION.md - neither rebuilds nor holds another copy.  Reference
+// counted per device under a mutex; the last context to go frees them.
+namespace {
+struct gtable_slot {
+  uint32_t* table = nullptr;
+  int refs = 0;
+};
+std::mutex g_gtable_mutex;
+gtable_slot g_gtable[64];
+}  // namespace
+static hipError_t gtable_acquire(int device, uint32_t** out) {
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_gtable_mutex);
+  gtable_slot& g = g_gtable[device];
+  if (!g.table) {
+    uint32_t *table = nullptr, *bases = nullptr;
+    hipError_t e = hipMalloc((void**)&table, GT_ENTRIES * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&bases, (GT_WINDOWS + 1) * 64);
+    if (e == hipSuccess) {
+      k_gen_gtable_bases<<<1, 1>>>(bases);
+      k_gen_gtable<<<(unsigned)(GT_ENTRIES / 256), 256>>>(table, bases);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (bases) (void)hipFree(bases);
+    if (e != hipSuccess) {
+      if (table) (void)hipFree(table);
+      return e;
+    }
+    g.table = table;
+  }
+  ++g.refs;
+  *out = g.table;
+  return hipSuccess;
+}
+static void gtable_release(int device) {
+  std::lock_guard<std::mutex> lock(g_gtable_mutex);
+  gtable_slot& g = g_gtable[device];
+  if (g.refs > 0 && --g.refs == 0) {
+    (void)hipSetDevice(device);
+    (void)hipFree(g.table);
+    g.table = nullptr;
+  }
+}
+
 int s2k_ctx_create(int device_index, s2k_ctx** out) {
   if (!out) return fail(nullptr, S2K_ERR_ARG, "s2k_ctx_create: out is NULL");
   *out = nullptr;
@@ -1358,19 +1406,9 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->clk, 64);
   if (e == hipSuccess) e = hipMemset(ctx->clk, 0, 64);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->gtable, GT_ENTRIES * 64);
-  uint32_t* bases = nullptr;
-  if (e == hipSuccess) e = hipMalloc((void**)&bases, (GT_WINDOWS + 1) * 64);
-  if (e == hipSuccess) {
-    k_gen_gtable_bases<<<1, 1>>>(bases);
-    k_gen_gtable<<<(unsigned)(GT_ENTRIES / 256), 256>>>(ctx->gtable, bases);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (bases) (void)hipFree(bases);
+  if (e == hipSuccess) e = gtable_acquire(device_index, &ctx->gtable);
   if (e != hipSuccess) {
     int rc = fail(nullptr, S2K_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
-    if (ctx->gtable) (void)hipFree(ctx->gtable);
     if (ctx->clk) (void)hipFree(ctx->clk);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     delete ctx;
@@ -1383,7 +1421,7 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
 void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->gtable) (void)hipFree(ctx->gtable);
+  if (ctx->gtable) gtable_release(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->rlc_save) (void)hipFree(ctx->rlc_save);

@@ -122,3 +122,83 @@ def test_bench_two_ranks_full_per_rank_size():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "2^22 in total" in d["config"]["workload"], d["config"]
+
+
+def test_compiler_miscompile_reproducer_and_shipped_shape(eng, tmp_path):
+    """hipcc 7.2 miscompiled the first form of the point worklist kernel (per-lane garbage for 1 * G; DESIGN.md section 2);
+    the shipped kernel avoids the shape.  This builds tools/dbg/miscompile_point_fallback.hip with the box's compiler and
+    runs it: the two variants whose shapes the product code relies on (kB: no generator part, kD: no worklist
+    indirection) must be right - if a toolchain change breaks one of THOSE, the worklist kernels are at risk and the
+    end-to-end tests below would be the only other witness - and the status of the four known-bad variants is recorded.
+    Then the shipped worklist kernel itself: k * P for every lane forced onto it (P + (-P) sums inside the ladder)."""
+    import shutil
+    import secp256k1_voi_amd as S
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "mpf")
+    src = os.path.join(ROOT, "tools", "dbg", "miscompile_point_fallback.hip")
+    c = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", src, "-o", exe], capture_output=True, text=True, timeout=900)
+    assert c.returncode == 0, c.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    status = {}
+    for ln in r.stdout.splitlines():
+        name, rest = ln.split(":")
+        status[name.strip()] = int(rest.split()[0])
+    assert set(status) == {"kA", "kB", "kC", "kD", "kE", "kF"}, r.stdout
+    assert status["kB"] == 0 and status["kD"] == 0, status
+    print("miscompile reproducer with this toolchain (items wrong of 8):", status)
+    # the shipped kernel: u1 = 0, u2 = n - 1 ... on points whose ladder meets P - P; every result against big integers
+    rnd = __import__("random").Random(9)
+    pts, ks = [], []
+    for _ in range(300):
+        p = R.mul(rnd.randrange(1, R.N), R.G)
+        pts.append(p)
+        ks.append(rnd.choice([1, 2, R.N - 1, R.N - 2, R.LAMBDA, R.N - R.LAMBDA, rnd.randrange(R.N)]))
+    recs = [b"\x04" + b32(p[0]) + b32(p[1]) for p in pts]
+    out = eng.double_scalar_mult_basepoint_batch_ex(S.IMPL_FAST, None, [b32(k) for k in ks], recs)
+    for k, p, o in zip(ks, pts, out):
+        e = R.mul(k, p)
+        assert bytes(o) == (bytes(65) if e is None else b"\x04" + b32(e[0]) + b32(e[1]))
+
+
+def test_second_context_shares_generator_tables(eng, oracle):
+    """The 3 GiB generator tables are shared by the contexts of a device (reference counted): a second context neither
+    rebuilds nor holds another copy, both give the oracle's verdicts, and the first keeps working after the second is gone."""
+    import time
+
+    import torch
+    import secp256k1_voi_amd as S
+    from workload import make_ecdsa_batch
+    w = make_ecdsa_batch(oracle, 600, seed=77, corrupt_every=5)
+    exp = oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], nthreads=os.cpu_count() or 1)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    t0 = time.perf_counter()
+    e2 = S.Engine(0)
+    dt = time.perf_counter() - t0
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (512 << 20), "a second context took %.1f MiB" % ((free0 - free1) / 2**20)
+    assert dt < 0.1, "second context took %.3f s to create" % dt
+    assert np.array_equal(e2.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"]), exp)
+    e2.close()
+    assert np.array_equal(eng.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"]), exp)
+
+
+def test_synthetic_signatures_against_libcrypto(eng):
+    """The synthetic workload is made by the engine itself (synth.py: batched base multiplications and scalar arithmetic on
+    the device).  An oracle that shares nothing with this repository - libcrypto's ECDSA_do_verify - accepts 2^12 of
+    those signatures and rejects them once damaged, exactly as the engine does (second oracle)."""
+    import openssl_ref
+    if not openssl_ref.available():
+        pytest.skip("no usable libcrypto")
+    from secp256k1_voi_amd.synth import synth_batch
+    n = 1 << 12
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, 256, seed=31337))
+    rng = np.random.default_rng(8)
+    for i in range(0, n, 5):
+        a = (dig, r, s)[int(rng.integers(0, 3))]
+        a[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+    got = eng.ecdsa_verify_batch(pub, dig, r, s)
+    ref = np.array([openssl_ref.ecdsa_verify(bytes(pub[i]), bytes(dig[i]), bytes(r[i]), bytes(s[i])) for i in range(n)], dtype=np.uint8)
+    assert np.array_equal(got, ref)
+    assert int(got.sum()) >= n - n // 5 - 1 and int(got.sum()) < n

@@ -323,3 +323,18 @@ def test_recovery_random(oracle):
         assert oracle.ecdsa_recover(dig, b32(R.N), b32(s), rid) is None
         if r >= R.P - R.N:
             assert oracle.ecdsa_recover(dig, b32(r), b32(s), rid | 2) is None     # r + n >= p
+
+
+def test_oracle_against_libcrypto(oracle):
+    """Second, independent oracle: libcrypto's ECDSA_do_verify and the C restatement agree on valid and
+    damaged signatures (keys off the curve excluded: libcrypto refuses to build such a key, the reference returns false)."""
+    import openssl_ref
+    if not openssl_ref.available():
+        pytest.skip("no usable libcrypto")
+    from workload import make_ecdsa_batch
+    w = make_ecdsa_batch(oracle, 400, seed=4242, corrupt_every=3)
+    got = oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+    for i in range(400):
+        ref = openssl_ref.ecdsa_verify(bytes(w["pub"][i]), bytes(w["digest"][i]), bytes(w["r"][i]), bytes(w["s"][i]))
+        assert bool(got[i]) == ref, (i, w["kinds"][i])
+    assert 0 < int(got.sum()) < 400
