@@ -159,6 +159,30 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx *ctx, size_t n, const void *d_digest3
                                    const void *d_recovery_id, uint32_t flags, void *d_pub65, void *d_ok,
                                    void *hip_stream);
 
+/* ---- key sets: per-key precomputation kept across calls ------------------------------- */
+/* The reference caches per-key state in secec.PublicKey (secec/secec.go:80-85: the decoded point and its encodings,
+ * built once by NewPublicKey, :188-216) and every Verify starts from it.  The device analogue: a KEY SET holds, for a
+ * fixed list of n_keys public keys (X || Y, 64 bytes each), the per-key tables the verification ladder otherwise
+ * builds inside every call for keys that repeat in the batch (9 KiB per key; a key that is not a valid public key gets
+ * a table entry marked invalid: every signature under it verifies false, as NewPublicKey would have refused the key).
+ * s2k_ecdsa_verify_batch_keyset[_device]: valid[i] = PublicKey(keys[key_index[i]]).VerifyRaw(digest_i, r_i, s_i)
+ * (ecdsa.go:234) with the same rules as s2k_ecdsa_verify_batch; key_index[i] >= n_keys names no key: valid[i] = 0.
+ * Same verdicts as s2k_ecdsa_verify_batch on the expanded key array, bit for bit; what is saved is the grouping and the
+ * table build of every call (about a third of a 2^20-signature step at 16 signatures per key).  A key set belongs to
+ * the context that made it; it may be used by any number of calls and must be destroyed before the context. */
+typedef struct s2k_keyset s2k_keyset;
+int s2k_keyset_create(s2k_ctx *ctx, size_t n_keys, const uint8_t *pub_xy /* n_keys*64, host */, s2k_keyset **out);
+void s2k_keyset_destroy(s2k_keyset *ks);
+size_t s2k_keyset_size(const s2k_keyset *ks);
+size_t s2k_keyset_device_bytes(const s2k_keyset *ks);
+/* valid[k] = 1 iff key k is a valid public key (canonical coordinates, on the curve): NewPublicKey's verdict per key. */
+int s2k_keyset_valid_keys(s2k_keyset *ks, uint8_t *valid /* n_keys, host */);
+int s2k_ecdsa_verify_batch_keyset(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const uint32_t *key_index /* n */,
+                                  const uint8_t *digest32, const uint8_t *r, const uint8_t *s, uint32_t flags, uint8_t *valid);
+int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const void *d_key_index /* n uint32 */,
+                                         const void *d_digest32, const void *d_r, const void *d_s, uint32_t flags,
+                                         void *d_valid, void *hip_stream);
+
 /* Page-locked host buffers for the host-pointer entry points (no reference counterpart: the reference never leaves the
  * host; this is the price of the boundary, cf. secec.PublicKey.Verify, ecdsa.go:171-228, which a cgo shim batches into
  * s2k_ecdsa_verify_batch).  From pageable memory every copy is staged by the runtime and 2^20 verifications cost

@@ -180,6 +180,16 @@ def load_library() -> C.CDLL:
     lib.s2k_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_ecdsa_recover_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp, vp]
     lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.s2k_keyset_create.argtypes = [vp, sz, vp, C.POINTER(vp)]
+    lib.s2k_keyset_destroy.argtypes = [vp]
+    lib.s2k_keyset_destroy.restype = None
+    lib.s2k_keyset_size.argtypes = [vp]
+    lib.s2k_keyset_size.restype = sz
+    lib.s2k_keyset_device_bytes.argtypes = [vp]
+    lib.s2k_keyset_device_bytes.restype = sz
+    lib.s2k_keyset_valid_keys.argtypes = [vp, vp]
+    lib.s2k_ecdsa_verify_batch_keyset.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp]
+    lib.s2k_ecdsa_verify_batch_keyset_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_host_alloc.argtypes = [sz]
     lib.s2k_host_alloc.restype = vp
     lib.s2k_host_free.argtypes = [vp]
@@ -229,6 +239,8 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages", "s2k_ctx_profile_msm", "s2k_ctx_profile_read_msm",
     "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
+    "s2k_keyset_create", "s2k_keyset_destroy", "s2k_keyset_size", "s2k_keyset_device_bytes", "s2k_keyset_valid_keys",
+    "s2k_ecdsa_verify_batch_keyset", "s2k_ecdsa_verify_batch_keyset_device",
     "s2k_pack_valid_device", "s2k_host_alloc", "s2k_host_free", "s2k_host_register", "s2k_host_unregister", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
@@ -358,6 +370,29 @@ class Engine:
                                                      (REJECT_MALLEABLE if reject_malleable else 0) |
                                                      (FORCE_COMPLETE if force_complete else 0), out.ctypes.data))
         return out
+
+    # ---- key sets ----------------------------------------------------------------------
+    def keyset_create(self, pub_xy) -> "KeySet":
+        """Per-key tables of a fixed list of public keys (n_keys x 64 bytes), built once (s2k_keyset_create)."""
+        return KeySet(self, pub_xy)
+
+    def ecdsa_verify_batch_keyset(self, keyset, key_index, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
+        """valid bits for n (key index into `keyset`, digest, r, s) tuples; host buffers."""
+        r = _arr(r, 32)
+        n = r.shape[0]
+        digest32, s = _arr(digest32, 32, n), _arr(s, 32, n)
+        ki = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
+        if ki.shape[0] != n:
+            raise ValueError(f"length mismatch: expected {n} key indices, got {ki.shape[0]}")
+        out = np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.s2k_ecdsa_verify_batch_keyset(self._h, keyset._k, n, ki.ctypes.data, digest32.ctypes.data,
+                                                            r.ctypes.data, s.ctypes.data,
+                                                            REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data))
+        return out
+
+    def ecdsa_verify_batch_keyset_device(self, keyset, n, d_key_index, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):
+        self._check(self._lib.s2k_ecdsa_verify_batch_keyset_device(self._h, keyset._k, int(n), d_key_index, d_digest32, d_r, d_s,
+                                                                   int(flags), d_valid, stream))
 
     def ecdsa_verify_encoded_batch(self, pubs, digests, sigs, encoding=ENCODING_ASN1, digest_len=0,
                                    reject_malleable=False, bip0066=False, force_complete=False) -> np.ndarray:
@@ -666,3 +701,36 @@ class Engine:
         out = np.zeros(64, dtype=np.uint8)
         self._check(self._lib.s2k_debug_gtable_entry(self._h, i, d, out.ctypes.data))
         return out.tobytes()
+
+
+class KeySet:
+    """Handle of s2k_keyset_*: the per-key tables of a fixed key list on the engine's device."""
+
+    def __init__(self, engine: "Engine", pub_xy):
+        pub_xy = _arr(pub_xy, 64)
+        self._eng = engine
+        k = C.c_void_p()
+        engine._check(engine._lib.s2k_keyset_create(engine._h, pub_xy.shape[0], pub_xy.ctypes.data, C.byref(k)))
+        self._k = k
+
+    def __len__(self):
+        return int(self._eng._lib.s2k_keyset_size(self._k))
+
+    def device_bytes(self):
+        return int(self._eng._lib.s2k_keyset_device_bytes(self._k))
+
+    def valid_keys(self) -> np.ndarray:
+        out = np.zeros(len(self), dtype=np.uint8)
+        self._eng._check(self._eng._lib.s2k_keyset_valid_keys(self._k, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._k:
+            self._eng._lib.s2k_keyset_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

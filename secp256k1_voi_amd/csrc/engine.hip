@@ -246,7 +246,8 @@ S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe
   return acc;
 }
 
-S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
+// (`key`: the 64 bytes X || Y of the signature's public key)
+S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, const uint8_t* __restrict__ dig,
                                   const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
                                   const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride, size_t lane) {
   // idx: the signature; lane: the table column this thread may use (the worklist kernel passes the worklist
@@ -259,8 +260,8 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ pub, c
   load_be32(r.v, rsig + idx * 32);
   load_be32(s.v, ssig + idx * 32);
   load_be32(e_raw, dig + idx * 32);
-  load_be32(q.x.v, pub + idx * 64);
-  load_be32(q.y.v, pub + idx * 64 + 32);
+  load_be32(q.x.v, key);
+  load_be32(q.y.v, key + 32);
   bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
   if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
   ok = ok && fe_is_canonical_raw(q.x.v) && fe_is_canonical_raw(q.y.v);
@@ -304,7 +305,19 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
     size_t idx = wl[w];
-    out[idx] = verify_complete29(idx, pub, dig, rsig, ssig, flags, gt, qt, stride, w);
+    out[idx] = verify_complete29(idx, pub + idx * 64, dig, rsig, ssig, flags, gt, qt, stride, w);
+  }
+}
+// the same for a batch verified against a key set: the key of signature idx is keys[kidx[idx]]
+__global__ void __launch_bounds__(256)
+k_verify_fallback_keyset(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ keys,
+                         const uint32_t* __restrict__ kidx, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
+                         const uint8_t* __restrict__ ssig, uint32_t flags, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt,
+                         uint32_t* __restrict__ qt, size_t stride) {
+  uint32_t count = *wl_count;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
+    size_t idx = wl[w];
+    out[idx] = verify_complete29(idx, keys + (size_t)kidx[idx] * 64, dig, rsig, ssig, flags, gt, qt, stride, w);
   }
 }
 
@@ -1637,6 +1650,158 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Key sets: the per-key tables of a fixed list of public keys, built once and kept (the device analogue of what a
+// secec.PublicKey caches per key, secec/secec.go:80-85,188-216: the decoded point and its encoding).  A verification
+// call names each signature's key by index; nothing is grouped and no table is built inside the call.
+// ---------------------------------------------------------------------------------------
+struct s2k_keyset {
+  s2k_ctx* ctx;       // the owner (compared, never followed after creation: the set may outlive it by accident)
+  int device;
+  size_t n;
+  uint8_t* base;      // device: keys | tables | validity | identity | counters (s2k_internal_keyset_bytes)
+  size_t bytes;
+};
+
+int s2k_keyset_create(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, s2k_keyset** out) {
+  if (!ctx || !out) return fail(ctx, S2K_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (n_keys == 0 || !pub_xy) return fail(ctx, S2K_ERR_ARG, "empty key set");
+  if (n_keys > 0x0fffffffu) return fail(ctx, S2K_ERR_ARG, "key set too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ctx_streams(ctx);
+  if (rc) return rc;
+  s2k_keyset* ks = new (std::nothrow) s2k_keyset();
+  if (!ks) return fail(ctx, S2K_ERR_NOMEM, "out of host memory");
+  ks->ctx = ctx;
+  ks->device = ctx->device;
+  ks->n = n_keys;
+  size_t off[5];
+  ks->bytes = s2k_internal_keyset_bytes(n_keys, off);
+  hipError_t e = hipMalloc((void**)&ks->base, ks->bytes);
+  if (e != hipSuccess) {
+    delete ks;
+    return fail(ctx, S2K_ERR_HIP, "key set of %zu keys (%zu bytes): %s", n_keys, ks->bytes, hipGetErrorString(e));
+  }
+  hipStream_t st = ctx->s_comp;
+  rc = ctx_enter(ctx, st);
+  if (rc == S2K_OK && hipMemcpyAsync(ks->base + off[0], pub_xy, n_keys * 64, hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = fail(ctx, S2K_ERR_HIP, "copy of the keys failed");
+  if (rc == S2K_OK) rc = s2k_internal_keyset_build(ctx, ks->base, n_keys, st);
+  if (rc == S2K_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "key set build failed");
+  ctx->have_last = false;
+  if (rc) {
+    (void)hipFree(ks->base);
+    delete ks;
+    return rc;
+  }
+  *out = ks;
+  return S2K_OK;
+}
+void s2k_keyset_destroy(s2k_keyset* ks) {
+  if (!ks) return;
+  (void)hipSetDevice(ks->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(ks->base);
+  delete ks;
+}
+size_t s2k_keyset_size(const s2k_keyset* ks) { return ks ? ks->n : 0; }
+size_t s2k_keyset_device_bytes(const s2k_keyset* ks) { return ks ? ks->bytes : 0; }
+int s2k_keyset_valid_keys(s2k_keyset* ks, uint8_t* valid) {
+  if (!ks || !valid) return fail(nullptr, S2K_ERR_ARG, "null argument");
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(ks->n, off);
+  HIP_TRY(nullptr, hipSetDevice(ks->device));
+  HIP_TRY(nullptr, hipMemcpy(valid, ks->base + off[2], ks->n, hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const void* d_key_index, const void* d_dig,
+                                         const void* d_r, const void* d_s, uint32_t flags, void* d_valid, void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (!ks || ks->ctx != ctx) return fail(ctx, S2K_ERR_ARG, "key set of another context");
+  if (n == 0) return S2K_OK;
+  if (!d_key_index || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (flags & S2K_ECDSA_FORCE_COMPLETE) return fail(ctx, S2K_ERR_ARG, "S2K_ECDSA_FORCE_COMPLETE does not apply to key sets");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  rc = s2k_internal_ensure_ws(ctx, n);
+  if (rc) return rc;
+  rc = ctx_aux_streams(ctx);
+  if (rc) return rc;
+  rc = s2k_internal_keyset_reserve(ctx, ks->n, n);      // before the fork: growing a buffer synchronises the device
+  if (rc) return rc;
+  const size_t stride = lane_stride(n);
+  uint32_t* ws = (uint32_t*)ctx->ws;
+  uint32_t* qt = ws + WS_QT * stride;
+  uint32_t* fin = ws + WS_FIN * stride;
+  uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* gp = ws + WS_GP * stride;
+  uint32_t* pref = ws + WS_PREF * stride;
+  uint32_t* smont = ws + WS_SMONT * stride;
+  uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
+  uint32_t* wl = wl_count + 64;
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(ks->n, off);
+  ctx->last_wl_count = wl_count;
+  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(d_valid, 0, n, st));       // signatures naming no key of the set stay invalid
+  const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  // second stream: scalar preparation and generator part; caller's: the sort by key index
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+  k_scalar_prep<<<(T + 63) / 64, 64, 0, ctx->s_aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s,
+                                                      nullptr, flags, prep, pref, smont, stride);
+  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, ctx->gtable, gp, stride);
+  rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "launch failed");
+  key_groups kg{};
+  if (rc == S2K_OK) rc = s2k_internal_keyset_sort(ctx, ks->base, ks->n, n, (const uint32_t*)d_key_index, st, &kg);
+  ctx_aux_join(ctx, st);
+  if (rc) {
+    (void)ctx_leave(ctx, st);
+    return rc;
+  }
+  kg.gp = gp;
+  k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
+                                                                 (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
+  HIP_TRY(ctx, hipGetLastError());
+  k_verify_fallback_keyset<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, ks->base + off[0], (const uint32_t*)d_key_index,
+                                                                    (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s, flags,
+                                                                    (uint8_t*)d_valid, ctx->gtable, qt, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  return ctx_leave(ctx, st);
+}
+
+int s2k_ecdsa_verify_batch_keyset(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const uint32_t* key_index, const uint8_t* dig,
+                                  const uint8_t* r, const uint8_t* s, uint32_t flags, uint8_t* valid) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!key_index || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ctx_streams(ctx);
+  if (rc) return rc;
+  const size_t sizes[5] = {n * 4, n * 32, n * 32, n * 32, n};
+  uint8_t* d[5];
+  rc = ctx_stage(ctx, sizes, 5, d);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d[0], key_index, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[1], dig, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[2], r, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[3], s, n * 32, hipMemcpyHostToDevice, st));
+  rc = s2k_ecdsa_verify_batch_keyset_device(ctx, ks, n, d[0], d[1], d[2], d[3], flags, d[4], st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
+  return S2K_OK;
 }
 
 int s2k_ctx_set_key_grouping(s2k_ctx* ctx, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables) {

@@ -283,6 +283,12 @@ struct key_groups32 {
 };
 int s2k_internal_key_group32(s2k_ctx* ctx, size_t n, const uint8_t* d_pk32, hipStream_t st, key_groups32* out);
 int s2k_internal_key_reserve32(s2k_ctx* ctx, size_t n);
+// key sets (s2k_keyset_*): buffer layout, table build, scratch reservation, sort of a batch by key index
+size_t s2k_internal_keyset_bytes(size_t n, size_t off[5]);
+int s2k_internal_keyset_build(s2k_ctx* ctx, uint8_t* base, size_t n, hipStream_t st);
+int s2k_internal_keyset_reserve(s2k_ctx* ctx, size_t nkeys, size_t n);
+int s2k_internal_keyset_sort(s2k_ctx* ctx, const uint8_t* set_base, size_t nkeys, size_t n, const uint32_t* d_kidx, hipStream_t st,
+                             key_groups* out);
 
 struct dev_buf {
   void* p = nullptr;

@@ -67,6 +67,35 @@ S2K_DEV uint32_t mix32(uint32_t h) {
 constexpr uint32_t KG_MAX_PROBES = 64;
 constexpr int KG_SHARE_ROUNDS = 4;
 
+// Rank of this lane's signature in its group `found` (KG_NONE: none): one atomic per lane, except that lanes of this wave
+// which share a slot go together.  Up to KG_SHARE_ROUNDS times the first unserved lane collects everyone with its slot (a
+// batch under one key, or four: 1 or 4 atomics per wave instead of 64 on the same address, 13 ms -> 0.2 ms); a round
+// that serves a single lane ends the sharing (a wave of distinct keys) and the rest go alone.  (Lanes that have left the kernel simply take no part.)
+S2K_DEV uint32_t kg_take_rank(uint32_t found, uint32_t* __restrict__ cnt) {
+  const uint32_t lane = threadIdx.x & 63u;
+  bool pending = found != KG_NONE;
+  uint32_t pos = 0;
+#pragma unroll 1
+  for (int round = 0; round < KG_SHARE_ROUNDS; ++round) {
+    const unsigned long long act = __ballot(pending);
+    if (!act) break;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t s0 = __shfl(found, leader, 64);
+    const bool mine = pending && found == s0;
+    const unsigned long long m = __ballot(mine);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cnt[s0], (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (mine) {
+      pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      pending = false;
+    }
+    if (__popcll(m) == 1) break;   // nobody shared the leader's slot: a wave of distinct keys, the rest go alone
+  }
+  if (pending) pos = atomicAdd(&cnt[found], 1u);
+  return pos;
+}
+
 // slot_of[i]: the hash slot = group of signature i (KG_NONE: probe chain too long, general kernel);
 // pos_of[i]: its rank in the group.  rep[] starts as KG_NONE, cnt[] as 0.
 // KEYBYTES: 64 (X || Y, ECDSA) or 32 (x-only BIP-340 keys: the whole-batch check sums the coefficients of
@@ -118,35 +147,9 @@ k_key_insert(uint32_t n, const uint8_t* __restrict__ pub, uint32_t hmask, uint64
     s = (s + 1) & hmask;
   }
   slot_of[i] = found;
-  // Rank in the group: one atomic per lane, except that lanes of this wave which share a slot go together.
-  // Up to KG_SHARE_ROUNDS times the first unserved lane collects everyone with its slot (a batch under one
-  // key, or four: 1 or 4 atomics per wave instead of 64 on the same address, 13 ms -> 0.2 ms); a round
-  // that serves a single lane ends the sharing (a wave of distinct keys) and the rest go alone, as before.
-  const uint32_t lane = threadIdx.x & 63u;
-  bool pending = found != KG_NONE;
-  uint32_t pos = 0;
-#pragma unroll 1
-  for (int round = 0; round < KG_SHARE_ROUNDS; ++round) {
-    const unsigned long long act = __ballot(pending);
-    if (!act) break;
-    const int leader = __ffsll((long long)act) - 1;
-    const uint32_t s0 = __shfl(found, leader, 64);
-    const bool mine = pending && found == s0;
-    const unsigned long long m = __ballot(mine);
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(&cnt[s0], (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (mine) {
-      pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      pending = false;
-    }
-    if (__popcll(m) == 1) break;   // nobody shared the leader's slot: a wave of distinct keys, the rest go alone
-  }
-  if (pending) pos = atomicAdd(&cnt[found], 1u);
-  pos_of[i] = pos;
+  pos_of[i] = kg_take_rank(found, cnt);
 }
 
-// Each workgroup takes ALLOC_ITEMS * 256 slots (PLACE_ITEMS * 256 signatures), strided by 256 per thread.
 constexpr int ALLOC_ITEMS = 16, PLACE_ITEMS = 4;
 
 // Two counts per thread, ONE 64-bit atomic per workgroup (tables in the high word, signatures in the low):
@@ -614,7 +617,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
 // the doubling chains of ALL tables (one launch: its duration is one lane's latency whatever the count)
 __attribute__((visibility("hidden"))) int s2k_internal_key_chains(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st,
                                                                   const key_groups* g) {
-  uint4* ktab = (uint4*)ctx->ktab;
+  uint4* ktab = const_cast<uint4*>(g->ktab);     // (the context's table buffer, or a key set's own)
   const size_t max_tables = g->max_tables;
   if (g->key_bytes == 64)
     k_key_chain<false><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
@@ -627,7 +630,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_chains(s2k_ctx* ctx, 
 // odd multiples, inversion, scaling for the tables of part `part` of `nparts`
 __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, hipStream_t st, const key_groups* g, uint32_t part,
                                                                   uint32_t nparts, hipEvent_t ev_after_odd) {
-  uint4* ktab = (uint4*)ctx->ktab;
+  uint4* ktab = const_cast<uint4*>(g->ktab);
   const size_t max_tables = g->max_tables;
   k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
@@ -636,6 +639,131 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
   HIP_TRY(ctx, hipGetLastError());
   k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Key sets (s2k_keyset_*, engine.hip): tables of a fixed list of keys built ONCE; a verification call names each
+// signature's key by its index in the list.  What is left of the grouping is a counting sort of the signatures by key
+// index, so that the lanes of the ladder that share a table sit together: ranks as in k_key_insert (without the hash
+// table: the slot IS the key index), ranges from one atomic per workgroup, placement by k_key_place with the identity as
+// "table of slot".
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256)
+k_ks_rank(uint32_t n, uint32_t nkeys, const uint32_t* __restrict__ kidx, uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of,
+          uint32_t* __restrict__ pos_of) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = kidx[i];
+  const uint32_t s = k < nkeys ? k : KG_NONE;           // an index outside the set: no key, the signature is invalid
+  slot_of[i] = s;
+  pos_of[i] = kg_take_rank(s, cnt);
+}
+__global__ void __launch_bounds__(256)
+k_ks_alloc(uint32_t nkeys, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ base, uint32_t* __restrict__ counters) {
+  __shared__ uint32_t sh[8];
+  const uint32_t s0 = blockIdx.x * (256 * ALLOC_ITEMS) + threadIdx.x;
+  uint32_t c[ALLOC_ITEMS];
+  uint32_t nsig = 0;
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    const uint32_t s = s0 + k * 256;
+    c[k] = s < nkeys ? cnt[s] : 0u;
+    nsig += c[k];
+  }
+  uint32_t b = block_alloc(&counters[KG_NKEYED], nsig, sh);
+#pragma unroll
+  for (int k = 0; k < ALLOC_ITEMS; ++k) {
+    const uint32_t s = s0 + k * 256;
+    if (s >= nkeys) continue;
+    base[s] = b;
+    b += c[k];
+  }
+}
+__global__ void __launch_bounds__(256) k_ks_iota(uint32_t n, uint32_t* __restrict__ a, uint32_t* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = i;
+  if (i == 0) counters[KG_NTAB] = n;
+}
+}  // namespace
+
+// device memory of a key set of n keys: keys | tables | validity | identity | counters
+__attribute__((visibility("hidden"))) size_t s2k_internal_keyset_bytes(size_t n, size_t off[5]) {
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  off[0] = 0;
+  off[1] = off[0] + al(n * 64);
+  off[2] = off[1] + al(n * (size_t)KT_SLOTS * 128);
+  off[3] = off[2] + al(n + 64);
+  off[4] = off[3] + al(n * 4);
+  return off[4] + al(KG_COUNTERS * 4);
+}
+// builds the tables of the n keys at base + off[0] (already on the device) into the set's buffers
+__attribute__((visibility("hidden"))) int s2k_internal_keyset_build(s2k_ctx* ctx, uint8_t* base, size_t n, hipStream_t st) {
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(n, off);
+  key_groups g{};
+  g.counters = (uint32_t*)(base + off[4]);
+  g.ktab = (const uint4*)(base + off[1]);
+  g.tinfo = base + off[2];
+  g.trep = (const uint32_t*)(base + off[3]);          // table t is the key of "signature" t: the identity
+  g.max_tables = (uint32_t)n;
+  g.key_bytes = 64;
+  g.part = 0;
+  g.nparts = 1;
+  HIP_TRY(ctx, hipMemsetAsync(g.counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
+  k_ks_iota<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (uint32_t*)(base + off[3]), g.counters);
+  HIP_TRY(ctx, hipGetLastError());
+  int rc = s2k_internal_key_chains(ctx, base + off[0], st, &g);
+  if (rc) return rc;
+  return s2k_internal_key_tables(ctx, st, &g, 0, 1, nullptr);
+}
+// scratch of the sort below, in the context's grouping arrays: counters | cnt, base [nkeys] | slot_of, pos_of, perm, ptab, left [n]
+__attribute__((visibility("hidden"))) int s2k_internal_keyset_reserve(s2k_ctx* ctx, size_t nkeys, size_t n) {
+  const size_t np = (n + 63) & ~(size_t)63, kp = (nkeys + 63) & ~(size_t)63;
+  const size_t words = KG_COUNTERS + 2 * kp + 5 * np;
+  if (words * sizeof(uint32_t) > ctx->kg_bytes) ctx->kg_counters = nullptr;
+  return ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, words * sizeof(uint32_t));
+}
+// signatures sorted by key index -> the lane lists of the keyed ladder over the set's tables (enqueue only)
+__attribute__((visibility("hidden"))) int s2k_internal_keyset_sort(s2k_ctx* ctx, const uint8_t* set_base, size_t nkeys, size_t n,
+                                                                   const uint32_t* d_kidx, hipStream_t st, key_groups* out) {
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(nkeys, off);
+  int rc = s2k_internal_keyset_reserve(ctx, nkeys, n);   // (a no-op when the caller has reserved already)
+  if (rc) return rc;
+  const size_t np = (n + 63) & ~(size_t)63, kp = (nkeys + 63) & ~(size_t)63;
+  uint32_t* w = (uint32_t*)ctx->kg;
+  uint32_t* counters = w;
+  uint32_t* cnt = w + KG_COUNTERS;
+  uint32_t* base = cnt + kp;
+  uint32_t* slot_of = base + kp;
+  uint32_t* pos_of = slot_of + np;
+  uint32_t* perm = pos_of + np;
+  uint32_t* ptab = perm + np;
+  uint32_t* left = ptab + np;
+  ctx->kg_counters = counters;
+  ctx->kg_last_max_tables = (uint32_t)nkeys;
+  HIP_TRY(ctx, hipMemsetAsync(counters, 0, (KG_COUNTERS + kp) * sizeof(uint32_t), st));     // counters and cnt[]
+  k_ks_rank<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (uint32_t)nkeys, d_kidx, cnt, slot_of, pos_of);
+  HIP_TRY(ctx, hipGetLastError());
+  k_ks_alloc<<<(unsigned)((nkeys + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)nkeys, cnt, base, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>(
+      (uint32_t)n, slot_of, pos_of, base, false, (const uint32_t*)(set_base + off[3]), perm, ptab, left, counters);
+  HIP_TRY(ctx, hipGetLastError());
+  *out = key_groups{};
+  out->counters = counters;
+  out->perm = perm;
+  out->ptab = ptab;
+  out->left = left;
+  out->ktab = (const uint4*)(set_base + off[1]);
+  out->tinfo = set_base + off[2];
+  out->trep = (const uint32_t*)(set_base + off[3]);
+  out->max_tables = (uint32_t)nkeys;
+  out->key_bytes = 64;
+  out->part = 0;
+  out->nparts = 1;
   return S2K_OK;
 }
 

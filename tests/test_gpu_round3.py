@@ -202,3 +202,78 @@ def test_synthetic_signatures_against_libcrypto(eng):
     ref = np.array([openssl_ref.ecdsa_verify(bytes(pub[i]), bytes(dig[i]), bytes(r[i]), bytes(s[i])) for i in range(n)], dtype=np.uint8)
     assert np.array_equal(got, ref)
     assert int(got.sum()) >= n - n // 5 - 1 and int(got.sum()) < n
+
+
+def test_keyset_matches_batch_verifier(eng, oracle):
+    """s2k_keyset_*: tables of a fixed key list built once, signatures name their key by index.  Same verdicts as
+    s2k_ecdsa_verify_batch on the expanded key array and as the oracle: valid and damaged signatures, keys that are no
+    public keys (off the curve, coordinate >= p, all zero: every signature under them false), key indices outside the set
+    (false), ragged use of the keys (some unused, some used hundreds of times), RejectMalleable, two calls on one set."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    rng = np.random.default_rng(77)
+    nk, n = 300, 20000
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, nk, seed=555))
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)          # the set: the distinct keys, in sorted order
+    kidx = inv.astype(np.uint32)
+    keys = keys.copy()
+    # three keys of the set that are no public keys
+    bad_keys = [5, 77, len(keys) - 1]
+    keys[5, 63] ^= 1                                                   # off the curve
+    keys[77, :32] = 0xFF                                               # x >= p
+    keys[len(keys) - 1, :] = 0
+    for i in range(0, n, 6):                                           # damaged signatures
+        a = (dig, r, s)[int(rng.integers(0, 3))]
+        a[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+    kidx[11] = len(keys)                                               # outside the set
+    kidx[12] = 0xFFFFFFFF
+    ks = eng.keyset_create(keys)
+    assert len(ks) == len(keys) and ks.device_bytes() >= len(keys) * 9216
+    vk = ks.valid_keys()
+    assert [k for k in range(len(keys)) if not vk[k]] == sorted(bad_keys)
+    got = eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s)
+    # the same through the batch verifier on the expanded key array (indices outside the set: an all-zero key)
+    full = np.zeros((n, 64), np.uint8)
+    inside = kidx < len(keys)
+    full[inside] = keys[kidx[inside]]
+    for mode in (S.KEYS_AUTO, S.KEYS_OFF):
+        eng.set_key_grouping(mode)
+        assert np.array_equal(got, eng.ecdsa_verify_batch(full, dig, r, s))
+    eng.set_key_grouping(S.KEYS_AUTO)
+    m = 3000
+    assert np.array_equal(got[:m], oracle.ecdsa_verify_batch(full[:m], dig[:m], r[:m], s[:m], nthreads=os.cpu_count() or 1))
+    assert not got[11] and not got[12] and not got[np.isin(kidx, bad_keys)].any()
+    assert 0.7 * n < int(got.sum()) < n
+    # high-s forms of valid signatures: accepted, rejected with RejectMalleable; second call on the same set
+    s2 = s.copy()
+    for i in range(1, 200, 2):
+        s2[i] = np.frombuffer(b32(R.N - int.from_bytes(bytes(s[i]), "big")), np.uint8)
+    a1 = eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s2)
+    a2 = eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s2, reject_malleable=True)
+    assert np.array_equal(a1, eng.ecdsa_verify_batch(full, dig, r, s2))
+    assert np.array_equal(a2, eng.ecdsa_verify_batch(full, dig, r, s2, reject_malleable=True))
+    assert int(a1.sum()) > int(a2.sum())
+    ks.close()
+
+
+def test_keyset_worklist_and_full_size(eng):
+    """Key set at BASELINE size: 2^20 signatures of 2^16 keys against the batch verifier (grouping on), and an adversarial
+    batch whose every lane ends on the complete-formula worklist (u1 G + u2 Q = infinity), which must reach the worklist
+    kernel's key-set form and come back all false."""
+    from secp256k1_voi_amd.synth import synth_all_fallback_batch, synth_batch
+    n, nk = 1 << 20, 1 << 16
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, nk, seed=4))
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)
+    ks = eng.keyset_create(keys)
+    r[::9, 3] ^= 4
+    got = eng.ecdsa_verify_batch_keyset(ks, inv.astype(np.uint32), dig, r, s)
+    assert np.array_equal(got, eng.ecdsa_verify_batch(pub, dig, r, s))
+    assert int(got.sum()) == n - len(range(0, n, 9))
+    ks.close()
+    m = 1 << 14
+    pub, dig, r, s = (np.array(a) for a in synth_all_fallback_batch(eng, m, 64, seed=6))
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)
+    ks = eng.keyset_create(keys)
+    got = eng.ecdsa_verify_batch_keyset(ks, inv.astype(np.uint32), dig, r, s)
+    assert not got.any() and eng.key_grouping_stats()["complete"] == m
+    ks.close()
