@@ -364,7 +364,7 @@ def worker(args):
         extras = world == 1 and not args.no_extras
         if extras:
             try:
-                line.update(extra_measurements(eng, dev, n, n_keys, step, sync, st, args))
+                line.update(extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=pub, resident=(d_dig, d_r, d_s)))
             except AssertionError as e:      # a failed guard must be visible, and must fail the run
                 line["extras_error"] = str(e) or "assertion failed"
                 rc = 1
@@ -477,7 +477,7 @@ def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_
     return roof
 
 
-def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
+def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None, resident=None):
     """The other BASELINE configurations and side figures on one GPU; every number is guarded by a
     check of the full result."""
     import ctypes
@@ -506,6 +506,27 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args):
     def verify_on(inputs):
         p, d, rr, ss = inputs
         eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(), d_valid.data_ptr(), 0, st)
+
+    # ---- key set: the same batch with the per-key tables built ONCE, outside the timed region (s2k_keyset_*).  What a
+    # caller with a stable key set (a validator set, say) pays per batch; never `value`: the headline builds its tables
+    # inside every step. ----
+    if host_pub is not None and resident is not None and n_keys < n:
+        keys, inv = np.unique(host_pub, axis=0, return_inverse=True)
+        ks = eng.keyset_create(keys)
+        d_kidx = torch.from_numpy(inv.astype(np.uint32).view(np.int32)).to(dev)
+        dd, dr, ds = resident
+
+        def with_keyset():
+            eng.ecdsa_verify_batch_keyset_device(ks, n, d_kidx.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_valid.data_ptr(), 0, st)
+        d_valid.zero_()
+        ms = timed(with_keyset, 10)
+        assert int(d_valid.sum().item()) == n, "key-set verification did not accept the synthetic batch"
+        out["keyset_resident"] = {"keys": int(len(ks)), "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
+                                  "keyset_device_bytes": ks.device_bytes(),
+                                  "note": "s2k_ecdsa_verify_batch_keyset_device: tables of the %d keys built once by s2k_keyset_create "
+                                          "(not timed); per call: scalar preparation, generator part, sort by key index, ladder" % len(ks)}
+        ks.close()
+        del d_kidx
 
     # ---- the same batch with key grouping off: every signature as if its key were new (the reference's way) ----
     from secp256k1_voi_amd import KEYS_AUTO, KEYS_OFF
