@@ -159,7 +159,7 @@ def load_profile_json(name):
 
 def committed_counts():
     """PMC-derived per-signature figures of the path's kernels (profiles/, newest round first)."""
-    for name in ("r02_valu_counts.json", "r01_valu_counts.json"):
+    for name in ("r03_valu_counts.json", "r02_valu_counts.json", "r01_valu_counts.json"):
         d = load_profile_json(name)
         if d:
             return d, name
