@@ -446,13 +446,30 @@ S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
 __global__ void __launch_bounds__(256, S2K_MSM_WAVES)
 k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
                  const uint32_t* __restrict__ lanekey, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
-                 uint32_t* __restrict__ sums) {
+                 uint32_t* __restrict__ sums, uint32_t part, uint32_t split_key) {
+  // part 0: the whole list.  Two-part flow (msm_core): part 1 = the keys from split_key on (the upper windows), part 2 =
+  // the keys below it; the one range that holds the split position takes part in both, each side up to the split - which
+  // is a bucket border, so no piece is cut by it.
   const uint32_t lane = blockIdx.x * 256 + threadIdx.x;
   const uint32_t total = offset[nkeys];
   const uint64_t lo64 = (uint64_t)lane * L;
   if (lo64 >= total) return;
-  const uint32_t lo = (uint32_t)lo64, hi = total - lo > L ? lo + L : total;
+  uint32_t lo = (uint32_t)lo64, hi = total - lo > L ? lo + L : total;
   uint32_t key = lanekey[lane];                            // offset[key] <= lo < offset[key + 1] (k_msm_fine_sort)
+  if (part) {
+    const uint32_t split_pos = offset[split_key];
+    if (part == 1) {
+      if (hi <= split_pos) return;
+      if (lo < split_pos) {                                // starts at the split: the first non-empty bucket from split_key on
+        lo = split_pos;
+        key = split_key;
+        while (offset[key + 1] <= lo) ++key;
+      }
+    } else {
+      if (lo >= split_pos) return;
+      if (hi > split_pos) hi = split_pos;
+    }
+  }
   uint32_t border = offset[key + 1];                       // > lo
   bool open_left = offset[key] < lo;
   pt29 acc = pt29_identity();
@@ -488,9 +505,9 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
 // pieces (see above); a bucket inside one range has been written by that range's lane
 __global__ void __launch_bounds__(256)
 k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
-             uint32_t* __restrict__ sums, uint32_t* __restrict__ big /* [0] count, [1 ..] keys */) {
-  const uint32_t key = blockIdx.x * 256 + threadIdx.x;
-  if (key >= nkeys) return;
+             uint32_t* __restrict__ sums, uint32_t* __restrict__ big /* [0] count, [1 ..] keys */, uint32_t key_lo, uint32_t key_hi) {
+  const uint32_t key = key_lo + blockIdx.x * 256 + threadIdx.x;      // the keys [key_lo, key_hi) of this launch
+  if (key >= key_hi) return;
   const uint32_t b = offset[key], e = offset[key + 1];
   if (b == e) {
     pt_store(sums, stride, key, pt29_identity());
@@ -541,11 +558,11 @@ k_msm_stitch_big(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
 // This kernel, the tree and the Horner tail below are serial chains of group operations on a chip that has nothing else
 // to do: they run the quad-spread formulas (pt29q.h), FOUR LANES PER CHUNK, each holding one coordinate.
 __global__ void __launch_bounds__(256)
-k_msm_reduce(msm_geom g, const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ partial) {
-  const size_t th = (size_t)blockIdx.x * 256 + threadIdx.x, id = th >> 2;
+k_msm_reduce(msm_geom g, const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ partial, uint32_t slot_lo, uint32_t slot_hi) {
+  const size_t th = (size_t)blockIdx.x * 256 + threadIdx.x, id = (size_t)slot_lo * g.nchunk + (th >> 2);   // the slots [slot_lo, slot_hi)
   const uint32_t q = (uint32_t)th & 3u, cc = q < 2 ? q : 2u;
   const size_t nslots = (size_t)g.nslot * g.nchunk;
-  if (id >= nslots) return;                                   // (whole quads leave together)
+  if (id >= (size_t)slot_hi * g.nchunk) return;               // (whole quads leave together)
   const uint32_t sl = (uint32_t)(id / g.nchunk), j = (uint32_t)(id % g.nchunk);
   const int CHUNK_LOG2 = (int)g.chunk_log2, CHUNK = 1 << CHUNK_LOG2;
   const size_t base = (size_t)sl * g.nb + (size_t)j * CHUNK;
@@ -570,15 +587,15 @@ k_msm_reduce(msm_geom g, const uint32_t* __restrict__ sums, size_t stride, uint3
 #pragma unroll 1
   for (int t = 0; t < CHUNK_LOG2; ++t) m = pt29q_double(m, q);
   tot = pt29q_add(tot, m, q);
-  if (q < 3) ptq_store(partial, nslots, id, cc, tot);
+  if (q < 3) ptq_store(partial, nslots + 1, id, cc, tot);     // (plane stride nslots + 1: the Horner tail's carry slot follows)
 }
 
 // tree sum of a slot's chunk results, partial[s][0..nchunk) -> partial[s][0], in two launches of 256-thread workgroups:
 // `span` consecutive slots are folded into the first one by each workgroup, a quad per addition
 __global__ void __launch_bounds__(256) k_msm_tree(uint32_t nslots_total, uint32_t span, uint32_t stride_slots,
-                                                  uint32_t* __restrict__ partial) {
-  // workgroup b folds slots [b * span * stride_slots, ...) taken every stride_slots
-  const size_t base = (size_t)blockIdx.x * span * stride_slots;
+                                                  uint32_t* __restrict__ partial, uint32_t block_lo) {
+  // workgroup b folds slots [b * span * stride_slots, ...) taken every stride_slots (b counted from block_lo)
+  const size_t base = (size_t)(block_lo + blockIdx.x) * span * stride_slots;
   const uint32_t q = threadIdx.x & 3u, cc = q < 2 ? q : 2u, pair = threadIdx.x >> 2;
   for (uint32_t half = span >> 1; half >= 1; half >>= 1) {
     for (uint32_t t = pair; t < half; t += 64) {
@@ -594,19 +611,34 @@ __global__ void __launch_bounds__(256) k_msm_tree(uint32_t nslots_total, uint32_
 // Horner over the window sums, then the 65-byte record: 128 - c doublings, a serial chain on one wave (its sixteen
 // quads all run the same recurrence), lane 0 writes the result.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_msm_final(msm_geom g, const uint32_t* __restrict__ partial, uint8_t* __restrict__ out65, int affine) {
+__global__ void __launch_bounds__(64) k_msm_final(msm_geom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ out65, int affine,
+                                                  uint32_t w_from, uint32_t w_to) {
   // out65: the 65-byte record of the sum (all zero for the identity); affine == 0: only identity or not is wanted
-  // (first byte 0x00 / 0x04, coordinates left zero): the whole-batch BIP-340 verdict skips the inversion
+  // (first byte 0x00 / 0x04, coordinates left zero): the whole-batch BIP-340 verdict skips the inversion.
+  // The recurrence runs over the windows w_from - 1 down to w_to.  w_from == nw: from the top (the top window's two slots
+  // first); otherwise it continues from the point an earlier launch has left in the carry slot.  w_to > 0: the point goes
+  // to the carry slot for the launch that continues (two-part flow, msm_core); w_to == 0: it is the result.
   const uint32_t q = threadIdx.x & 3u, cc = q < 2 ? q : 2u;
-  const size_t nslots = (size_t)g.nslot * g.nchunk;
-  // the two slots of the top window carry the same weight
-  fe29 accq = pt29q_add(ptq_load(partial, nslots, (size_t)g.nw * g.nchunk, cc), ptq_load(partial, nslots, (size_t)(g.nw - 1) * g.nchunk, cc), q);
+  const size_t nslots = (size_t)g.nslot * g.nchunk, carry = nslots;          // (one slot beyond the chunk results)
+  fe29 accq;
+  int w;
+  if (w_from == g.nw) {   // the two slots of the top window carry the same weight
+    accq = pt29q_add(ptq_load(partial, nslots + 1, (size_t)g.nw * g.nchunk, cc), ptq_load(partial, nslots + 1, (size_t)(g.nw - 1) * g.nchunk, cc), q);
+    w = (int)g.nw - 2;
+  } else {
+    accq = ptq_load(partial, nslots + 1, carry, cc);
+    w = (int)w_from - 1;
+  }
 #pragma unroll 1
-  for (int w = (int)g.nw - 2; w >= 0; --w) {
-    const fe29 add = ptq_load(partial, nslots, (size_t)w * g.nchunk, cc);
+  for (; w >= (int)w_to; --w) {
+    const fe29 add = ptq_load(partial, nslots + 1, (size_t)w * g.nchunk, cc);
 #pragma unroll 1
     for (uint32_t t = 0; t < g.c; ++t) accq = pt29q_double(accq, q);
     accq = pt29q_add(accq, add, q);
+  }
+  if (w_to > 0) {
+    if (threadIdx.x < 3) ptq_store(partial, nslots + 1, carry, cc, accq);
+    return;
   }
   const pt29 acc = pt29q_gather(accq);
   if (threadIdx.x != 0) return;
@@ -690,11 +722,11 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);
   m.nblk_pad = (m.nsortblk + 1 + 1023) / 1024 * 1024;   // one spare column: the scan total lands in it
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
-  size_t o_status = carve(256), o_big = carve((STITCH_BIG_CAP + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
+  size_t o_status = carve(256), o_big = carve(2 * (STITCH_BIG_CAP + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
          o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
          o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_sums = carve(m.sum_stride * PT_WORDS * 4),
-         o_partial = carve(m.nslots * PT_WORDS * 4), o_lanekey = carve((size_t)m.lanes_cap * 4), o_aux = carve(aux_bytes);
+         o_partial = carve((m.nslots + 1) * PT_WORDS * 4), o_lanekey = carve((size_t)m.lanes_cap * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
@@ -748,24 +780,69 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   }
   HIP_TRY(ctx, hipGetLastError());
   msm_prof_mark(ctx, st, 2);
-  k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums);
-  HIP_TRY(ctx, hipGetLastError());
-  msm_prof_mark(ctx, st, 3);
-  k_msm_stitch<<<blocks_for(m.nkeys), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
-  k_msm_stitch_big<<<64, 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, m.big);
-  HIP_TRY(ctx, hipGetLastError());
-  k_msm_reduce<<<blocks_for(4 * m.nslots), 256, 0, st>>>(g, m.sums, m.sum_stride, m.partial);
-  HIP_TRY(ctx, hipGetLastError());
-  {
-    // level 1: groups of up to 512 chunk results; level 2: the group sums of each window
+  // Two-part flow (S2K_MSM_SPLIT_WINDOW=ws, OFF by default; 16-bit windows, large inputs): the bucket pass of the windows
+  // from ws up first; their stitching, reduction, tree and their share of the Horner recurrence then on the second stream
+  // beside the bucket pass of the lower windows, and the caller's stream continues the recurrence from the carried point.
+  // Built, tested (same results) and MEASURED SLOWER: 2^20 inputs 1.82 ms in one part, 1.93 / 1.91 / 1.88 / 1.88 / 2.05 ms
+  // split at window 1 / 2 / 3 / 4 / 6.  Two reasons.  The lanes of a part are a SUBSET of the ranges (the ranges are cut
+  // from the whole list), so the lower part runs at under one wave per SIMD, i.e. at half the issue rate; and the tail
+  // kernels find no room beside the bucket pass anyway: its waves hold 3 x 134 of a SIMD's 512 VGPRs, the tail kernels need
+  // 113 to 140, and because every range is equally long no wave of the bucket pass ends before all of them do.
+  static const int split_env = [] {   // S2K_MSM_SPLIT_WINDOW (0 = single part)
+    const char* e = getenv("S2K_MSM_SPLIT_WINDOW");
+    return e ? atoi(e) : 0;
+  }();
+  const uint32_t ws = (g.c == 16 && n >= ((size_t)1 << 17) && split_env > 0 && split_env < (int)g.nw) ? (uint32_t)split_env : 0u;
+  uint32_t* big2 = m.big + (STITCH_BIG_CAP + 1);
+  auto tail = [&](hipStream_t s_, uint32_t slot_lo, uint32_t slot_hi, uint32_t* big) -> int {   // stitch, reduce, tree of the slots [slot_lo, slot_hi)
+    const uint32_t key_lo = slot_lo * g.nb, key_hi = slot_hi == g.nslot ? (uint32_t)m.nkeys : slot_hi * g.nb;
+    k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, big, key_lo, key_hi);
+    k_msm_stitch_big<<<64, 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, big);
+    HIP_TRY(ctx, hipGetLastError());
+    k_msm_reduce<<<blocks_for(4 * (size_t)(slot_hi - slot_lo) * g.nchunk), 256, 0, s_>>>(g, m.sums, m.sum_stride, m.partial, slot_lo, slot_hi);
+    HIP_TRY(ctx, hipGetLastError());
+    // level 1: groups of up to 512 chunk results; level 2: the group sums of each slot
     const uint32_t span1 = g.nchunk < 512 ? g.nchunk : 512, groups = g.nchunk / span1;
-    k_msm_tree<<<g.nslot * groups, 256, 0, st>>>((uint32_t)m.nslots, span1, 1u, m.partial);
-    if (groups > 1) k_msm_tree<<<g.nslot, 256, 0, st>>>((uint32_t)m.nslots, groups, span1, m.partial);
+    k_msm_tree<<<(slot_hi - slot_lo) * groups, 256, 0, s_>>>((uint32_t)m.nslots + 1, span1, 1u, m.partial, slot_lo * groups);
+    if (groups > 1) k_msm_tree<<<slot_hi - slot_lo, 256, 0, s_>>>((uint32_t)m.nslots + 1, groups, span1, m.partial, slot_lo);
+    HIP_TRY(ctx, hipGetLastError());
+    return S2K_OK;
+  };
+  if (ws == 0) {
+    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums, 0u, 0u);
+    HIP_TRY(ctx, hipGetLastError());
+    msm_prof_mark(ctx, st, 3);
+    int rc = tail(st, 0, g.nslot, m.big);
+    if (rc) return rc;
+    msm_prof_mark(ctx, st, 4);
+    k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, g.nw, 0u);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    int rc = ctx_aux_streams(ctx);
+    if (rc) return rc;
+    const uint32_t split_key = ws * g.nb;
+    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums, 1u, split_key);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums, 2u, split_key);
+    rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "k_msm_accumulate launch failed");
+    if (rc == S2K_OK) rc = tail(ctx->s_aux, ws, g.nslot, big2);
+    if (rc == S2K_OK) {
+      k_msm_final<<<1, 64, 0, ctx->s_aux>>>(g, m.partial, d_out65, 0, g.nw, ws);     // upper windows -> carry slot
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "k_msm_final launch failed");
+    }
+    msm_prof_mark(ctx, st, 3);
+    if (rc == S2K_OK) rc = tail(st, 0, ws, m.big);
+    ctx_aux_join(ctx, st);            // error or not: nothing stays in flight on the second stream alone
+    if (rc) {
+      (void)ctx_leave(ctx, st);
+      return rc;
+    }
+    msm_prof_mark(ctx, st, 4);
+    k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, ws, 0u);
+    HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipGetLastError());
-  msm_prof_mark(ctx, st, 4);
-  k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0);
-  HIP_TRY(ctx, hipGetLastError());
   msm_prof_mark(ctx, st, 5);
   return S2K_OK;
 }
