@@ -522,7 +522,11 @@ k_generator_part(uint32_t first, uint32_t n, const uint32_t* __restrict__ prep, 
 }
 
 template <int MODE>
+#ifdef S2K_FAST_MAX_WAVES   // experiment: cap the occupancy (leaves VGPRs for a kernel of another stream to run beside the ladder)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S2K_FAST_MAX_WAVES, S2K_FAST_MAX_WAVES)))
+#else
 __global__ void __launch_bounds__(256, S2K_FAST_WAVES)
+#endif
 k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
