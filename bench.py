@@ -167,7 +167,7 @@ def committed_counts():
 
 
 def committed_traffic(kernel="k_verify_fast"):
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         d = load_profile_json(name)
         if d and kernel in d:
             return d[kernel]["hbm_bytes_per_launch"], name
