@@ -430,30 +430,31 @@ k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_
   const uint32_t t = lo + blockIdx.x * 64 + threadIdx.x;
   if (t >= hi) return;
   uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
-  fe29 prefix = scr_load(kt, 0);
-  scr_store(kt, 9, prefix);
-#pragma unroll 1
-  for (int c = 1; c < KT_CHUNKS; ++c) {
-    prefix = fe29_mul(prefix, scr_load(kt, c));
-    scr_store(kt, 9 + c, prefix);
-  }
+  // everything this lane needs is loaded up front (nine independent loads: one memory latency instead of the thirty a
+  // load-multiply-store chain through the scratch entries paid), the prefix products stay in registers
+  fe29 z[KT_CHUNKS], pre[KT_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < KT_CHUNKS; ++c) z[c] = scr_load(kt, c);
   uint4* el = kt + (size_t)KT_LEAD * 8;
-  const fe29 zl = ke_load(el, TB_BX);
-  fe29 inv = fe29_inv_gcd(fe29_mul(prefix, zl));   // safegcd (fe29_inv.h): a third of the Fermat chain, and this kernel is one serial lane per key
+  const fe29 zl = ke_load(el, TB_BX), lx = ke_load(el, TB_X), ly = ke_load(el, TB_Y);
+  pre[0] = z[0];
+#pragma unroll
+  for (int c = 1; c < KT_CHUNKS; ++c) pre[c] = fe29_mul(pre[c - 1], z[c]);
+  fe29 inv = fe29_inv_gcd(fe29_mul(pre[KT_CHUNKS - 1], zl));   // safegcd (fe29_inv.h): a third of the Fermat chain, and this kernel is one serial lane per key
   {
-    fe29 zi = fe29_mul(inv, prefix);
+    fe29 zi = fe29_mul(inv, pre[KT_CHUNKS - 1]);
     inv = fe29_mul(inv, zl);
     fe29 zi2 = fe29_sqr(zi);
-    fe29 x = fe29_mul(ke_load(el, TB_X), zi2);
-    fe29 y = fe29_mul(fe29_mul(ke_load(el, TB_Y), zi2), zi);
+    fe29 x = fe29_mul(lx, zi2);
+    fe29 y = fe29_mul(fe29_mul(ly, zi2), zi);
     ke_store(el, TB_X, x);
     ke_store(el, TB_Y, y);
     ke_store(el, TB_BX, fe29_mul(x, fe29_from_words(FE_BETA)));
   }
-#pragma unroll 1
+#pragma unroll
   for (int c = KT_CHUNKS - 1; c >= 0; --c) {
-    fe29 zi = c > 0 ? fe29_mul(inv, scr_load(kt, 9 + c - 1)) : inv;   // 1 / Z_total of chunk c
-    if (c > 0) inv = fe29_mul(inv, scr_load(kt, c));
+    fe29 zi = c > 0 ? fe29_mul(inv, pre[c - 1]) : inv;   // 1 / Z_total of chunk c
+    if (c > 0) inv = fe29_mul(inv, z[c]);
     scr_store(kt, c, zi);
   }
 }
