@@ -277,3 +277,22 @@ def test_keyset_worklist_and_full_size(eng):
     got = eng.ecdsa_verify_batch_keyset(ks, inv.astype(np.uint32), dig, r, s)
     assert not got.any() and eng.key_grouping_stats()["complete"] == m
     ks.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"S2K_MSM_WIDE_PAIRS": "1"}, {"S2K_MSM_SPLIT_WINDOW": "3"}, {"S2K_MSM_LANES": "4096", "S2K_MSM_CHUNK_LOG2": "5"}])
+def test_msm_randomised_stress(env):
+    """tools/stress_msm.py: random sizes around every geometry switch, scalar patterns that stress the signed recoding and
+    spread buckets over many ranges, repeated / negated / identity points, against big-integer arithmetic on points with
+    known discrete logarithms - as shipped, with two-word sort pairs, with the two-part flow, and with long ranges."""
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_msm.py"), "30", str(len(env) + 11)], env=e,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "ok:" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_schnorr_batch_randomised_stress():
+    """tools/stress_rlc.py: random batch sizes and key multiplicities through the two-stream whole-batch check (accepts the
+    valid batch, rejects it with damaged signatures) and the bisection (per-signature verdicts equal the per-signature verifier's)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_rlc.py"), "25", "77"], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "ok:" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
