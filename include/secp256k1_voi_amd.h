@@ -391,7 +391,10 @@ enum {
   /* pt29q.h: the complete formulas spread over the four lanes of a quad (the serial tail of the multi-scalar
    * multiplication); inputs and outputs as PT29_DBL / PT29_ADD (Q scaled by c as well).  Bits 20.. of `lazy`: how often
    * the operation is chained on its own result (P + Q + Q + ..., 2^k P); 0 means once. */
-  S2K_HP_PT29Q_DBL, S2K_HP_PT29Q_ADD
+  S2K_HP_PT29Q_DBL, S2K_HP_PT29Q_ADD,
+  /* xyzz29_add_affine (xyzz29.h: the bucket pass's incomplete mixed addition): P = (a, b) lifted to ZZ = c^2, ZZZ = c^3,
+   * Q = (d, e); flag = 0 when P and Q share their x (ZZ3 = 0: the piece is re-done with the complete formulas) */
+  S2K_HP_XYZZ_ADD
 };
 int s2k_fp_op_batch_ex(s2k_ctx *ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t *const in[5],
                        uint8_t *out, uint8_t *out2, uint8_t *flag);

@@ -34,13 +34,14 @@
 #include "fe29_inv.h"
 #include "pt29.h"
 #include "pt29q.h"
+#include "xyzz29.h"
 #include "sc.h"
 #include "sha256.h"
 
 namespace {
 
 #ifndef S2K_MSM_WAVES
-#define S2K_MSM_WAVES 3   // waves per SIMD the bucket pass is built for (register budget 168) and sized to fill once
+#define S2K_MSM_WAVES 4   // waves per SIMD the bucket pass is built for (127 VGPRs) and sized to fill once
 #endif
 #ifndef S2K_MSM_CHUNK_LOG2
 #define S2K_MSM_CHUNK_LOG2 3   // default of the buckets per reduction chunk (log2); S2K_MSM_CHUNK_LOG2 in the environment overrides it
@@ -415,9 +416,8 @@ constexpr uint32_t STITCH_SERIAL = 8, STITCH_BIG_CAP = 4096;
 
 // A list entry is a term index with the digit's sign: a negative digit adds -P = (x, p - y), formed on the 32-bit
 // words before the limbs are cut.  The record (a random 64-byte read from the term array) is fetched one addition
-// ahead, into registers: 16 of them, which is why the kernel is built for three waves per SIMD (with four the record
-// had to be fetched in two halves, and the second half's line had left the L2 by the time it was asked for: 5.4 GB
-// fetched per 2^20-term call instead of 3.5).
+// ahead, into registers (fetching it in two halves to save registers cost more than it saved: the second half's line
+// had left the L2 by the time it was asked for, 5.4 GB fetched per 2^20-term call instead of 3.0).
 struct msm_rec {
   uint4 a, b, c, d;
 };
@@ -443,10 +443,38 @@ S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
   x = fe29_from_words(xw);
   y = fe29_from_words(yw);
 }
+// The additions are the incomplete XYZZ mixed additions of xyzz29.h: a piece STARTS as its first point, and it is flushed
+// as it is - four coordinates, 36 words, to the slot's column of `xsum`: the hot loop pays stores only (some lane of a wave
+// flushes in nearly every trip, so whatever the flush does, the whole wave waits for).  k_msm_stitch, one lane per key and
+// outside the hot loop, turns the pieces into projective points; a piece whose ZZ is 0 - it met P + P or P - P, or it
+// really sums to the identity - is walked again there with the complete formulas (msm_piece).
+constexpr int XZ_WORDS = 36;
+S2K_DEV void xz_store(uint32_t* __restrict__ base, size_t stride, size_t slot, const xyzz29& p) {
+#pragma unroll
+  for (int w = 0; w < 9; ++w) base[(size_t)w * stride + slot] = p.x.n[w];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) base[(size_t)(9 + w) * stride + slot] = p.y.n[w];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) base[(size_t)(18 + w) * stride + slot] = p.zz.n[w];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) base[(size_t)(27 + w) * stride + slot] = p.zzz.n[w];
+}
+S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t stride, size_t slot) {
+  xyzz29 p;
+#pragma unroll
+  for (int w = 0; w < 9; ++w) p.x.n[w] = base[(size_t)w * stride + slot];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) p.y.n[w] = base[(size_t)(9 + w) * stride + slot];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) p.zz.n[w] = base[(size_t)(18 + w) * stride + slot];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) p.zzz.n[w] = base[(size_t)(27 + w) * stride + slot];
+  return p;
+}
 __global__ void __launch_bounds__(256, S2K_MSM_WAVES)
 k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
                  const uint32_t* __restrict__ lanekey, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
-                 uint32_t* __restrict__ sums, uint32_t part, uint32_t split_key) {
+                 uint32_t* __restrict__ xsum, uint32_t part, uint32_t split_key) {
   // part 0: the whole list.  Two-part flow (msm_core): part 1 = the keys from split_key on (the upper windows), part 2 =
   // the keys below it; the one range that holds the split position takes part in both, each side up to the split - which
   // is a bucket border, so no piece is cut by it.
@@ -472,15 +500,16 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
   }
   uint32_t border = offset[key + 1];                       // > lo
   bool open_left = offset[key] < lo;
-  pt29 acc = pt29_identity();
+  bool fresh = true;                                       // the next point starts a piece
+  xyzz29 acc = xyzz29_from_affine(fe29_zero(), fe29_zero());
   uint32_t e_cur = list[lo], e_nxt = lo + 1 < hi ? list[lo + 1] : 0u;
   msm_rec r_cur = msm_load_rec(ptw, e_cur);
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
     if (j == border) {                                     // a bucket ends here: flush, next non-empty bucket
-      pt_store(sums, stride, open_left ? (size_t)nkeys + lane : (size_t)key, acc);
+      xz_store(xsum, stride, open_left ? (size_t)nkeys + lane : (size_t)key, acc);
       open_left = false;
-      acc = pt29_identity();
+      fresh = true;
       do {
         ++key;
         border = offset[key + 1];
@@ -490,7 +519,12 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
     const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;
     fe29 qx, qy;
     msm_point_of(r_cur, e_cur, qx, qy);
-    acc = pt29_add_mixed(acc, qx, qy);
+    if (fresh) {                                           // (a few lanes of the wave at a time: the others wait out 36 moves)
+      acc = xyzz29_from_affine(qx, qy);
+      fresh = false;
+    } else {
+      acc = xyzz29_add_affine(acc, qx, qy);
+    }
     r_cur = r_nxt;
     e_cur = e_nxt;
     e_nxt = e_nn;
@@ -498,13 +532,37 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
   // the last piece: left edge if it came in from the previous range (then it may go on as well: a range inside one
   // bucket), right edge if it goes on into the next range, else a whole bucket
   const bool open_right = border > hi;
-  pt_store(sums, stride, open_left ? (size_t)nkeys + lane : (open_right ? (size_t)nkeys + nlanes + lane : (size_t)key), acc);
+  xz_store(xsum, stride, open_left ? (size_t)nkeys + lane : (open_right ? (size_t)nkeys + nlanes + lane : (size_t)key), acc);
 }
-
-// one lane per key: the identity for an empty bucket; a bucket that crosses range borders is put together from its
-// pieces (see above); a bucket inside one range has been written by that range's lane
+// the piece in `slot` (the list entries [first, end) of one bucket) as a projective point; ZZ = 0: walked again, complete formulas
+S2K_DEV pt29 msm_piece(const uint32_t* __restrict__ xsum, size_t stride, size_t slot, uint32_t first, uint32_t end,
+                       const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw) {
+  const xyzz29 x = xz_load(xsum, stride, slot);
+  if (!fe29_is_zero(x.zz)) return xyzz29_to_pt29(x);
+  pt29 acc = pt29_identity();
+#pragma unroll 1
+  for (uint32_t j = first; j < end; ++j) {
+    const uint32_t e = list[j];
+    fe29 qx, qy;
+    msm_point_of(msm_load_rec(ptw, e), e, qx, qy);
+    acc = pt29_add_mixed(acc, qx, qy);
+  }
+  return acc;
+}
+// piece of the bucket [b, e) in range k
+S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, size_t stride, uint32_t nkeys, uint32_t nlanes, uint32_t L, uint32_t b,
+                          uint32_t e, uint32_t k, uint32_t k_lo, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw) {
+  const uint64_t r0 = (uint64_t)k * L, r1 = r0 + L;
+  const uint32_t first = b > r0 ? b : (uint32_t)r0, end = e < r1 ? e : (uint32_t)r1;
+  // the first range's piece is a right edge (the bucket starts in it or at its border and goes on), the others' left edges
+  return msm_piece(xsum, stride, k == k_lo ? (size_t)nkeys + nlanes + k : (size_t)nkeys + k, first, end, list, ptw);
+}
+// one lane per key: sums[key] = the bucket as a projective point - the identity for an empty bucket, the converted piece
+// for a bucket inside one range, the sum of its pieces for a bucket that crosses range borders (one addition for an ordinary
+// bucket; buckets spread over more than STITCH_SERIAL ranges are queued for k_msm_stitch_big)
 __global__ void __launch_bounds__(256)
 k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+             const uint32_t* __restrict__ xsum, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
              uint32_t* __restrict__ sums, uint32_t* __restrict__ big /* [0] count, [1 ..] keys */, uint32_t key_lo, uint32_t key_hi) {
   const uint32_t key = key_lo + blockIdx.x * 256 + threadIdx.x;      // the keys [key_lo, key_hi) of this launch
   if (key >= key_hi) return;
@@ -514,7 +572,10 @@ k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const u
     return;
   }
   const uint32_t k_lo = b / L, k_hi = (e - 1) / L;
-  if (k_lo == k_hi) return;
+  if (k_lo == k_hi) {
+    pt_store(sums, stride, key, msm_piece(xsum, stride, key, b, e, list, ptw));
+    return;
+  }
   if (k_hi - k_lo > STITCH_SERIAL) {
     const uint32_t pos = atomicAdd(&big[0], 1u);
     if (pos < STITCH_BIG_CAP) {
@@ -522,26 +583,26 @@ k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const u
       return;
     }                                       // more oversized buckets than the queue holds: serial after all
   }
-  // first piece: the bucket starts at a range border (then that range's piece is a right edge too, unless the bucket
-  // IS the rest of the range... it is open to the right, so: right edge) or inside the range (right edge)
-  pt29 r = pt_load(sums, stride, (size_t)nkeys + nlanes + k_lo);
+  pt29 r = msm_piece_of(xsum, stride, nkeys, nlanes, L, b, e, k_lo, k_lo, list, ptw);
 #pragma unroll 1
-  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, pt_load(sums, stride, (size_t)nkeys + k));
+  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, nlanes, L, b, e, k, k_lo, list, ptw));
   pt_store(sums, stride, key, r);
 }
 // one workgroup per queued bucket: the threads take the pieces round robin, then a tree in LDS
 __global__ void __launch_bounds__(256)
 k_msm_stitch_big(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+                 const uint32_t* __restrict__ xsum, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
                  uint32_t* __restrict__ sums, const uint32_t* __restrict__ big) {
   __shared__ uint32_t sh[PT_WORDS][128];
   const uint32_t nbig = big[0] < STITCH_BIG_CAP ? big[0] : STITCH_BIG_CAP;
   for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
     const uint32_t key = big[1 + q];
-    const uint32_t k_lo = offset[key] / L, k_hi = (offset[key + 1] - 1) / L;
+    const uint32_t b = offset[key], e = offset[key + 1];
+    const uint32_t k_lo = b / L, k_hi = (e - 1) / L;
     pt29 r = pt29_identity();
 #pragma unroll 1
     for (uint32_t k = k_lo + threadIdx.x; k <= k_hi; k += 256)
-      r = pt29_add(r, pt_load(sums, stride, k == k_lo ? (size_t)nkeys + nlanes + k : (size_t)nkeys + k));
+      r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, nlanes, L, b, e, k, k_lo, list, ptw));
     for (uint32_t half = 128; half >= 1; half >>= 1) {
       __syncthreads();
       if (threadIdx.x >= half && threadIdx.x < 2 * half) pt_store(&sh[0][0], 128, threadIdx.x - half, r);
@@ -666,7 +727,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct msm_ws {
   msm_geom g;
   size_t nkeys, nslots;
-  uint32_t *status, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *partial, *big, *lanekey;
+  uint32_t *status, *matrix, *offset, *bsum, *scw, *ptw, *list, *sums, *xsum, *partial, *big, *lanekey;
   size_t cap;          // term capacity the workspace was carved for = plane stride of scw (a call may run on fewer terms)
   uint32_t lanes_cap;  // bucket pass: most ranges any term count up to cap can make
   size_t sum_stride;   // slots of `sums`: nkeys buckets, then the left and the right edge piece of every range
@@ -726,7 +787,8 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
          o_offset = carve((m.nkeys + 1) * 4), o_bsum = carve((mat_words / 1024 + 1) * 4),
          o_pairs = carve(n * (size_t)g.nw * 8), o_scw = carve(n * SCW_WORDS * 4), o_ptw = carve(n * 16 * 4), o_flag = carve(n),
          o_list = carve(n * (size_t)g.nw * 4), o_sums = carve(m.sum_stride * PT_WORDS * 4),
-         o_partial = carve((m.nslots + 1) * PT_WORDS * 4), o_lanekey = carve((size_t)m.lanes_cap * 4), o_aux = carve(aux_bytes);
+         o_partial = carve((m.nslots + 1) * PT_WORDS * 4), o_lanekey = carve((size_t)m.lanes_cap * 4),
+         o_xsum = carve(m.sum_stride * XZ_WORDS * 4), o_aux = carve(aux_bytes);
   int rc = ctx_reserve(ctx, &ctx->msm_ws, &ctx->msm_ws_bytes, off);
   if (rc) return rc;
   uint8_t* ws = (uint8_t*)ctx->msm_ws;
@@ -745,6 +807,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.partial = (uint32_t*)(ws + o_partial);
   m.big = (uint32_t*)(ws + o_big);
   m.lanekey = (uint32_t*)(ws + o_lanekey);
+  m.xsum = (uint32_t*)(ws + o_xsum);
   m.aux = ws + o_aux;
   m.zero_bytes = o_offset;   // status, the queue of oversized buckets and the coarse matrix
   return S2K_OK;
@@ -796,8 +859,8 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   uint32_t* big2 = m.big + (STITCH_BIG_CAP + 1);
   auto tail = [&](hipStream_t s_, uint32_t slot_lo, uint32_t slot_hi, uint32_t* big) -> int {   // stitch, reduce, tree of the slots [slot_lo, slot_hi)
     const uint32_t key_lo = slot_lo * g.nb, key_hi = slot_hi == g.nslot ? (uint32_t)m.nkeys : slot_hi * g.nb;
-    k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, big, key_lo, key_hi);
-    k_msm_stitch_big<<<64, 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.sums, big);
+    k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
+    k_msm_stitch_big<<<64, 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big);
     HIP_TRY(ctx, hipGetLastError());
     k_msm_reduce<<<blocks_for(4 * (size_t)(slot_hi - slot_lo) * g.nchunk), 256, 0, s_>>>(g, m.sums, m.sum_stride, m.partial, slot_lo, slot_hi);
     HIP_TRY(ctx, hipGetLastError());
@@ -809,7 +872,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     return S2K_OK;
   };
   if (ws == 0) {
-    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums, 0u, 0u);
+    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum, 0u, 0u);
     HIP_TRY(ctx, hipGetLastError());
     msm_prof_mark(ctx, st, 3);
     int rc = tail(st, 0, g.nslot, m.big);
@@ -821,11 +884,11 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     int rc = ctx_aux_streams(ctx);
     if (rc) return rc;
     const uint32_t split_key = ws * g.nb;
-    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums, 1u, split_key);
+    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum, 1u, split_key);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
-    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.sums, 2u, split_key);
+    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum, 2u, split_key);
     rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "k_msm_accumulate launch failed");
     if (rc == S2K_OK) rc = tail(ctx->s_aux, ws, g.nslot, big2);
     if (rc == S2K_OK) {

@@ -13,6 +13,7 @@
 #include "jacobian29.h"
 #include "pt29.h"
 #include "pt29q.h"
+#include "xyzz29.h"
 #include "sc26.h"
 
 using namespace s2k;
@@ -292,6 +293,25 @@ k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__
       }
       break;
     }
+    case S2K_HP_XYZZ_ADD: {
+      // P = (a, b) lifted to XYZZ with ZZ = c^2, ZZZ = c^3 (c non-zero): X = a c^2, Y = b c^3; Q = (d, e) affine; the result
+      // goes back through the projective form the bucket pass stores (flag = 0: ZZ3 = 0, an exceptional input)
+      xyzz29 p;
+      const fe29 c2 = fe29_sqr(c), c3 = fe29_mul(c2, c);
+      p.x = fe29_mul(a, c2);
+      p.y = fe29_mul(b, c3);
+      p.zz = c2;
+      p.zzz = c3;
+      const pt29 q = xyzz29_to_pt29(xyzz29_add_affine(p, fe29_normalize_weak(d), fe29_normalize_weak(e)));
+      if (fe29_is_zero(q.z)) {
+        f = 0;
+      } else {
+        fe29 zi = fe29_inv(q.z);
+        r = fe29_mul(q.x, zi);
+        r2 = fe29_mul(q.y, zi);
+      }
+      break;
+    }
     case S2K_HP_PT29_DBL:
     case S2K_HP_PT29_ADD:
     case S2K_HP_PT29_ADD_MIXED: {
@@ -561,7 +581,7 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
   if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fp_op_batch_ex serves S2K_IMPL_FAST only (8x32: s2k_fp_op_batch)");
   const uint32_t reps = lazy >> 20;           // quad operations: bits 20.. of `lazy` = how often the operation is chained (0: once)
   lazy &= 0xfffffu;
-  if (op < 0 || op > S2K_HP_PT29Q_ADD) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (op < 0 || op > S2K_HP_XYZZ_ADD) return fail(ctx, S2K_ERR_ARG, "bad op");
   if (n == 0) return S2K_OK;
   if (!in || !in[0] || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");

@@ -304,6 +304,30 @@ def test_pt29q_quad_formulas(eng, oracle, codes):
         check(*eng.fp_op_batch_ex(S.HP_PT29Q_DBL, cols, lazy(*codes) | reps << 20), expect("dbl", reps))
 
 
+@pytest.mark.parametrize("codes", [(0, 0, 0, 0, 0), (0, 0, 4, 0, 0), (1, 0, 1, 0, 0)])
+def test_xyzz_mixed_addition_random_zz(eng, oracle, codes):
+    """xyzz29_add_affine (the bucket pass's incomplete mixed addition, x = X/ZZ, y = Y/ZZZ) on P lifted to a random ZZ = c^2,
+    ZZZ = c^3, through the projective form the bucket pass stores: exact for every generic pair, and EXACTLY the exceptional
+    inputs (P + P, P - P: same x) come back with ZZ3 = 0 (flag 0) - that is what sends a piece of a bucket to the
+    complete-formula redo kernel."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(140)
+    pts = wycheproof_points(oracle)[:200] + curve_points(rnd, 600)
+    qs = shuffled(pts, 141)
+    for i in range(0, len(pts), 7):      # exceptional pairs
+        qs[i] = pts[i] if (i // 7) % 2 == 0 else R.neg(pts[i])
+    z = [rnd.randrange(1, 2**256) for _ in pts]
+    z[:4] = [1, P - 1, 2**256 - 1, 2]
+    cols = [[b32(p[0]) for p in pts], [b32(p[1]) for p in pts], [b32(v) for v in z],
+            [b32(q[0]) for q in qs], [b32(q[1]) for q in qs]]
+    x, y, flag = eng.fp_op_batch_ex(S.HP_XYZZ_ADD, cols, lazy(*codes))
+    for p, q, xi, yi, f in zip(pts, qs, ints(x), ints(y), flag):
+        if p[0] == q[0]:
+            assert f == 0
+        else:
+            assert f == 1 and (xi, yi) == R.add(p, q)
+
+
 # ---- scalars: odd GLV split and safegcd inversion ----
 def test_split_glv_odd(eng):
     """sc_split_glv_odd (hot path): k == +-k1 +- k2*lambda (mod n), k1 and k2 odd and below 2^129, for the
