@@ -268,10 +268,10 @@ __global__ void __launch_bounds__(256) k_msm_scan_apply(const uint32_t* count, c
 // term index fits 23 bits (fine key << 24 | sign << 23 | term: up to 2^22 inputs), two words beyond (WIDE).
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t FINE_BITS = 8, FINE = 1u << FINE_BITS;
-#ifndef S2K_MSM_SORT_TERMS
-#define S2K_MSM_SORT_TERMS 8192
-#endif
-constexpr uint32_t SORT_THREADS = 1024, SORT_TERMS = S2K_MSM_SORT_TERMS;
+constexpr uint32_t SORT_THREADS = 1024;
+// terms per workgroup of the coarse kernels (a run-time value, msm_setup): 2048 where the workgroup's pairs fit the LDS
+// stage of k_msm_coarse_scatter_staged, 8192 otherwise
+constexpr uint32_t SORT_TERMS_STAGED = 2048, SORT_TERMS_DIRECT = 8192, STAGE_PAIRS = 16384;
 constexpr uint32_t MAX_COARSE = 1152;     // nkeys / FINE, at most 9 * 2^15 / 2^8 (c = 16, the largest geometry)
 constexpr uint32_t NARROW_TERM_BITS = 23;
 constexpr uint32_t FS_THREADS = 512, FS_STAGE = 19456;   // fine sort: threads, list entries staged in LDS (76 KiB: two workgroups per CU)
@@ -293,12 +293,12 @@ template <> struct msm_pair<true> {
 // matrix[coarse * nblk_pad + block] = pairs of this workgroup's terms falling into `coarse`
 __global__ void __launch_bounds__(SORT_THREADS)
 k_msm_coarse_count(uint32_t n, size_t nstride, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
-                   uint32_t ncoarse, uint32_t nblk_pad, uint32_t* __restrict__ matrix) {
+                   uint32_t ncoarse, uint32_t nblk_pad, uint32_t* __restrict__ matrix, uint32_t sort_terms) {
   __shared__ uint32_t h[MAX_COARSE];
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) h[t] = 0;
   __syncthreads();
-  size_t base = (size_t)blockIdx.x * SORT_TERMS;
-  for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
+  size_t base = (size_t)blockIdx.x * sort_terms;
+  for (uint32_t t = threadIdx.x; t < sort_terms; t += SORT_THREADS) {
     size_t i = base + t;
     if (i >= n || flag[i] != 1) continue;
     msm_for_digits(scw, nstride, i, g, [&](uint32_t key, bool) { atomicAdd(&h[key >> FINE_BITS], 1u); });
@@ -311,18 +311,77 @@ template <bool WIDE>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_msm_coarse_scatter(uint32_t n, size_t nstride, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
                      uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase,
-                     typename msm_pair<WIDE>::type* __restrict__ pairs) {
+                     typename msm_pair<WIDE>::type* __restrict__ pairs, uint32_t sort_terms) {
   __shared__ uint32_t cur[MAX_COARSE];
   for (uint32_t t = threadIdx.x; t < ncoarse; t += SORT_THREADS) cur[t] = mbase[(size_t)t * nblk_pad + blockIdx.x];
   __syncthreads();
-  size_t base = (size_t)blockIdx.x * SORT_TERMS;
-  for (uint32_t t = threadIdx.x; t < SORT_TERMS; t += SORT_THREADS) {
+  size_t base = (size_t)blockIdx.x * sort_terms;
+  for (uint32_t t = threadIdx.x; t < sort_terms; t += SORT_THREADS) {
     size_t i = base + t;
     if (i >= n || flag[i] != 1) continue;
     msm_for_digits(scw, nstride, i, g, [&](uint32_t key, bool neg) {
       uint32_t pos = atomicAdd(&cur[key >> FINE_BITS], 1u);
       pairs[pos] = msm_pair<WIDE>::make(key & (FINE - 1), (uint32_t)i, neg);
     });
+  }
+}
+// The same with the workgroup's pairs put in order in LDS first and written out run by run (one-word pairs, at most
+// STAGE_PAIRS of them per workgroup).  Scattered straight to memory, a workgroup's 4-byte stores went to 1152 places at
+// once, 32 workgroups per XCD kept more partly written lines open than the 4 MiB L2 holds, and the lines left it a few
+// words at a time: 358 MB of write traffic for 65 MB of pairs.  The counts of this workgroup are the differences of
+// neighbouring entries of the scanned matrix (its row is [coarse][workgroup]: the next entry is the next workgroup's
+// base in the same coarse bucket, or the next bucket's first).
+__global__ void __launch_bounds__(SORT_THREADS)
+k_msm_coarse_scatter_staged(uint32_t n, size_t nstride, msm_geom g, const uint32_t* __restrict__ scw, const uint8_t* __restrict__ flag,
+                            uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint32_t* __restrict__ pairs,
+                            uint32_t sort_terms) {
+  __shared__ uint32_t gbase[MAX_COARSE], lofs[MAX_COARSE], lcur[MAX_COARSE], part[SORT_THREADS], stage[STAGE_PAIRS];
+  __shared__ uint16_t sbin[STAGE_PAIRS];
+  const uint32_t t = threadIdx.x;
+  // this workgroup's count per coarse bucket, two buckets per thread, and their exclusive scan
+  uint32_t c0 = 0, c1 = 0;
+  {
+    const uint32_t b0 = 2 * t, b1 = 2 * t + 1;
+    if (b0 < ncoarse) {
+      const size_t at = (size_t)b0 * nblk_pad + blockIdx.x;
+      gbase[b0] = mbase[at];
+      c0 = mbase[at + 1] - mbase[at];
+    }
+    if (b1 < ncoarse) {
+      const size_t at = (size_t)b1 * nblk_pad + blockIdx.x;
+      gbase[b1] = mbase[at];
+      c1 = mbase[at + 1] - mbase[at];
+    }
+  }
+  part[t] = c0 + c1;
+  __syncthreads();
+  for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+    const uint32_t a = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += a;
+    __syncthreads();
+  }
+  {
+    const uint32_t ex = part[t] - (c0 + c1);
+    if (2 * t < ncoarse) lofs[2 * t] = lcur[2 * t] = ex;
+    if (2 * t + 1 < ncoarse) lofs[2 * t + 1] = lcur[2 * t + 1] = ex + c0;
+  }
+  const uint32_t total = part[SORT_THREADS - 1];
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * sort_terms;
+  for (uint32_t k = t; k < sort_terms; k += SORT_THREADS) {
+    const size_t i = base + k;
+    if (i >= n || flag[i] != 1) continue;
+    msm_for_digits(scw, nstride, i, g, [&](uint32_t key, bool neg) {
+      const uint32_t b = key >> FINE_BITS, lp = atomicAdd(&lcur[b], 1u);
+      stage[lp] = msm_pair<false>::make(key & (FINE - 1), (uint32_t)i, neg);
+      sbin[lp] = (uint16_t)b;
+    });
+  }
+  __syncthreads();
+  for (uint32_t k = t; k < total; k += SORT_THREADS) {
+    const uint32_t b = sbin[k];
+    pairs[gbase[b] + (k - lofs[b])] = stage[k];
   }
 }
 // one workgroup per coarse bucket: pairs -> list (term index | sign << 31, grouped by key), offset[key], lanekey[range];
@@ -733,7 +792,7 @@ struct msm_ws {
   size_t sum_stride;   // slots of `sums`: nkeys buckets, then the left and the right edge piece of every range
   void* pairs;
   bool wide;           // two-word pairs (term indices beyond 23 bits)
-  uint32_t ncoarse, nsortblk, nblk_pad;
+  uint32_t ncoarse, nsortblk, nblk_pad, sort_terms;
   uint8_t* flag;
   size_t zero_bytes;   // status + size bins + coarse matrix, contiguous from the start
   uint8_t* aux;        // extra caller-requested scratch
@@ -780,7 +839,8 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   }
   // status word, then the queue of oversized buckets (counter + keys), zeroed with the counters
   m.ncoarse = (uint32_t)(m.nkeys >> FINE_BITS);
-  m.nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);
+  m.sort_terms = (n <= ((size_t)1 << 22) && g.nw * SORT_TERMS_STAGED <= STAGE_PAIRS) ? SORT_TERMS_STAGED : SORT_TERMS_DIRECT;
+  m.nsortblk = (uint32_t)((n + m.sort_terms - 1) / m.sort_terms);
   m.nblk_pad = (m.nsortblk + 1 + 1023) / 1024 * 1024;   // one spare column: the scan total lands in it
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
   size_t o_status = carve(256), o_big = carve(2 * (STITCH_BIG_CAP + 1) * 4), o_matrix = carve((mat_words + 1) * 4),
@@ -817,7 +877,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
 int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65, bool affine = true) {
   const msm_geom& g = m.g;
   if (n > m.cap) return fail(ctx, S2K_ERR_ARG, "internal: more terms than the multiscalar workspace was carved for");
-  const uint32_t nsortblk = (uint32_t)((n + SORT_TERMS - 1) / SORT_TERMS);      // <= m.nsortblk: the matrix columns beyond stay zero
+  const uint32_t nsortblk = (uint32_t)((n + m.sort_terms - 1) / m.sort_terms);  // <= m.nsortblk: the matrix columns beyond stay zero
   // ranges of the bucket pass: as long as it takes for the lanes to fill the chip once
   const size_t pairs_max = n * (size_t)g.nw;
   size_t L = (pairs_max + msm_lanes_target() - 1) / msm_lanes_target();
@@ -825,7 +885,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   const uint32_t nlanes = (uint32_t)((pairs_max + L - 1) / L);                   // <= m.lanes_cap
   // sort: coarse partition (counts -> scan -> scatter), then one workgroup per coarse bucket
   msm_prof_mark(ctx, st, 1);
-  k_msm_coarse_count<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix);
+  k_msm_coarse_count<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, m.sort_terms);
   HIP_TRY(ctx, hipGetLastError());
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
   const unsigned scan_blocks = (unsigned)(mat_words / 1024);
@@ -835,10 +895,13 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
   if (m.wide) {
-    k_msm_coarse_scatter<true><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs);
+    k_msm_coarse_scatter<true><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs, m.sort_terms);
     k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list, (uint32_t)L, m.lanekey);
   } else {
-    k_msm_coarse_scatter<false><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs);
+    if (m.sort_terms == SORT_TERMS_STAGED)
+      k_msm_coarse_scatter_staged<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs, m.sort_terms);
+    else
+      k_msm_coarse_scatter<false><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs, m.sort_terms);
     k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list, (uint32_t)L, m.lanekey);
   }
   HIP_TRY(ctx, hipGetLastError());
