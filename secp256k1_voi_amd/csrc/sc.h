@@ -24,14 +24,8 @@ __device__ static const uint32_t SC_R2[8] = {0x67d7d140u, 0x896cf214u, 0x0e7cf87
 __device__ static const uint32_t SC_ONE_M[8] = {0x2fc9bebfu, 0x402da173u, 0x50b75fc4u, 0x45512319u,
                                                 0x00000001u, 0, 0, 0};   // R mod n
 __device__ static const uint32_t SC_HALF_N[8] = {0x681b20a0u, 0xdfe92f46u, 0x57a4501du, 0x5d576e73u,
-                                                 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};   // scalar.go:33-38
-// GLV constants (point_mul_glv.go:37-57); the three multipliers are kept in Montgomery form
-__device__ static const uint32_t SC_NEG_LAMBDA_M[8] = {0x06a3d4a3u, 0xcf54734fu, 0x2b820beeu, 0x8e1af539u,
-                                                       0xad96826du, 0x8c5699f9u, 0x7aa729c6u, 0xacd7bfe8u};
-__device__ static const uint32_t SC_NEG_B1_M[8] = {0x0ad9263cu, 0xc50468d0u, 0xfaa6ed42u, 0x1b1c8205u,
-                                                   0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu};
-__device__ static const uint32_t SC_NEG_B2_M[8] = {0x6a144696u, 0x0cac5e50u, 0xf3ba5939u, 0x1e8a8dc5u,
-                                                   0xba244fceu, 0x176cdf65u, 0x8e173580u, 0xc25575ebu};
+                                                 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
+// g1, g2 of splitGLV (point_mul_glv.go:59-117): round(2^384 b2 / n), round(2^384 (-b1) / n)
 __device__ static const uint32_t SC_G1[8] = {0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u,
                                              0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};
 __device__ static const uint32_t SC_G2[8] = {0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu,
@@ -237,15 +231,68 @@ S2K_DEV sc sc_mul_g_floored_div(const sc& k, const uint32_t g[8]) {
 // splitGLV (point_mul_glv.go:59-117) followed by the sign normalisation of
 // scalarMultVartimeGLV (:212-220): k = (-1)^neg1*k1 + (-1)^neg2*k2*lambda (mod n), with
 // k1, k2 < 2^128 (limbs 4..7 zero).
+// out[0..7] -= / += a[0..3] * b[0..4] (a 128-bit times a 129-bit value, b[4] is 0 or 1), modulo 2^256
+S2K_DEV void u256_mac_128(uint32_t out[8], const uint32_t a[4], const uint32_t b[5], bool subtract) {
+  uint32_t p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t t = (uint64_t)a[i] * b[j] + p[i + j] + carry;    // < 2^64: no overflow
+      p[i + j] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+    p[i + 4] = carry;
+  }
+  {   // + a * b[4] * 2^128
+    const uint32_t m = 0u - b[4];
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[4 + i] = __builtin_addc(p[4 + i], a[i] & m, c, &c);
+  }
+  unsigned c = 0;
+  if (subtract) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = __builtin_subc(out[i], p[i], c, &c);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = __builtin_addc(out[i], p[i], c, &c);
+  }
+}
+// The reference computes k2 = c1 (-b1) + c2 (-b2) and k1 = k - k2 lambda with three products mod n.  With the lattice
+// basis (a1, b1), (a2, b2) behind c1, c2 (a_i + b_i lambda = 0 mod n) the same two values are k1 = k - c1 a1 - c2 a2 and
+// k2 = -c1 b1 - c2 b2 as INTEGERS, both below 2^128 in magnitude: four 128-bit products modulo 2^256, no reduction, and
+// the sign is the top bit (a quarter of the instructions; same k1, k2 and signs for every k: tests/test_glv_odd_model.py,
+// and on the device tests/test_gpu_parity.py test_fn_ops against the reference's boundary scalars).
+__device__ static const uint32_t GLV_LAT_A1[5] = {0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u, 0u};    // a1 = b2
+__device__ static const uint32_t GLV_LAT_NB1[5] = {0x0abfe4c3u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u, 0u};   // -b1
+__device__ static const uint32_t GLV_LAT_A2[5] = {0x9d44cfd8u, 0x57c1108du, 0xa8e2f3f6u, 0x14ca50f7u, 1u};    // a2
 S2K_DEV void sc_split_glv(const sc& k, sc& k1, bool& neg1, sc& k2, bool& neg2) {
-  sc c1 = sc_mul_g_floored_div(k, SC_G1);
-  sc c2 = sc_mul_g_floored_div(k, SC_G2);
-  k2 = sc_add(sc_montmul(c1, sc_from_limbs(SC_NEG_B1_M)), sc_montmul(c2, sc_from_limbs(SC_NEG_B2_M)));
-  k1 = sc_add(k, sc_montmul(k2, sc_from_limbs(SC_NEG_LAMBDA_M)));
-  neg1 = sc_is_gt_half_n(k1);
-  neg2 = sc_is_gt_half_n(k2);
-  k1 = neg1 ? sc_neg(k1) : k1;
-  k2 = neg2 ? sc_neg(k2) : k2;
+  const sc c1 = sc_mul_g_floored_div(k, SC_G1);
+  const sc c2 = sc_mul_g_floored_div(k, SC_G2);
+  uint32_t d1[8], d2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    d1[i] = k.v[i];
+    d2[i] = 0;
+  }
+  u256_mac_128(d1, c1.v, GLV_LAT_A1, true);      // k - c1 a1
+  u256_mac_128(d1, c2.v, GLV_LAT_A2, true);      //   - c2 a2
+  u256_mac_128(d2, c1.v, GLV_LAT_NB1, false);    // c1 (-b1)
+  u256_mac_128(d2, c2.v, GLV_LAT_A1, true);      //   - c2 b2
+  neg1 = (d1[7] >> 31) != 0;
+  neg2 = (d2[7] >> 31) != 0;
+  // magnitudes: two's complement negation where negative (|.| < 2^128: the upper words end up zero)
+  const uint32_t m1 = 0u - (uint32_t)neg1, m2 = 0u - (uint32_t)neg2;
+  unsigned cy1 = neg1 ? 1u : 0u, cy2 = neg2 ? 1u : 0u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    k1.v[i] = __builtin_addc(d1[i] ^ m1, 0u, cy1, &cy1);
+    k2.v[i] = __builtin_addc(d2[i] ^ m2, 0u, cy2, &cy2);
+  }
 }
 
 

@@ -71,3 +71,26 @@ def test_worst_case_bound_is_structural():
     assert lim + A1 < (1 << 129) and lim + abs(B1) < (1 << 129)                  # (even, even): any signs
     assert max(lim, A2) < (1 << 129) and lim + B2 < (1 << 129)                  # (odd, even): A2 against k1
     assert lim + (A2 - A1) < (1 << 129) and max(lim, B2 - B1) < (1 << 129)      # (even, odd): B2-B1 against k2
+
+
+def split_lattice_form(k):
+    """sc_split_glv as the device computes it since round 3: k1 = k - c1 a1 - c2 a2, k2 = -c1 b1 - c2 b2 as integers modulo
+    2^256 (four 128-bit products, no reduction mod n), the sign taken from bit 255"""
+    M = 1 << 256
+    c1 = (k * G1 + (1 << 383)) >> 384
+    c2 = (k * G2 + (1 << 383)) >> 384
+    d1 = (k - c1 * A1 - c2 * A2) % M
+    d2 = (-c1 * B1 - c2 * B2) % M
+    return (d1 - M if d1 >> 255 else d1), (d2 - M if d2 >> 255 else d2)
+
+
+def test_lattice_form_split_is_the_reference_split():
+    """same (k1, k2), signs included, as the reference's three products mod n - for the boundary values, values on the
+    lattice's short vectors and 10^5 random scalars; c1, c2 below 2^128 (the device multiplies 128-bit operands)"""
+    rnd = random.Random(2025)
+    ks = [0, 1, 2, 3, N - 1, N - 2, N // 2, N // 2 + 1, LAM, N - LAM, (1 << 128) - 1, 1 << 128, (1 << 255) + 5]
+    ks += [rnd.randrange(N) for _ in range(100000)]
+    ks += [(rnd.randrange(1 << 16) * A1 + rnd.randrange(1 << 16) * A2) % N for _ in range(2000)]
+    for k in ks:
+        assert split_lattice_form(k) == split_reference(k), hex(k)
+        assert ((k * G1 + (1 << 383)) >> 384) < (1 << 128) and ((k * G2 + (1 << 383)) >> 384) < (1 << 128)
