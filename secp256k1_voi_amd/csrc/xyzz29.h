@@ -15,6 +15,7 @@
 // Invariant of an xyzz29: x [1], y [<= 2], zz [1], zzz [1].
 #pragma once
 #include "fe29.h"
+#include "jacobian29.h"
 #include "pt29.h"
 
 namespace s2k {
@@ -23,7 +24,7 @@ struct xyzz29 {
   fe29 x, y, zz, zzz;
 };
 
-// (bx, by) affine [1] -> accumulator
+// (bx, by) affine [bx 1, by <= 2] -> accumulator
 S2K_DEV xyzz29 xyzz29_from_affine(const fe29& bx, const fe29& by) {
   xyzz29 r;
   r.x = bx;
@@ -33,11 +34,11 @@ S2K_DEV xyzz29 xyzz29_from_affine(const fe29& bx, const fe29& by) {
   return r;
 }
 
-// p + (bx, by), the addend affine [bx 1, by 1] and not the identity.  Same x as p: ZZ3 = ZZZ3 = 0 (see above).
+// p + (bx, by), the addend affine [bx 1, by <= 2] and not the identity.  Same x as p: ZZ3 = ZZZ3 = 0 (see above).
 S2K_DEV xyzz29 xyzz29_add_affine(const xyzz29& p, const fe29& bx, const fe29& by) {
   const fe29 nx = fe29_negate(p.x, 1);                                 // [2]   -X1
   const fe29 pp_ = fe29_mul_plus(bx, p.zz, nx);                        // [1]*[1] + [2] -> [1]   P = U2 - X1
-  const fe29 rn = fe29_mul_plus(fe29_negate(by, 1), p.zzz, p.y);       // [2]*[1] + [2] -> [1]   -R = Y1 - S2
+  const fe29 rn = fe29_mul_plus(fe29_negate(by, 2), p.zzz, p.y);       // [3]*[1] + [2] -> [1]   -R = Y1 - S2
   const fe29 pp = fe29_sqr(pp_);                                       // [1]   P^2
   const fe29 pppn = fe29_mul(pp, fe29_negate(pp_, 1));                 // [1]*[2] -> [1]   -P^3
   const fe29 qn = fe29_mul(nx, pp);                                    // [2]*[1] -> [1]   -Q = -X1 P^2
@@ -47,6 +48,24 @@ S2K_DEV xyzz29 xyzz29_add_affine(const xyzz29& p, const fe29& bx, const fe29& by
   r.y = fe29_mul_add_mul(t, rn, pppn, p.y);                            // [2]*[1] + [1]*[2] -> [1]   R (Q - X3) - Y1 P^3
   r.zz = fe29_mul(p.zz, pp);                                           // [1]
   r.zzz = fe29_mul(p.zzz, fe29_negate(pppn, 1));                       // [1]*[2] -> [1]
+  return r;
+}
+
+// the same point in Jacobian coordinates (x = X'/Z'^2, y = Y'/Z'^3) with Z' = ZZ: (X ZZ, Y ZZZ, ZZ); ZZ = 0 gives Z' = 0
+S2K_DEV jpt29 xyzz29_to_jacobian(const xyzz29& p) {
+  jpt29 r;
+  r.x = fe29_mul(p.x, p.zz);
+  r.y = fe29_mul(p.y, p.zzz);     // [2]*[1]
+  r.z = p.zz;
+  return r;
+}
+// and back: (X, Y, Z^2, Z^3); Z = 0 gives ZZ = ZZZ = 0
+S2K_DEV xyzz29 xyzz29_from_jacobian(const jpt29& p) {
+  xyzz29 r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = fe29_sqr(p.z);
+  r.zzz = fe29_mul(r.zz, p.z);
   return r;
 }
 
