@@ -202,9 +202,17 @@ def worker(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # test hook: S2K_FORCE_COLLECTIVES=1 runs a single rank as an RCCL group of one, so that the step's two collectives go
+    # through RCCL on a one-GPU box (secp256k1_voi_amd/sharding.py); the driver never sets it
+    forced_group = world == 1 and os.environ.get("S2K_FORCE_COLLECTIVES") == "1"
+    if world > 1 or forced_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced_group:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -352,7 +360,8 @@ def worker(args):
             "config": {"workload": "2^%d ECDSA verifies (u1*G+u2*P per lane) per GPU%s, %d distinct keys per GPU, all valid, low-s"
                                    % (batch_log2, " = 2^%d in total (BASELINE config 5 shape)" % (batch_log2 + world.bit_length() - 1)
                                       if world > 1 else " (BASELINE config 2)", n_keys),
-                       "parallelism": "shard%d%s" % (world, " (ranks share devices, gloo: test hook)" if shared_device else ""),
+                       "parallelism": "shard%d%s%s" % (world, " (ranks share devices, gloo: test hook)" if shared_device else "",
+                                                         " (RCCL group of one: test hook)" if forced_group else ""),
                        "inputs": "resident in HBM", "collective": "all-gather bitmap + all-reduce count per step",
                        "build": eng._lib.s2k_build_config().decode()},
             "roofline": roof,

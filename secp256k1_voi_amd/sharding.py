@@ -8,7 +8,17 @@ box, gloo in the CPU tests).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+
+def _alone(dist) -> bool:
+    """No process group, or a group of one: nothing to exchange.  S2K_FORCE_COLLECTIVES=1 (test hook) sends a
+    group of one through the collectives anyway, which is how the single-GPU box exercises the RCCL calls."""
+    if dist is None or not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("S2K_FORCE_COLLECTIVES") != "1"
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -38,7 +48,7 @@ def gather_valid(valid_shard, n_total: int, dist=None, device=None):
     """
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone(dist):
         v = valid_shard.cpu().numpy() if hasattr(valid_shard, "cpu") else np.asarray(valid_shard)
         return v.astype(np.uint8), int(v.sum())
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -85,7 +95,7 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
         w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=valid.device)
         bitmap.copy_((valid.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8))
         count.copy_(valid.sum(dtype=torch.int64).reshape(1))
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone(dist):
         return bitmap, count
     world = dist.get_world_size()
     assert n * world == n_total, "gather_valid_device needs equal shards"
@@ -113,7 +123,7 @@ def msm_sharded(engine, scalars, points, dist=None):
     import torch
 
     part = engine.multi_scalar_mult(scalars, points)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone(dist):
         return part
     world = dist.get_world_size()
     mine = torch.tensor(list(part), dtype=torch.uint8)
@@ -139,7 +149,7 @@ def schnorr_batch_verify_sharded(engine, pks, msgs, sigs, seed: bytes, dist=None
 
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     ok = bool(engine.schnorr_batch_verify_rlc(pks, msgs, sigs, hashlib.sha256(seed + rank.to_bytes(4, "big")).digest()))
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone(dist):
         return ok
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
     if dist.get_backend() != "gloo":

@@ -2,7 +2,11 @@
 collectives - the shape of `bench.py --oversubscribe`.  Runs the sharded entry points of secp256k1_voi_amd.sharding with
 the REAL engine and prints one JSON line.
 
-    python multirank_worker.py <rank> <world> <port> <log2 n>
+    python multirank_worker.py <rank> <world> <port> <log2 n> [backend]
+
+backend nccl (= RCCL) needs one GPU per rank; on the one-GPU box it runs as a group of ONE with S2K_FORCE_COLLECTIVES=1,
+so that the same calls (all_gather_into_tensor of uint8, all_reduce SUM of int64 and MIN of int32, barrier) go through
+RCCL on device buffers.
 """
 import hashlib
 import json
@@ -12,6 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rank, world, port, log2n = (int(x) for x in sys.argv[1:5])
+backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 os.environ["MASTER_PORT"] = str(port)
 
@@ -23,11 +28,15 @@ import secp256k1_voi_amd as S
 from secp256k1_voi_amd.sharding import gather_valid_device, msm_sharded, schnorr_batch_verify_sharded, shard_range
 from secp256k1_voi_amd.synth import synth_batch, synth_msm_terms, synth_schnorr_batch
 
-dist.init_process_group("gloo", rank=rank, world_size=world)
-eng = S.Engine(0)
 dev = torch.device("cuda", 0)
+if backend == "nccl":
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
+eng = S.Engine(0)
 n = 1 << log2n
-out = {"rank": rank}
+out = {"rank": rank, "backend": dist.get_backend()}
 
 # ---- multi-scalar multiplication: every rank builds the same terms (seeded), takes its shard ----
 k, pts, tot = synth_msm_terms(eng, n, seed=11)

@@ -110,6 +110,27 @@ def test_sharded_entry_points_two_ranks_real_engine():
     assert outs[0]["msm_sum"] == outs[1]["msm_sum"]
 
 
+def test_sharded_entry_points_through_rccl_group_of_one():
+    """The same worker with backend nccl (= RCCL): a one-GPU box cannot hold two RCCL ranks (one device per rank), so the
+    group has ONE member and S2K_FORCE_COLLECTIVES=1 sends it through the collectives anyway: all_gather_into_tensor of the
+    uint8 bitmap and of the 65-byte partial sum, all_reduce SUM of the int64 count and MIN of the int32 verdict and the
+    barrier all run in RCCL on device buffers, and the results are the single-process ones.  (What two or eight RCCL ranks
+    add is transport over xGMI, which this box does not have.)"""
+    port = _free_port()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["S2K_FORCE_COLLECTIVES"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), "0", "1", str(port), "14", "nccl"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert o["backend"] == "nccl", o
+    assert o["msm_ok"] and o["schnorr_all_valid"] and not o["schnorr_one_bad"], o
+    assert o["ecdsa_bitmap_ok"] and o["ecdsa_count_ok"] and o["keyed"] > 0, o
+
+
 def test_bench_two_ranks_full_per_rank_size():
     """`bench.py --gpus 2 --oversubscribe` at the REAL per-rank size of BASELINE config 5 (2^21 verifications per rank), two
     ranks sharing GPU 0: the corrupted-bitmap guard on the gathered bitmap must pass and the line must describe 2^22 in
@@ -122,6 +143,21 @@ def test_bench_two_ranks_full_per_rank_size():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "2^22 in total" in d["config"]["workload"], d["config"]
+
+
+def test_bench_step_through_rccl_group_of_one():
+    """bench.py with S2K_FORCE_COLLECTIVES=1: one rank, but the step's bitmap all-gather and count all-reduce, the barrier
+    and the MAX over ranks of the time all go through RCCL (backend nccl), with the same guards on the gathered bitmap."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["S2K_FORCE_COLLECTIVES"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-pcie",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "RCCL group of one" in d["config"]["parallelism"], d["config"]
 
 
 def test_compiler_miscompile_reproducer_and_shipped_shape(eng, tmp_path):
