@@ -506,17 +506,15 @@ k_generator_part(uint32_t first, uint32_t n, const uint32_t* __restrict__ prep, 
 #pragma unroll
   for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + idx];
   apt g = gt_load(gt, 0, gt_next_digit(u));
-  jpt29 acc;
-  acc.x = fe29_from_words(g.x.v);
-  acc.y = fe29_from_words(g.y.v);
-  acc.z = fe29_one();
+  xyzz29 xa = xyzz29_from_affine(fe29_from_words(g.x.v), fe29_from_words(g.y.v));   // XYZZ additions, as in the keyed ladder
   g = gt_load(gt, 1, gt_next_digit(u));
 #pragma unroll 1
   for (uint32_t w = 1; w < GT_WINDOWS; ++w) {
     const fe29 gx = fe29_from_words(g.x.v), gy = fe29_from_words(g.y.v);
     if (w + 1 < GT_WINDOWS) g = gt_load(gt, w + 1, gt_next_digit(u));   // in flight during this addition
-    acc = jpt29_add_affine(acc, gx, gy);
+    xa = xyzz29_add_affine(xa, gx, gy);
   }
+  const jpt29 acc = xyzz29_to_jacobian(xa);
   fq_store(gp, stride, idx, 0, acc.x);
   fq_store(gp, stride, idx, 1, acc.y);
   fq_store(gp, stride, idx, 2, acc.z);

@@ -71,12 +71,18 @@ def main():
                     # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
                     "clock_mhz_from_gui_active": gui / 8 / sec / 1e6}
     # the other kernels of a step: VALU instructions per signature of the batch (wave counts differ per kernel)
+    # (a kernel launched several times per step - the generator part runs in two pieces - counts with all its launches:
+    # launches per step = its dispatches / the ladder's dispatches, averaged over the last TIMED steps' worth of them)
+    steps_total = max((len(acc[(k, "SQ_INSTS_VALU")]) for k in set(k for k, _ in acc) if k.startswith("k_verify_fast<4>") or k.startswith("k_verify_fast<0>")), default=0)
     for k in sorted(set(k for k, _ in acc)):
         if k.startswith("k_verify_fast") or not k.startswith("k_"):
             continue
-        v = avg(k, "SQ_INSTS_VALU")
+        nd = len(acc[(k, "SQ_INSTS_VALU")])
+        per_step = nd // steps_total if steps_total and nd >= steps_total and nd % steps_total == 0 else 1
+        v = avg(k, "SQ_INSTS_VALU", TIMED * per_step)
         if v:
-            res[k] = {"valu_instr_per_signature": v * 64 / (1 << 20), "launches_averaged": min(TIMED, len(acc[(k, "SQ_INSTS_VALU")]))}
+            res[k] = {"valu_instr_per_signature": v * per_step * 64 / (1 << 20), "launches_averaged": min(TIMED * per_step, nd),
+                      "launches_per_step": per_step}
     json.dump(res, open(out + "/valu_counts.json", "w"), indent=1)
 
 
