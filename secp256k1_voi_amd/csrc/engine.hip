@@ -687,6 +687,7 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     // 16^32 Q = 16^3 * 2^116 Q goes in first.
     const uint4* kt = kg.ktab + (size_t)kg.ptab[idx] * (KT_SLOTS * 8);
     digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);
+    const fe29 kw = ke_load(kt + (size_t)(KT_SCR + KT_W_SLOT / 3) * 8, KT_W_SLOT % 3);   // wanted at the very end: asked for early
     // The 66 additions of this ladder run in XYZZ coordinates (xyzz29.h: 8 M + 2 S in 9 reductions against 8 M + 3 S in
     // 10 for the Jacobian mixed addition: 1 441 instead of 1 578 instructions); the 12 doublings stay Jacobian (7 products
     // against 9), so the accumulator changes form at the three round borders (3 M + 1 S each way together).  The
@@ -755,6 +756,8 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       }
     }
 #endif
+    // the table's points are affine on the curve isomorphic by W (keyed.hip): back on secp256k1 itself
+    acc.z = fe29_mul(acc.z, kw);
   } else {
     digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
     {

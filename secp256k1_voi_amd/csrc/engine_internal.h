@@ -244,6 +244,8 @@ constexpr int KT_CHUNKS = 8;
 constexpr int KT_LEAD = KT_CHUNKS * 8;          // entry of 2^116 Q
 constexpr int KT_ENTRIES = KT_LEAD + 1;
 constexpr int KT_SLOTS = 72;                    // entries of 128 bytes reserved per key: 65 + 7 of build scratch
+constexpr int KT_SCR = KT_ENTRIES;              // first scratch entry: 21 field elements, three per entry (keyed.hip: kt_scratch)
+constexpr int KT_W_SLOT = 9;                    // scratch element that stays part of the table: W, the Z all entries of the key share
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
 constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grouping
@@ -271,7 +273,7 @@ int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key
 int s2k_internal_key_reserve(s2k_ctx* ctx, size_t n, int key_bytes);   // grow the grouping arrays / table buffer (before any fork)
 size_t s2k_internal_key_bytes(const s2k_ctx* ctx, size_t n);            // what those hold for a batch of n
 int s2k_internal_key_chains(s2k_ctx* ctx, const uint8_t* d_pub, hipStream_t st, const key_groups* g);
-// (ev_after_odd, if any, is recorded on st between k_key_odd and k_key_invert)
+// (ev_after_odd, if any, is recorded on st between k_key_odd and k_key_cofactors)
 int s2k_internal_key_tables(s2k_ctx* ctx, hipStream_t st, const key_groups* g, uint32_t part, uint32_t nparts,
                             hipEvent_t ev_after_odd);
 

@@ -16,9 +16,11 @@
 //                  lane order is table order; k_key_counts then fixes the split of the two-part flow
 //   k_key_place    one lane per signature: writes itself into its table's lane range (perm / ptab) or
 //                  appends itself to the list of the general kernel (left)
-//   k_key_chain / k_key_odd / k_key_invert / k_key_scale   the tables: key validation as NewPublicKey
+//   k_key_chain / k_key_odd / k_key_cofactors / k_key_scale   the tables: key validation as NewPublicKey
 //                  (secec.go:188-216, point_s11n.go:298-307), the chain of 116 doublings per key, the eight
-//                  8-entry tables of odd multiples, ONE inversion for the key's 65 points, beta*x column
+//                  8-entry tables of odd multiples, NO inversion: the key's 65 points are brought to one common
+//                  Z (the product W of the nine Z the build produces) and stored as affine points of the curve
+//                  isomorphic by W; beta*x column
 //
 // Nothing here touches the host between the launches; the counts stay on the device and the
 // ladder kernels read them.
@@ -283,12 +285,16 @@ k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __
 //                affine: neither the doubling nor the addition formula contains the curve constant b,
 //                so this computes on the curve isomorphic by the base's Z, and the chunk's points end
 //                up with the common Z_total = Z_7 * C * Z_base (scratch slot c)
-//   k_key_invert lane per key: the nine Z_total (eight chunks and the lead point) inverted together
-//                (Montgomery's trick, prefix products in scratch slots 9..16); the lead point made affine
-//   k_key_scale  lane per (key, chunk): the scaling pass of k_key_odd's table starts from 1 / Z_total
-//                instead of 1: the points come out affine on secp256k1 itself; beta*x column
-// Cost per key: 116 doublings, 8 * (1 doubling + 7 additions), 1 inversion, ~7 products per point.
-constexpr int KT_SCR = KT_ENTRIES;   // first scratch entry
+//   k_key_cofactors lane per key: for each of the nine Z_total (eight chunks and the lead point) the product of the
+//                other eight, W / Z_total, by prefix and suffix products (23 products; the inversion this replaces was
+//                ~10 k instructions of one serial lane per key on the critical path); W itself stays in the table
+//                (scratch element KT_W_SLOT); the lead point is finished here
+//   k_key_scale  lane per (key, chunk): the scaling pass of k_key_odd's table starts from W / Z_total
+//                instead of 1: the points come out as (W^2 x, W^3 y), i.e. affine on the curve y^2 = x^3 + 7 W^6
+//                that (x, y) -> (W^2 x, W^3 y) maps secp256k1 onto; beta*x column (beta commutes with the map).
+//                The ladder's formulas (a = 0, no curve constant) run on that curve unchanged and its result
+//                (X, Y, Z) is the secp256k1 point (X, Y, Z W): one product per signature.
+// Cost per key: 116 doublings, 8 * (1 doubling + 7 additions), 23 products, ~7 products per point.
 S2K_DEV uint4* kt_scratch(uint4* kt, int slot, int& which) {   // 21 field elements in the 7 scratch entries
   which = slot % 3;
   return kt + (size_t)(KT_SCR + slot / 3) * 8;
@@ -424,38 +430,36 @@ k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t p
 }
 
 __global__ void __launch_bounds__(64)
-k_key_invert(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
+k_key_cofactors(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
   uint32_t lo, hi;
   table_range(counters, max_tables, part, nparts, lo, hi);
   const uint32_t t = lo + blockIdx.x * 64 + threadIdx.x;
   if (t >= hi) return;
   uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
-  // everything this lane needs is loaded up front (nine independent loads: one memory latency instead of the thirty a
-  // load-multiply-store chain through the scratch entries paid), the prefix products stay in registers
-  fe29 z[KT_CHUNKS], pre[KT_CHUNKS];
+  // everything this lane needs is loaded up front (nine independent loads: one memory latency)
+  fe29 z[KT_CHUNKS + 1], pre[KT_CHUNKS + 1];
 #pragma unroll
   for (int c = 0; c < KT_CHUNKS; ++c) z[c] = scr_load(kt, c);
   uint4* el = kt + (size_t)KT_LEAD * 8;
-  const fe29 zl = ke_load(el, TB_BX), lx = ke_load(el, TB_X), ly = ke_load(el, TB_Y);
+  fe29 lx, ly;
+  ke_load3(el, lx, ly, z[KT_CHUNKS]);
   pre[0] = z[0];
 #pragma unroll
-  for (int c = 1; c < KT_CHUNKS; ++c) pre[c] = fe29_mul(pre[c - 1], z[c]);
-  fe29 inv = fe29_inv_gcd(fe29_mul(pre[KT_CHUNKS - 1], zl));   // safegcd (fe29_inv.h): a third of the Fermat chain, and this kernel is one serial lane per key
-  {
-    fe29 zi = fe29_mul(inv, pre[KT_CHUNKS - 1]);
-    inv = fe29_mul(inv, zl);
-    fe29 zi2 = fe29_sqr(zi);
-    fe29 x = fe29_mul(lx, zi2);
-    fe29 y = fe29_mul(fe29_mul(ly, zi2), zi);
-    ke_store(el, TB_X, x);
-    ke_store(el, TB_Y, y);
-    ke_store(el, TB_BX, fe29_mul(x, fe29_from_words(FE_BETA)));
-  }
+  for (int c = 1; c <= KT_CHUNKS; ++c) pre[c] = fe29_mul(pre[c - 1], z[c]);   // z_0 ... z_c
+  scr_store(kt, KT_W_SLOT, pre[KT_CHUNKS]);                                    // W
+  fe29 suf = fe29_one();                                                       // z_(c+1) ... z_8
 #pragma unroll
-  for (int c = KT_CHUNKS - 1; c >= 0; --c) {
-    fe29 zi = c > 0 ? fe29_mul(inv, pre[c - 1]) : inv;   // 1 / Z_total of chunk c
-    if (c > 0) inv = fe29_mul(inv, z[c]);
-    scr_store(kt, c, zi);
+  for (int c = KT_CHUNKS; c >= 0; --c) {
+    const fe29 co = c == KT_CHUNKS ? pre[c - 1] : (c > 0 ? fe29_mul(pre[c - 1], suf) : suf);   // W / z_c
+    if (c == KT_CHUNKS) {   // the lead point, finished here
+      const fe29 s2 = fe29_sqr(co);
+      const fe29 x = fe29_mul(lx, s2);
+      const fe29 y = fe29_mul(fe29_mul(ly, s2), co);
+      ke_store3(el, x, y, fe29_mul(x, fe29_from_words(FE_BETA)));
+    } else {
+      scr_store(kt, c, co);
+    }
+    if (c > 0) suf = c == KT_CHUNKS ? z[c] : fe29_mul(suf, z[c]);
   }
 }
 
@@ -469,14 +473,20 @@ k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t
   uint4* e0 = kt + (size_t)(c * 8) * 8;
   const fe29 beta = fe29_from_words(FE_BETA);
   fe29 rr = scr_load(kt, (int)c);
+  // entry j - 1 is in flight while entry j is scaled (a lane walks its eight entries one after the other: with the
+  // load at the top of each step the kernel waited for memory eight times per lane)
+  fe29 ex, ey, eh;
+  ke_load3(e0 + (size_t)7 * 8, ex, ey, eh);
 #pragma unroll 1
   for (int j = 7; j >= 0; --j) {
     uint4* e = e0 + (size_t)j * 8;
+    const fe29 cx = ex, cy = ey, ch = eh;
+    if (j > 0) ke_load3(e - 8, ex, ey, eh);
     fe29 r2 = fe29_sqr(rr);
     fe29 r3 = fe29_mul(r2, rr);
-    fe29 x = fe29_mul(ke_load(e, TB_X), r2);
-    fe29 y = fe29_mul(ke_load(e, TB_Y), r3);
-    if (j > 0) rr = fe29_mul(rr, ke_load(e, TB_BX));   // H_j: entry j - 1 sits one addition lower
+    fe29 x = fe29_mul(cx, r2);
+    fe29 y = fe29_mul(cy, r3);
+    if (j > 0) rr = fe29_mul(rr, ch);                  // H_j: entry j - 1 sits one addition lower
     ke_store3(e, x, y, fe29_mul(x, beta));
   }
 }
@@ -636,7 +646,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
   k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
-  k_key_invert<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+  k_key_cofactors<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());

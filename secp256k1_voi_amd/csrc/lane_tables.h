@@ -100,6 +100,16 @@ S2K_DEV fe29 ke_load(const uint4* __restrict__ e, int which) {
   r.n[8] = reinterpret_cast<const uint32_t*>(e + 6)[which];
   return r;
 }
+// a whole entry in seven 16-byte loads
+S2K_DEV void ke_load3(const uint4* __restrict__ e, fe29& x, fe29& y, fe29& bx) {
+  const uint4 a = e[0], b = e[1], c = e[2], d = e[3], f = e[4], g = e[5], t = e[6];
+  x.n[0] = a.x; x.n[1] = a.y; x.n[2] = a.z; x.n[3] = a.w; x.n[4] = b.x; x.n[5] = b.y; x.n[6] = b.z; x.n[7] = b.w;
+  y.n[0] = c.x; y.n[1] = c.y; y.n[2] = c.z; y.n[3] = c.w; y.n[4] = d.x; y.n[5] = d.y; y.n[6] = d.z; y.n[7] = d.w;
+  bx.n[0] = f.x; bx.n[1] = f.y; bx.n[2] = f.z; bx.n[3] = f.w; bx.n[4] = g.x; bx.n[5] = g.y; bx.n[6] = g.z; bx.n[7] = g.w;
+  x.n[8] = t.x;
+  y.n[8] = t.y;
+  bx.n[8] = t.z;
+}
 S2K_DEV void ke_load_xy(const uint4* __restrict__ e, bool lam, fe29& x, fe29& y) {
   const uint4* qx = e + (lam ? 4 : 0);
   uint4 a = qx[0], b = qx[1], c = e[2], d = e[3], t = e[6];
