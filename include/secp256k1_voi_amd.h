@@ -189,7 +189,11 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx *ctx, const s2k_keyset *ks, siz
  * 8.4-9.5 ms against 5.2-5.7 resident; from pinned memory the copies are asynchronous and the batch is processed in one
  * grouped call whose table phase overlaps the transfer of the digests and signatures.  s2k_host_alloc / s2k_host_free:
  * hipHostMalloc / hipHostFree (NULL on failure).  s2k_host_register / s2k_host_unregister: pin memory the caller
- * already owns (e.g. a Go slice held for the call: pass &slice[0]); unregister before the memory is freed or moved.
+ * already owns; unregister before the memory is freed or moved.  The buffer must start on a page boundary and cover
+ * whole pages (S2K_ERR_ARG otherwise): the runtime pins and unmaps pages, and a block of the C or Go heap shares its
+ * first and last page with its neighbours - on ROCm 7.2 a later pageable copy from such a re-used page takes the
+ * process down with a GPU memory access fault.  Memory from mmap / aligned_alloc(page, k * page) qualifies; a Go
+ * slice does not (take the buffers from s2k_host_alloc instead).
  * s2k_ecdsa_verify_batch detects pinned buffers by itself (all four inputs must be pinned). */
 void *s2k_host_alloc(size_t bytes);
 void s2k_host_free(void *p);

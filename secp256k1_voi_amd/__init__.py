@@ -52,11 +52,30 @@ def pinned_array(shape, dtype=np.uint8) -> np.ndarray:
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
+def page_aligned_array(shape, dtype=np.uint8) -> np.ndarray:
+    """A numpy array that owns whole pages (anonymous mmap, length rounded up to the page size): the kind of buffer to
+    hand to host_register.  Registering a piece of the C heap pins and later unmaps pages that the allocator goes on
+    using for other blocks (see s2k_host_register in the header)."""
+    import mmap
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    page = mmap.PAGESIZE
+    m = mmap.mmap(-1, max((nbytes + page - 1) // page * page, page))
+    return np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 def host_register(a: np.ndarray) -> None:
     """Pin an existing (contiguous) array for asynchronous copies (s2k_host_register); undo with host_unregister
-    before the array is released."""
+    before the array is released.  The array must own whole pages (page_aligned_array); a heap array is refused."""
+    import mmap
     lib = load_library()
-    if lib.s2k_host_register(a.ctypes.data, a.nbytes) != 0:
+    nbytes, base = a.nbytes, a
+    while getattr(base, "base", None) is not None:
+        base = base.base
+    if isinstance(base, memoryview):
+        base = base.obj
+    if isinstance(base, mmap.mmap) and a.ctypes.data % mmap.PAGESIZE == 0:
+        nbytes = (nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE   # the mapping owns the rest of its last page
+    if lib.s2k_host_register(a.ctypes.data, nbytes) != 0:
         raise EngineError(lib.s2k_last_error(None).decode())
 
 

@@ -12,6 +12,7 @@
 #include <new>
 
 #include <sys/random.h>
+#include <unistd.h>
 
 #include <mutex>
 
@@ -2058,6 +2059,14 @@ void s2k_host_free(void* p) {
 }
 int s2k_host_register(void* p, size_t bytes) {
   if (!p || !bytes) return fail(nullptr, S2K_ERR_ARG, "s2k_host_register: null buffer");
+  // Whole pages only.  The runtime pins and, on unregister, unmaps PAGES: registering a block of the C heap takes the
+  // neighbouring blocks of its first and last page along.  Seen on ROCm 7.2 / MI355X: four small malloc'ed arrays
+  // registered and unregistered, the allocator hands the same pages out again as part of a 2 MB block, and a plain
+  // pageable hipMemcpy from that block dies with a GPU memory access fault (tests/test_gpu_round3.py history).
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  if (((uintptr_t)p % page) || (bytes % page))
+    return fail(nullptr, S2K_ERR_ARG, "s2k_host_register: buffer must start on a page boundary and cover whole pages (%zu bytes): "
+                                      "register memory that owns its pages (mmap, aligned_alloc), or use s2k_host_alloc", page);
   hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
   if (e != hipSuccess) {
     (void)hipGetLastError();

@@ -76,3 +76,24 @@ def test_hot_kernel_register_budget():
     assert vgpr <= 168 and spill == 0 and scratch == 0, fast[0]
     acc = [v for k, v in info.items() if "k_msm_accumulate" in k]
     assert acc and acc[0][0] <= 168 and acc[0][2] == 0 and acc[0][3] == 0, acc
+
+
+def test_host_register_refuses_heap_blocks():
+    """s2k_host_register takes whole pages only (the check precedes every HIP call, so it runs without a GPU): a numpy
+    heap array is refused with S2K_ERR_ARG, and so is a page-aligned buffer whose length is not a multiple of the page.
+    (Why: tests/test_gpu_round3.py::test_host_buffers_pinned_registered_pageable and the header.)"""
+    import numpy as np
+    import secp256k1_voi_amd as S
+    lib = S.load_library()
+    a = np.zeros(300 * 64 + 8, dtype=np.uint8)[8:]           # never page aligned and whole-paged at once
+    assert lib.s2k_host_register(a.ctypes.data, a.nbytes) == -3          # S2K_ERR_ARG
+    assert b"page" in lib.s2k_last_error(None)
+    b = S.page_aligned_array((8192,))
+    assert b.ctypes.data % 4096 == 0
+    assert lib.s2k_host_register(b.ctypes.data, 5000) == -3
+    try:
+        S.host_register(a)
+    except S.EngineError as e:
+        assert "page" in str(e)
+    else:
+        raise AssertionError("heap array accepted")

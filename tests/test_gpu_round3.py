@@ -45,7 +45,9 @@ def test_host_buffers_pinned_registered_pageable(eng, oracle, n):
     pinned = [S.pinned_array(a.shape) for a in arrs]
     for d, a in zip(pinned, arrs):
         d[...] = a
-    registered = [a.copy() for a in arrs]
+    registered = [S.page_aligned_array(a.shape) for a in arrs]   # buffers that own their pages (see s2k_host_register)
+    for d, a in zip(registered, arrs):
+        d[...] = a
     for a in registered:
         S.host_register(a)
     try:

@@ -12,7 +12,9 @@ arrs[2][5, 7] ^= 1                          # one bad signature: verdicts are no
 pinned = [S.pinned_array(a.shape) for a in arrs]
 for d, a in zip(pinned, arrs):
     d[...] = a
-registered = [a.copy() for a in arrs]
+registered = [S.page_aligned_array(a.shape) for a in arrs]   # whole pages (s2k_host_register refuses heap blocks)
+for d, a in zip(registered, arrs):
+    d[...] = a
 ref = None
 for mode, name in ((S.KEYS_OFF, "grouping off"), (S.KEYS_AUTO, "grouping auto")):
     eng.set_key_grouping(mode)
