@@ -367,7 +367,7 @@ def worker(args):
             "roofline": roof,
             "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)", "signatures_on_key_tables": grouping["keyed"],
                              "tables_built_per_step": grouping["tables"], "signatures_on_general_ladder": grouping["general"],
-                             "note": "signatures are grouped by public key inside every step; keys with >= 6 signatures get a "
+                             "note": "signatures are grouped by public key inside every step; keys with >= 4 signatures get a "
                                      "precomputed table (built inside the step) and their signatures a 12-doubling ladder"},
         }
         extras = world == 1 and not args.no_extras

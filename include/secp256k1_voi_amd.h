@@ -132,7 +132,7 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
  *   mode        S2K_KEYS_OFF: every signature through the general kernel (the round-1/2 path)
  *               S2K_KEYS_AUTO (default): as described
  *               S2K_KEYS_ALWAYS: tables even for keys with a single signature (tests)
- *   min_group   0 = default (6): measured break-even between 5 and 6 signatures per key
+ *   min_group   0 = default (4): measured break-even between 3 and 4 signatures per key
  *   hash_bits   0 = default (slots >= 2n); smaller values force probe chains (tests)
  *   max_tables  0 = default (2^18 tables of 9 KiB).  The threshold is raised until n / threshold tables
  *               fit: a batch of n signatures builds tables for keys with at least

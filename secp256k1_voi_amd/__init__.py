@@ -580,7 +580,7 @@ class Engine:
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         """How ecdsa_verify_batch[_device] treats signatures that share a public key (s2k_ctx_set_key_grouping):
         KEYS_OFF = every signature through the general kernel, KEYS_AUTO (default) = keys with at least
-        `min_group` (default 6, the measured break-even) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does."""
+        `min_group` (default 4, the measured break-even) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does."""
         self._check(self._lib.s2k_ctx_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
 
     def key_grouping_stats(self):

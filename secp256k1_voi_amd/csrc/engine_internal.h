@@ -252,7 +252,7 @@ constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grou
 // Signatures per key from which a table pays, measured (MI355X, 2^20 signatures, ms with tables / without):
 // 4 per key 7.94 / 8.02, 5 per key 8.08 / 8.01 (the table kernels do not scale linearly and the clock sags),
 // 6 per key 6.65 / 7.93, 8 per key 6.02 / 7.96, 16 per key 5.1 / 8.0
-constexpr uint32_t KG_MIN_GROUP = 6;
+constexpr uint32_t KG_MIN_GROUP = 4;   // measured break-even: 4 per key 7.78 against 8.14 ms without tables, 3 per key no gain
 struct key_groups {        // device pointers of one call
   uint32_t* counters;      // [KG_NKEYED] signatures on the keyed path, [KG_NTAB] tables, [KG_NLEFT] the rest
   uint32_t* perm;          // keyed lane -> signature
