@@ -9,8 +9,8 @@ pack) over one batch of synthetic signatures per GPU, inputs already resident in
 N = 1: BASELINE config 2, 2^20 verifications on one MI355X.
 N > 1: BASELINE config 5 shape, 2^21 verifications per GPU (2^24 over 8), one process per GPU
 (torch.distributed, backend nccl = RCCL); every rank verifies its own contiguous shard (no
-data-path collective) and per step the ranks all-gather the packed valid bitmap and
-all-reduce the valid count.  Started without a launcher (`python bench.py --gpus N`, no
+data-path collective) and per step the ranks all-gather the packed valid bitmap, each shard
+with its rank's valid count behind it (one collective).  Started without a launcher (`python bench.py --gpus N`, no
 RANK/WORLD_SIZE in the environment) this script starts its N rank processes itself, as fresh
 children, before anything in the parent touches a GPU; started by torch.distributed.run it
 is one of the ranks.  `--oversubscribe` (test hook for a 1-GPU box) puts rank r on device
@@ -33,6 +33,13 @@ import socket
 import subprocess
 import sys
 import time
+
+# The verification call overlaps two streams (grouping / tables beside preparation / generator part).  The HIP runtime
+# spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues, four by default, and streams that share a queue
+# run one after the other: with a process group in the process (RCCL brings streams of its own) the engine's two
+# streams ended up on one queue and the step grew from 5.00 to 5.28 ms; with eight queues it is 5.03.
+# Read by the runtime when it initialises, so set before anything touches the GPU; the package sets the same default.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -228,6 +235,7 @@ def worker(args):
     d_bitmap = torch.zeros(n // 8, dtype=torch.uint8, device=dev)
     d_count = torch.zeros(1, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    gather_scratch = {}
 
     def step(inputs=None):
         p, d, rr, ss = inputs or (d_pub, d_dig, d_r, d_s)
@@ -235,8 +243,8 @@ def worker(args):
         d_valid.zero_()
         eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(),
                                       d_valid.data_ptr(), 0, st)
-        # the only collective of the path: all-gather of the valid bitmap + all-reduce of the count
-        return gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count)
+        # the only collective of the path: one all-gather of the valid bitmap shards, each with its rank's count behind it
+        return gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count, scratch=gather_scratch)
 
     def sync():
         if dist is not None:
@@ -362,7 +370,7 @@ def worker(args):
                                       if world > 1 else " (BASELINE config 2)", n_keys),
                        "parallelism": "shard%d%s%s" % (world, " (ranks share devices, gloo: test hook)" if shared_device else "",
                                                          " (RCCL group of one: test hook)" if forced_group else ""),
-                       "inputs": "resident in HBM", "collective": "all-gather bitmap + all-reduce count per step",
+                       "inputs": "resident in HBM", "collective": "one all-gather per step: bitmap shard + valid count of every rank",
                        "build": eng._lib.s2k_build_config().decode()},
             "roofline": roof,
             "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)", "signatures_on_key_tables": grouping["keyed"],

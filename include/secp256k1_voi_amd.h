@@ -202,7 +202,7 @@ int s2k_host_unregister(void *p);
 
 /* Packs valid[n] (0/1 bytes, device) into a bitmap (bit i of byte i/8, LSB first; (n+7)/8
  * bytes, device) and writes the number of valid items to *d_count (uint64, device).  This is
- * the payload of the multi-GPU bitmap all-gather / count all-reduce. */
+ * the payload of the multi-GPU bitmap all-gather (the count travels behind the bitmap shard). */
 int s2k_pack_valid_device(s2k_ctx *ctx, size_t n, const void *d_valid, void *d_bitmap, void *d_count,
                           void *hip_stream);
 /* Bytes of the per-signature device workspace (tables, scratch, worklist) for batches of up to n signatures.  It is

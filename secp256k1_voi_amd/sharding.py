@@ -2,8 +2,8 @@
 
 Signatures are independent, so a batch is cut into contiguous index ranges, one per rank
 (one process per GPU); there is no exchange during compute.  The only collectives are at
-the end: an all-gather of the per-rank valid-bitmap shards and an all-reduce (sum) of the
-valid counts.  Works on any torch.distributed backend (nccl = RCCL over xGMI on the GPU
+the end: one all-gather of the per-rank valid-bitmap shards with the rank's valid count behind
+each (the host-side helper gather_valid keeps the two-collective form).  Works on any torch.distributed backend (nccl = RCCL over xGMI on the GPU
 box, gloo in the CPU tests).
 """
 from __future__ import annotations
@@ -73,21 +73,62 @@ def gather_valid(valid_shard, n_total: int, dist=None, device=None):
     return out, int(cnt.item())
 
 
-def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None, count=None):
+def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None, count=None, scratch=None):
     """Device-resident variant used on the hot path: `valid` is this rank's uint8 0/1 torch
-    tensor (equal shard length on every rank, a multiple of 8).  Packs the bitmap on the
-    device (engine.pack_valid_device when an Engine is given, torch ops otherwise),
-    all-gathers the shards and all-reduces the count; returns (bitmap tensor of n_total/8
-    bytes, int64 count tensor).  No host round trip.  `bitmap` / `count` may be preallocated
-    (n/8 uint8, 1 int64) to keep the step allocation-free."""
+    tensor (equal shard length on every rank, a multiple of 64).  Packs the bitmap on the
+    device (engine.pack_valid_device when an Engine is given, torch ops otherwise) and exchanges it
+    in ONE collective: the rank's valid count rides behind its bitmap shard in the same buffer
+    (all_gather_into_tensor of n/8 + 8 bytes per rank), and every rank adds up the gathered counts
+    itself - a second collective (an all_reduce of one int64) cost as much as the first: both are
+    launch latency, about 0.13 ms each per step through RCCL on MI355X.  Returns (bitmap tensor of
+    n_total/8 bytes, int64 count tensor of one element).  No host round trip on the nccl backend.
+    `bitmap` / `count` (alone) or `scratch` (a dict the caller keeps between calls; in a group) hold
+    preallocated buffers to keep the step allocation-free."""
     import torch
 
     n = valid.numel()
-    assert n % 8 == 0
-    if bitmap is None:
-        bitmap = torch.empty(n // 8, dtype=torch.uint8, device=valid.device)
-    if count is None:
-        count = torch.zeros(1, dtype=torch.int64, device=valid.device)
+    assert n % 64 == 0
+    nb = n // 8
+    if _alone(dist):
+        if bitmap is None:
+            bitmap = torch.empty(nb, dtype=torch.uint8, device=valid.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int64, device=valid.device)
+        _pack(valid, bitmap, count, engine)
+        return bitmap, count
+    world = dist.get_world_size()
+    assert n * world == n_total, "gather_valid_device needs equal shards"
+    scratch = scratch if scratch is not None else {}
+    key = ("packed", n, world, str(valid.device))
+    if scratch.get("key") != key:
+        scratch["key"] = key
+        scratch["packed"] = torch.zeros(nb + 8, dtype=torch.uint8, device=valid.device)
+        scratch["full"] = torch.empty((nb + 8) * world, dtype=torch.uint8, device=valid.device)
+        scratch["bitmap"] = torch.empty(nb * world, dtype=torch.uint8, device=valid.device)
+    packed = scratch["packed"]
+    _pack(valid, packed[:nb], packed[nb:].view(torch.int64), engine)
+    # One code path for both backends: the same collective on the same shape; the only difference is where the
+    # tensors live (gloo moves bytes between host buffers, nccl = RCCL between device buffers over xGMI).  What the
+    # 2-rank tests exercise on one GPU with gloo is therefore the logic an 8-GPU RCCL run executes.
+    on_host = dist.get_backend() == "gloo"
+    mine = packed.cpu() if on_host else packed
+    full = torch.empty(mine.numel() * world, dtype=torch.uint8) if on_host else scratch["full"]
+    dist.all_gather_into_tensor(full, mine)
+    if on_host:
+        full = full.to(valid.device)
+    rows = full.view(world, nb + 8)
+    out_bitmap = bitmap if (bitmap is not None and bitmap.numel() == nb * world) else scratch["bitmap"]
+    out_bitmap.view(world, nb).copy_(rows[:, :nb])                           # (the shards are nb + 8 bytes apart in `full`)
+    out_count = rows[:, nb:].contiguous().view(torch.int64).sum().reshape(1)
+    if count is not None:
+        count.copy_(out_count)
+        out_count = count
+    return out_bitmap, out_count
+
+
+def _pack(valid, bitmap, count, engine):
+    import torch
+    n = valid.numel()
     if engine is not None:
         engine.pack_valid_device(n, valid.data_ptr(), bitmap.data_ptr(), count.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream)
@@ -95,23 +136,6 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
         w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=valid.device)
         bitmap.copy_((valid.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8))
         count.copy_(valid.sum(dtype=torch.int64).reshape(1))
-    if _alone(dist):
-        return bitmap, count
-    world = dist.get_world_size()
-    assert n * world == n_total, "gather_valid_device needs equal shards"
-    # One code path for both backends: the same two collectives on the same shapes; the only difference is where the
-    # tensors live (gloo moves bytes between host buffers, nccl = RCCL between device buffers over xGMI).  What the
-    # 2-rank tests exercise on one GPU with gloo is therefore the logic an 8-GPU RCCL run executes.
-    on_host = dist.get_backend() == "gloo"
-    mine = bitmap.cpu() if on_host else bitmap
-    cnt = count.cpu() if on_host else count
-    full = torch.empty(mine.numel() * world, dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(full, mine)
-    dist.all_reduce(cnt)
-    if on_host:
-        full, cnt = full.to(valid.device), cnt.to(valid.device)
-        count.copy_(cnt)
-    return full, cnt
 
 
 def msm_sharded(engine, scalars, points, dist=None):

@@ -149,3 +149,46 @@ def test_two_rank_msm_and_schnorr_batch(oracle):
     for rank, total, ok_all, ok_bad in res:
         assert total == exp
         assert ok_all is True and ok_bad is False
+
+
+def _worker_device_form(rank, world, port, n, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    from secp256k1_voi_amd.sharding import gather_valid_device
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scratch = {}
+    out = []
+    for rep in range(2):                                   # second call: the kept buffers are reused
+        v = torch.from_numpy(np.random.default_rng(100 * rep + rank).integers(0, 2, n).astype(np.uint8))
+        bitmap, count = gather_valid_device(v, n * world, dist, scratch=scratch)
+        out.append((bitmap.numpy().tobytes(), int(count.item())))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_device_form_one_collective():
+    """gather_valid_device (the hot-path form: equal shards, ONE all_gather_into_tensor carrying every rank's bitmap shard
+    with its valid count behind it) in two gloo ranks on CPU tensors with the torch packing: every rank ends with the
+    concatenated bitmaps and the sum of the counts.  The nccl backend runs the same statements on device buffers."""
+    world, port, n = 2, _free_port(), 1024
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_device_form, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rep in range(2):
+        shards = [np.random.default_rng(100 * rep + r).integers(0, 2, n).astype(np.uint8) for r in range(world)]
+        exp_bits = b"".join(pack_bitmap(v).tobytes() for v in shards)
+        exp_count = int(sum(int(v.sum()) for v in shards))
+        for r in range(world):
+            assert res[r][rep] == (exp_bits, exp_count)
