@@ -17,7 +17,8 @@ using namespace s2k;
 #ifndef S2K_GT_BITS
 // Window width of the resident generator tables.  Same-box A/B on MI355X (tools/ab_gtbits.sh, ms per
 // 2^20 verifications / table size / context creation): 16 bits 9.21 / 64 MiB / 0.05 s, 20 bits 9.10 /
-// 0.8 GiB, 22 bits 9.04 / 3 GiB / 0.3 s, 24 bits 9.03 / 11 GiB / 0.9 s.
+// 0.8 GiB, 22 bits 9.04 / 3 GiB / 0.3 s, 24 bits 9.03 / 11 GiB / 0.9 s.  Grouped flow, end of round 3 (generator part
+// on the second stream, tools/gpu_variant_ab.sh): 22 bits 5.05 ms, 24 bits 5.05 ms - one addition fewer hides nowhere.
 #define S2K_GT_BITS 22
 #endif
 constexpr int GT_BITS = S2K_GT_BITS;

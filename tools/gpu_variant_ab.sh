@@ -3,7 +3,7 @@
 # 2^20 signatures of 2^16 and 2^17 keys; stage times from the engine's own events)
 V=${1:?variant name}
 export PROBE_MODES=auto
-for rep in 1 2 3 4 5; do
+for rep in 1 2 3; do
 for L in default $V; do
   if [ "$L" != default ]; then export S2K_LIB=$PWD/secp256k1_voi_amd/libsecp256k1_voi_amd.$L.so; else unset S2K_LIB; fi
   echo "== $L"
