@@ -398,7 +398,11 @@ enum {
   S2K_HP_PT29Q_DBL, S2K_HP_PT29Q_ADD,
   /* xyzz29_add_affine (xyzz29.h: the bucket pass's incomplete mixed addition): P = (a, b) lifted to ZZ = c^2, ZZZ = c^3,
    * Q = (d, e); flag = 0 when P and Q share their x (ZZ3 = 0: the piece is re-done with the complete formulas) */
-  S2K_HP_XYZZ_ADD
+  S2K_HP_XYZZ_ADD,
+  /* one round border of the keyed ladder as k_verify_fast<ECDSA_KEYED> runs it: P lifted as for XYZZ_ADD, + Q in XYZZ,
+   * XYZZ -> Jacobian, two Jacobian doublings, Jacobian -> XYZZ, + Q in XYZZ, XYZZ -> Jacobian: out = 4 P + 5 Q;
+   * flag = 0 when Z ends as 0 (P = +-Q: ZZ = 0 must survive the changes of form and the doublings) */
+  S2K_HP_XYZZ_ROUND
 };
 int s2k_fp_op_batch_ex(s2k_ctx *ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t *const in[5],
                        uint8_t *out, uint8_t *out2, uint8_t *flag);

@@ -312,6 +312,29 @@ k_fp29_op(int op, uint32_t lazy, uint32_t n, hp_args args, uint8_t* __restrict__
       }
       break;
     }
+    case S2K_HP_XYZZ_ROUND: {
+      xyzz29 xa;
+      const fe29 c2 = fe29_sqr(c), c3 = fe29_mul(c2, c);
+      xa.x = fe29_mul(a, c2);
+      xa.y = fe29_mul(b, c3);
+      xa.zz = c2;
+      xa.zzz = c3;
+      const fe29 qx = fe29_normalize_weak(d), qy = fe29_normalize_weak(e);
+      xa = xyzz29_add_affine(xa, qx, qy);
+      jpt29 j = xyzz29_to_jacobian(xa);
+      j = jpt29_double(jpt29_double(j));
+      xa = xyzz29_from_jacobian(j);
+      xa = xyzz29_add_affine(xa, qx, fe29_cond_negate1(qy, false));     // (y in the form the ladder passes it)
+      j = xyzz29_to_jacobian(xa);
+      if (fe29_is_zero(j.z)) {
+        f = 0;
+      } else {
+        const fe29 zi = fe29_inv(j.z), zi2 = fe29_sqr(zi);
+        r = fe29_mul(j.x, zi2);
+        r2 = fe29_mul(fe29_mul(j.y, zi2), zi);
+      }
+      break;
+    }
     case S2K_HP_PT29_DBL:
     case S2K_HP_PT29_ADD:
     case S2K_HP_PT29_ADD_MIXED: {
@@ -581,7 +604,7 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
   if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fp_op_batch_ex serves S2K_IMPL_FAST only (8x32: s2k_fp_op_batch)");
   const uint32_t reps = lazy >> 20;           // quad operations: bits 20.. of `lazy` = how often the operation is chained (0: once)
   lazy &= 0xfffffu;
-  if (op < 0 || op > S2K_HP_XYZZ_ADD) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (op < 0 || op > S2K_HP_XYZZ_ROUND) return fail(ctx, S2K_ERR_ARG, "bad op");
   if (n == 0) return S2K_OK;
   if (!in || !in[0] || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");

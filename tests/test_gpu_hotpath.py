@@ -328,6 +328,32 @@ def test_xyzz_mixed_addition_random_zz(eng, oracle, codes):
             assert f == 1 and (xi, yi) == R.add(p, q)
 
 
+@pytest.mark.parametrize("codes", [(0, 0, 0, 0, 0), (0, 0, 4, 0, 0), (1, 0, 1, 0, 0)])
+def test_xyzz_jacobian_round_border(eng, oracle, codes):
+    """The keyed ladder's round border as the kernel runs it: XYZZ addition, XYZZ -> Jacobian (X ZZ, Y ZZZ, ZZ), two Jacobian
+    doublings, Jacobian -> XYZZ (X, Y, Z^2, Z^3), XYZZ addition, XYZZ -> Jacobian: 4 P + 5 Q for every generic pair, and Z = 0
+    at the end for exactly the pairs whose FIRST addition is exceptional (P = +-Q): ZZ = 0 has to survive both changes of
+    form, the doublings and the second addition, because that is what sends the signature to the complete formulas."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(150)
+    pts = wycheproof_points(oracle)[:150] + curve_points(rnd, 500)
+    qs = shuffled(pts, 151)
+    for i in range(0, len(pts), 9):
+        qs[i] = pts[i] if (i // 9) % 2 == 0 else R.neg(pts[i])
+    z = [rnd.randrange(1, 2**256) for _ in pts]
+    z[:4] = [1, P - 1, 2**256 - 1, 2]
+    cols = [[b32(p[0]) for p in pts], [b32(p[1]) for p in pts], [b32(v) for v in z],
+            [b32(q[0]) for q in qs], [b32(q[1]) for q in qs]]
+    x, y, flag = eng.fp_op_batch_ex(S.HP_XYZZ_ROUND, cols, lazy(*codes))
+    for p, q, xi, yi, f in zip(pts, qs, ints(x), ints(y), flag):
+        if p[0] == q[0]:
+            assert f == 0
+        else:
+            s = R.add(p, q)
+            s4 = R.add(R.add(s, s), R.add(s, s))
+            assert f == 1 and (xi, yi) == R.add(s4, q)
+
+
 # ---- scalars: odd GLV split and safegcd inversion ----
 def test_split_glv_odd(eng):
     """sc_split_glv_odd (hot path): k == +-k1 +- k2*lambda (mod n), k1 and k2 odd and below 2^129, for the
