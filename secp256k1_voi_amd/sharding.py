@@ -75,7 +75,7 @@ def gather_valid(valid_shard, n_total: int, dist=None, device=None):
 
 def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None, count=None, scratch=None):
     """Device-resident variant used on the hot path: `valid` is this rank's uint8 0/1 torch
-    tensor (equal shard length on every rank, a multiple of 64).  Packs the bitmap on the
+    tensor (equal shard length on every rank; a multiple of 8, in a group of 64).  Packs the bitmap on the
     device (engine.pack_valid_device when an Engine is given, torch ops otherwise) and exchanges it
     in ONE collective: the rank's valid count rides behind its bitmap shard in the same buffer
     (all_gather_into_tensor of n/8 + 8 bytes per rank), and every rank adds up the gathered counts
@@ -87,7 +87,7 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
     import torch
 
     n = valid.numel()
-    assert n % 64 == 0
+    assert n % 8 == 0
     nb = n // 8
     if _alone(dist):
         if bitmap is None:
@@ -98,6 +98,7 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
         return bitmap, count
     world = dist.get_world_size()
     assert n * world == n_total, "gather_valid_device needs equal shards"
+    assert n % 64 == 0, "in a group the shard length must be a multiple of 64 (the count sits 8-byte aligned behind the bitmap)"
     scratch = scratch if scratch is not None else {}
     key = ("packed", n, world, str(valid.device))
     if scratch.get("key") != key:
