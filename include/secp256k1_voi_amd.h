@@ -134,7 +134,7 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
  *               S2K_KEYS_ALWAYS: tables even for keys with a single signature (tests)
  *   min_group   0 = default (4): measured break-even between 3 and 4 signatures per key
  *   hash_bits   0 = default (slots >= 2n); smaller values force probe chains (tests)
- *   max_tables  0 = default (2^18 tables of 9 KiB).  The threshold is raised until n / threshold tables
+ *   max_tables  0 = default (2^22 tables of 9 KiB; the buffer is sized by the batch: n / min_group tables).  The threshold is raised until n / threshold tables
  *               fit: a batch of n signatures builds tables for keys with at least
  *               max(min_group, ceil(n / max_tables)) signatures */
 #define S2K_KEYS_OFF 0
@@ -211,7 +211,7 @@ size_t s2k_ecdsa_workspace_bytes(size_t n);
 /* Device memory the context holds once it has verified a batch of n signatures with its current key-grouping
  * settings (s2k_ctx_set_key_grouping): the resident generator tables (3 GiB), the per-signature workspace above, and -
  * with the grouping on, the default, for n >= 256 - the grouping arrays and the per-key table buffer (n / min_group
- * tables of 9 KiB, at most max_tables: 1.6 GB at n = 2^20, whether or not keys repeat).  The multi-scalar and BIP-340
+ * tables of 9 KiB, at most max_tables: 2.4 GB at n = 2^20, 38 GB at 2^24, whether or not keys repeat).  The multi-scalar and BIP-340
  * batch entry points keep a workspace of their own on top (about 1.4 KB per term).  Size HBM by this, not by
  * s2k_ecdsa_workspace_bytes alone, when several contexts share a device. */
 size_t s2k_ctx_device_bytes(const s2k_ctx *ctx, size_t n);

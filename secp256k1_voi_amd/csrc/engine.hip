@@ -1858,7 +1858,7 @@ int s2k_ctx_set_key_grouping(s2k_ctx* ctx, int mode, uint32_t min_group, uint32_
   ctx->kg_mode = mode;
   ctx->kg_min_group = min_group;
   ctx->kg_hash_bits = hash_bits;
-  ctx->kg_max_tables = max_tables ? max_tables : (1u << 18);
+  ctx->kg_max_tables = max_tables ? max_tables : KG_MAX_TABLES_DEFAULT;
   return S2K_OK;
 }
 

@@ -13,6 +13,11 @@
 
 using namespace s2k;
 
+// Most per-key tables a verification call builds (9 KiB each: 36 GiB at the cap; the buffer is sized by the batch,
+// n / min_group tables, so a 2^20 batch holds 2.4 GB whatever this says).  Was 2^18 until the end of round 3: a batch of
+// 2^24 signatures of 2^20 keys then built no tables at all (threshold raised to 64 per key) and took 129 ms instead of 80.
+constexpr uint32_t KG_MAX_TABLES_DEFAULT = 1u << 22;
+
 // ---- generator tables (layout: engine.hip) ----
 #ifndef S2K_GT_BITS
 // Window width of the resident generator tables.  Same-box A/B on MI355X (tools/ab_gtbits.sh, ms per
@@ -98,7 +103,7 @@ struct s2k_ctx {
   bool msm_prof_on = false;
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
   int kg_mode = S2K_KEYS_AUTO;
-  uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = 1u << 18;
+  uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = KG_MAX_TABLES_DEFAULT;
   uint64_t kg_seed = 0;              // hash seed of the key grouping (operating-system randomness, per context)
   hipStream_t s_aux = nullptr;       // scalar preparation runs here, beside the grouping and the table kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_part0 = nullptr, ev_part1 = nullptr;
