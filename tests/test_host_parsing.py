@@ -96,3 +96,44 @@ def test_bip0066_vectors(oracle):
         assert not S.is_valid_signature_encoding_bip0066(H(v["der"]) + b"\x45"), v["exception"]
     assert not S.is_valid_signature_encoding_bip0066(b"")
     assert not S.is_valid_signature_encoding_bip0066(bytes(74))
+
+
+def test_bip340_challenge_midstate_constant():
+    """csrc/sha256.h starts every BIP-340 challenge hash from a constant state instead of compressing the block
+    SHA256(tag) || SHA256(tag) per signature: the constant in the header must be that state (FIPS 180-4 compression
+    re-done here), and hashing on from it must give hashlib's digest of the whole tagged message."""
+    import hashlib
+    import os
+    import re
+    import struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "secp256k1_voi_amd", "csrc", "sha256.h")).read()
+
+    def table(name):
+        m = re.search(name + r"\[\d+\]\s*=\s*\{([^}]*)\}", src)
+        return [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",") if x.strip()]
+    K, IV, mid = table("SHA256_K"), table("SHA256_IV"), table("BIP340_CHALLENGE_MIDSTATE")
+    assert len(K) == 64 and len(IV) == 8 and len(mid) == 8
+    rotr = lambda x, n: ((x >> n) | (x << (32 - n))) & 0xFFFFFFFF
+
+    def compress(st, block):
+        w = list(struct.unpack(">16I", block))
+        for i in range(16, 64):
+            s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)
+            s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10)
+            w.append((w[i - 16] + s0 + w[i - 7] + s1) & 0xFFFFFFFF)
+        a, b, c, d, e, f, g, h = st
+        for i in range(64):
+            t1 = (h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i]) & 0xFFFFFFFF
+            t2 = ((rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))) & 0xFFFFFFFF
+            h, g, f, e, d, c, b, a = g, f, e, (d + t1) & 0xFFFFFFFF, c, b, a, (t1 + t2) & 0xFFFFFFFF
+        return [(x + y) & 0xFFFFFFFF for x, y in zip(st, [a, b, c, d, e, f, g, h])]
+    tag = hashlib.sha256(b"BIP0340/challenge").digest()
+    assert compress(IV, tag + tag) == mid
+    body = bytes(range(96)) + b"message"
+    msg = body + b"\x80"
+    msg += b"\0" * ((56 - len(msg)) % 64) + struct.pack(">Q", (64 + len(body)) * 8)
+    st = mid
+    for i in range(0, len(msg), 64):
+        st = compress(st, msg[i:i + 64])
+    assert b"".join(struct.pack(">I", x) for x in st) == hashlib.sha256(tag + tag + body).digest()
