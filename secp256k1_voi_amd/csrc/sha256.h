@@ -21,7 +21,9 @@ __device__ static const uint32_t SHA256_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef
                                                  0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 // The hash state after the first block of every BIP-340 challenge, SHA256("BIP0340/challenge") twice
 // (7bb52d7a 9fef5832 3eb1bf7a 407db382 d2f3f2d8 1bb1224f 49fe518f 6d48d37c as big-endian words): a constant, so the
-// compression of that block is not run per signature (tools: the value is re-derived by tests/test_host_parsing.py).
+// compression of that block is not run per signature.  (The compiler had been folding that compression at compile time
+// already - the instruction count of the preparation kernel did not move, 669.7 M before and after - so this states in
+// the source what the binary did; the value is re-derived by tests/test_host_parsing.py.)
 __device__ static const uint32_t BIP340_CHALLENGE_MIDSTATE[8] = {0x9cecba11u, 0x23925381u, 0x11679112u, 0xd1627e0fu,
                                                                  0x97c87550u, 0x003cc765u, 0x90f61164u, 0x33e9b66au};
 
