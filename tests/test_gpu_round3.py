@@ -334,3 +334,44 @@ def test_schnorr_batch_randomised_stress():
     valid batch, rejects it with damaged signatures) and the bisection (per-signature verdicts equal the per-signature verifier's)."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_rlc.py"), "25", "77"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "ok:" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_full_size_ragged_keys_differential_vs_oracle(eng, oracle):
+    """2^20 signatures whose keys repeat 1, 3, 4 (the table threshold), 5, 64 and 2048 times, shuffled together, one in
+    six damaged (bit flips in r / s / digest / key, another signer's key): the batch splits between the per-key tables
+    and the general ladder inside one call, and every verdict must be the CPU oracle's - with the grouping on (default
+    threshold), forced, and off."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    parts = [(1 << 18, 1 << 18), (3 << 16, 1 << 16), (1 << 18, 1 << 16), (5 << 14, 1 << 14), (1 << 17, 1 << 11), (1 << 16, 1 << 5)]
+    used = sum(p[0] for p in parts)
+    parts.append(((1 << 20) - used, max(((1 << 20) - used) >> 3, 1)))
+    cols = [[], [], [], []]
+    for j, (m, k) in enumerate(parts):
+        for c, a in zip(cols, synth_batch(eng, m, k, seed=900 + j)):
+            c.append(np.array(a))
+    pub, dig, r, s = (np.concatenate(c) for c in cols)
+    n = pub.shape[0]
+    assert n == 1 << 20
+    rng = np.random.default_rng(901)
+    perm = rng.permutation(n)
+    pub, dig, r, s = pub[perm], dig[perm], r[perm], s[perm]
+    kind = rng.integers(0, 30, size=n)
+    idx = lambda k: np.nonzero(kind == k)[0]
+    for k, a in ((0, r), (1, s), (2, dig), (3, pub)):
+        i = idx(k)
+        a[i, rng.integers(0, a.shape[1], size=i.size)] ^= (1 << rng.integers(0, 8, size=i.size)).astype(np.uint8)
+    i = idx(4)
+    pub[i] = pub[(i + 12345) % n]
+    exp = oracle.ecdsa_verify_batch(pub, dig, r, s, nthreads=os.cpu_count() or 1)
+    assert 0 < int(exp.sum()) < n and exp[kind >= 5].all()
+    try:
+        for mode in (S.KEYS_AUTO, S.KEYS_ALWAYS, S.KEYS_OFF):
+            eng.set_key_grouping(mode)
+            got = eng.ecdsa_verify_batch(pub, dig, r, s)
+            assert np.array_equal(got, exp), (mode, np.nonzero(got != exp)[0][:10])
+            st = eng.key_grouping_stats()
+            if mode == S.KEYS_AUTO:
+                assert st["keyed"] > 0 and st["general"] > 0, st      # both ladders took part
+    finally:
+        eng.set_key_grouping(S.KEYS_AUTO)
