@@ -685,23 +685,21 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   if constexpr (KEYED) {
     // k = 16^32 + sum_i d_i 16^i with d_i = 2 nib_i - 15, i = 4c + j: round j (3 down to 0) adds
     // d_(4c+j) * 2^(16c) Q for the eight chunks c, with four doublings between rounds; the leading
-    // 16^32 Q = 16^3 * 2^116 Q goes in first.
+    // 16^32 Q = 16^3 * 2^116 Q goes in first (for both halves at once: one table point, see below).
     const uint4* kt = kg.ktab + (size_t)kg.ptab[idx] * (KT_SLOTS * 8);
     digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);
     const fe29 kw = ke_load(kt + (size_t)(KT_SCR + KT_W_SLOT / 3) * 8, KT_W_SLOT % 3);   // wanted at the very end: asked for early
-    // The 66 additions of this ladder run in XYZZ coordinates (xyzz29.h: 8 M + 2 S in 9 reductions against 8 M + 3 S in
+    // The 64 additions of this ladder run in XYZZ coordinates (xyzz29.h: 8 M + 2 S in 9 reductions against 8 M + 3 S in
     // 10 for the Jacobian mixed addition: 1 441 instead of 1 578 instructions); the 12 doublings stay Jacobian (7 products
     // against 9), so the accumulator changes form at the three round borders (3 M + 1 S each way together).  The
     // exceptional-case rule carries over: equal x makes ZZ = 0, ZZ = 0 is sticky through additions, conversions and
     // doublings, and ends as Z = 0 -> worklist.
-#ifndef S2K_KEYED_JACOBIAN_ADDS
     xyzz29 xa;
     {
-      fe29 lx, ly, lbx, ly2;
-      ke_load_xy(kt + (size_t)KT_LEAD * 8, false, lx, ly);
-      ke_load_xy(kt + (size_t)KT_LEAD * 8, true, lbx, ly2);
+      // +-L +- phi(L): the table holds L + phi(L) and L - phi(L) (keyed.hip), the other two are their negatives
+      fe29 lx, ly;
+      ke_load_xy(kt + (size_t)(neg1 == neg2 ? KT_LEAD : KT_LEAD + 1) * 8, false, lx, ly);
       xa = xyzz29_from_affine(lx, fe29_cond_negate1(ly, neg1));
-      xa = xyzz29_add_affine(xa, lbx, fe29_cond_negate1(ly2, neg2));
     }
 #pragma unroll 1
     for (int round = 0; round < 4; ++round) {
@@ -726,37 +724,6 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       }
     }
     acc = xyzz29_to_jacobian(xa);
-#else
-    {
-      fe29 lx, ly, lbx, ly2;
-      ke_load_xy(kt + (size_t)KT_LEAD * 8, false, lx, ly);
-      ke_load_xy(kt + (size_t)KT_LEAD * 8, true, lbx, ly2);
-      acc.x = lx;
-      acc.y = fe29_cond_negate1(ly, neg1);
-      acc.z = fe29_one();
-      acc = jpt29_add_affine(acc, lbx, fe29_cond_negate1(ly2, neg2));
-    }
-#pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
-      if (round) {
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) acc = jpt29_double(acc);
-      }
-#pragma unroll 1
-      for (int c = 0; c < KT_CHUNKS; ++c) {
-        uint32_t w1 = ds4_next(d1), w2 = ds4_next(d2);
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-          uint32_t w = t ? w2 : w1;
-          bool neg = (t ? neg2 : neg1) != (w < 8u);
-          uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
-          fe29 x, y;
-          ke_load_xy(kt + (size_t)(c * 8 + entry) * 8, t != 0, x, y);
-          acc = jpt29_add_affine(acc, x, fe29_cond_negate1(y, neg));
-        }
-      }
-    }
-#endif
     // the table's points are affine on the curve isomorphic by W (keyed.hip): back on secp256k1 itself
     acc.z = fe29_mul(acc.z, kw);
   } else {

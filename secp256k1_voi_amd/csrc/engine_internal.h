@@ -247,10 +247,10 @@ inline int ctx_stage(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** ptr
 // the recoding's leading digit, all affine (one shared inversion per key) with their beta*x column.
 // A signature's ladder is then 12 doublings instead of 128 around the same 66 additions.
 constexpr int KT_CHUNKS = 8;
-constexpr int KT_LEAD = KT_CHUNKS * 8;          // entry of 2^116 Q
-constexpr int KT_ENTRIES = KT_LEAD + 1;
-constexpr int KT_SLOTS = 72;                    // entries of 128 bytes reserved per key: 65 + 7 of build scratch
-constexpr int KT_SCR = KT_ENTRIES;              // first scratch entry: 21 field elements, three per entry (keyed.hip: kt_scratch)
+constexpr int KT_LEAD = KT_CHUNKS * 8;          // entries of L + phi(L) and (KT_LEAD + 1) L - phi(L), L = 2^116 Q: the two starting points of a ladder
+constexpr int KT_ENTRIES = KT_LEAD + 2;
+constexpr int KT_SLOTS = 72;                    // entries of 128 bytes reserved per key: 66 + 6 of build scratch
+constexpr int KT_SCR = KT_ENTRIES;              // first scratch entry: 18 field elements, three per entry (keyed.hip: kt_scratch)
 constexpr int KT_W_SLOT = 9;                    // scratch element that stays part of the table: W, the Z all entries of the key share
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;

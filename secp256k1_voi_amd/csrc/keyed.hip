@@ -276,10 +276,11 @@ k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __
 
 // ---- per-key tables ----
 // Entry layout: lane_tables.h (x, y, beta*x in eight quads).  Entries 8c + j (c < 8, j < 8) hold
-// (2j + 1) * 2^(16c) Q, entry 64 holds 2^116 Q.  Four launches (only the first is a serial chain per key;
+// (2j + 1) * 2^(16c) Q, entries 64 and 65 hold L + phi(L) and L - phi(L) for L = 2^116 Q.  Four launches (only the first is a serial chain per key;
 // one lane doing everything took 1.5 ms for 2^16 keys, latency bound at one wave per SIMD):
 //   k_key_chain  lane per key: key validation, doubling chain from Q; the Jacobian 2^(16c) Q (c = 1..7)
-//                and 2^116 Q are parked in the entries 8c and 64 (X, Y, and Z in the beta*x slot)
+//                are parked in the entries 8c (X, Y, and Z in the beta*x slot), the two lead points (one co-Z
+//                addition of L and phi(L), common Z) in the entries 64 and 65
 //   k_key_odd    lane per (key, chunk): the common-Z table of odd multiples exactly as k_verify_fast
 //                builds its per-signature table, started from the base's JACOBIAN X, Y as if they were
 //                affine: neither the doubling nor the addition formula contains the curve constant b,
@@ -288,14 +289,14 @@ k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __
 //   k_key_cofactors lane per key: for each of the nine Z_total (eight chunks and the lead point) the product of the
 //                other eight, W / Z_total, by prefix and suffix products (23 products; the inversion this replaces was
 //                ~10 k instructions of one serial lane per key on the critical path); W itself stays in the table
-//                (scratch element KT_W_SLOT); the lead point is finished here
+//                (scratch element KT_W_SLOT); the two lead points are finished here
 //   k_key_scale  lane per (key, chunk): the scaling pass of k_key_odd's table starts from W / Z_total
 //                instead of 1: the points come out as (W^2 x, W^3 y), i.e. affine on the curve y^2 = x^3 + 7 W^6
 //                that (x, y) -> (W^2 x, W^3 y) maps secp256k1 onto; beta*x column (beta commutes with the map).
 //                The ladder's formulas (a = 0, no curve constant) run on that curve unchanged and its result
 //                (X, Y, Z) is the secp256k1 point (X, Y, Z W): one product per signature.
 // Cost per key: 116 doublings, 8 * (1 doubling + 7 additions), 23 products, ~7 products per point.
-S2K_DEV uint4* kt_scratch(uint4* kt, int slot, int& which) {   // 21 field elements in the 7 scratch entries
+S2K_DEV uint4* kt_scratch(uint4* kt, int slot, int& which) {   // 18 field elements in the 6 scratch entries
   which = slot % 3;
   return kt + (size_t)(KT_SCR + slot / 3) * 8;
 }
@@ -390,10 +391,34 @@ k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const ui
     const int nd = c < KT_CHUNKS ? 16 : 4;
 #pragma unroll 1
     for (int j = 0; j < nd; ++j) cur = jpt29_double(cur);
-    uint4* e = kt + (size_t)(c * 8) * 8;     // c == 8: the lead entry
+    if (c == KT_CHUNKS) break;               // the lead point: below
+    uint4* e = kt + (size_t)(c * 8) * 8;
     ke_store(e, TB_X, cur.x);
     ke_store(e, TB_Y, cur.y);
     ke_store(e, TB_BX, cur.z);
+  }
+  // The ladder starts from +-L +- phi(L), L = 2^116 Q (the recoding's leading digit, engine.hip): instead of L and one
+  // addition per SIGNATURE, the table holds L + phi(L) and L - phi(L) (the other two combinations are their negatives).
+  // L = (X, Y, Z) and phi(L) = (beta X, Y, Z) share their Z, so both sums come from one co-Z addition (Meloni):
+  // with A = (X2 - X1)^2, B = X1 A, C = X2 A:  X3 = (Y2 - Y1)^2 - B - C,  Y3 = (Y2 - Y1)(B - X3) - Y1 (C - B),
+  // Z3 = Z (X2 - X1) - the same Z3 for the sum (Y2 = Y) and the difference (Y2 = -Y).  8 products per key.
+  {
+    const fe29 bx = fe29_mul(cur.x, fe29_from_words(FE_BETA));
+    const fe29 h = fe29_normalize_weak(fe29_add(bx, fe29_negate(cur.x, 1)));          // X2 - X1 [1] (never 0: no point has x = 0)
+    const fe29 z3 = fe29_mul(cur.z, h);
+    const fe29 a = fe29_sqr(h);
+    const fe29 b = fe29_mul(cur.x, a), c = fe29_mul(bx, a);
+    const fe29 bc = fe29_add(b, c);                                                   // [2]
+    const fe29 yn = fe29_normalize_weak(cur.y);                                       // [1]
+    // sum: Y2 - Y1 = 0
+    const fe29 xs = fe29_normalize_weak(fe29_negate(bc, 2));                          // -(B + C)
+    const fe29 ys = fe29_mul(fe29_negate(yn, 1), fe29_normalize_weak(fe29_add(c, fe29_negate(b, 1))));   // -Y (C - B)
+    // difference: Y2 - Y1 = -2 Y:  X3 = 4 Y^2 - B - C,  Y3 = -Y (B + C - 2 X3)
+    const fe29 xd = fe29_normalize_weak(fe29_add(fe29_sqr(fe29_mul_int(yn, 2)), fe29_negate(bc, 2)));
+    const fe29 yd = fe29_mul(fe29_negate(yn, 1), fe29_normalize_weak(fe29_add(bc, fe29_negate(fe29_mul_int(xd, 2), 2))));
+    uint4* e = kt + (size_t)KT_LEAD * 8;
+    ke_store3(e, xs, ys, z3);
+    ke_store3(e + 8, xd, yd, z3);
   }
 }
 
@@ -441,8 +466,9 @@ k_key_cofactors(const uint32_t* __restrict__ counters, uint32_t max_tables, uint
 #pragma unroll
   for (int c = 0; c < KT_CHUNKS; ++c) z[c] = scr_load(kt, c);
   uint4* el = kt + (size_t)KT_LEAD * 8;
-  fe29 lx, ly;
+  fe29 lx, ly, dx, dy, dz;
   ke_load3(el, lx, ly, z[KT_CHUNKS]);
+  ke_load3(el + 8, dx, dy, dz);                                               // (the two lead points share their Z)
   pre[0] = z[0];
 #pragma unroll
   for (int c = 1; c <= KT_CHUNKS; ++c) pre[c] = fe29_mul(pre[c - 1], z[c]);   // z_0 ... z_c
@@ -451,11 +477,10 @@ k_key_cofactors(const uint32_t* __restrict__ counters, uint32_t max_tables, uint
 #pragma unroll
   for (int c = KT_CHUNKS; c >= 0; --c) {
     const fe29 co = c == KT_CHUNKS ? pre[c - 1] : (c > 0 ? fe29_mul(pre[c - 1], suf) : suf);   // W / z_c
-    if (c == KT_CHUNKS) {   // the lead point, finished here
-      const fe29 s2 = fe29_sqr(co);
-      const fe29 x = fe29_mul(lx, s2);
-      const fe29 y = fe29_mul(fe29_mul(ly, s2), co);
-      ke_store3(el, x, y, fe29_mul(x, fe29_from_words(FE_BETA)));
+    if (c == KT_CHUNKS) {   // the two lead points, finished here
+      const fe29 s2 = fe29_sqr(co), s3 = fe29_mul(s2, co);
+      ke_store3(el, fe29_mul(lx, s2), fe29_mul(ly, s3), fe29_zero());
+      ke_store3(el + 8, fe29_mul(dx, s2), fe29_mul(dy, s3), fe29_zero());
     } else {
       scr_store(kt, c, co);
     }
