@@ -461,27 +461,39 @@ k_split_glv_odd(uint32_t n, const uint8_t* __restrict__ k, uint8_t* __restrict__
   signs[idx] = (n1 ? 1 : 0) | (n2 ? 2 : 0);
 }
 
-// valid bytes -> bitmap (bit i of byte i/8, LSB first) + number of valid items.  One lane
-// per 8 items; the count is reduced per wave with a ballot-free popcount sum and one atomic.
+// valid bytes -> bitmap (bit i of byte i/8, LSB first) + number of valid items.  One lane per 32 items (four bitmap
+// bytes); the count is summed per wave, then per workgroup in LDS, and ONE atomic per workgroup reaches the counter:
+// atomics on one address cost about 12 ns each on MI355X, and one per wave (2048 for 2^20 items) made this kernel 27 us.
+constexpr int PACK_BYTES = 4;   // bitmap bytes per lane
 __global__ void __launch_bounds__(256)
 k_pack_valid(uint32_t n, const uint8_t* __restrict__ valid, uint8_t* __restrict__ bitmap,
              unsigned long long* __restrict__ count) {
-  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  size_t base = t * 8;
-  uint32_t bits = 0;
-  if (base + 8 <= n) {
-    uint2 v = *reinterpret_cast<const uint2*>(valid + base);
-    uint32_t lo = v.x & 0x01010101u, hi = v.y & 0x01010101u;
-    // gather bit 0 of each byte: multiply trick
-    bits = ((lo * 0x10204080u) >> 28) | (((hi * 0x10204080u) >> 28) << 4);
-  } else if (base < n) {
-    for (uint32_t j = 0; base + j < n; ++j) bits |= (uint32_t)(valid[base + j] & 1u) << j;
+  __shared__ uint32_t wsum[4];
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t c = 0;
+#pragma unroll
+  for (int g = 0; g < PACK_BYTES; ++g) {
+    const size_t byte = t * PACK_BYTES + g, base = byte * 8;
+    uint32_t bits = 0;
+    if (base + 8 <= n) {
+      uint2 v = *reinterpret_cast<const uint2*>(valid + base);
+      uint32_t lo = v.x & 0x01010101u, hi = v.y & 0x01010101u;
+      // gather bit 0 of each byte: multiply trick
+      bits = ((lo * 0x10204080u) >> 28) | (((hi * 0x10204080u) >> 28) << 4);
+    } else if (base < n) {
+      for (uint32_t j = 0; base + j < n; ++j) bits |= (uint32_t)(valid[base + j] & 1u) << j;
+    }
+    if (base < n) bitmap[byte] = (uint8_t)bits;
+    c += __popc(bits);
   }
-  if (base < n) bitmap[t] = (uint8_t)bits;
-  uint32_t c = __popc(bits);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (s) atomicAdd(count, (unsigned long long)s);
+  }
 }
 
 __global__ void k_gtable_entry(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit, uint8_t* out64) {
@@ -664,7 +676,7 @@ int s2k_pack_valid_device(s2k_ctx* ctx, size_t n, const void* d_valid, void* d_b
   HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, st));
   if (n == 0) return S2K_OK;
   if (!d_valid || !d_bitmap) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  k_pack_valid<<<blocks_for((n + 7) / 8), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_valid, (uint8_t*)d_bitmap,
+  k_pack_valid<<<blocks_for((n + 8 * PACK_BYTES - 1) / (8 * PACK_BYTES)), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_valid, (uint8_t*)d_bitmap,
                                                         (unsigned long long*)d_count);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
