@@ -611,9 +611,9 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   if (rc) return rc;
   uint32_t* w = (uint32_t*)ctx->kg;
   uint32_t* counters = w;
-  uint32_t* rep = w + KG_COUNTERS;
-  uint32_t* cnt = rep + slots;
-  uint32_t* tix = cnt + slots;
+  uint32_t* cnt = w + KG_COUNTERS;      // (counters and cnt[] are cleared together: one fill instead of two)
+  uint32_t* rep = cnt + slots;
+  uint32_t* tix = rep + slots;
   uint32_t* slot_of = tix + slots;
   uint32_t* pos_of = slot_of + np;
   uint32_t* perm = pos_of + np;
@@ -624,9 +624,8 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   uint8_t* tinfo = (uint8_t*)(tbase + tp);
   ctx->kg_counters = counters;
   ctx->kg_last_max_tables = (uint32_t)max_tables;
-  HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(counters, 0, (KG_COUNTERS + slots) * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
-  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
   if (key_bytes == 64)
     k_key_insert<64><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pub, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
   else
@@ -829,9 +828,9 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx,
   if (rc) return rc;
   uint32_t* w = (uint32_t*)ctx->kg;
   uint32_t* counters = w;
-  uint32_t* rep = w + KG_COUNTERS;
-  uint32_t* cnt = rep + slots;
-  uint32_t* base = cnt + slots;
+  uint32_t* cnt = w + KG_COUNTERS;      // (counters and cnt[] are cleared together)
+  uint32_t* rep = cnt + slots;
+  uint32_t* base = rep + slots;
   uint32_t* tix = base + slots;
   uint32_t* slot_of = tix + slots;
   uint32_t* pos_of = slot_of + np;
@@ -839,9 +838,8 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group32(s2k_ctx* ctx,
   uint32_t* ptab = perm + np;
   uint32_t* left = ptab + np;
   uint32_t* vslot = left + np;
-  HIP_TRY(ctx, hipMemsetAsync(counters, 0, KG_COUNTERS * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(counters, 0, (KG_COUNTERS + slots) * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(rep, 0xff, slots * sizeof(uint32_t), st));
-  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, slots * sizeof(uint32_t), st));
   k_key_insert<32><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_pk32, (uint32_t)(slots - 1), ctx->kg_seed, rep, cnt, slot_of, pos_of);
   HIP_TRY(ctx, hipGetLastError());
   k_key_alloc_all<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, cnt, base, tix, vslot, counters);
