@@ -63,6 +63,7 @@ enum {
 /* SignatureEncoding (ecdsa.go:39-53) */
 #define S2K_ENCODING_ASN1 0
 #define S2K_ENCODING_COMPACT 1
+#define S2K_ENCODING_COMPACT_RECOVERABLE 2 /* [R | S | V], 65 bytes: ParseCompactRecoverableSignature (s11n.go:156-168) */
 
 #define S2K_POINT_RECORD 65
 #define S2K_SCALAR_SIZE 32 /* ScalarSize, scalar.go:17 */
@@ -200,6 +201,59 @@ void s2k_host_free(void *p);
 int s2k_host_register(void *p, size_t bytes);
 int s2k_host_unregister(void *p);
 
+/* ---- submit / wait: the host-pointer entry points without the wait at their end ------------ */
+/* The reference's caller has its data in host memory (secec.PublicKey.Verify, ecdsa.go:171-228) and a cgo shim batches
+ * it into s2k_ecdsa_verify_batch, which pays the PCIe transfer and the kernels in series (7.1 ms from pinned, 8.2 ms
+ * from pageable memory against 4.9 ms resident per 2^20 signatures).  s2k_ecdsa_verify_batch_submit returns as soon as
+ * the batch is enqueued (from page-locked buffers: at once; from pageable ones: when the runtime has staged the copies)
+ * and s2k_wait blocks until the verdicts of that ticket are in `valid`.  The context keeps TWO batches in flight on two
+ * internal child contexts (own workspaces and streams on the same device; the generator tables are shared): batch k+1's
+ * transfer, grouping and per-key tables run beside batch k's ladder, so a caller that submits batch k+1 before it waits
+ * for batch k sees the resident rate.  A third submit first retires the oldest ticket (delivers its verdicts; a later
+ * s2k_wait on it returns at once).  Same verdicts as s2k_ecdsa_verify_batch, bit for bit; the inputs and `valid` must
+ * stay untouched until the ticket has been waited for (or retired).  Submit, wait and the other calls of one context
+ * must come from one thread at a time, like all calls on a context; the key-grouping settings are those the context
+ * has at submit time.  s2k_wait_all retires everything in flight (oldest first; s2k_ctx_destroy does the same).
+ * Each child holds what s2k_ctx_device_bytes reports minus the generator tables.  Set GPU_MAX_HW_QUEUES=8 in the
+ * process environment: two batches in flight use six streams. */
+typedef uint64_t s2k_ticket;
+int s2k_ecdsa_verify_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy, const uint8_t *digest32, const uint8_t *r,
+                                  const uint8_t *s, uint32_t flags, uint8_t *valid, s2k_ticket *ticket);
+int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
+int s2k_wait_all(s2k_ctx *ctx);
+/* s2k_ecdsa_verify_encoded_batch (below) in the same form */
+int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
+                                          const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,
+                                          const uint64_t *sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                          uint8_t *valid, s2k_ticket *ticket);
+
+/* ---- several devices in one process ------------------------------------------------------------ */
+/* north_star: "batches shard trivially across the 8 GPUs of one node".  A Go process cannot be one rank of a
+ * torch.distributed job; in ONE process no collective is needed at all.  A GROUP owns one context and one host thread per
+ * listed device (a device may be listed more than once: two members then share it, each with its own context).  A batch
+ * is cut into contiguous index shards, one per member (signature i belongs to shard i * members / n
+ * up to rounding to 256), every member runs s2k_ecdsa_verify_batch_submit / s2k_wait on its shard from its own thread,
+ * and the verdicts land in the caller's `valid` at the shard's offset - the "all-gather" is the host array itself.
+ * Verdicts are those of s2k_ecdsa_verify_batch on the whole batch, bit for bit (signatures are independent; only the
+ * grouping by key is per shard).  s2k_group_ecdsa_verify_batch = submit + wait.  Up to two group batches are in flight
+ * per member (a third submit blocks until the oldest is done).  Group calls may come from any ONE thread at a time.
+ * s2k_device_count: devices visible to the runtime (0 when there is none). */
+typedef struct s2k_group s2k_group;
+int s2k_device_count(void);
+int s2k_group_create(const int *devices, size_t n_devices, s2k_group **out);
+void s2k_group_destroy(s2k_group *g);
+size_t s2k_group_size(const s2k_group *g);
+const char *s2k_group_last_error(const s2k_group *g);
+int s2k_group_set_key_grouping(s2k_group *g, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables);
+int s2k_group_ecdsa_verify_batch(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32, const uint8_t *r,
+                                 const uint8_t *s, uint32_t flags, uint8_t *valid);
+int s2k_group_ecdsa_verify_batch_submit(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32,
+                                        const uint8_t *r, const uint8_t *s, uint32_t flags, uint8_t *valid, s2k_ticket *ticket);
+int s2k_group_wait(s2k_group *g, s2k_ticket ticket);
+/* stats[m * 4 + 0..3] for member m, of its last finished shard: signatures, first index, milliseconds from the member's
+ * submit to its verdicts (host clock), device index. */
+int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
+
 /* Packs valid[n] (0/1 bytes, device) into a bitmap (bit i of byte i/8, LSB first; (n+7)/8
  * bytes, device) and writes the number of valid items to *d_count (uint64, device).  This is
  * the payload of the multi-GPU bitmap all-gather (the count travels behind the bitmap shard). */
@@ -232,7 +286,12 @@ int s2k_is_valid_signature_encoding_bip0066(const uint8_t *sig_with_sighash, siz
  * (ecdsa.go:184-188).  flags: S2K_ECDSA_REJECT_MALLEABLE, S2K_ECDSA_BIP0066,
  * S2K_ECDSA_FORCE_COMPLETE.  The bytes are uploaded as they are; parsing, decompression of
  * compressed keys and verification all run on the device.  valid[i] is the bool the
- * reference's Verify returns; keys it could not even construct give 0. */
+ * reference's Verify returns; keys it could not even construct give 0.
+ * encoding S2K_ENCODING_COMPACT_RECOVERABLE (ecdsa.go:204-205,220-226): the key is recovered from (digest, r, s, v) on
+ * the verification ladder (RecoverPublicKey, ecdsa.go:244-282) and compared with the supplied one on the device
+ * (PublicKey.Equal: the serialised points, secec.go:121-129); RejectMalleable applies before the recovery (ecdsa.go:212).
+ * s2k_ecdsa_verify_encoded_batch_submit: the same without the wait at the end (s2k_wait; see
+ * s2k_ecdsa_verify_batch_submit). */
 int s2k_ecdsa_verify_encoded_batch(s2k_ctx *ctx, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
                                    const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,
                                    const uint64_t *sig_off, int encoding, size_t digest_len, uint32_t flags,

@@ -32,7 +32,7 @@ CSRC = os.path.join(_HERE, "csrc")
 REJECT_MALLEABLE = 1
 BIP0066 = 2
 FORCE_COMPLETE = 0x80000000
-ENCODING_ASN1, ENCODING_COMPACT = 0, 1
+ENCODING_ASN1, ENCODING_COMPACT, ENCODING_COMPACT_RECOVERABLE = 0, 1, 2
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 IMPL_COMPLETE, IMPL_FAST = 0, 1
@@ -229,6 +229,24 @@ def load_library() -> C.CDLL:
     lib.s2k_parse_compact_signature.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_char_p]
     lib.s2k_is_valid_signature_encoding_bip0066.argtypes = [C.c_char_p, sz]
     lib.s2k_ecdsa_verify_encoded_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, ci, sz, u32, vp]
+    u64 = C.c_uint64
+    lib.s2k_ecdsa_verify_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, C.POINTER(u64)]
+    lib.s2k_ecdsa_verify_encoded_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, ci, sz, u32, vp, C.POINTER(u64)]
+    lib.s2k_wait.argtypes = [vp, u64]
+    lib.s2k_wait_all.argtypes = [vp]
+    lib.s2k_device_count.restype = ci
+    lib.s2k_group_create.argtypes = [C.POINTER(ci), sz, C.POINTER(vp)]
+    lib.s2k_group_destroy.argtypes = [vp]
+    lib.s2k_group_destroy.restype = None
+    lib.s2k_group_size.argtypes = [vp]
+    lib.s2k_group_size.restype = sz
+    lib.s2k_group_last_error.argtypes = [vp]
+    lib.s2k_group_last_error.restype = C.c_char_p
+    lib.s2k_group_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
+    lib.s2k_group_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
+    lib.s2k_group_ecdsa_verify_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, C.POINTER(u64)]
+    lib.s2k_group_wait.argtypes = [vp, u64]
+    lib.s2k_group_member_stats.argtypes = [vp, vp]
     lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci)]
@@ -269,6 +287,10 @@ EXPORTED_SYMBOLS = [
     "s2k_pack_valid_device", "s2k_host_alloc", "s2k_host_free", "s2k_host_register", "s2k_host_unregister", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
+    "s2k_ecdsa_verify_batch_submit", "s2k_ecdsa_verify_encoded_batch_submit", "s2k_wait", "s2k_wait_all",
+    "s2k_device_count", "s2k_group_create", "s2k_group_destroy", "s2k_group_size", "s2k_group_last_error",
+    "s2k_group_set_key_grouping", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
+    "s2k_group_member_stats",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_schnorr_verify_batch_bisect", "s2k_schnorr_verify_batch_bisect_device",
@@ -382,6 +404,9 @@ class Engine:
         if rc != 0:
             raise EngineError(f"engine call failed ({rc}): {self._lib.s2k_last_error(self._h).decode()}")
 
+    def _wait(self, ticket):
+        self._check(self._lib.s2k_wait(self._h, ticket))
+
     # ---- hot path -------------------------------------------------------------------
     def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False,
                            force_complete: bool = False) -> np.ndarray:
@@ -395,6 +420,52 @@ class Engine:
                                                      (REJECT_MALLEABLE if reject_malleable else 0) |
                                                      (FORCE_COMPLETE if force_complete else 0), out.ctypes.data))
         return out
+
+    # ---- submit / wait -------------------------------------------------------------------
+    def ecdsa_verify_batch_submit(self, pub_xy, digest32, r, s, out=None, reject_malleable: bool = False) -> "Ticket":
+        """s2k_ecdsa_verify_batch_submit: enqueue the batch and return; `Ticket.wait()` gives the valid bits.  The input
+        arrays are used as they are (no copies: pass contiguous uint8 arrays of the right shapes, page-locked ones
+        from pinned_array for asynchronous transfers) and are kept alive by the ticket."""
+        arrs = []
+        n = None
+        for a, w in ((pub_xy, 64), (digest32, 32), (r, 32), (s, 32)):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]):
+                a = _arr(a, w)
+            a = a.reshape(-1, w)
+            if n is None:
+                n = a.shape[0]
+            elif a.shape[0] != n:
+                raise ValueError(f"length mismatch: expected {n} items, got {a.shape[0]}")
+            arrs.append(a)
+        if out is None:
+            out = np.zeros(n, dtype=np.uint8)
+        elif out.shape != (n,) or out.dtype != np.uint8:
+            raise ValueError("out must be a uint8 array of n items")
+        t = C.c_uint64(0)
+        self._check(self._lib.s2k_ecdsa_verify_batch_submit(self._h, n, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                                                            arrs[3].ctypes.data, REJECT_MALLEABLE if reject_malleable else 0,
+                                                            out.ctypes.data, C.byref(t)))
+        return Ticket(self, int(t.value), out, arrs)
+
+    def ecdsa_verify_encoded_batch_submit(self, pubs, digests, sigs, encoding=ENCODING_ASN1, digest_len=0,
+                                          reject_malleable=False, bip0066=False) -> "Ticket":
+        """s2k_ecdsa_verify_encoded_batch_submit for lists of byte strings (or pre-built (blob, offsets) pairs)."""
+        def cat(x):
+            return x if isinstance(x, tuple) else _concat(list(x))
+        (pb, po), (db, do), (sb, so) = cat(pubs), cat(digests), cat(sigs)
+        n = len(po) - 1
+        if len(do) - 1 != n or len(so) - 1 != n:
+            raise ValueError("length mismatch")
+        out = np.zeros(n, dtype=np.uint8)
+        flags = (REJECT_MALLEABLE if reject_malleable else 0) | (BIP0066 if bip0066 else 0)
+        t = C.c_uint64(0)
+        self._check(self._lib.s2k_ecdsa_verify_encoded_batch_submit(self._h, n, pb.ctypes.data, po.ctypes.data, db.ctypes.data,
+                                                                    do.ctypes.data, sb.ctypes.data, so.ctypes.data, encoding,
+                                                                    digest_len, flags, out.ctypes.data, C.byref(t)))
+        return Ticket(self, int(t.value), out, [pb, po, db, do, sb, so])
+
+    def wait_all(self):
+        self._check(self._lib.s2k_wait_all(self._h))
 
     # ---- key sets ----------------------------------------------------------------------
     def keyset_create(self, pub_xy) -> "KeySet":
@@ -726,6 +797,90 @@ class Engine:
         out = np.zeros(64, dtype=np.uint8)
         self._check(self._lib.s2k_debug_gtable_entry(self._h, i, d, out.ctypes.data))
         return out.tobytes()
+
+
+class Ticket:
+    """A batch in flight (s2k_ticket): wait() blocks until its verdicts are there and returns them."""
+
+    def __init__(self, owner, ticket, out, keep):
+        self._owner, self.ticket, self._out, self._keep = owner, ticket, out, keep
+        self._done = False
+
+    def wait(self) -> np.ndarray:
+        if not self._done:
+            self._owner._wait(self.ticket)
+            self._done = True
+            self._keep = None
+        return self._out
+
+
+def device_count() -> int:
+    """Devices the HIP runtime sees (s2k_device_count); 0 without a GPU."""
+    return int(load_library().s2k_device_count())
+
+
+class Group:
+    """Several devices behind one process (s2k_group): one context and one host thread per listed device, contiguous
+    index shards, verdicts written straight into the result array."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.s2k_group_create(devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"s2k_group_create failed ({rc})")
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s2k_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.s2k_group_size(self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(f"group call failed ({rc}): {self._lib.s2k_group_last_error(self._h).decode()}")
+
+    def _wait(self, ticket):
+        self._check(self._lib.s2k_group_wait(self._h, ticket))
+
+    def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
+        self._check(self._lib.s2k_group_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
+
+    def ecdsa_verify_batch_submit(self, pub_xy, digest32, r, s, out=None, reject_malleable: bool = False) -> Ticket:
+        arrs = [(_arr(a, w) if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]) else a.reshape(-1, w))
+                for a, w in ((pub_xy, 64), (digest32, 32), (r, 32), (s, 32))]
+        n = arrs[2].shape[0]
+        if any(a.shape[0] != n for a in arrs):
+            raise ValueError("length mismatch")
+        if out is None:
+            out = np.zeros(n, dtype=np.uint8)
+        t = C.c_uint64(0)
+        self._check(self._lib.s2k_group_ecdsa_verify_batch_submit(self._h, n, arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                                                  arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                                                  REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data,
+                                                                  C.byref(t)))
+        return Ticket(self, int(t.value), out, arrs)
+
+    def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
+        return self.ecdsa_verify_batch_submit(pub_xy, digest32, r, s, reject_malleable=reject_malleable).wait()
+
+    def member_stats(self):
+        """Per member, of its last finished shard: dict(n, first, ms, device)."""
+        st = (C.c_double * (4 * len(self)))()
+        self._check(self._lib.s2k_group_member_stats(self._h, st))
+        return [{"n": int(st[4 * i]), "first": int(st[4 * i + 1]), "ms": float(st[4 * i + 2]), "device": int(st[4 * i + 3])}
+                for i in range(len(self))]
 
 
 class KeySet:

@@ -14,6 +14,7 @@
 #include <sys/random.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "engine_internal.h"
@@ -1309,7 +1310,7 @@ static int grouped_front(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* 
 
 extern "C" {
 
-const char* s2k_version(void) { return "secp256k1_voi_amd 0.2 (gfx950)"; }
+const char* s2k_version(void) { return "secp256k1_voi_amd 0.4 (gfx950)"; }
 #define S2K_STR2(x) #x
 #define S2K_STR(x) S2K_STR2(x)
 #ifndef S2K_BUILD_FLAGS
@@ -1321,6 +1322,14 @@ const char* s2k_build_config(void) {
          " flags=[" S2K_BUILD_FLAGS "]";
 }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
+int s2k_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count;
+}
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
 //   [0,256)    per-lane point table of the fast path: 8 entries x 8 quads (tb_*); the complete path
@@ -1416,6 +1425,10 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   s2k_ctx* ctx = new (std::nothrow) s2k_ctx();
   if (!ctx) return fail(nullptr, S2K_ERR_NOMEM, "out of host memory");
   ctx->device = device_index;
+  {
+    static std::atomic<uint64_t> next_generation{1};
+    ctx->generation = next_generation.fetch_add(1);
+  }
   if (getrandom(&ctx->kg_seed, sizeof ctx->kg_seed, 0) != (ssize_t)sizeof ctx->kg_seed) ctx->kg_seed = 0x5ec9u;   // hash seed of the key grouping
   if (const char* v = getenv("S2K_KEYED_PARTS")) {        // measurement knob: 2 = the two-part flow (grouped_front)
     int np = atoi(v);
@@ -1447,6 +1460,15 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
 void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  for (s2k_ctx::pipe_slot& sl : ctx->pipe) {          // batches still in flight are waited for (their verdicts are delivered)
+    if (sl.ctx) {
+      (void)s2k_internal_pipe_retire(ctx, sl);
+      s2k_ctx_destroy(sl.ctx);
+      sl.ctx = nullptr;
+    }
+    if (sl.h_valid) (void)hipHostFree(sl.h_valid);
+    sl.h_valid = nullptr;
+  }
   if (ctx->gtable) gtable_release(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
@@ -1672,6 +1694,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
 // ---------------------------------------------------------------------------------------
 struct s2k_keyset {
   s2k_ctx* ctx;       // the owner (compared, never followed after creation: the set may outlive it by accident)
+  uint64_t generation;   // of the owner: a context destroyed and another created at the same address is not the owner
   int device;
   size_t n;
   uint8_t* base;      // device: keys | tables | validity | identity | counters (s2k_internal_keyset_bytes)
@@ -1689,6 +1712,7 @@ int s2k_keyset_create(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, s2k_ke
   s2k_keyset* ks = new (std::nothrow) s2k_keyset();
   if (!ks) return fail(ctx, S2K_ERR_NOMEM, "out of host memory");
   ks->ctx = ctx;
+  ks->generation = ctx->generation;
   ks->device = ctx->device;
   ks->n = n_keys;
   size_t off[5];
@@ -1734,7 +1758,8 @@ int s2k_keyset_valid_keys(s2k_keyset* ks, uint8_t* valid) {
 int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const void* d_key_index, const void* d_dig,
                                          const void* d_r, const void* d_s, uint32_t flags, void* d_valid, void* hip_stream) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
-  if (!ks || ks->ctx != ctx) return fail(ctx, S2K_ERR_ARG, "key set of another context");
+  if (!ks || ks->ctx != ctx || ks->generation != ctx->generation || ks->device != ctx->device)
+    return fail(ctx, S2K_ERR_ARG, "key set of another context");
   if (n == 0) return S2K_OK;
   if (!d_key_index || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
@@ -2005,13 +2030,17 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
 // callers' memory the copy costs about half as much as the verification, so most of it hides.
 // Staging buffers and streams live in the context (no hipMalloc per call).
 // page-locked host memory the runtime can copy from asynchronously (hipHostMalloc or hipHostRegister)
-static bool host_pinned(const void* p) {
+static bool host_pinned_at(const void* p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();          // an ordinary malloc'ed pointer: "invalid value", not an error of ours
     return false;
   }
   return a.type == hipMemoryTypeHost;
+}
+// (first AND last byte: a buffer registered for fewer bytes than the call reads must not take the asynchronous path)
+static bool host_pinned(const void* p, size_t bytes) {
+  return host_pinned_at(p) && (bytes < 2 || host_pinned_at((const uint8_t*)p + bytes - 1));
 }
 void* s2k_host_alloc(size_t bytes) {
   void* p = nullptr;
@@ -2051,11 +2080,12 @@ int s2k_host_unregister(void* p) {
   return S2K_OK;
 }
 
-int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
-                           const uint8_t* s, uint32_t flags, uint8_t* valid) {
-  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
-  if (n == 0) return S2K_OK;
-  if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+// Everything of a host-buffer verification except the final wait: copies in, kernels, verdicts to h_out (host memory; the
+// copy is asynchronous when h_out is page-locked).  All work ends on ctx->s_comp.  one_shot: the batch is not cut into
+// chunks (submit / wait: the other slot's batch is what this one's transfer hides behind, and ONE grouped call sees every
+// signature of a key).  On an error nothing of the call is left in flight.
+static int verify_batch_enqueue_inner(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                                      const uint8_t* s, uint32_t flags, uint8_t* h_out, bool one_shot) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ctx_streams(ctx);
   if (rc) return rc;
@@ -2071,7 +2101,7 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   // grouping and the per-key tables start on them, and the digests and signatures cross PCIe meanwhile (the scalar
   // preparation on the second stream waits for them).  From pageable memory a copy is staged by the runtime and the
   // same order measured slower than two independent halves (9.0 against 8.4-8.6 ms per 2^20), which stay the path there.
-  const bool pinned = host_pinned(pub) && host_pinned(dig) && host_pinned(r) && host_pinned(s);
+  const bool pinned = host_pinned(pub, n * 64) && host_pinned(dig, n * 32) && host_pinned(r, n * 32) && host_pinned(s, n * 32);
   if (pinned && ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH) {
     rc = ctx_arrival_events(ctx);
     if (rc) return rc;
@@ -2095,18 +2125,14 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
     while (arr.count > 1 && arr.cnt[arr.count - 1] == 0) --arr.count;
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comp, ctx->ev_copied[0], 0));
     rc = verify_batch_device(ctx, n, d_pub, d_dig, d_r, d_s, flags, d_valid, ctx->s_comp, &arr);
-    if (rc) {
-      (void)hipDeviceSynchronize();
-      return rc;
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, ctx->s_comp));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, d_valid, n, hipMemcpyDeviceToHost, ctx->s_comp));
     return S2K_OK;
   }
   const size_t round = (size_t)S2K_FAST_WAVES * 4 * (size_t)ctx->cu_count * 64;
   // chunks are whole rounds of the ladder kernel; the first one is a single round, because its copy is
   // the only one nothing hides (63 -> 31 MB up front at 256 CUs), the others two rounds
-  const bool chunked = n > 3 * round;                      // small batches: one shot
+  const bool chunked = !one_shot && n > 3 * round;         // small batches: one shot
   // with key grouping on, every chunk groups (and builds tables) on its own, so fewer and larger chunks:
   // two halves, the second copy hidden behind the first half's kernels
   const bool halves = chunked && ctx->kg_mode != S2K_KEYS_OFF;
@@ -2124,14 +2150,145 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comp, ctx->ev_copied[k & 1], 0));
     rc = s2k_ecdsa_verify_batch_device(ctx, cnt, d_pub + lo * 64, d_dig + lo * 32, d_r + lo * 32, d_s + lo * 32, flags,
                                        d_valid + lo, ctx->s_comp);
-    if (rc) {
-      (void)hipDeviceSynchronize();
-      return rc;
-    }
+    if (rc) return rc;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, ctx->s_comp));
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, d_valid, n, hipMemcpyDeviceToHost, ctx->s_comp));
+  return S2K_OK;
+}
+// An error return leaves copies from (and to) caller-owned memory in flight on the context's streams: wait for them before the
+// caller may free or unregister that memory (the message of the error is kept).
+}  // extern "C"
+__attribute__((visibility("hidden"))) void s2k_internal_drain(s2k_ctx* ctx) {
+  if (ctx->s_copy) (void)hipStreamSynchronize(ctx->s_copy);
+  if (ctx->s_aux) (void)hipStreamSynchronize(ctx->s_aux);
+  if (ctx->s_comp) (void)hipStreamSynchronize(ctx->s_comp);
+  (void)hipGetLastError();
+}
+extern "C" {
+static int verify_batch_enqueue(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                                const uint8_t* s, uint32_t flags, uint8_t* h_out, bool one_shot) {
+  const int rc = verify_batch_enqueue_inner(ctx, n, pub, dig, r, s, flags, h_out, one_shot);
+  if (rc) s2k_internal_drain(ctx);
+  return rc;
+}
+
+int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                           const uint8_t* s, uint32_t flags, uint8_t* valid) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  int rc = verify_batch_enqueue(ctx, n, pub, dig, r, s, flags, valid, /*one_shot=*/false);
+  if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
   return S2K_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// submit / wait: the host-pointer entry points without the wait at their end.  The reference's caller holds its data in
+// host memory (secec/ecdsa.go:171-228) and a synchronous call pays transfer and compute in series: 7.1 ms from pinned
+// memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns two child
+// contexts ("slots": own workspaces, staging buffers and streams; the 3 GiB generator tables are shared per device)
+// that take the submitted batches alternately: batch k+1's 160 MiB cross PCIe (3.0 ms) and its grouping and per-key
+// tables run while batch k's ladder holds the multipliers.  At most two batches are in flight; a third submit first
+// retires the older one (its verdicts are delivered; a later s2k_wait on its ticket returns at once).
+// ---------------------------------------------------------------------------------------
+}  // extern "C"
+static void pipe_note_failure(s2k_ctx* ctx, uint64_t ticket, int rc) {
+  const unsigned i = ctx->pipe_failed_n++ % 8u;
+  ctx->pipe_failed[i] = ticket;
+  ctx->pipe_failed_rc[i] = rc;
+}
+// waits for the slot's batch and delivers its verdicts; the slot is free afterwards
+__attribute__((visibility("hidden"))) int s2k_internal_pipe_retire(s2k_ctx* ctx, s2k_ctx::pipe_slot& sl) {
+  if (!sl.ticket) return S2K_OK;
+  int rc = S2K_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(sl.ctx->s_comp) != hipSuccess) {
+    rc = fail(ctx, S2K_ERR_HIP, "ticket %llu: the batch did not complete: %s", (unsigned long long)sl.ticket,
+              hipGetErrorString(hipGetLastError()));
+    s2k_internal_drain(sl.ctx);
+  } else if (!sl.direct) {
+    memcpy(sl.dst, sl.h_valid, sl.n);
+  }
+  sl.ticket = 0;
+  return rc;
+}
+// the slot the next ticket runs on, free, with its child context and landing buffer in place
+__attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, size_t n, uint8_t* valid, s2k_ctx::pipe_slot** out) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  s2k_ctx::pipe_slot& sl = ctx->pipe[ctx->pipe_next & 1u];
+  if (sl.ticket) {                                   // two batches in flight already: the older one is retired first
+    const uint64_t t = sl.ticket;
+    const int rc = s2k_internal_pipe_retire(ctx, sl);
+    if (rc) pipe_note_failure(ctx, t, rc);           // (reported by s2k_wait on that ticket)
+  }
+  if (!sl.ctx) {
+    int rc = s2k_ctx_create(ctx->device, &sl.ctx);
+    if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
+  }
+  // the child verifies with the parent's settings of the moment
+  sl.ctx->kg_mode = ctx->kg_mode;
+  sl.ctx->kg_min_group = ctx->kg_min_group;
+  sl.ctx->kg_hash_bits = ctx->kg_hash_bits;
+  sl.ctx->kg_max_tables = ctx->kg_max_tables;
+  sl.direct = host_pinned(valid, n);
+  if (!sl.direct && sl.h_valid_bytes < n) {
+    if (sl.h_valid) (void)hipHostFree(sl.h_valid);
+    sl.h_valid = nullptr;
+    sl.h_valid_bytes = 0;
+    const size_t want = (n + 4095) & ~(size_t)4095;
+    HIP_TRY(ctx, hipHostMalloc((void**)&sl.h_valid, want, hipHostMallocDefault));
+    sl.h_valid_bytes = want;
+  }
+  sl.dst = valid;
+  sl.n = n;
+  *out = &sl;
+  return S2K_OK;
+}
+__attribute__((visibility("hidden"))) void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, s2k_ticket* ticket) {
+  sl->ticket = ctx->pipe_next++;
+  *ticket = sl->ticket;
+}
+__attribute__((visibility("hidden"))) bool s2k_internal_host_pinned(const void* p, size_t bytes) { return host_pinned(p, bytes); }
+
+extern "C" {
+int s2k_ecdsa_verify_batch_submit(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                                  const uint8_t* s, uint32_t flags, uint8_t* valid, s2k_ticket* ticket) {
+  if (!ctx || !ticket) return fail(ctx, S2K_ERR_ARG, "null argument");
+  *ticket = 0;
+  if (n && (!pub || !dig || !r || !s || !valid)) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  s2k_ctx::pipe_slot* sl = nullptr;
+  int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
+  if (rc) return rc;
+  if (n) {
+    rc = verify_batch_enqueue(sl->ctx, n, pub, dig, r, s, flags, sl->direct ? valid : sl->h_valid, /*one_shot=*/true);
+    if (rc) return fail(ctx, rc, "%s", sl->ctx->err);
+  }
+  s2k_internal_pipe_issue(ctx, sl, ticket);
+  return S2K_OK;
+}
+
+int s2k_wait(s2k_ctx* ctx, s2k_ticket ticket) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (ticket == 0 || ticket >= ctx->pipe_next) return fail(ctx, S2K_ERR_ARG, "s2k_wait: ticket %llu was never issued", (unsigned long long)ticket);
+  for (s2k_ctx::pipe_slot& sl : ctx->pipe)
+    if (sl.ticket == ticket) return s2k_internal_pipe_retire(ctx, sl);
+  for (unsigned i = 0; i < 8; ++i)                    // retired by a later submit: its verdicts are delivered (or it failed then)
+    if (ctx->pipe_failed[i] == ticket) return fail(ctx, ctx->pipe_failed_rc[i], "ticket %llu failed when it was retired", (unsigned long long)ticket);
+  return S2K_OK;
+}
+
+int s2k_wait_all(s2k_ctx* ctx) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  int rc = S2K_OK;
+  // oldest first
+  s2k_ctx::pipe_slot* order[2] = {&ctx->pipe[0], &ctx->pipe[1]};
+  if (order[0]->ticket > order[1]->ticket) { s2k_ctx::pipe_slot* t = order[0]; order[0] = order[1]; order[1] = t; }
+  for (s2k_ctx::pipe_slot* sl : order) {
+    const int r1 = s2k_internal_pipe_retire(ctx, *sl);
+    if (r1 && !rc) rc = r1;
+  }
+  return rc;
 }
 
 int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs,

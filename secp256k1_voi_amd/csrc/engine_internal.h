@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/secp256k1_voi_amd.h"
@@ -117,6 +118,24 @@ struct s2k_ctx {
   uint32_t* kg_counters = nullptr;   // device, KG_COUNTERS words (of the last call; null: it did not group)
   uint32_t kg_last_max_tables = 0;   // table cap of that call (the device counter of tables is not clamped)
   uint32_t* last_wl_count = nullptr; // device: the last verification call's complete-formula worklist length
+  // submit / wait (s2k_ecdsa_verify_batch_submit, s2k_wait): two child contexts on the same device take the submitted
+  // batches alternately, so that one batch's transfer, grouping and tables run beside the other's ladder.  A child owns
+  // its own workspaces, staging and streams (the generator tables are shared per device); `pipe` is empty in a child.
+  struct pipe_slot {
+    s2k_ctx* ctx = nullptr;        // the child context (created on first use)
+    uint64_t ticket = 0;           // ticket in flight on it (0: none)
+    uint8_t* dst = nullptr;        // where its verdicts go (the caller's array)
+    size_t n = 0;
+    uint8_t* h_valid = nullptr;    // page-locked landing buffer of the verdicts (when dst is pageable)
+    size_t h_valid_bytes = 0;
+    bool direct = false;           // dst is page-locked itself: the device-to-host copy lands there
+  };
+  pipe_slot pipe[2];
+  uint64_t pipe_next = 1;          // next ticket
+  uint64_t pipe_failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tickets retired with an error (by a later submit), and their codes
+  int pipe_failed_rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned pipe_failed_n = 0;
+  uint64_t generation = 0;         // distinguishes contexts that reuse an address (key sets compare it)
   char err[512] = {0};
 };
 
@@ -210,6 +229,13 @@ inline void msm_prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
   (void)hipEventRecord(ctx->msm_prof_ev[ctx->msm_prof_used + slot], st);
   if (slot == MSM_PROF_EV - 1) ctx->msm_prof_used += MSM_PROF_EV;
 }
+
+// submit / wait plumbing (engine.hip), shared with the encoded entry point (ingest.hip)
+int s2k_internal_pipe_slot(s2k_ctx* ctx, size_t n, uint8_t* valid, s2k_ctx::pipe_slot** out);   // free slot for the next ticket
+int s2k_internal_pipe_retire(s2k_ctx* ctx, s2k_ctx::pipe_slot& sl);                             // wait + deliver verdicts
+void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, uint64_t* ticket);
+void s2k_internal_drain(s2k_ctx* ctx);                                                          // after an error: nothing left in flight
+bool s2k_internal_host_pinned(const void* p, size_t bytes);
 
 // copy / compute streams and the events chaining them, for the host-buffer entry points
 inline int ctx_streams(s2k_ctx* ctx) {

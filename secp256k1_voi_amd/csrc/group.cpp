@@ -1,0 +1,320 @@
+// group.cpp — several devices behind ONE host process (s2k_group_*, include/secp256k1_voi_amd.h).
+//
+// The reference verifies on the caller's goroutine (secec.PublicKey.Verify, secec/ecdsa.go:171-228) and scales by running
+// more goroutines; north_star's "batches shard trivially across the 8 GPUs" is the same independence, per signature.  The
+// multi-process form of that (one rank per GPU, torch.distributed, one bitmap all-gather: secp256k1_voi_amd/sharding.py)
+// is what bench.py runs; a cgo shim lives in ONE process and cannot be a rank.  In one process nothing has to be
+// exchanged at all: a group is one context + one host thread per device, a batch is cut into contiguous index shards
+// (SURVEY.md section 8e), every member pushes its shard through its own context's submit / wait pair, and the verdicts
+// land in the caller's array at the shard's offset.  No RCCL, no device-to-device traffic; the only shared state is the
+// job queue.  Host code only: everything that touches a GPU goes through the C-ABI of the context.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/secp256k1_voi_amd.h"
+
+namespace {
+
+struct shard_job {
+  uint64_t ticket = 0;
+  size_t lo = 0, n = 0;            // the member's shard of the batch
+  const uint8_t *pub = nullptr, *dig = nullptr, *r = nullptr, *s = nullptr;
+  uint32_t flags = 0;
+  uint8_t* valid = nullptr;
+  std::chrono::steady_clock::time_point t0;
+};
+
+struct member {
+  s2k_group* group = nullptr;
+  int device = -1;
+  s2k_ctx* ctx = nullptr;
+  int create_rc = S2K_OK;
+  char create_err[256] = {0};
+  bool created = false;
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<shard_job> q;
+  bool stop = false;
+  // statistics of the last finished shard
+  double st_n = 0, st_lo = 0, st_ms = 0;
+};
+
+struct pending {
+  int remaining = 0;
+  int rc = S2K_OK;
+};
+
+}  // namespace
+
+struct s2k_group {
+  std::vector<member*> members;
+  std::mutex m;                    // pending, err, settings
+  std::condition_variable cv;
+  std::map<uint64_t, pending> pend;
+  uint64_t next_ticket = 1;
+  char err[512] = {0};
+};
+
+namespace {
+
+int gfail(s2k_group* g, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (g) {
+    std::lock_guard<std::mutex> lock(g->m);
+    snprintf(g->err, sizeof g->err, "%s", buf);
+  }
+  return code;
+}
+
+void complete(member* me, const shard_job& job, int rc) {
+  s2k_group* g = me->group;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t0).count();
+  std::lock_guard<std::mutex> lock(g->m);
+  me->st_n = (double)job.n;
+  me->st_lo = (double)job.lo;
+  me->st_ms = ms;
+  auto it = g->pend.find(job.ticket);
+  if (it == g->pend.end()) return;
+  if (rc && !it->second.rc) {
+    it->second.rc = rc;
+    snprintf(g->err, sizeof g->err, "member on device %d, signatures [%zu, %zu): %s", me->device, job.lo, job.lo + job.n,
+             s2k_last_error(me->ctx));
+  }
+  if (--it->second.remaining == 0) g->cv.notify_all();
+}
+
+// One member: its context is created here (the generator tables of the devices are built side by side), then shards are
+// taken from the queue.  A shard is submitted as soon as it arrives; the previous one is waited for only after that, so
+// two consecutive group batches overlap on the member's device exactly as two s2k_ecdsa_verify_batch_submit calls do.
+void member_main(member* me) {
+  {
+    s2k_ctx* ctx = nullptr;
+    const int rc = s2k_ctx_create(me->device, &ctx);
+    std::lock_guard<std::mutex> lock(me->m);
+    me->ctx = ctx;
+    me->create_rc = rc;
+    if (rc) snprintf(me->create_err, sizeof me->create_err, "%s", s2k_last_error(nullptr));
+    me->created = true;
+    me->cv.notify_all();
+    if (rc) return;
+  }
+  bool have_prev = false;
+  shard_job prev;
+  s2k_ticket prev_ticket = 0;
+  for (;;) {
+    shard_job job;
+    bool have_job = false;
+    {
+      std::unique_lock<std::mutex> lock(me->m);
+      if (!have_prev) me->cv.wait(lock, [&] { return me->stop || !me->q.empty(); });
+      if (!me->q.empty()) {
+        job = me->q.front();
+        me->q.pop_front();
+        have_job = true;
+      } else if (!have_prev && me->stop) {
+        break;
+      }
+    }
+    if (have_job) {
+      s2k_ticket t = 0;
+      int rc = S2K_OK;
+      if (job.n)
+        rc = s2k_ecdsa_verify_batch_submit(me->ctx, job.n, job.pub + job.lo * 64, job.dig + job.lo * 32, job.r + job.lo * 32,
+                                           job.s + job.lo * 32, job.flags, job.valid + job.lo, &t);
+      if (have_prev) {
+        complete(me, prev, s2k_wait(me->ctx, prev_ticket));
+        have_prev = false;
+      }
+      if (rc || !job.n) {
+        complete(me, job, rc);
+      } else {
+        prev = job;
+        prev_ticket = t;
+        have_prev = true;
+      }
+    } else if (have_prev) {
+      complete(me, prev, s2k_wait(me->ctx, prev_ticket));
+      have_prev = false;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2k_group_create(const int* devices, size_t n_devices, s2k_group** out) {
+  if (!out) return S2K_ERR_ARG;
+  *out = nullptr;
+  if (!devices || n_devices == 0 || n_devices > 1024) return S2K_ERR_ARG;
+  const int count = s2k_device_count();
+  if (count <= 0) return S2K_ERR_NO_DEVICE;
+  for (size_t i = 0; i < n_devices; ++i)
+    if (devices[i] < 0 || devices[i] >= count) return S2K_ERR_ARG;
+  s2k_group* g = new (std::nothrow) s2k_group();
+  if (!g) return S2K_ERR_NOMEM;
+  for (size_t i = 0; i < n_devices; ++i) {
+    member* me = new (std::nothrow) member();
+    if (!me) {
+      s2k_group_destroy(g);
+      return S2K_ERR_NOMEM;
+    }
+    me->group = g;
+    me->device = devices[i];
+    g->members.push_back(me);
+    me->th = std::thread(member_main, me);
+  }
+  int rc = S2K_OK;
+  for (member* me : g->members) {
+    std::unique_lock<std::mutex> lock(me->m);
+    me->cv.wait(lock, [&] { return me->created; });
+    if (me->create_rc && !rc) {
+      rc = me->create_rc;
+      snprintf(g->err, sizeof g->err, "device %d: %s", me->device, me->create_err);
+    }
+  }
+  if (rc) {
+    fprintf(stderr, "s2k_group_create: %s\n", g->err);
+    s2k_group_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return S2K_OK;
+}
+
+void s2k_group_destroy(s2k_group* g) {
+  if (!g) return;
+  for (member* me : g->members) {
+    {
+      std::lock_guard<std::mutex> lock(me->m);
+      me->stop = true;
+    }
+    me->cv.notify_all();
+    if (me->th.joinable()) me->th.join();          // (shards still queued are verified first)
+    if (me->ctx) s2k_ctx_destroy(me->ctx);
+    delete me;
+  }
+  delete g;
+}
+
+size_t s2k_group_size(const s2k_group* g) { return g ? g->members.size() : 0; }
+const char* s2k_group_last_error(const s2k_group* g) { return g ? g->err : "group is NULL"; }
+
+static void group_wait_idle(s2k_group* g) {
+  std::unique_lock<std::mutex> lock(g->m);
+  g->cv.wait(lock, [&] {
+    for (auto& kv : g->pend)
+      if (kv.second.remaining) return false;
+    return true;
+  });
+}
+
+int s2k_group_set_key_grouping(s2k_group* g, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables) {
+  if (!g) return S2K_ERR_ARG;
+  group_wait_idle(g);                              // the members' threads are parked: their contexts may be touched from here
+  for (member* me : g->members) {
+    const int rc = s2k_ctx_set_key_grouping(me->ctx, mode, min_group, hash_bits, max_tables);
+    if (rc) return gfail(g, rc, "%s", s2k_last_error(me->ctx));
+  }
+  return S2K_OK;
+}
+
+int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                                        const uint8_t* s, uint32_t flags, uint8_t* valid, s2k_ticket* ticket) {
+  if (!g || !ticket) return S2K_ERR_ARG;
+  *ticket = 0;
+  if (n && (!pub || !dig || !r || !s || !valid)) return gfail(g, S2K_ERR_ARG, "null buffer");
+  const size_t D = g->members.size();
+  // contiguous index shards, rounded up to whole workgroups so that no member gets a ragged tail but the last
+  size_t per = (n + D - 1) / D;
+  per = (per + 255) & ~(size_t)255;
+  if (per > 0x7fffffffu) return gfail(g, S2K_ERR_ARG, "batch too large");
+  uint64_t t;
+  {
+    std::unique_lock<std::mutex> lock(g->m);
+    // at most two group batches in flight: every member keeps two batches on its device
+    g->cv.wait(lock, [&] {
+      int busy = 0;
+      for (auto& kv : g->pend) busy += kv.second.remaining ? 1 : 0;
+      return busy < 2;
+    });
+    t = g->next_ticket++;
+    while (g->pend.size() > 16 && g->pend.begin()->second.remaining == 0) g->pend.erase(g->pend.begin());   // old results
+    pending p;
+    p.remaining = (int)D;
+    g->pend[t] = p;
+  }
+  const auto now = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < D; ++i) {
+    member* me = g->members[i];
+    shard_job job;
+    job.ticket = t;
+    job.lo = i * per < n ? i * per : n;
+    job.n = job.lo + per <= n ? per : n - job.lo;
+    job.pub = pub;
+    job.dig = dig;
+    job.r = r;
+    job.s = s;
+    job.flags = flags;
+    job.valid = valid;
+    job.t0 = now;
+    {
+      std::lock_guard<std::mutex> lock(me->m);
+      me->q.push_back(job);
+    }
+    me->cv.notify_all();
+  }
+  *ticket = t;
+  return S2K_OK;
+}
+
+int s2k_group_wait(s2k_group* g, s2k_ticket ticket) {
+  if (!g) return S2K_ERR_ARG;
+  std::unique_lock<std::mutex> lock(g->m);
+  if (ticket == 0 || ticket >= g->next_ticket) {
+    snprintf(g->err, sizeof g->err, "s2k_group_wait: ticket %llu was never issued", (unsigned long long)ticket);
+    return S2K_ERR_ARG;
+  }
+  auto it = g->pend.find(ticket);
+  if (it == g->pend.end()) return S2K_OK;          // long done, its result dropped from the table
+  g->cv.wait(lock, [&] { return it->second.remaining == 0; });
+  return it->second.rc;
+}
+
+int s2k_group_ecdsa_verify_batch(s2k_group* g, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r, const uint8_t* s,
+                                 uint32_t flags, uint8_t* valid) {
+  s2k_ticket t = 0;
+  const int rc = s2k_group_ecdsa_verify_batch_submit(g, n, pub, dig, r, s, flags, valid, &t);
+  if (rc) return rc;
+  return s2k_group_wait(g, t);
+}
+
+int s2k_group_member_stats(s2k_group* g, double* stats) {
+  if (!g || !stats) return S2K_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g->m);
+  for (size_t i = 0; i < g->members.size(); ++i) {
+    const member* me = g->members[i];
+    stats[4 * i + 0] = me->st_n;
+    stats[4 * i + 1] = me->st_lo;
+    stats[4 * i + 2] = me->st_ms;
+    stats[4 * i + 3] = (double)me->device;
+  }
+  return S2K_OK;
+}
+
+}  // extern "C"

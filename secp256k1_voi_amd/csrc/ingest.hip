@@ -23,8 +23,8 @@ namespace {
 __global__ void __launch_bounds__(256)
 k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, const uint64_t* __restrict__ pub_off,
                 const uint8_t* __restrict__ digests, const uint64_t* __restrict__ dig_off, const uint8_t* __restrict__ sigs,
-                const uint64_t* __restrict__ sig_off, int encoding, uint32_t digest_len, int bip66, uint8_t* __restrict__ xy,
-                uint8_t* __restrict__ dg, uint8_t* __restrict__ rr, uint8_t* __restrict__ ss) {
+                const uint64_t* __restrict__ sig_off, int encoding, uint32_t digest_len, int bip66, int low_s, uint8_t* __restrict__ xy,
+                uint8_t* __restrict__ dg, uint8_t* __restrict__ rr, uint8_t* __restrict__ ss, uint8_t* __restrict__ recid) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   i += first;                                            // items [first, first + n) of the batch
@@ -43,9 +43,27 @@ k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, co
     ok = s2k_der::is_valid_signature_encoding_bip0066(sg, sg_len) != 0;
     --sg_len;                                            // drop the sighash byte
   }
+  uint8_t v = 0;
   if (ok) {
-    int rc = encoding == S2K_ENCODING_ASN1 ? s2k_der::parse_asn1_signature(sg, sg_len, r, s)
-                                           : s2k_der::parse_compact_signature(sg, sg_len, r, s);
+    int rc;
+    if (encoding == S2K_ENCODING_ASN1) {
+      rc = s2k_der::parse_asn1_signature(sg, sg_len, r, s);
+    } else if (encoding == S2K_ENCODING_COMPACT) {
+      rc = s2k_der::parse_compact_signature(sg, sg_len, r, s);
+    } else {   // ParseCompactRecoverableSignature (s11n.go:156-168): [R | S | V], 65 bytes
+      rc = sg_len == 65 ? s2k_der::parse_compact_signature(sg, 64, r, s) : 1;
+      if (rc == 0) v = sg[64];
+      // the recovery path takes no options: the low-s rule of Verify (ecdsa.go:212) is applied here
+      if (rc == 0 && low_s) {
+        // (n - 1) / 2, big-endian (scalar.go:190 IsGreaterThanHalfN)
+        const uint8_t half[32] = {0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
+                                  0x5d, 0x57, 0x6e, 0x73, 0x57, 0xa4, 0x50, 0x1d, 0xdf, 0xe9, 0x2f, 0x46, 0x68, 0x1b, 0x20, 0xa0};
+        int cmp = 0;
+        for (int j = 0; j < 32; ++j)
+          if (cmp == 0 && s[j] != half[j]) cmp = s[j] < half[j] ? -1 : 1;
+        if (cmp > 0) rc = 2;
+      }
+    }
     ok = rc == 0;
   }
   if (ok) {
@@ -81,6 +99,23 @@ k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, co
     rr[i * 32 + j] = ok ? r[j] : 0;
     ss[i * 32 + j] = ok ? s[j] : 0;
   }
+  if (recid) recid[i] = ok ? v : 0xff;                   // (0xff: no recovery id, RecoverPublicKey refuses it)
+}
+
+// EncodingCompactRecoverable: valid iff the key recovered from (digest, r, s, v) is the key the caller holds
+// (k.Equal(q), ecdsa.go:220-226; PublicKey.Equal compares the serialised points, secec.go:121-129).  A supplied key
+// that NewPublicKey would have refused (off the curve, non-canonical: parsed to whatever bytes it carried, or zeros)
+// equals no recovered key: those are always canonical points of the curve.
+__global__ void __launch_bounds__(256)
+k_recovered_equals(uint32_t n, const uint8_t* __restrict__ xy, const uint8_t* __restrict__ rec65, const uint8_t* __restrict__ ok,
+                   uint8_t* __restrict__ valid) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* a = xy + i * 64;
+  const uint8_t* b = rec65 + i * 65;
+  uint32_t diff = b[0] ^ 0x04u;
+  for (int j = 0; j < 64; ++j) diff |= (uint32_t)(a[j] ^ b[1 + j]);
+  valid[i] = (ok[i] == 1 && diff == 0) ? 1 : 0;
 }
 
 }  // namespace
@@ -104,8 +139,8 @@ int s2k_is_valid_signature_encoding_bip0066(const uint8_t* d, size_t n) {
 
 // PublicKey.Verify(digest, sig, opts) for n encoded items (ecdsa.go:171-228).
 //   pubs / digests / sigs: concatenated byte strings with n+1 offsets each
-//   encoding: S2K_ENCODING_ASN1 or S2K_ENCODING_COMPACT (EncodingCompactRecoverable is not a
-//             batch verification: it is public-key recovery, ecdsa.go:220-226)
+//   encoding: S2K_ENCODING_ASN1, S2K_ENCODING_COMPACT, or S2K_ENCODING_COMPACT_RECOVERABLE (the key is recovered from
+//             [R | S | V] and compared with the supplied one, ecdsa.go:204-205,220-226)
 //   digest_len: 0 = opts == nil (any length >= 32 is taken, leftmost 32 bytes used);
 //               otherwise opts.Hash.Size(): other lengths verify false (ecdsa.go:184-188)
 //   flags: S2K_ECDSA_REJECT_MALLEABLE, S2K_ECDSA_BIP0066 (bitcoin.VerifyASN1,
@@ -113,27 +148,21 @@ int s2k_is_valid_signature_encoding_bip0066(const uint8_t* d, size_t n) {
 // Public keys are any SEC1 encoding NewPublicKey accepts (33 or 65 bytes).  A malformed key or
 // signature makes that item false (the reference could not have constructed the PublicKey / returns
 // false from Verify).
-int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off,
-                                   const uint8_t* digests, const uint64_t* dig_off, const uint8_t* sigs,
-                                   const uint64_t* sig_off, int encoding, size_t digest_len, uint32_t flags,
-                                   uint8_t* valid) {
-  if (!ctx) return S2K_ERR_ARG;
-  if (n == 0) return S2K_OK;
-  if (!pubs || !pub_off || !digests || !dig_off || !sigs || !sig_off || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (encoding != S2K_ENCODING_ASN1 && encoding != S2K_ENCODING_COMPACT) return fail(ctx, S2K_ERR_ARG, "unknown encoding");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+// Enqueue only (all work ends on ctx->s_comp; verdicts go to h_out, asynchronously when that is page-locked);
+// one_shot: the whole batch in one piece (submit / wait).
+static int encoded_enqueue_inner(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off, const uint8_t* digests,
+                                 const uint64_t* dig_off, const uint8_t* sigs, const uint64_t* sig_off, int encoding, size_t digest_len,
+                                 uint32_t flags, uint8_t* h_out, bool one_shot) {
   const bool bip66 = (flags & S2K_ECDSA_BIP0066) != 0;
-  if (bip66) {
-    if (encoding != S2K_ENCODING_ASN1) return fail(ctx, S2K_ERR_ARG, "BIP-0066 needs the ASN.1 encoding");
-    digest_len = 32;                                  // optsShitcoin: SHA-256
-    flags |= S2K_ECDSA_REJECT_MALLEABLE;
-  }
+  const bool recoverable = encoding == S2K_ENCODING_COMPACT_RECOVERABLE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pub_bytes = pub_off[n], dig_bytes = dig_off[n], sig_bytes = sig_off[n];
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_pub = 0, o_dig = o_pub + al(pub_bytes), o_sig = o_dig + al(dig_bytes), o_po = o_sig + al(sig_bytes),
                o_do = o_po + al((n + 1) * 8), o_so = o_do + al((n + 1) * 8), o_xy = o_so + al((n + 1) * 8), o_dg = o_xy + al(n * 64),
-               o_r = o_dg + al(n * 32), o_s = o_r + al(n * 32), o_v = o_s + al(n * 32), total = o_v + al(n);
+               o_r = o_dg + al(n * 32), o_s = o_r + al(n * 32), o_v = o_s + al(n * 32), o_id = o_v + al(n),
+               o_rec = o_id + (recoverable ? al(n) : 0), o_ok = o_rec + (recoverable ? al(n * 65) : 0),
+               total = o_ok + (recoverable ? al(n) : 0);
   int rc = ctx_reserve(ctx, &ctx->io, &ctx->io_bytes, total);
   if (rc) return rc;
   uint8_t* io = (uint8_t*)ctx->io;
@@ -149,7 +178,7 @@ int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, 
   // with key grouping on, every chunk groups (and builds tables) on its own, so fewer and larger chunks: two halves
   // (s2k_ecdsa_verify_batch does the same; three chunks of a 2^20 batch left under 6 signatures per key and chunk,
   // below the table threshold: the whole batch went through the general ladder)
-  const size_t chunk = n <= 3 * round ? n : (ctx->kg_mode != S2K_KEYS_OFF ? ((n / 2 + 255) & ~(size_t)255) : 2 * round);
+  const size_t chunk = (one_shot || n <= 3 * round) ? n : ((ctx->kg_mode != S2K_KEYS_OFF && !recoverable) ? ((n / 2 + 255) & ~(size_t)255) : 2 * round);
   int k = 0;
   for (size_t lo = 0; lo < n; lo += chunk, ++k) {
     const size_t cnt = n - lo < chunk ? n - lo : chunk, hi = lo + cnt;
@@ -160,17 +189,82 @@ int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, 
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comp, ctx->ev_copied[k & 1], 0));
     k_parse_encoded<<<(unsigned)((cnt + 255) / 256), 256, 0, ctx->s_comp>>>(
         (uint32_t)lo, (uint32_t)cnt, io + o_pub, (const uint64_t*)(io + o_po), io + o_dig, (const uint64_t*)(io + o_do), io + o_sig,
-        (const uint64_t*)(io + o_so), encoding, (uint32_t)digest_len, bip66 ? 1 : 0, io + o_xy, io + o_dg, io + o_r, io + o_s);
+        (const uint64_t*)(io + o_so), encoding, (uint32_t)digest_len, bip66 ? 1 : 0, (flags & S2K_ECDSA_REJECT_MALLEABLE) ? 1 : 0,
+        io + o_xy, io + o_dg, io + o_r, io + o_s, recoverable ? io + o_id : nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    rc = s2k_ecdsa_verify_batch_device(ctx, cnt, io + o_xy + lo * 64, io + o_dg + lo * 32, io + o_r + lo * 32, io + o_s + lo * 32,
-                                       flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE), io + o_v + lo, ctx->s_comp);
-    if (rc) {
-      (void)hipDeviceSynchronize();
-      return rc;
+    if (recoverable) {
+      // RecoverPublicKey (ecdsa.go:244-282) on the shared ladder, then k.Equal(q) on the device
+      rc = s2k_ecdsa_recover_batch_device(ctx, cnt, io + o_dg + lo * 32, io + o_r + lo * 32, io + o_s + lo * 32, io + o_id + lo,
+                                          flags & S2K_ECDSA_FORCE_COMPLETE, io + o_rec + lo * 65, io + o_ok + lo, ctx->s_comp);
+      if (rc) return rc;
+      k_recovered_equals<<<(unsigned)((cnt + 255) / 256), 256, 0, ctx->s_comp>>>((uint32_t)cnt, io + o_xy + lo * 64, io + o_rec + lo * 65,
+                                                                                 io + o_ok + lo, io + o_v + lo);
+      HIP_TRY(ctx, hipGetLastError());
+    } else {
+      rc = s2k_ecdsa_verify_batch_device(ctx, cnt, io + o_xy + lo * 64, io + o_dg + lo * 32, io + o_r + lo * 32, io + o_s + lo * 32,
+                                         flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE), io + o_v + lo, ctx->s_comp);
+      if (rc) return rc;
     }
   }
-  HIP_TRY(ctx, hipMemcpyAsync(valid, io + o_v, n, hipMemcpyDeviceToHost, ctx->s_comp));
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, io + o_v, n, hipMemcpyDeviceToHost, ctx->s_comp));
+  return S2K_OK;
+}
+
+static int encoded_check_args(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off, const uint8_t* digests,
+                              const uint64_t* dig_off, const uint8_t* sigs, const uint64_t* sig_off, int encoding, size_t* digest_len,
+                              uint32_t* flags, const uint8_t* valid) {
+  if (!pubs || !pub_off || !digests || !dig_off || !sigs || !sig_off || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (encoding != S2K_ENCODING_ASN1 && encoding != S2K_ENCODING_COMPACT && encoding != S2K_ENCODING_COMPACT_RECOVERABLE)
+    return fail(ctx, S2K_ERR_ARG, "unknown encoding");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (*flags & S2K_ECDSA_BIP0066) {
+    if (encoding != S2K_ENCODING_ASN1) return fail(ctx, S2K_ERR_ARG, "BIP-0066 needs the ASN.1 encoding");
+    *digest_len = 32;                                 // optsShitcoin: SHA-256
+    *flags |= S2K_ECDSA_REJECT_MALLEABLE;
+  }
+  return S2K_OK;
+}
+
+int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off,
+                                   const uint8_t* digests, const uint64_t* dig_off, const uint8_t* sigs,
+                                   const uint64_t* sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                   uint8_t* valid) {
+  if (!ctx) return S2K_ERR_ARG;
+  if (n == 0) return S2K_OK;
+  int rc = encoded_check_args(ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, &digest_len, &flags, valid);
+  if (rc) return rc;
+  rc = encoded_enqueue_inner(ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, digest_len, flags, valid, /*one_shot=*/false);
+  if (rc) {
+    s2k_internal_drain(ctx);
+    return rc;
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+  return S2K_OK;
+}
+
+// the same without the wait at the end (s2k_wait / s2k_wait_all; see s2k_ecdsa_verify_batch_submit)
+int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off,
+                                          const uint8_t* digests, const uint64_t* dig_off, const uint8_t* sigs,
+                                          const uint64_t* sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                          uint8_t* valid, s2k_ticket* ticket) {
+  if (!ctx || !ticket) return fail(ctx, S2K_ERR_ARG, "null argument");
+  *ticket = 0;
+  if (n) {
+    int rc = encoded_check_args(ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, &digest_len, &flags, valid);
+    if (rc) return rc;
+  }
+  s2k_ctx::pipe_slot* sl = nullptr;
+  int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
+  if (rc) return rc;
+  if (n) {
+    rc = encoded_enqueue_inner(sl->ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, digest_len, flags,
+                               sl->direct ? valid : sl->h_valid, /*one_shot=*/true);
+    if (rc) {
+      s2k_internal_drain(sl->ctx);
+      return fail(ctx, rc, "%s", sl->ctx->err);
+    }
+  }
+  s2k_internal_pipe_issue(ctx, sl, ticket);
   return S2K_OK;
 }
 

@@ -4,6 +4,8 @@
  *       -Wl,-rpath,$PWD/secp256k1_voi_amd
  *   /tmp/abi_harness cpu      host-only entry points (parsers, constant-time twins): runs anywhere
  *   /tmp/abi_harness gpu      context + batch verification of signatures made with the CT signer
+ *   /tmp/abi_harness group    (built with -DWITH_ORACLE and the oracle library) submit / wait on one context and a
+ *                             two-member group on device 0, verdicts against the synchronous call AND the CPU oracle
  *
  * Exit code 0 = every check passed.  tests/test_c_harness.py builds and runs it. */
 #include <stdint.h>
@@ -143,7 +145,107 @@ static int gpu_part(void) {
   return failures;
 }
 
+/* What a cgo BatchVerifier over several devices does: pinned packed arrays, two batches in flight. */
+#ifdef WITH_ORACLE
+#include "secp256k1_oracle.h"
+#endif
+static void make_batch(int n, int salt, uint8_t* pub, uint8_t* dig, uint8_t* r, uint8_t* s) {
+  uint8_t d[32], k[32], Q[65], rid;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < 32; ++j) {
+      d[j] = (uint8_t)((i % 97) * 131 + j * 7 + 1 + salt);      /* 97 keys */
+      k[j] = (uint8_t)(i * 17 + j * 23 + 9 + salt * 3);
+      dig[i * 32 + j] = (uint8_t)(i * 5 + j * 3 + salt);
+    }
+    d[0] &= 0x7f;
+    k[0] &= 0x7f;
+    s2k_ct_scalar_base_mult(d, Q);
+    memcpy(pub + i * 64, Q + 1, 64);
+    if (s2k_ct_ecdsa_sign_raw(d, dig + i * 32, k, r + i * 32, s + i * 32, &rid) != S2K_OK) ++failures;
+    if (i % 5 == salt % 5) dig[i * 32 + (i % 32)] ^= 0x10;      /* every fifth one damaged */
+    if (i % 11 == 3) s[i * 32 + 31] ^= 1;
+  }
+}
+static int group_part(void) {
+  enum { N = 6000, B = 3 };
+  const int devices[2] = {0, 0};
+  s2k_ctx* ctx = NULL;
+  s2k_group* grp = NULL;
+  CHECK(s2k_device_count() >= 1, "s2k_device_count");
+  if (s2k_ctx_create(0, &ctx) != S2K_OK) {
+    fprintf(stderr, "s2k_ctx_create: %s\n", s2k_last_error(NULL));
+    return 1;
+  }
+  CHECK(s2k_group_create(devices, 2, &grp) == S2K_OK && s2k_group_size(grp) == 2, "s2k_group_create (two members on device 0)");
+  if (!grp) return 1;
+  uint8_t *pub[B], *dig[B], *r[B], *s[B], *sync[B], *piped[B], *grouped[B], *expect[B];
+  for (int b = 0; b < B; ++b) {
+    /* page-locked like a long-lived verifier's packed arrays; the verdict arrays are plain heap memory */
+    pub[b] = s2k_host_alloc(N * 64);
+    dig[b] = s2k_host_alloc(N * 32);
+    r[b] = s2k_host_alloc(N * 32);
+    s[b] = s2k_host_alloc(N * 32);
+    sync[b] = malloc(N);
+    piped[b] = malloc(N);
+    grouped[b] = malloc(N);
+    expect[b] = malloc(N);
+    CHECK(pub[b] && dig[b] && r[b] && s[b], "s2k_host_alloc");
+    make_batch(N - 100 * b, b, pub[b], dig[b], r[b], s[b]);
+    memset(piped[b], 9, N);
+    memset(grouped[b], 9, N);
+    CHECK(s2k_ecdsa_verify_batch(ctx, N - 100 * b, pub[b], dig[b], r[b], s[b], S2K_ECDSA_REJECT_MALLEABLE, sync[b]) == S2K_OK, "synchronous call");
+#ifdef WITH_ORACLE
+    orc_ecdsa_verify_batch(N - 100 * b, pub[b], dig[b], r[b], s[b], 1, expect[b], 8);
+    CHECK(memcmp(sync[b], expect[b], N - 100 * b) == 0, "synchronous call against the oracle");
+#endif
+  }
+  /* one context, submit / wait: three batches, two in flight */
+  s2k_ticket t[B];
+  for (int b = 0; b < B; ++b)
+    CHECK(s2k_ecdsa_verify_batch_submit(ctx, N - 100 * b, pub[b], dig[b], r[b], s[b], S2K_ECDSA_REJECT_MALLEABLE, piped[b], &t[b]) == S2K_OK, "submit");
+  for (int b = 0; b < B; ++b) {
+    CHECK(s2k_wait(ctx, t[b]) == S2K_OK, "wait");
+    CHECK(memcmp(piped[b], sync[b], N - 100 * b) == 0, "submit / wait verdicts");
+  }
+  CHECK(s2k_wait(ctx, t[B - 1] + 1) == S2K_ERR_ARG, "unknown ticket refused");
+  CHECK(s2k_wait_all(ctx) == S2K_OK, "wait_all with nothing in flight");
+  /* the group: the same three batches, all submitted before the first wait */
+  s2k_ticket gt[B];
+  for (int b = 0; b < B; ++b)
+    CHECK(s2k_group_ecdsa_verify_batch_submit(grp, N - 100 * b, pub[b], dig[b], r[b], s[b], S2K_ECDSA_REJECT_MALLEABLE, grouped[b], &gt[b]) == S2K_OK,
+          "group submit");
+  int good = 0;
+  for (int b = 0; b < B; ++b) {
+    CHECK(s2k_group_wait(grp, gt[b]) == S2K_OK, s2k_group_last_error(grp));
+    CHECK(memcmp(grouped[b], sync[b], N - 100 * b) == 0, "group verdicts against the single-context call");
+#ifdef WITH_ORACLE
+    CHECK(memcmp(grouped[b], expect[b], N - 100 * b) == 0, "group verdicts against the oracle");
+#endif
+    for (int i = 0; i < N - 100 * b; ++i) good += grouped[b][i];
+  }
+  double st[8];
+  CHECK(s2k_group_member_stats(grp, st) == S2K_OK && st[0] + st[4] == N - 100 * (B - 1) && st[1] == 0 && st[5] == st[0], "member statistics");
+  CHECK(s2k_group_ecdsa_verify_batch(grp, N, pub[0], dig[0], r[0], s[0], 0, grouped[0]) == S2K_OK, "synchronous group call");
+  CHECK(good > 0 && good < B * N, "mixed verdicts");
+  const int bad_dev[1] = {s2k_device_count()};
+  s2k_group* none = NULL;
+  CHECK(s2k_group_create(bad_dev, 1, &none) == S2K_ERR_ARG && none == NULL, "unknown device refused");
+#ifdef WITH_ORACLE
+  printf("group: %s (%d valid of %d, checked against the oracle)\n", failures ? "FAILED" : "ok", good, B * N - 300);
+#else
+  printf("group: %s (%d valid of %d)\n", failures ? "FAILED" : "ok", good, B * N - 300);
+#endif
+  s2k_group_destroy(grp);
+  s2k_ctx_destroy(ctx);
+  for (int b = 0; b < B; ++b) {
+    s2k_host_free(pub[b]); s2k_host_free(dig[b]); s2k_host_free(r[b]); s2k_host_free(s[b]);
+    free(sync[b]); free(piped[b]); free(grouped[b]); free(expect[b]);
+  }
+  return failures;
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && strcmp(argv[1], "gpu") == 0) return gpu_part() ? 1 : 0;
+  if (argc > 1 && strcmp(argv[1], "group") == 0) return group_part() ? 1 : 0;
   return cpu_part() ? 1 : 0;
 }

@@ -1,0 +1,327 @@
+"""Round-4 GPU tests: the boundary.  submit / wait (two batches in flight per context), the single-process group of
+devices, EncodingCompactRecoverable in the encoded entry point.  Everything through the C-ABI, verdicts against the
+synchronous entry points and the CPU oracle.  Needs a real MI355X.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyref as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+b32 = R.b32
+H = bytes.fromhex
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.init()
+    import secp256k1_voi_amd as S
+    return S.Engine(0)
+
+
+def damaged_batch(eng, n, n_keys, seed):
+    """synthetic valid signatures with every seventh item damaged somewhere (key, digest, r or s)"""
+    from secp256k1_voi_amd.synth import synth_batch
+    arrs = [np.array(a) for a in synth_batch(eng, n, n_keys, seed=seed)]
+    rng = np.random.default_rng(seed)
+    for i in range(0, n, 7):
+        a = arrs[int(rng.integers(0, 4))]
+        a[i, int(rng.integers(0, a.shape[1]))] ^= 1 << int(rng.integers(0, 8))
+    return arrs
+
+
+# ---- submit / wait ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submit_wait_matches_synchronous_call(eng, oracle, pinned):
+    """Five batches of different sizes (one empty, one below the grouping threshold, ragged ones) submitted back to back
+    with two in flight: every ticket's verdicts equal the synchronous call's and the oracle's; the third submit retires
+    the first ticket by itself and a later wait on it returns at once."""
+    import secp256k1_voi_amd as S
+    sizes = [70001, 200, 0, 300003, 4096]
+    batches = [damaged_batch(eng, n, max(n // 11, 3), 400 + n) if n else [np.zeros((0, w), np.uint8) for w in (64, 32, 32, 32)]
+               for n in sizes]
+    refs = [eng.ecdsa_verify_batch(*b) if b[0].shape[0] else np.zeros(0, np.uint8) for b in batches]
+    for b, ref in zip(batches, refs):
+        m = min(b[0].shape[0], 2048)
+        if m:
+            assert np.array_equal(ref[:m], oracle.ecdsa_verify_batch(*(a[:m] for a in b), nthreads=os.cpu_count() or 1))
+            assert 0 < int(ref.sum()) < ref.size
+    if pinned:
+        src = []
+        for b in batches:
+            pb = [S.pinned_array(a.shape) for a in b]
+            for d, a in zip(pb, b):
+                d[...] = a
+            src.append(pb)
+        outs = [S.pinned_array((b[0].shape[0],)) for b in batches]
+    else:
+        src, outs = batches, [None] * len(batches)
+    for mode in (S.KEYS_AUTO, S.KEYS_OFF):
+        eng.set_key_grouping(mode)
+        try:
+            tickets = []
+            for b, o in zip(src, outs):
+                if o is not None:
+                    o[...] = 7
+                tickets.append(eng.ecdsa_verify_batch_submit(*b, out=o))
+            # tickets 1..3 have been retired by the submits behind them; waiting in reverse order is allowed
+            for t, ref in reversed(list(zip(tickets, refs))):
+                assert np.array_equal(t.wait(), ref)
+        finally:
+            eng.set_key_grouping(S.KEYS_AUTO)
+    assert [t.ticket for t in tickets] == sorted(t.ticket for t in tickets)
+    # a ticket that was never issued is refused; a context without anything in flight waits for nothing
+    with pytest.raises(S.EngineError):
+        eng._wait(tickets[-1].ticket + 100)
+    eng.wait_all()
+
+
+def test_submit_wait_interleaved_with_synchronous_calls(eng, oracle):
+    """A synchronous call on the context while two tickets are in flight uses the context's own workspaces: none of the
+    three results is disturbed.  RejectMalleable travels with the submit."""
+    n = 50000
+    a = damaged_batch(eng, n, 900, 61)
+    b = damaged_batch(eng, n, 5000, 62)
+    c = damaged_batch(eng, 3000, 10, 63)
+    # make some s high so that the low-s rule has something to reject
+    for arrs in (a, b):
+        s_int = [int.from_bytes(bytes(x), "big") for x in arrs[3][:64]]
+        for i, v in enumerate(s_int):
+            if 0 < v < R.N and i % 2:
+                arrs[3][i] = np.frombuffer(b32(R.N - v), np.uint8)
+    ref_a = eng.ecdsa_verify_batch(*a, reject_malleable=True)
+    ref_b = eng.ecdsa_verify_batch(*b)
+    ref_c = eng.ecdsa_verify_batch(*c)
+    exp_a = oracle.ecdsa_verify_batch(*(x[:1024] for x in a), reject_malleable=True, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(ref_a[:1024], exp_a)
+    ta = eng.ecdsa_verify_batch_submit(*a, reject_malleable=True)
+    tb = eng.ecdsa_verify_batch_submit(*b)
+    got_c = eng.ecdsa_verify_batch(*c)
+    assert np.array_equal(got_c, ref_c)
+    assert np.array_equal(tb.wait(), ref_b)
+    assert np.array_equal(ta.wait(), ref_a)
+    assert not np.array_equal(ref_a, eng.ecdsa_verify_batch(*a))      # (the rule did reject something)
+
+
+def test_submit_wait_full_size_pipeline(eng, oracle):
+    """2^20 signatures per batch, four batches through the two slots from pinned memory, each batch damaged at its own
+    seeded positions: every ticket's verdicts are the expected pattern (a slot that delivered another batch's verdicts,
+    or none, cannot pass), and the head of one batch is checked against the oracle."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    n = 1 << 20
+    base = [np.array(x) for x in synth_batch(eng, n, 1 << 16, seed=0x5EC9)]
+    bufs, outs, masks = [], [], []
+    for k in range(4):
+        pb = [S.pinned_array(x.shape) for x in base]
+        for d, x in zip(pb, base):
+            d[...] = x
+        i = np.arange(n, dtype=np.uint64)
+        bad = ((i * np.uint64(2654435761) + np.uint64(k * 7919 + 5)) % np.uint64(53)) == 0
+        pb[3][bad, 31] ^= 1
+        bufs.append(pb)
+        masks.append(~bad)
+        o = S.pinned_array((n,))
+        o[...] = 9
+        outs.append(o)
+    tickets = [eng.ecdsa_verify_batch_submit(*bufs[0], out=outs[0]), eng.ecdsa_verify_batch_submit(*bufs[1], out=outs[1])]
+    for k in range(2, 4):
+        assert np.array_equal(tickets[k - 2].wait(), masks[k - 2].astype(np.uint8))
+        tickets.append(eng.ecdsa_verify_batch_submit(*bufs[k], out=outs[k]))
+    for k in range(2, 4):
+        assert np.array_equal(tickets[k].wait(), masks[k].astype(np.uint8))
+    m = 4096
+    assert np.array_equal(outs[3][:m], oracle.ecdsa_verify_batch(*(x[:m] for x in bufs[3]), nthreads=os.cpu_count() or 1))
+
+
+def test_encoded_submit_wait(eng, oracle):
+    """s2k_ecdsa_verify_encoded_batch_submit: DER and compact forms of a damaged batch, two in flight, against the
+    synchronous encoded call and the raw verifier."""
+    import secp256k1_voi_amd as S
+    n = 30000
+    arrs = damaged_batch(eng, n, 700, 77)
+    ref = eng.ecdsa_verify_batch(*arrs)
+
+    def der_int(b):
+        b = bytes(b).lstrip(b"\0") or b"\0"
+        if b[0] & 0x80:
+            b = b"\0" + b
+        return b"\x02" + bytes([len(b)]) + b
+    pubs = [b"\x04" + bytes(q) for q in arrs[0]]
+    digs = [bytes(d) for d in arrs[1]]
+    der = []
+    for r, s in zip(arrs[2], arrs[3]):
+        body = der_int(r) + der_int(s)
+        der.append(b"\x30" + bytes([len(body)]) + body)
+    compact = [bytes(r) + bytes(s) for r, s in zip(arrs[2], arrs[3])]
+    sync_der = eng.ecdsa_verify_encoded_batch(pubs, digs, der)
+    # (an r or s of zero or >= n does not parse: both paths say invalid)
+    assert np.array_equal(sync_der, ref)
+    t1 = eng.ecdsa_verify_encoded_batch_submit(pubs, digs, der)
+    t2 = eng.ecdsa_verify_encoded_batch_submit(pubs, digs, compact, encoding=S.ENCODING_COMPACT)
+    t3 = eng.ecdsa_verify_encoded_batch_submit(pubs, digs, der, digest_len=48)      # wrong digest length: all false
+    assert np.array_equal(t1.wait(), ref)
+    assert np.array_equal(t2.wait(), ref)
+    assert not t3.wait().any()
+
+
+# ---- several members in one process ----------------------------------------------------------------------------------
+def test_group_two_members_one_device(eng, oracle):
+    """A group with two members (both on device 0 on this pool: two contexts, two host threads) verifies contiguous
+    shards of one batch; verdicts equal the single-context call's and the oracle's, for ragged sizes, sizes below the
+    member count, an empty batch, grouping on and off, and two group batches in flight."""
+    import secp256k1_voi_amd as S
+    assert S.device_count() >= 1
+    g = S.Group([0, 0])
+    try:
+        assert len(g) == 2
+        for n in (100001, 3, 0, 257):
+            if n == 0:
+                assert g.ecdsa_verify_batch(np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8),
+                                            np.zeros((0, 32), np.uint8)).size == 0
+                continue
+            arrs = damaged_batch(eng, n, max(n // 13, 2), 900 + n)
+            ref = eng.ecdsa_verify_batch(*arrs)
+            m = min(n, 2048)
+            assert np.array_equal(ref[:m], oracle.ecdsa_verify_batch(*(a[:m] for a in arrs), nthreads=os.cpu_count() or 1))
+            for mode in (S.KEYS_AUTO, S.KEYS_OFF):
+                g.set_key_grouping(mode)
+                assert np.array_equal(g.ecdsa_verify_batch(*arrs), ref)
+            g.set_key_grouping(S.KEYS_AUTO)
+            st = g.member_stats()
+            assert sum(x["n"] for x in st) == n and st[0]["first"] == 0 and [x["device"] for x in st] == [0, 0]
+            assert n < 2 or st[1]["first"] == st[0]["n"]
+        # pipelined: three group batches submitted before the first wait (the third submit blocks until the first is done)
+        batches = [damaged_batch(eng, 60000 + 1000 * k, 500, 950 + k) for k in range(3)]
+        refs = [eng.ecdsa_verify_batch(*b) for b in batches]
+        tickets = [g.ecdsa_verify_batch_submit(*b) for b in batches]
+        for t, ref in zip(tickets, refs):
+            assert np.array_equal(t.wait(), ref)
+        # low-s rule through the group
+        a = batches[0]
+        assert np.array_equal(g.ecdsa_verify_batch(*a, reject_malleable=True), eng.ecdsa_verify_batch(*a, reject_malleable=True))
+        with pytest.raises(S.EngineError):
+            g._wait(10 ** 6)
+    finally:
+        g.close()
+    with pytest.raises(S.EngineError):
+        S.Group([S.device_count()])            # no such device
+
+
+# ---- EncodingCompactRecoverable -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fn", ["wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"])
+def test_wycheproof_compact_recoverable(eng, oracle, fn):
+    """secec/wycheproof_test.go:417-438 builds the recoverable forms of every parseable case with all four recovery
+    ids and asks whether one of them gives the signer's key.  Here every (case, id) pair is one item of
+    s2k_ecdsa_verify_encoded_batch(S2K_ENCODING_COMPACT_RECOVERABLE) = PublicKey.Verify with EncodingCompactRecoverable
+    (ecdsa.go:204-205,220-226): valid iff RecoverPublicKey succeeds and the key equals the supplied one (oracle's recover
+    + equality); per case, some id verifies iff the case is valid."""
+    import secp256k1_voi_amd as S
+    d = load_golden(fn)
+    pubs, digs, sigs, exp, meta = [], [], [], [], []
+    for c in d["cases"]:
+        rs = oracle.parse_asn1_signature(H(c["sig"]))
+        if rs is None:
+            continue
+        for rid in range(5):                      # 4 is no recovery id
+            pubs.append(H(c["pub"]))
+            digs.append(H(c["digest"]))
+            sigs.append(rs[0] + rs[1] + bytes([rid]))
+            q = oracle.ecdsa_recover(H(c["digest"])[:32], rs[0], rs[1], rid)
+            exp.append(int(q is not None and q == H(c["pub"])))
+            meta.append((c, rid))
+    got = eng.ecdsa_verify_encoded_batch(pubs, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE)
+    assert got.tolist() == exp
+    assert eng.ecdsa_verify_encoded_batch(pubs, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE, force_complete=True).tolist() == exp
+    by_case = {}
+    for (c, rid), v in zip(meta, got):
+        by_case[c["tcId"]] = by_case.get(c["tcId"], 0) | int(v)
+    for c in d["cases"]:
+        if c["tcId"] in by_case:
+            assert by_case[c["tcId"]] == int(c["valid"]), c["tcId"]
+    # compressed keys name the same key
+    comp = [oracle.point_compressed(p) for p in pubs]
+    assert eng.ecdsa_verify_encoded_batch(comp, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE).tolist() == exp
+    # opts.Hash = SHA-256 (ecdsa.go:184-188)
+    got32 = eng.ecdsa_verify_encoded_batch(pubs, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE, digest_len=32).tolist()
+    assert got32 == (exp if fn.endswith("sha256.json") else [0] * len(exp))
+    # submit form
+    assert eng.ecdsa_verify_encoded_batch_submit(pubs, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE).wait().tolist() == exp
+
+
+def test_compact_recoverable_options_and_edges(eng, oracle):
+    """Random signatures with their true recovery id (found with the oracle), then: a wrong id, the signature of another
+    key, wrong lengths (64, 66 bytes), V = 4 and 255, r / s out of range, high s with and without RejectMalleable,
+    malformed supplied keys.  Expected values from the oracle's recover + byte equality."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(404)
+    pubs, digs, sigs, exp, exp_low = [], [], [], [], []
+
+    def add(pub, dg, sig):
+        pubs.append(pub); digs.append(dg); sigs.append(sig)
+        ok, ok_low = 0, 0
+        if len(sig) == 65 and len(dg) >= 32:
+            r, s, v = sig[:32], sig[32:64], sig[64]
+            ri, si = int.from_bytes(r, "big"), int.from_bytes(s, "big")
+            if 0 < ri < R.N and 0 < si < R.N:
+                q = oracle.ecdsa_recover(dg[:32], r, s, v) if v < 4 else None
+                ok = int(q is not None and len(pub) == 65 and q == pub)
+                if q is not None and len(pub) == 33:
+                    ok = int(oracle.point_compressed(q) == pub)
+                ok_low = ok if si <= R.N // 2 else 0
+        exp.append(ok); exp_low.append(ok_low)
+
+    keys = []
+    for _ in range(8):
+        d = rnd.randrange(1, R.N)
+        keys.append((d, oracle.scalar_base_mult_vartime(b32(d))))
+    for i in range(300):
+        d, q = keys[i % len(keys)]
+        dg = rnd.randbytes(32)
+        k = rnd.randrange(1, R.N)
+        r, s = R.ecdsa_sign(d, dg, k)
+        if i % 3 == 0:
+            s = R.N - s                                           # high s: still recovers (with the other parity)
+        rid = next(v for v in range(4) if oracle.ecdsa_recover(dg, b32(r), b32(s), v) == q)
+        sig = b32(r) + b32(s) + bytes([rid])
+        kind = i % 10
+        if kind == 0:
+            add(q, dg, sig)
+        elif kind == 1:
+            add(q, dg, sig[:64] + bytes([rid ^ 1]))                # the other y: another key
+        elif kind == 2:
+            add(keys[(i + 1) % len(keys)][1], dg, sig)             # somebody else's key
+        elif kind == 3:
+            add(q, dg, rnd.choice([sig[:64], sig + b"\0", b""]))   # wrong length
+        elif kind == 4:
+            add(q, dg, sig[:64] + bytes([rnd.choice([4, 5, 255])]))
+        elif kind == 5:
+            add(q, dg, rnd.choice([b32(0), b32(R.N), b32(R.N + 5)]) + sig[32:])   # r out of range
+        elif kind == 6:
+            add(q, dg, sig[:32] + rnd.choice([b32(0), b32(R.N)]) + sig[64:])      # s out of range
+        elif kind == 7:
+            add(oracle.point_compressed(q), dg, sig)               # compressed form of the same key
+        elif kind == 8:
+            bad = bytearray(q); bad[64] ^= 1
+            add(rnd.choice([bytes(bad), b"\x05" + q[1:], q[:64], b"\x00"]), dg, sig)   # not a key NewPublicKey accepts
+        else:
+            add(q, rnd.randbytes(32), sig)                         # another digest: recovers some other key
+    got = eng.ecdsa_verify_encoded_batch(pubs, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE)
+    assert got.tolist() == exp
+    assert 0 < sum(exp) < len(exp)
+    got_low = eng.ecdsa_verify_encoded_batch(pubs, digs, sigs, encoding=S.ENCODING_COMPACT_RECOVERABLE, reject_malleable=True)
+    assert got_low.tolist() == exp_low and exp_low != exp
+    # the other two encodings refuse 65-byte signatures; BIP-0066 goes with ASN.1 only
+    assert not eng.ecdsa_verify_encoded_batch(pubs[:10], digs[:10], [s_ for s_ in sigs[:10]], encoding=S.ENCODING_COMPACT)[
+        [len(s_) == 65 for s_ in sigs[:10]]].any()
+    with pytest.raises(S.EngineError):
+        eng.ecdsa_verify_encoded_batch(pubs[:4], digs[:4], sigs[:4], encoding=S.ENCODING_COMPACT_RECOVERABLE, bip0066=True)
+    with pytest.raises(S.EngineError):
+        eng.ecdsa_verify_encoded_batch(pubs[:4], digs[:4], sigs[:4], encoding=3)
