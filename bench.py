@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe inclusive) measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip configs 3/4, K=N and the worst case (e.g. under a profiler)")
+    ap.add_argument("--key-grouping", choices=("auto", "off"), default="auto",
+                    help="off: every signature through the general ladder (profiling the K = N kernel; not the headline)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="test hook: allow more ranks than devices (rank r -> device r mod count, gloo collectives)")
     return ap.parse_args()
@@ -148,7 +150,21 @@ def cpu_baseline(pub, digest, r, s, budget_s=15.0):
         ok = oracle.ecdsa_verify_asn1(b"\x04" + bytes(pub[i]), bytes(digest[i]), b"\x30" + bytes([len(body)]) + body)
         assert ok == 1
     config1 = m1 / (time.perf_counter() - t0)
-    return {"value": value, "unit": "verifications/s", "cores": best_th, "kind": "port",
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            with open(path) as f:
+                quota = parse(f.read().strip())
+            break
+        except Exception:
+            continue
+    return {"value": value, "unit": "verifications/s", "cores": best_th, "threads": best_th, "kind": "port",
+            "single_thread_value": single, "speedup_vs_1_thread": value / single,
+            "host_logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": cores, "cgroup_cpu_quota": quota,
+            "threads_note": "`cores` = `threads` = worker threads the oracle ran on (static split of the sample); the speed-up over "
+                            "one thread is what the box gave them - SMT siblings, a cgroup quota or other tenants make it smaller "
+                            "than the thread count",
             "config1_der_single_thread": {"value": config1, "unit": "verifications/s", "sample": f"{m1} DER signatures, "
                                           "single-signature verify incl. parsing"},
             "sample": f"first {m} signatures of the rank-0 batch, {best_th} threads (best of 1..{cores} host cores, "
@@ -166,15 +182,38 @@ def load_profile_json(name):
 
 def committed_counts():
     """PMC-derived per-signature figures of the path's kernels (profiles/, newest round first)."""
-    for name in ("r03_valu_counts.json", "r02_valu_counts.json", "r01_valu_counts.json"):
+    for name in ("r04_valu_counts.json", "r03_valu_counts.json", "r02_valu_counts.json", "r01_valu_counts.json"):
         d = load_profile_json(name)
         if d:
             return d, name
     return None, None
 
 
+def recount_shipped_binary(lib_path, counts):
+    """Static trip-weighted VALU counts of the two ladder kernels from the code object of the library that is LOADED
+    (tools/isa_count.py: disassembly, loops from backward branches) against the committed figures: `counts_stale` says the
+    kernels changed since the counters were read."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_count
+        live = isa_count.static_counts(lib_path)
+    except Exception as e:                      # no llvm-objdump on the box: say so, do not guess
+        return {"counts_stale": None, "recount_error": repr(e)[:200]}
+    out = {"counts_head": (counts or {}).get("head"), "static_recount": {k: v["valu_instr_static"] for k, v in live.items()}}
+    stale = False
+    for kname, skey in (("k_verify_fast", "static"), ("k_verify_fast_keyed", "static_keyed")):
+        ref = (counts or {}).get(skey, {}).get("valu_instr_static")
+        pmc = (counts or {}).get(kname, {}).get("valu_instr_per_signature")
+        got = live[kname]["valu_instr_static"]
+        for want in (ref, pmc):
+            if want is None or abs(got - want) > 0.005 * want:
+                stale = True
+    out["counts_stale"] = stale
+    return out
+
+
 def committed_traffic(kernel="k_verify_fast"):
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         d = load_profile_json(name)
         if d and kernel in d:
             return d[kernel]["hbm_bytes_per_launch"], name
@@ -229,6 +268,8 @@ def worker(args):
     n = 1 << batch_log2
     n_keys = min(n, 1 << args.keys_log2)
     eng = S.Engine(local_rank)
+    if args.key_grouping == "off":
+        eng.set_key_grouping(S.KEYS_OFF)
     pub, digest, r, s = synth_batch(eng, n, n_keys, seed=0x5EC9 + rank)
     d_pub, d_dig, d_r, d_s = (torch.from_numpy(x).to(dev) for x in (pub, digest, r, s))
     d_valid = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -292,7 +333,40 @@ def worker(args):
     assert bitmap.numel() == n * world // 8 and bool((bitmap == 0xFF).all().item())
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    multi = None
     if dist is not None:
+        # what a first run on N devices needs to tell a straggler from a slow collective: every rank's own time for the K
+        # timed steps, and (a short untimed pass behind them) its step split at the collective by events on the stream:
+        # local = verification + bitmap packing, collective = the all-gather of the bitmap shards
+        own = torch.tensor([dt], dtype=torch.float64, device=t.device)
+        every = torch.zeros(world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(every, own)
+        k2 = max(1, min(args.steps, 10))
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(k2)]
+        sync()
+        for e in evs:
+            e[0].record()
+            d_valid.zero_()
+            eng.ecdsa_verify_batch_device(n, d_pub.data_ptr(), d_dig.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), d_valid.data_ptr(), 0, st)
+            gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count, scratch=gather_scratch, events=(e[1], e[2]))
+            e[3].record()
+        sync()
+        split = torch.tensor([sum(e[0].elapsed_time(e[1]) for e in evs) / k2, sum(e[1].elapsed_time(e[2]) for e in evs) / k2,
+                              sum(e[0].elapsed_time(e[3]) for e in evs) / k2], dtype=torch.float64, device=t.device)
+        splits = torch.zeros(3 * world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(splits, split)
+        splits = splits.view(world, 3).cpu().tolist()
+        multi = {"per_rank_ms": [x * 1e3 / args.steps for x in every.cpu().tolist()],
+                 "per_rank_local_ms": [x[0] for x in splits], "collective_ms": [x[1] for x in splits],
+                 "per_rank_step_ms_diagnostic_pass": [x[2] for x in splits],
+                 "value_without_collective": n * world / (max(x[0] for x in splits) * 1e-3),
+                 "per_gpu_value_without_collective": n / (max(x[0] for x in splits) * 1e-3),
+                 "group_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                 "note": "per_rank_ms: each rank's own wall time per step over the K timed steps (value uses the maximum); "
+                         "per_rank_local_ms / collective_ms: HIP events on the rank's stream around verification + packing and around "
+                         "the all-gather, %d untimed steps behind the timed region; value_without_collective: all ranks' signatures "
+                         "over the slowest rank's local time - what N independent single-GPU runs would give in this launch" % k2}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -322,6 +396,7 @@ def worker(args):
                 "shader_clock_mhz": prof["shader_mhz"], "shader_clock_mhz_first_wave": prof["shader_mhz_first_wave"],
                 "shader_clock_mhz_last_round": prof["shader_mhz_last_round"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
                 "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
+        counts_all = counts
         if counts and kname not in counts:
             counts = None
         if counts:
@@ -373,11 +448,14 @@ def worker(args):
                        "inputs": "resident in HBM", "collective": "one all-gather per step: bitmap shard + valid count of every rank",
                        "build": eng._lib.s2k_build_config().decode()},
             "roofline": roof,
-            "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)", "signatures_on_key_tables": grouping["keyed"],
+            "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)" if args.key_grouping == "auto" else "off (--key-grouping off)", "signatures_on_key_tables": grouping["keyed"],
                              "tables_built_per_step": grouping["tables"], "signatures_on_general_ladder": grouping["general"],
                              "note": "signatures are grouped by public key inside every step; keys with >= 4 signatures get a "
                                      "precomputed table (built inside the step) and their signatures a 12-doubling ladder"},
         }
+        if multi is not None:
+            line["multi_rank"] = multi
+        roof.update(recount_shipped_binary(S.LIB_PATH, counts_all))
         extras = world == 1 and not args.no_extras
         if extras:
             try:
@@ -414,10 +492,42 @@ def worker(args):
             line["pcie_inclusive"]["pinned"] = {"value": n / (median(pin_ms) * 1e-3), "unit": "verifications/s", "ms_each": pin_ms,
                                                 "note": "the same call from s2k_host_alloc buffers; 160 MiB over PCIe take 3.0 ms on their "
                                                         "own (55 GB/s), the keys' 64 MiB of it are exposed"}
-            del pinned
+            # submit / wait: three batches in flight on the context's child contexts, a new one submitted whenever one
+            # is done - what a caller that streams batches gets (s2k_ecdsa_verify_batch_submit / s2k_wait); the verdict
+            # arrays are page-locked too
+            def pipelined(submit, nb, depth=3):
+                tickets, t_0 = [], time.perf_counter()
+                for k in range(nb):
+                    tickets.append(submit(k))
+                    if len(tickets) >= depth:
+                        assert int(tickets.pop(0).wait().sum()) == n
+                for tk in tickets:
+                    assert int(tk.wait().sum()) == n
+                return (time.perf_counter() - t_0) * 1e3 / nb
+            pin3 = [pinned] + [[pinned_array(a.shape) for a in pinned] for _ in range(2)]
+            for q in pin3[1:]:
+                for dst, src in zip(q, pinned):
+                    dst[...] = src
+            outs3 = [pinned_array((n,)) for _ in range(3)]
+            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 3], out=outs3[k % 3]), 6)
+            pl_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 3], out=outs3[k % 3]), 12) for _ in range(3)]
+            line["pcie_inclusive"]["pipelined"] = {"value": n / (median(pl_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl_ms),
+                                                   "ms_per_batch_each": pl_ms, "batches": 12, "in_flight": 3,
+                                                   "fraction_of_resident_value": (n / (median(pl_ms) * 1e-3)) / value,
+                                                   "note": "s2k_ecdsa_verify_batch_submit / s2k_wait from page-locked buffers, 12 batches of 2^%d, "
+                                                           "three in flight; host bytes to host verdicts" % batch_log2}
+            pg3 = [(pub, digest, r, s)] + [tuple(a.copy() for a in (pub, digest, r, s)) for _ in range(2)]
+            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 3]), 4)
+            pg_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 3]), 12) for _ in range(3)]
+            line["pcie_inclusive"]["pipelined_pageable"] = {"value": n / (median(pg_ms) * 1e-3), "unit": "verifications/s",
+                                                            "ms_per_batch": median(pg_ms), "ms_per_batch_each": pg_ms,
+                                                            "note": "the same from pageable memory (the runtime stages the copies; submit "
+                                                                    "blocks while it does, beside the other batches' kernels)"}
+            del pinned, pin3, outs3, pg3
             # the encoded boundary (SEC1 keys + DER signatures, what secec.PublicKey.Verify takes): bytes parsed on the device
             if not args.no_extras:
                 line["encoded_2p%d" % batch_log2] = encoded_measurement(eng, pub, digest, r, s)
+            eng.wait_all()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(pub, digest, r, s)
         print(json.dumps(line), flush=True)
@@ -456,9 +566,41 @@ def encoded_measurement(eng, pub, digest, r, s, reps=3):
         if rep:
             ms.append((time.perf_counter() - t0) * 1e3)
         assert int(out.sum()) == n
+    def pipelined(nb, depth=3):
+        tickets, t_0 = [], time.perf_counter()
+        for k in range(nb):
+            tickets.append(eng.ecdsa_verify_encoded_batch_submit((pb, po), (db, do), (sb, so), digest_len=32))
+            if len(tickets) >= depth:
+                assert int(tickets.pop(0).wait().sum()) == n
+        for tk in tickets:
+            assert int(tk.wait().sum()) == n
+        return (time.perf_counter() - t_0) * 1e3 / nb
+    pipelined(4)
+    pl = [pipelined(12) for _ in range(3)]
     return {"value": n / (median(ms) * 1e-3), "unit": "verifications/s", "ms_each": ms, "bytes_per_item": (len(pb) + len(db) + len(sb)) / n,
+            "pipelined": {"value": n / (median(pl) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl), "ms_per_batch_each": pl,
+                          "note": "s2k_ecdsa_verify_encoded_batch_submit / s2k_wait, 12 batches, three in flight, pageable host memory"},
             "note": "s2k_ecdsa_verify_encoded_batch: 65-byte SEC1 keys, 32-byte digests, DER signatures from pageable host memory; "
                     "strict DER parsing and key decoding on the device, then the batch verifier"}
+
+
+def general_roofline(kernel_ms, shader_mhz, n):
+    """`roofline` of the general ladder k_verify_fast<ECDSA> (what a batch without key reuse runs on): PMC count x signatures
+    / live kernel time against the 4-cycle issue peak."""
+    counts, src = committed_counts()
+    roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA>", "kernel_ms": kernel_ms, "shader_clock_mhz": shader_mhz,
+            "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12}
+    if counts and "k_verify_fast" in counts:
+        ipv = counts["k_verify_fast"]["valu_instr_per_signature"]
+        lane_ops = ipv * n / (kernel_ms * 1e-3)
+        roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS, "valu_instr_per_verify": ipv,
+                     "counts_from": "profiles/" + src})
+        if shader_mhz > 0:
+            roof["frac_at_measured_clock"] = ipv * n / 64.0 * 4.0 / (SIMDS * kernel_ms * 1e-3 * shader_mhz * 1e6)
+        st_ = counts.get("static", {})
+        if "mad_u64_u32_per_verify" in st_:
+            roof["mad_u64_u32_per_verify"] = st_["mad_u64_u32_per_verify"]
+    return roof
 
 
 def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_stage):
@@ -565,29 +707,43 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
                                           "shader_clock_mhz": pr["shader_mhz"],
                                           "note": "s2k_ctx_set_key_grouping(S2K_KEYS_OFF): per-signature table and 128 doublings "
                                                   "for every signature, step includes the same bitmap exchange"}
-        counts, _ = committed_counts()
-        if counts and "k_verify_fast" in counts and pr["shader_mhz"] > 0:
-            wave_instr = counts["k_verify_fast"]["valu_instr_per_signature"] * n / 64.0
-            out["general_path_same_batch"]["frac_at_measured_clock"] = wave_instr * 4.0 / (SIMDS * pr["fast_ms"] / pr["calls"] * 1e-3 * pr["shader_mhz"] * 1e6)
-            out["general_path_same_batch"]["frac"] = counts["k_verify_fast"]["valu_instr_per_signature"] * n / (pr["fast_ms"] / pr["calls"] * 1e-3) / VALU_PEAK_LANE_OPS
+        general_ms = pr["fast_ms"] / pr["calls"]
+        out["general_path_same_batch"]["roofline"] = general_roofline(general_ms, pr["shader_mhz"], n)
 
-    # ---- K = N: every signature under its own key (SURVEY 8d "also report K = N") ----
+    # ---- K = N: every signature under its own key (SURVEY 8d "also report K = N").  The grouping finds nothing to share
+    # and must cost (next to) nothing: auto and off are measured ALTERNATELY, five rounds of five calls each, medians - the
+    # clock drifts by more than the difference between two consecutive blocks of calls ----
     if n_keys < n:
         inp = tuple(torch.from_numpy(x).to(dev) for x in synth_batch(eng, n, n, seed=0xD157))
-        d_valid.zero_()
-        ms = timed(lambda: verify_on(inp), 5)
-        assert int(d_valid.sum().item()) == n, "K = N batch did not verify"
-        eng.set_key_grouping(KEYS_OFF)
+        ms_auto, ms_off, kern = [], [], None
         try:
-            d_valid.zero_()
-            ms_off = timed(lambda: verify_on(inp), 5)
-            assert int(d_valid.sum().item()) == n, "K = N batch did not verify (grouping off)"
+            for rnd_ in range(5):
+                eng.set_key_grouping(KEYS_AUTO)
+                d_valid.zero_()
+                ms_auto.append(timed(lambda: verify_on(inp), 5))
+                assert int(d_valid.sum().item()) == n, "K = N batch did not verify"
+                gs = eng.key_grouping_stats()
+                assert gs["keyed"] == 0 and gs["general"] == n, gs
+                eng.set_key_grouping(KEYS_OFF)
+                d_valid.zero_()
+                if rnd_ == 4:
+                    eng.profile(True)
+                ms_off.append(timed(lambda: verify_on(inp), 5))
+                assert int(d_valid.sum().item()) == n, "K = N batch did not verify (grouping off)"
+            pr2 = eng.profile_read_stages(cap=8)
+            kern = (pr2["fast_ms"] / pr2["calls"], pr2["shader_mhz"])
         finally:
+            eng.profile(False)
             eng.set_key_grouping(KEYS_AUTO)
+        ms, ms_off_med = median(ms_auto), median(ms_off)
         out["distinct_keys"] = {"keys": n, "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
-                                "ms_with_key_grouping_off": ms_off,
+                                "ms_with_key_grouping_off": ms_off_med, "grouping_overhead": ms / ms_off_med - 1.0,
+                                "ms_rounds_auto": ms_auto, "ms_rounds_off": ms_off,
+                                "roofline": general_roofline(kern[0], kern[1], n),
                                 "note": "every signature under its own key: the grouping finds nothing to share and all "
-                                        "signatures take the general ladder; same call without the grouping beside it"}
+                                        "signatures take the general ladder; the same call with the grouping off measured "
+                                        "alternately with it (5 x 5 calls each, medians); roofline: k_verify_fast<ECDSA> of the "
+                                        "grouping-off calls"}
         del inp
 
     # ---- adversarial worst case: every lane undecided by the fast ladder (u1 G + u2 Q = infinity) ----

@@ -47,7 +47,8 @@ enum {
   S2K_ERR_NO_DEVICE = -1, /* no usable gfx950 device */
   S2K_ERR_HIP = -2,       /* a HIP runtime call failed; see s2k_last_error */
   S2K_ERR_ARG = -3,       /* null pointer / bad length / length mismatch (the reference panics: point_mul_multi.go:27) */
-  S2K_ERR_NOMEM = -4
+  S2K_ERR_NOMEM = -4,
+  S2K_PENDING = 1         /* s2k_poll: the ticket is still in flight (not an error) */
 };
 
 /* flags for the ECDSA entry points */
@@ -206,20 +207,22 @@ int s2k_host_unregister(void *p);
  * it into s2k_ecdsa_verify_batch, which pays the PCIe transfer and the kernels in series (7.1 ms from pinned, 8.2 ms
  * from pageable memory against 4.9 ms resident per 2^20 signatures).  s2k_ecdsa_verify_batch_submit returns as soon as
  * the batch is enqueued (from page-locked buffers: at once; from pageable ones: when the runtime has staged the copies)
- * and s2k_wait blocks until the verdicts of that ticket are in `valid`.  The context keeps TWO batches in flight on two
+ * and s2k_wait blocks until the verdicts of that ticket are in `valid`.  The context keeps up to THREE batches in flight on
  * internal child contexts (own workspaces and streams on the same device; the generator tables are shared): batch k+1's
- * transfer, grouping and per-key tables run beside batch k's ladder, so a caller that submits batch k+1 before it waits
- * for batch k sees the resident rate.  A third submit first retires the oldest ticket (delivers its verdicts; a later
- * s2k_wait on it returns at once).  Same verdicts as s2k_ecdsa_verify_batch, bit for bit; the inputs and `valid` must
+ * transfer, grouping and per-key tables run beside batch k's ladder, so a caller that submits batch k+1 (better: k+2)
+ * before it waits for batch k sees the resident rate.  A fourth submit first retires the oldest ticket (delivers its
+ * verdicts; a later s2k_wait on it returns at once).  s2k_poll is s2k_wait without the blocking: S2K_PENDING while the
+ * ticket is in flight.  Same verdicts as s2k_ecdsa_verify_batch, bit for bit; the inputs and `valid` must
  * stay untouched until the ticket has been waited for (or retired).  Submit, wait and the other calls of one context
  * must come from one thread at a time, like all calls on a context; the key-grouping settings are those the context
  * has at submit time.  s2k_wait_all retires everything in flight (oldest first; s2k_ctx_destroy does the same).
  * Each child holds what s2k_ctx_device_bytes reports minus the generator tables.  Set GPU_MAX_HW_QUEUES=8 in the
- * process environment: two batches in flight use six streams. */
+ * process environment: three batches in flight use nine streams. */
 typedef uint64_t s2k_ticket;
 int s2k_ecdsa_verify_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy, const uint8_t *digest32, const uint8_t *r,
                                   const uint8_t *s, uint32_t flags, uint8_t *valid, s2k_ticket *ticket);
 int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
+int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
 /* s2k_ecdsa_verify_encoded_batch (below) in the same form */
 int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
@@ -235,8 +238,8 @@ int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t 
  * up to rounding to 256), every member runs s2k_ecdsa_verify_batch_submit / s2k_wait on its shard from its own thread,
  * and the verdicts land in the caller's `valid` at the shard's offset - the "all-gather" is the host array itself.
  * Verdicts are those of s2k_ecdsa_verify_batch on the whole batch, bit for bit (signatures are independent; only the
- * grouping by key is per shard).  s2k_group_ecdsa_verify_batch = submit + wait.  Up to two group batches are in flight
- * per member (a third submit blocks until the oldest is done).  Group calls may come from any ONE thread at a time.
+ * grouping by key is per shard).  s2k_group_ecdsa_verify_batch = submit + wait.  Up to three group batches are in flight
+ * per member (a fourth submit blocks until the oldest is done).  Group calls may come from any ONE thread at a time.
  * s2k_device_count: devices visible to the runtime (0 when there is none). */
 typedef struct s2k_group s2k_group;
 int s2k_device_count(void);

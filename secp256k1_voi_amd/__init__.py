@@ -233,6 +233,7 @@ def load_library() -> C.CDLL:
     lib.s2k_ecdsa_verify_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, C.POINTER(u64)]
     lib.s2k_ecdsa_verify_encoded_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, ci, sz, u32, vp, C.POINTER(u64)]
     lib.s2k_wait.argtypes = [vp, u64]
+    lib.s2k_poll.argtypes = [vp, u64]
     lib.s2k_wait_all.argtypes = [vp]
     lib.s2k_device_count.restype = ci
     lib.s2k_group_create.argtypes = [C.POINTER(ci), sz, C.POINTER(vp)]
@@ -287,7 +288,7 @@ EXPORTED_SYMBOLS = [
     "s2k_pack_valid_device", "s2k_host_alloc", "s2k_host_free", "s2k_host_register", "s2k_host_unregister", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
-    "s2k_ecdsa_verify_batch_submit", "s2k_ecdsa_verify_encoded_batch_submit", "s2k_wait", "s2k_wait_all",
+    "s2k_ecdsa_verify_batch_submit", "s2k_ecdsa_verify_encoded_batch_submit", "s2k_wait", "s2k_poll", "s2k_wait_all",
     "s2k_device_count", "s2k_group_create", "s2k_group_destroy", "s2k_group_size", "s2k_group_last_error",
     "s2k_group_set_key_grouping", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
     "s2k_group_member_stats",
@@ -406,6 +407,13 @@ class Engine:
 
     def _wait(self, ticket):
         self._check(self._lib.s2k_wait(self._h, ticket))
+
+    def _poll(self, ticket) -> bool:
+        rc = self._lib.s2k_poll(self._h, ticket)
+        if rc == 1:          # S2K_PENDING
+            return False
+        self._check(rc)
+        return True
 
     # ---- hot path -------------------------------------------------------------------
     def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False,
@@ -812,6 +820,13 @@ class Ticket:
             self._done = True
             self._keep = None
         return self._out
+
+    def done(self) -> bool:
+        """s2k_poll: True once the verdicts are delivered (never blocks)."""
+        if not self._done and hasattr(self._owner, "_poll") and self._owner._poll(self.ticket):
+            self._done = True
+            self._keep = None
+        return self._done
 
 
 def device_count() -> int:

@@ -2186,11 +2186,13 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
 // ---------------------------------------------------------------------------------------
 // submit / wait: the host-pointer entry points without the wait at their end.  The reference's caller holds its data in
 // host memory (secec/ecdsa.go:171-228) and a synchronous call pays transfer and compute in series: 7.1 ms from pinned
-// memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns two child
+// memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns child
 // contexts ("slots": own workspaces, staging buffers and streams; the 3 GiB generator tables are shared per device)
-// that take the submitted batches alternately: batch k+1's 160 MiB cross PCIe (3.0 ms) and its grouping and per-key
-// tables run while batch k's ladder holds the multipliers.  At most two batches are in flight; a third submit first
-// retires the older one (its verdicts are delivered; a later s2k_wait on its ticket returns at once).
+// that take the submitted batches in turn: batch k+1's 160 MiB cross PCIe (3.0 ms) and its grouping and per-key
+// tables run while batch k's ladder holds the multipliers.  Up to three batches are in flight (two keep the device busy;
+// the third takes the caller's turn-around time out of the rate: with two, batch k+1 has to be submitted the moment batch
+// k-1 ends, or its transfer no longer fits under batch k's ladder); a fourth submit first retires the oldest one (its
+// verdicts are delivered; a later s2k_wait on its ticket returns at once).
 // ---------------------------------------------------------------------------------------
 }  // extern "C"
 static void pipe_note_failure(s2k_ctx* ctx, uint64_t ticket, int rc) {
@@ -2215,8 +2217,8 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_retire(s2k_ctx* ctx,
 // the slot the next ticket runs on, free, with its child context and landing buffer in place
 __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, size_t n, uint8_t* valid, s2k_ctx::pipe_slot** out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  s2k_ctx::pipe_slot& sl = ctx->pipe[ctx->pipe_next & 1u];
-  if (sl.ticket) {                                   // two batches in flight already: the older one is retired first
+  s2k_ctx::pipe_slot& sl = ctx->pipe[ctx->pipe_next % s2k_ctx::PIPE_SLOTS];
+  if (sl.ticket) {                                   // every slot holds a batch: the oldest one (this slot's) is retired first
     const uint64_t t = sl.ticket;
     const int rc = s2k_internal_pipe_retire(ctx, sl);
     if (rc) pipe_note_failure(ctx, t, rc);           // (reported by s2k_wait on that ticket)
@@ -2278,14 +2280,32 @@ int s2k_wait(s2k_ctx* ctx, s2k_ticket ticket) {
   return S2K_OK;
 }
 
+// S2K_OK: the ticket's verdicts are delivered (as s2k_wait); S2K_PENDING: still in flight.  Never blocks.
+int s2k_poll(s2k_ctx* ctx, s2k_ticket ticket) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (ticket == 0 || ticket >= ctx->pipe_next) return fail(ctx, S2K_ERR_ARG, "s2k_poll: ticket %llu was never issued", (unsigned long long)ticket);
+  for (s2k_ctx::pipe_slot& sl : ctx->pipe)
+    if (sl.ticket == ticket) {
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      const hipError_t e = hipStreamQuery(sl.ctx->s_comp);
+      if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return S2K_PENDING;
+      }
+      return s2k_internal_pipe_retire(ctx, sl);
+    }
+  return s2k_wait(ctx, ticket);                       // retired earlier
+}
+
 int s2k_wait_all(s2k_ctx* ctx) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   int rc = S2K_OK;
-  // oldest first
-  s2k_ctx::pipe_slot* order[2] = {&ctx->pipe[0], &ctx->pipe[1]};
-  if (order[0]->ticket > order[1]->ticket) { s2k_ctx::pipe_slot* t = order[0]; order[0] = order[1]; order[1] = t; }
-  for (s2k_ctx::pipe_slot* sl : order) {
-    const int r1 = s2k_internal_pipe_retire(ctx, *sl);
+  for (;;) {                                          // oldest first
+    s2k_ctx::pipe_slot* oldest = nullptr;
+    for (s2k_ctx::pipe_slot& sl : ctx->pipe)
+      if (sl.ticket && (!oldest || sl.ticket < oldest->ticket)) oldest = &sl;
+    if (!oldest) break;
+    const int r1 = s2k_internal_pipe_retire(ctx, *oldest);
     if (r1 && !rc) rc = r1;
   }
   return rc;

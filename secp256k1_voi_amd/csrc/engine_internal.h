@@ -118,8 +118,8 @@ struct s2k_ctx {
   uint32_t* kg_counters = nullptr;   // device, KG_COUNTERS words (of the last call; null: it did not group)
   uint32_t kg_last_max_tables = 0;   // table cap of that call (the device counter of tables is not clamped)
   uint32_t* last_wl_count = nullptr; // device: the last verification call's complete-formula worklist length
-  // submit / wait (s2k_ecdsa_verify_batch_submit, s2k_wait): two child contexts on the same device take the submitted
-  // batches alternately, so that one batch's transfer, grouping and tables run beside the other's ladder.  A child owns
+  // submit / wait (s2k_ecdsa_verify_batch_submit, s2k_wait): child contexts on the same device take the submitted
+  // batches in turn, so that one batch's transfer, grouping and tables run beside another's ladder.  A child owns
   // its own workspaces, staging and streams (the generator tables are shared per device); `pipe` is empty in a child.
   struct pipe_slot {
     s2k_ctx* ctx = nullptr;        // the child context (created on first use)
@@ -130,8 +130,11 @@ struct s2k_ctx {
     size_t h_valid_bytes = 0;
     bool direct = false;           // dst is page-locked itself: the device-to-host copy lands there
   };
-  pipe_slot pipe[2];
-  uint64_t pipe_next = 1;          // next ticket
+  static constexpr unsigned PIPE_SLOTS = 3;   // batches in flight: with two, batch k+1 must be submitted the moment batch k-1
+                                              // ends or its transfer no longer fits under batch k's ladder; the third slot
+                                              // takes the caller's (and a group's thread hand-over) latency out of the rate
+  pipe_slot pipe[PIPE_SLOTS];
+  uint64_t pipe_next = 1;          // next ticket (ticket t runs on slot t mod PIPE_SLOTS)
   uint64_t pipe_failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tickets retired with an error (by a later submit), and their codes
   int pipe_failed_rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned pipe_failed_n = 0;

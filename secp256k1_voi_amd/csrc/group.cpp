@@ -95,12 +95,13 @@ void complete(member* me, const shard_job& job, int rc) {
     snprintf(g->err, sizeof g->err, "member on device %d, signatures [%zu, %zu): %s", me->device, job.lo, job.lo + job.n,
              s2k_last_error(me->ctx));
   }
-  if (--it->second.remaining == 0) g->cv.notify_all();
+  --it->second.remaining;
+  g->cv.notify_all();
 }
 
 // One member: its context is created here (the generator tables of the devices are built side by side), then shards are
-// taken from the queue.  A shard is submitted as soon as it arrives; the previous one is waited for only after that, so
-// two consecutive group batches overlap on the member's device exactly as two s2k_ecdsa_verify_batch_submit calls do.
+// taken from the queue.  A shard is submitted as soon as it arrives, so consecutive group batches overlap on the
+// member's device exactly as consecutive s2k_ecdsa_verify_batch_submit calls do.
 void member_main(member* me) {
   {
     s2k_ctx* ctx = nullptr;
@@ -113,43 +114,56 @@ void member_main(member* me) {
     me->cv.notify_all();
     if (rc) return;
   }
-  bool have_prev = false;
-  shard_job prev;
-  s2k_ticket prev_ticket = 0;
+  // Shards in flight on this member's context, oldest first (at most as many as the context has slots).  New shards are
+  // preferred over waiting: the oldest shard in flight is POLLED (s2k_poll) between looks at the queue, so a shard that
+  // arrives while one is being waited for is submitted within ~0.1 ms - its transfer has to fit under the ladder of the
+  // shard before it.
+  constexpr size_t MAX_IN_FLIGHT = 3;
+  struct flying {
+    shard_job job;
+    s2k_ticket ticket;
+  };
+  std::deque<flying> inflight;
+  auto finish_oldest = [&](bool block) -> bool {     // true: the oldest shard is done (and reported)
+    flying& f = inflight.front();
+    const int rc = block ? s2k_wait(me->ctx, f.ticket) : s2k_poll(me->ctx, f.ticket);
+    if (rc == S2K_PENDING) return false;
+    complete(me, f.job, rc);
+    inflight.pop_front();
+    return true;
+  };
   for (;;) {
     shard_job job;
     bool have_job = false;
     {
       std::unique_lock<std::mutex> lock(me->m);
-      if (!have_prev) me->cv.wait(lock, [&] { return me->stop || !me->q.empty(); });
+      if (inflight.empty())
+        me->cv.wait(lock, [&] { return me->stop || !me->q.empty(); });
+      else if (me->q.empty())
+        me->cv.wait_for(lock, std::chrono::microseconds(100), [&] { return !me->q.empty(); });
       if (!me->q.empty()) {
         job = me->q.front();
         me->q.pop_front();
         have_job = true;
-      } else if (!have_prev && me->stop) {
+      } else if (inflight.empty() && me->stop) {
         break;
       }
     }
     if (have_job) {
+      while (inflight.size() >= MAX_IN_FLIGHT) (void)finish_oldest(true);
       s2k_ticket t = 0;
       int rc = S2K_OK;
       if (job.n)
         rc = s2k_ecdsa_verify_batch_submit(me->ctx, job.n, job.pub + job.lo * 64, job.dig + job.lo * 32, job.r + job.lo * 32,
                                            job.s + job.lo * 32, job.flags, job.valid + job.lo, &t);
-      if (have_prev) {
-        complete(me, prev, s2k_wait(me->ctx, prev_ticket));
-        have_prev = false;
-      }
       if (rc || !job.n) {
+        while (!inflight.empty()) (void)finish_oldest(true);   // completions are reported in submit order
         complete(me, job, rc);
       } else {
-        prev = job;
-        prev_ticket = t;
-        have_prev = true;
+        inflight.push_back(flying{job, t});
       }
-    } else if (have_prev) {
-      complete(me, prev, s2k_wait(me->ctx, prev_ticket));
-      have_prev = false;
+    }
+    while (!inflight.empty() && finish_oldest(false)) {
     }
   }
 }
@@ -247,11 +261,11 @@ int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* p
   uint64_t t;
   {
     std::unique_lock<std::mutex> lock(g->m);
-    // at most two group batches in flight: every member keeps two batches on its device
+    // at most three group batches in flight: every member keeps up to three shards on its device
     g->cv.wait(lock, [&] {
       int busy = 0;
       for (auto& kv : g->pend) busy += kv.second.remaining ? 1 : 0;
-      return busy < 2;
+      return busy < 3;
     });
     t = g->next_ticket++;
     while (g->pend.size() > 16 && g->pend.begin()->second.remaining == 0) g->pend.erase(g->pend.begin());   // old results

@@ -73,7 +73,7 @@ def gather_valid(valid_shard, n_total: int, dist=None, device=None):
     return out, int(cnt.item())
 
 
-def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None, count=None, scratch=None):
+def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None, count=None, scratch=None, events=None):
     """Device-resident variant used on the hot path: `valid` is this rank's uint8 0/1 torch
     tensor (equal shard length on every rank; a multiple of 8, in a group of 64).  Packs the bitmap on the
     device (engine.pack_valid_device when an Engine is given, torch ops otherwise) and exchanges it
@@ -83,11 +83,15 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
     launch latency, about 0.13 ms each per step through RCCL on MI355X.  Returns (bitmap tensor of
     n_total/8 bytes, int64 count tensor of one element).  No host round trip on the nccl backend.
     `bitmap` / `count` (alone) or `scratch` (a dict the caller keeps between calls; in a group) hold
-    preallocated buffers to keep the step allocation-free."""
+    preallocated buffers to keep the step allocation-free.  The returned bitmap ALIASES `bitmap` / the scratch buffer: it is
+    overwritten by the next call with the same buffers (copy it if it has to outlive the step); without `scratch` a call in
+    a group allocates its three buffers afresh.  `events`: a pair of torch.cuda.Event recorded on the current stream right
+    before and right after the collective (bench.py's multi-rank diagnostics)."""
     import torch
 
     n = valid.numel()
-    assert n % 8 == 0
+    if n % 8:
+        raise ValueError("gather_valid_device: the shard length must be a multiple of 8")
     nb = n // 8
     if _alone(dist):
         if bitmap is None:
@@ -97,8 +101,10 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
         _pack(valid, bitmap, count, engine)
         return bitmap, count
     world = dist.get_world_size()
-    assert n * world == n_total, "gather_valid_device needs equal shards"
-    assert n % 64 == 0, "in a group the shard length must be a multiple of 64 (the count sits 8-byte aligned behind the bitmap)"
+    if n * world != n_total:
+        raise ValueError("gather_valid_device needs equal shards")
+    if n % 64:
+        raise ValueError("in a group the shard length must be a multiple of 64 (the count sits 8-byte aligned behind the bitmap)")
     scratch = scratch if scratch is not None else {}
     key = ("packed", n, world, str(valid.device))
     if scratch.get("key") != key:
@@ -114,9 +120,13 @@ def gather_valid_device(valid, n_total: int, dist=None, engine=None, bitmap=None
     on_host = dist.get_backend() == "gloo"
     mine = packed.cpu() if on_host else packed
     full = torch.empty(mine.numel() * world, dtype=torch.uint8) if on_host else scratch["full"]
+    if events is not None:
+        events[0].record()
     dist.all_gather_into_tensor(full, mine)
     if on_host:
         full = full.to(valid.device)
+    if events is not None:
+        events[1].record()
     rows = full.view(world, nb + 8)
     out_bitmap = bitmap if (bitmap is not None and bitmap.numel() == nb * world) else scratch["bitmap"]
     out_bitmap.view(world, nb).copy_(rows[:, :nb])                           # (the shards are nb + 8 bytes apart in `full`)

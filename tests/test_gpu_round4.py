@@ -41,8 +41,8 @@ def damaged_batch(eng, n, n_keys, seed):
 @pytest.mark.parametrize("pinned", [False, True])
 def test_submit_wait_matches_synchronous_call(eng, oracle, pinned):
     """Five batches of different sizes (one empty, one below the grouping threshold, ragged ones) submitted back to back
-    with two in flight: every ticket's verdicts equal the synchronous call's and the oracle's; the third submit retires
-    the first ticket by itself and a later wait on it returns at once."""
+    with up to three in flight: every ticket's verdicts equal the synchronous call's and the oracle's; the fourth submit
+    retires the first ticket by itself and a later wait on it returns at once; s2k_poll never blocks and ends as done."""
     import secp256k1_voi_amd as S
     sizes = [70001, 200, 0, 300003, 4096]
     batches = [damaged_batch(eng, n, max(n // 11, 3), 400 + n) if n else [np.zeros((0, w), np.uint8) for w in (64, 32, 32, 32)]
@@ -71,7 +71,12 @@ def test_submit_wait_matches_synchronous_call(eng, oracle, pinned):
                 if o is not None:
                     o[...] = 7
                 tickets.append(eng.ecdsa_verify_batch_submit(*b, out=o))
-            # tickets 1..3 have been retired by the submits behind them; waiting in reverse order is allowed
+            # the first tickets have been retired by the submits behind them; waiting in reverse order is allowed
+            assert tickets[0].done()
+            import time
+            t_end = time.time() + 60
+            while not tickets[-1].done():
+                assert time.time() < t_end
             for t, ref in reversed(list(zip(tickets, refs))):
                 assert np.array_equal(t.wait(), ref)
         finally:
