@@ -746,15 +746,46 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
                                         "grouping-off calls"}
         del inp
 
-    # ---- adversarial worst case: every lane undecided by the fast ladder (u1 G + u2 Q = infinity) ----
+    # ---- adversarial inputs.  What a key owner can force for GIVEN digests are the two exceptional cases of the final
+    # addition: u1 G = -u2 Q (r = -e/d, R = infinity) and u1 G = u2 Q (r = e/d, R = 2 u1 G).  Until round 3 the first sent
+    # every lane to the complete-formula worklist (3.4 x a step); now it is decided in the ladder kernel, the second by
+    # a short form of the worklist kernel.  `forced_worklist`: the all-valid batch with every lane pushed through the
+    # complete kernel by a diagnostic flag - what a batch of mid-ladder exceptional cases would cost if one could be
+    # made (DESIGN.md section 4 argues it cannot). ----
+    from secp256k1_voi_amd import FORCE_WORKLIST
+    from secp256k1_voi_amd.synth import synth_equal_points_batch
     inp = tuple(torch.from_numpy(x).to(dev) for x in synth_all_fallback_batch(eng, n, n_keys, seed=0xBAD))
     d_valid.fill_(1)
-    ms = timed(lambda: verify_on(inp), 2)
+    ms = timed(lambda: verify_on(inp), 3)
     assert int(d_valid.sum().item()) == 0, "R = infinity must reject"
-    out["worst_case_all_fallback"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
-                                      "note": "2^%d signatures built so that u1*G + u2*Q = infinity: all lanes re-done by the "
-                                              "complete-formula worklist kernel; all verdicts 0 (checked)" % (n.bit_length() - 1)}
+    gs = eng.key_grouping_stats()
+    out["worst_case_all_fallback"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s", "on_worklist": gs["complete"],
+                                      "note": "2^%d signatures built so that u1*G + u2*Q = infinity (r = -e/d): the final addition of "
+                                              "every lane is exceptional; decided in the ladder kernel since round 4 (was: every lane "
+                                              "re-done by the complete-formula kernel); all verdicts 0 (checked)" % (n.bit_length() - 1)}
     del inp
+    inp = tuple(torch.from_numpy(x).to(dev) for x in synth_equal_points_batch(eng, n, n_keys, seed=0xBAD2))
+    d_valid.fill_(1)
+    ms = timed(lambda: verify_on(inp), 3)
+    assert int(d_valid.sum().item()) == 0, "2 u1 G with a random r must reject"
+    gs = eng.key_grouping_stats()
+    out["worst_case_equal_points"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s", "on_worklist": gs["complete"],
+                                      "note": "u1*G = u2*Q in every lane (r = e/d): tagged worklist entries, R = 2 u1 G from the "
+                                              "generator tables with complete formulas; all verdicts 0 (checked)"}
+    del inp
+    if resident is not None:
+        dd, dr, ds = resident
+        d_pub_all = torch.from_numpy(host_pub).to(dev)
+        d_valid.zero_()
+
+        def forced():
+            eng.ecdsa_verify_batch_device(n, d_pub_all.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_valid.data_ptr(), FORCE_WORKLIST, st)
+        ms = timed(forced, 2)
+        assert int(d_valid.sum().item()) == n, "forced worklist lost verdicts"
+        out["forced_worklist"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
+                                  "note": "S2K_ECDSA_FORCE_WORKLIST on the all-valid batch: ladder, then every lane again through "
+                                          "the complete-formula kernel (diagnostic; no input is known that does this)"}
+        del d_pub_all
 
     # ---- config 3: 2^20-term multi-scalar multiplication, points with known discrete logs ----
     m = 1 << 20

@@ -56,6 +56,13 @@ enum {
 /* Diagnostics: send every signature through the complete-formula kernel that normally only
  * re-does the lanes the fast Jacobian kernel cannot decide.  Same results, ~3x slower. */
 #define S2K_ECDSA_FORCE_COMPLETE 0x80000000u
+/* Diagnostics: the fast ladder runs, then EVERY signature is queued for the complete-formula worklist kernel
+ * (9x29 field, what decides lanes whose incomplete formulas met an exceptional case inside the ladder).  Same results,
+ * ~3.4x a normal step: the price of a batch in which every lane is such a case.  No input is known that does this
+ * for hashed digests: the exceptional cases a key owner can force for given digests - u1 G = -u2 Q (r = -e/d: decided
+ * inside the ladder kernel) and u1 G = u2 Q (r = e/d: a short form of the worklist kernel, 2 u1 G) - arise in the final
+ * addition; u1 = 0 needs a digest that is 0 mod n. */
+#define S2K_ECDSA_FORCE_WORKLIST 0x40000000u
 
 /* bitcoin.VerifyASN1 (secec/bitcoin/ecdsa_shitcoin.go:29): BIP-0066 shape check, sighash byte
  * stripped, low-s required, 32-byte digest.  Only for s2k_ecdsa_verify_encoded_batch. */
@@ -138,7 +145,9 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
  *   hash_bits   0 = default (slots >= 2n); smaller values force probe chains (tests)
  *   max_tables  0 = default (2^22 tables of 9 KiB; the buffer is sized by the batch: n / min_group tables).  The threshold is raised until n / threshold tables
  *               fit: a batch of n signatures builds tables for keys with at least
- *               max(min_group, ceil(n / max_tables)) signatures */
+ *               max(min_group, ceil(n / max_tables)) signatures.  A device that has no memory for the buffer does not
+ *               fail the verification: the cap is halved until the buffer fits, and below 1024 tables the batch is
+ *               verified without tables (same verdicts) */
 #define S2K_KEYS_OFF 0
 #define S2K_KEYS_AUTO 1
 #define S2K_KEYS_ALWAYS 2
@@ -171,7 +180,10 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx *ctx, size_t n, const void *d_digest3
  * (ecdsa.go:234) with the same rules as s2k_ecdsa_verify_batch; key_index[i] >= n_keys names no key: valid[i] = 0.
  * Same verdicts as s2k_ecdsa_verify_batch on the expanded key array, bit for bit; what is saved is the grouping and the
  * table build of every call (about a third of a 2^20-signature step at 16 signatures per key).  A key set belongs to
- * the context that made it; it may be used by any number of calls and must be destroyed before the context. */
+ * the context that made it (a context destroyed and another created at the same address is NOT the owner: the set
+ * remembers the context's generation and device); it may be used by any number of calls and must be destroyed before the
+ * context.  Like every object of a context it is not locked: s2k_keyset_destroy / s2k_keyset_valid_keys must not run
+ * while a call that uses the set is in progress on another thread. */
 typedef struct s2k_keyset s2k_keyset;
 int s2k_keyset_create(s2k_ctx *ctx, size_t n_keys, const uint8_t *pub_xy /* n_keys*64, host */, s2k_keyset **out);
 void s2k_keyset_destroy(s2k_keyset *ks);

@@ -21,7 +21,15 @@ import numpy as np
 # runtime's four default hardware queues and then run one after the other where the engine means them to overlap
 # (measured: +0.28 ms on a 5.0 ms step once a process group exists).  The runtime reads this when
 # it initialises, i.e. at the first HIP call of the process: importing this package before that is enough.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"      # (process-wide: export your own value to overrule it)
+    import sys as _sys
+    _t = _sys.modules.get("torch")
+    if _t is not None and getattr(_t, "cuda", None) is not None and _t.cuda.is_initialized():
+        import warnings
+        warnings.warn("secp256k1_voi_amd: the HIP runtime was initialised before this package was imported, so "
+                      "GPU_MAX_HW_QUEUES=8 comes too late; streams of the engine may share hardware queues "
+                      "(export GPU_MAX_HW_QUEUES=8 in the environment instead)", RuntimeWarning)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # S2K_LIB: load another build of the library (a compile-time variant made with build(variant=...)), for
@@ -32,6 +40,7 @@ CSRC = os.path.join(_HERE, "csrc")
 REJECT_MALLEABLE = 1
 BIP0066 = 2
 FORCE_COMPLETE = 0x80000000
+FORCE_WORKLIST = 0x40000000
 ENCODING_ASN1, ENCODING_COMPACT, ENCODING_COMPACT_RECOVERABLE = 0, 1, 2
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
@@ -145,11 +154,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", '-DS2K_BUILD_FLAGS="%s"' % extra.replace('"', "'")]
     flags += extra.split()
+    # the stamp names the flags of the objects in the directory: it is withdrawn while they are being replaced, so that an
+    # interrupted build (a variant build, say) cannot leave objects of other flags under a stamp that vouches for them
+    if not (built_with == extra):
+        force = True
+    try:
+        os.remove(stamp)
+    except OSError:
+        pass
 
     # an object is reused when it is newer than its own source and every header, and was built with these flags
     headers = [d for d in deps if d.endswith(".h")]
     newest_header = max(os.path.getmtime(h) for h in headers)
-    same_flags = built_with == extra
+    same_flags = built_with == extra and built_with is not None
 
     def compile_one(u):
         obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
@@ -417,7 +434,7 @@ class Engine:
 
     # ---- hot path -------------------------------------------------------------------
     def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False,
-                           force_complete: bool = False) -> np.ndarray:
+                           force_complete: bool = False, force_worklist: bool = False) -> np.ndarray:
         """valid bits (uint8 0/1) for n (pubkey, digest, r, s) tuples; host buffers."""
         r = _arr(r, 32)
         n = r.shape[0]
@@ -426,7 +443,8 @@ class Engine:
         self._check(self._lib.s2k_ecdsa_verify_batch(self._h, n, pub_xy.ctypes.data, digest32.ctypes.data,
                                                      r.ctypes.data, s.ctypes.data,
                                                      (REJECT_MALLEABLE if reject_malleable else 0) |
-                                                     (FORCE_COMPLETE if force_complete else 0), out.ctypes.data))
+                                                     (FORCE_COMPLETE if force_complete else 0) |
+                                                     (FORCE_WORKLIST if force_worklist else 0), out.ctypes.data))
         return out
 
     # ---- submit / wait -------------------------------------------------------------------
@@ -480,7 +498,8 @@ class Engine:
         """Per-key tables of a fixed list of public keys (n_keys x 64 bytes), built once (s2k_keyset_create)."""
         return KeySet(self, pub_xy)
 
-    def ecdsa_verify_batch_keyset(self, keyset, key_index, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
+    def ecdsa_verify_batch_keyset(self, keyset, key_index, digest32, r, s, reject_malleable: bool = False,
+                                  force_worklist: bool = False) -> np.ndarray:
         """valid bits for n (key index into `keyset`, digest, r, s) tuples; host buffers."""
         r = _arr(r, 32)
         n = r.shape[0]
@@ -491,7 +510,8 @@ class Engine:
         out = np.zeros(n, dtype=np.uint8)
         self._check(self._lib.s2k_ecdsa_verify_batch_keyset(self._h, keyset._k, n, ki.ctypes.data, digest32.ctypes.data,
                                                             r.ctypes.data, s.ctypes.data,
-                                                            REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data))
+                                                            (REJECT_MALLEABLE if reject_malleable else 0) |
+                                                            (FORCE_WORKLIST if force_worklist else 0), out.ctypes.data))
         return out
 
     def ecdsa_verify_batch_keyset_device(self, keyset, n, d_key_index, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):

@@ -249,10 +249,15 @@ S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe
   return acc;
 }
 
+// A worklist entry of the ECDSA flows is the signature's index, plus (batches below 2^30) a tag in the top bits:
+// WL_DOUBLE_GEN = the fast ladder found u2 Q == u1 G, both finite, in its final addition: R = 2 u1 G.
+constexpr uint32_t WL_TAG_LIMIT = 1u << 30, WL_INDEX_MASK = WL_TAG_LIMIT - 1u, WL_DOUBLE_GEN = 1u << 30;
+
 // (`key`: the 64 bytes X || Y of the signature's public key)
 S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, const uint8_t* __restrict__ dig,
                                   const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride, size_t lane) {
+                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride, size_t lane,
+                                  uint32_t tag = 0) {
   // idx: the signature; lane: the table column this thread may use (the worklist kernel passes the worklist
   // POSITION, not the signature: the keyed ladder queues signatures in key order, and columns picked by
   // signature would scatter a wave's table accesses over 64 cache lines: 47 ms instead of 20 for a batch
@@ -287,7 +292,25 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, c
   sc e = sc_reduce_once(e_raw);
   sc26 s_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(s)));   // s^-1 * R (safegcd, modinv30.h)
   sc u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m)), u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
-  pt29 acc = dsm_complete29(u1, u2, qx, qy, gt, qt, stride, lane);
+  pt29 acc;
+  if (tag == WL_DOUBLE_GEN) {
+    // the fast ladder has established u2 Q == u1 G (engine.hip, k_verify_fast: verdict): R = 2 u1 G, from the resident
+    // tables with the complete formulas - no ladder
+    acc.x = fe29_zero();
+    acc.y = fe29_one();
+    acc.z = fe29_zero();
+    uint32_t u[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) u[w] = u1.v[w];
+#pragma unroll 1
+    for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
+      apt g = gt_load(gt, w, gt_next_digit(u));
+      acc = pt29_add_mixed(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
+    }
+    acc = pt29_double(acc);
+  } else {
+    acc = dsm_complete29(u1, u2, qx, qy, gt, qt, stride, lane);
+  }
   ok = ok && !fe29_is_zero(acc.z);                   // ecdsa.go:450
   // x(R) mod n == r  <=>  X == r*Z  or  (r + n < p and X == (r + n)*Z)   (ecdsa.go:459-465)
   bool match = fe29_eq(acc.x, fe29_mul(fe29_from_words(r.v), acc.z));
@@ -307,8 +330,9 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
                   size_t stride) {
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
-    size_t idx = wl[w];
-    out[idx] = verify_complete29(idx, pub + idx * 64, dig, rsig, ssig, flags, gt, qt, stride, w);
+    const uint32_t e = wl[w];
+    const size_t idx = e & WL_INDEX_MASK;
+    out[idx] = verify_complete29(idx, pub + idx * 64, dig, rsig, ssig, flags, gt, qt, stride, w, e & ~WL_INDEX_MASK);
   }
 }
 // the same for a batch verified against a key set: the key of signature idx is keys[kidx[idx]]
@@ -319,8 +343,9 @@ k_verify_fallback_keyset(const uint32_t* __restrict__ wl_count, const uint32_t* 
                          uint32_t* __restrict__ qt, size_t stride) {
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
-    size_t idx = wl[w];
-    out[idx] = verify_complete29(idx, keys + (size_t)kidx[idx] * 64, dig, rsig, ssig, flags, gt, qt, stride, w);
+    const uint32_t e = wl[w];
+    const size_t idx = e & WL_INDEX_MASK;
+    out[idx] = verify_complete29(idx, keys + (size_t)kidx[idx] * 64, dig, rsig, ssig, flags, gt, qt, stride, w, e & ~WL_INDEX_MASK);
   }
 }
 
@@ -437,6 +462,7 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
        MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
+constexpr uint32_t KVF_FORCE_WORKLIST = 0x80000000u;   // top bit of k_verify_fast's first argument (batches are below 2^31)
 
 // Digits of an odd half scalar k < 2^129 in the order the per-key ladder consumes them.  As in
 // ds_init, digit i is nib_i = bits 4i+1 .. 4i+4 of k (signed value 2 nib_i - 15); digit i = 4c + j
@@ -526,9 +552,11 @@ template <int MODE>
 #ifdef S2K_FAST_MAX_WAVES   // experiment: cap the occupancy (leaves VGPRs for a kernel of another stream to run beside the ladder)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S2K_FAST_MAX_WAVES, S2K_FAST_MAX_WAVES)))
 #else
+// (the ladders over per-key tables hold no per-lane table state and fit four waves per SIMD - 123 VGPRs before the in-place
+// decision of the final addition was added, which the allocator, left alone, took as licence to use 152)
 __global__ void __launch_bounds__(256, S2K_FAST_WAVES)
 #endif
-k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
+k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
@@ -536,6 +564,8 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED;
   constexpr bool GROUPED = KEYED || MODE == MODE_ECDSA_LEFT || MODE == MODE_SCHNORR_LEFT;
   constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT;
+  const bool force_wl = (n_and_flags & KVF_FORCE_WORKLIST) != 0;
+  const uint32_t n = n_and_flags & ~KVF_FORCE_WORKLIST;
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;         // lane: workspace column
   size_t sig = idx;                                            // signature: input / prep / verdict column
   uint32_t lanes = n;
@@ -755,11 +785,16 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
   }
 
   // ---- generator part: u1*G from the resident tables ----
+  // (final_only: Z was not 0 BEFORE the last addition and the addend is finite - then a zero after it arose in that addition,
+  // and the verdict code below decides it instead of queueing the lane for the complete-formula kernel)
+  uint32_t last_digit = 0;
+  bool final_only = false;
   if constexpr (GROUPED) {
     jpt29 q;                                            // computed by k_generator_part
     q.x = fq_load(kg.gp, stride, sig, 0);
     q.y = fq_load(kg.gp, stride, sig, 1);
     q.z = fq_load(kg.gp, stride, sig, 2);
+    if constexpr (ECDSA) final_only = !fe29_is_zero(acc.z) && !fe29_is_zero(q.z);
     acc = jpt29_add(acc, q);
   } else {
     uint32_t u[8];
@@ -767,7 +802,11 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
 #pragma unroll 1
     for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
-      apt g = gt_load(gt, w, gt_next_digit(u));
+      last_digit = gt_next_digit(u);
+      apt g = gt_load(gt, w, last_digit);
+      if constexpr (ECDSA) {
+        if (w == GT_WINDOWS - 1) final_only = !fe29_is_zero(acc.z);
+      }
       acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
   }
@@ -778,11 +817,48 @@ k_verify_fast(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     uint8_t* rec = out_pts + idx * 65;
     for (int i = 0; i < 65; ++i) rec[i] = 0;
   }
+  // Z = 0: infinity, or an exceptional case of the incomplete formulas somewhere on the way.  Where the zero first appears
+  // in the FINAL addition of two finite points (Z3 = Z1 Z2 H = 0: equal x) the answer is at hand.  With H = 0 the mixed
+  // addition leaves X3 = I^2, I = Y1 - S2 (jacobian29.h), so X3 != 0 says OPPOSITE points: R is the identity and verify
+  // rejects it (ecdsa.go:450).  That is what anyone who owns a key gets with r = -e/d in every lane, whatever the digests
+  // (the signature need not be valid), and it used to send the whole batch through the complete-formula kernel: 3.4 x a
+  // normal step; now the lane is done.  X3 = 0 says EQUAL points (r = e/d): R is twice the last addend - computed here when
+  // that is a table entry, and by the worklist kernel as 2 u1 G (tag WL_DOUBLE_GEN: a twelfth of a full verification)
+  // in the grouped flows, whose keyed ladder has no registers to spare.  Zeros from INSIDE the ladder or the generator
+  // part (and u1 = 0: a digest that is 0 mod n) go to the worklist as before.
+  bool undecided = ok && fe29_is_zero(acc.z), is_identity = false;
+  uint32_t wl_tag = 0;
+  if constexpr (ECDSA) {
+    if (force_wl && ok) {                                // S2K_ECDSA_FORCE_WORKLIST (diagnostic)
+      undecided = true;
+      final_only = false;
+    }
+  }
+  if constexpr (ECDSA) {
+    if (undecided && final_only) {
+      if (!fe29_is_zero(acc.x)) {
+        undecided = false;
+        is_identity = true;                              // P - P
+      } else if constexpr (GROUPED) {
+        if (n < WL_TAG_LIMIT) wl_tag = WL_DOUBLE_GEN;    // P + P, R = 2 u1 G
+      } else {
+        apt g = gt_load(gt, GT_WINDOWS - 1, last_digit);
+        jpt29 q;
+        q.x = fe29_from_words(g.x.v);
+        q.y = fe29_from_words(g.y.v);
+        q.z = fe29_one();
+        acc = jpt29_double(q);                           // P + P
+        undecided = false;
+      }
+    }
+  }
   if (ok) {
-    if (fe29_is_zero(acc.z)) {
-      // infinity or an exceptional case along the way: the complete kernel decides
+    if (undecided) {
+      // infinity or an exceptional case inside the ladder: the complete kernel decides
       uint32_t pos = atomicAdd(wl_count, 1u);
-      wl[pos] = (uint32_t)sig;
+      wl[pos] = (uint32_t)sig | wl_tag;
+    } else if (is_identity) {
+      verdict = 0;                                      // R = infinity (ecdsa.go:450)
     } else if constexpr (!ECDSA) {
       // affine epilogue (key bytes / even-y test) needs 1/Z: leave (X, Y, Z) in the SIGNATURE's fin
       // column (its own lane's when not grouped) and let k_affine_finish share one inversion between 16
@@ -1617,8 +1693,16 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   uint32_t* wl = wl_count + 64;
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
-  const bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  if (grouped) {
+    // the grouping arrays and the table buffer, before anything of this call is in flight; a device without room for the
+    // tables verifies without them
+    rc = s2k_internal_key_reserve(ctx, n, 64);
+    if (rc == S2K_ERR_NOMEM) grouped = false;
+    else if (rc) return rc;
+  }
   ctx->last_wl_count = wl_count;
   prof_mark(ctx, st, 0);
   if (grouped) {
@@ -1647,20 +1731,20 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                        &kg, /*gp_in_prep=*/arrivals != nullptr);
     if (rc) return rc;
     prof_mark(ctx, st, 2);
-    k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+    k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
                                                                    qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
                                                                    stride, nullptr, clk, kg);
     HIP_TRY(ctx, hipGetLastError());
     if (kg.nparts > 1) {   // the other side of the split, once its tables (third stream) are there
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_part1, 0));
       kg.part = 1;
-      k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+      k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
                                                                      qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
                                                                      stride, nullptr, nullptr, kg);
       HIP_TRY(ctx, hipGetLastError());
     }
     prof_mark(ctx, st, 3);
-    k_verify_fast<MODE_ECDSA_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+    k_verify_fast<MODE_ECDSA_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
                                                                   qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
                                                                   stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
@@ -1672,7 +1756,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
+    k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
                                                              ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk,
                                                              key_groups{});
     HIP_TRY(ctx, hipGetLastError());
@@ -1790,6 +1874,7 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(d_valid, 0, n, st));       // signatures naming no key of the set stay invalid
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   // second stream: scalar preparation and generator part; caller's: the sort by key index
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
@@ -1805,7 +1890,7 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
     return rc;
   }
   kg.gp = gp;
-  k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
+  k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
                                                                  (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback_keyset<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, ks->base + off[0], (const uint32_t*)d_key_index,
@@ -1851,6 +1936,7 @@ int s2k_ctx_set_key_grouping(s2k_ctx* ctx, int mode, uint32_t min_group, uint32_
   ctx->kg_min_group = min_group;
   ctx->kg_hash_bits = hash_bits;
   ctx->kg_max_tables = max_tables ? max_tables : KG_MAX_TABLES_DEFAULT;
+  ctx->kg_table_cap = 0;           // (a cap found by an earlier allocation failure is tried afresh)
   return S2K_OK;
 }
 
@@ -1982,7 +2068,13 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   ctx->kg_counters = nullptr;
   ctx->last_wl_count = wl_count;
-  if (ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH) {
+  bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  if (grouped) {
+    rc = s2k_internal_key_reserve(ctx, n, 32);
+    if (rc == S2K_ERR_NOMEM) grouped = false;      // no room for per-key tables: the general ladder for everything
+    else if (rc) return rc;
+  }
+  if (grouped) {
     // signatures that share an x-only key: the grouped flow of the ECDSA path (s2k_ctx_set_key_grouping)
     uint32_t* gp = ws + WS_GP * stride;
     key_groups kg;

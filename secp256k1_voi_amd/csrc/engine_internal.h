@@ -105,6 +105,7 @@ struct s2k_ctx {
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
   int kg_mode = S2K_KEYS_AUTO;
   uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = KG_MAX_TABLES_DEFAULT;
+  uint32_t kg_table_cap = 0;         // 0: none; else the table count the device had memory for (s2k_internal_key_reserve)
   uint64_t kg_seed = 0;              // hash seed of the key grouping (operating-system randomness, per context)
   hipStream_t s_aux = nullptr;       // scalar preparation runs here, beside the grouping and the table kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_part0 = nullptr, ev_part1 = nullptr;

@@ -202,7 +202,7 @@ static int encoded_enqueue_inner(s2k_ctx* ctx, size_t n, const uint8_t* pubs, co
       HIP_TRY(ctx, hipGetLastError());
     } else {
       rc = s2k_ecdsa_verify_batch_device(ctx, cnt, io + o_xy + lo * 64, io + o_dg + lo * 32, io + o_r + lo * 32, io + o_s + lo * 32,
-                                         flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE), io + o_v + lo, ctx->s_comp);
+                                         flags & (S2K_ECDSA_REJECT_MALLEABLE | S2K_ECDSA_FORCE_COMPLETE | S2K_ECDSA_FORCE_WORKLIST), io + o_v + lo, ctx->s_comp);
       if (rc) return rc;
     }
   }

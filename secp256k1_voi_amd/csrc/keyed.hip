@@ -26,6 +26,8 @@
 // ladder kernels read them.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "engine_internal.h"
 #include "fe29_inv.h"
 #include "jacobian29.h"
@@ -576,7 +578,9 @@ static key_group_sizes key_group_plan(const s2k_ctx* ctx, size_t n) {
   z.slots = (size_t)1 << bits;
   // tables are never refused on the device: the threshold is raised until n / threshold of them fit the cap
   z.min_group = min_group_asked;
-  if (n / z.min_group > ctx->kg_max_tables) z.min_group = (uint32_t)((n + ctx->kg_max_tables - 1) / ctx->kg_max_tables);
+  // (kg_table_cap: lowered by s2k_internal_key_reserve when the device could not give the buffer the setting allows)
+  const size_t cap = ctx->kg_table_cap && ctx->kg_table_cap < ctx->kg_max_tables ? ctx->kg_table_cap : ctx->kg_max_tables;
+  if (n / z.min_group > cap) z.min_group = (uint32_t)((n + cap - 1) / cap);
   z.max_tables = n / z.min_group;
   if (z.max_tables == 0) z.max_tables = 1;
   // grouping arrays: counters | rep, cnt, tix [slots] | slot_of, pos_of, perm, ptab, left [n] | trep, tbase [tables] | tinfo
@@ -594,12 +598,37 @@ __attribute__((visibility("hidden"))) size_t s2k_internal_key_bytes(const s2k_ct
 }
 // grows the context's grouping arrays and table buffer for a batch of n: to be called BEFORE work of the call is put on a
 // second stream (growing frees and allocates, which synchronises the device)
+// The table buffer is sized by the batch (n / min_group tables of 9 KiB: 2.4 GB at 2^20, 36 GiB at the default cap), whether
+// or not keys repeat.  A device that cannot give it - a busy one, several contexts, a large batch - is no reason to fail a
+// verification: the cap is halved (which raises the threshold: fewer, longer groups get tables) until the buffer fits, and
+// when not even 1024 tables fit the call is told S2K_ERR_NOMEM, which the verification entry points take as "verify
+// without tables" (the general ladder; same verdicts).
 __attribute__((visibility("hidden"))) int s2k_internal_key_reserve(s2k_ctx* ctx, size_t n, int key_bytes) {
   (void)key_bytes;
-  const key_group_sizes z = key_group_plan(ctx, n);
-  int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, z.kg_bytes);
-  if (rc) return rc;
-  return ctx_reserve(ctx, &ctx->ktab, &ctx->ktab_bytes, z.ktab_bytes);
+  for (;;) {
+    const key_group_sizes z = key_group_plan(ctx, n);
+    int rc = ctx_reserve(ctx, &ctx->kg, &ctx->kg_bytes, z.kg_bytes);
+    if (rc) return rc;
+    if (z.ktab_bytes <= ctx->ktab_bytes) return S2K_OK;
+    if (ctx->ktab) {
+      HIP_TRY(ctx, hipFree(ctx->ktab));
+      ctx->ktab = nullptr;
+      ctx->ktab_bytes = 0;
+    }
+    size_t want = z.ktab_bytes;
+    if (const char* v = getenv("S2K_TEST_TABLE_BYTES_LIMIT")) {   // test hook: pretend the device has no more than this for tables
+      if (want > (size_t)strtoull(v, nullptr, 10)) want = ~(size_t)0 >> 8;
+    }
+    const hipError_t e = want == (~(size_t)0 >> 8) ? hipErrorOutOfMemory : hipMalloc(&ctx->ktab, want);
+    if (e == hipSuccess) {
+      ctx->ktab_bytes = z.ktab_bytes;
+      return S2K_OK;
+    }
+    (void)hipGetLastError();
+    ctx->ktab = nullptr;
+    if (z.max_tables <= 1024) return fail(ctx, S2K_ERR_NOMEM, "no device memory for per-key tables (%zu bytes for %zu tables): verifying without them", z.ktab_bytes, z.max_tables);
+    ctx->kg_table_cap = (uint32_t)(z.max_tables / 2);
+  }
 }
 
 __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, size_t n, const uint8_t* d_pub, int key_bytes,

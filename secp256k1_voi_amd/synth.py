@@ -60,9 +60,10 @@ def _rand_scalars(rng, m):
 
 def synth_all_fallback_batch(eng, n, n_keys, seed):
     """Adversarial ECDSA inputs: u1*G + u2*Q = infinity for every item, so the
-    Jacobian ladder ends at Z = 0 in every lane and the whole batch goes through the
-    complete-formula worklist kernel.  Anyone holding a key pair d can make these: pick u2 and r,
-    set u1 = -u2*d, s = r/u2, e = u1*s.  All verdicts are 0 (R = infinity, ecdsa.go:450)."""
+    Jacobian ladder ends at Z = 0 in every lane.  Anyone holding a key pair d can make these: pick u2 and r,
+    set u1 = -u2*d, s = r/u2, e = u1*s (or, for given digests: r = -e/d, any s).  All verdicts are 0 (R = infinity,
+    ecdsa.go:450).  Until round 4 the whole batch then went through the complete-formula worklist kernel; the ladder
+    kernel now recognises the case in its final addition (the name of this function is history)."""
     rng = np.random.default_rng(seed)
     d = _rand_scalars(rng, n_keys)
     Q = eng.scalar_base_mult_batch(d)[:, 1:]
@@ -71,6 +72,22 @@ def synth_all_fallback_batch(eng, n, n_keys, seed):
     r = _rand_scalars(rng, n)
     u2d, _ = eng.fn_op_batch(OP_MUL, u2, d[key_idx])
     u1, _ = eng.fn_op_batch(OP_NEG, u2d)
+    u2inv, _ = eng.fn_op_batch(OP_INV, u2)
+    s, _ = eng.fn_op_batch(OP_MUL, r, u2inv)
+    e, _ = eng.fn_op_batch(OP_MUL, u1, s)
+    return np.ascontiguousarray(Q[key_idx]), e, r, s
+
+
+def synth_equal_points_batch(eng, n, n_keys, seed):
+    """The other exceptional case an input can force in the FINAL addition: u1*G == u2*Q (P + P), i.e. r = e/d - pick u2
+    and r, set u1 = u2*d, s = r/u2, e = u1*s.  R = 2*u1*G; with a random r the verdicts are 0 (x(R) != r)."""
+    rng = np.random.default_rng(seed)
+    d = _rand_scalars(rng, n_keys)
+    Q = eng.scalar_base_mult_batch(d)[:, 1:]
+    key_idx = np.arange(n) % n_keys
+    u2 = _rand_scalars(rng, n)
+    r = _rand_scalars(rng, n)
+    u1, _ = eng.fn_op_batch(OP_MUL, u2, d[key_idx])
     u2inv, _ = eng.fn_op_batch(OP_INV, u2)
     s, _ = eng.fn_op_batch(OP_MUL, r, u2inv)
     e, _ = eng.fn_op_batch(OP_MUL, u1, s)

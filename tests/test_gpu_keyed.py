@@ -10,6 +10,7 @@ import pytest
 import pyref as R
 
 pytestmark = pytest.mark.gpu
+R_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 P_FIELD = 2**256 - 2**32 - 977
 
 
@@ -143,14 +144,43 @@ def test_hash_table_pressure(eng, oracle):
 
 
 def test_exceptional_ladders_with_shared_keys(eng, oracle):
-    """Signatures built so that the incomplete formulas break down (synth_all_fallback_batch), many per key:
-    the table ladder must notice (Z = 0) and hand every one of them to the complete kernel."""
-    from secp256k1_voi_amd.synth import synth_all_fallback_batch
+    """Signatures built so that the incomplete formulas break down in the FINAL addition, many per key: u1 G = -u2 Q
+    (synth_all_fallback_batch: R = infinity, the reference says false) and u1 G = u2 Q (synth_equal_points_batch: R = 2 u1 G).
+    The ladders must notice (Z = 0) and decide: opposite points in place - nothing on the worklist -, equal points by the
+    worklist kernel's short form (tagged entries: twice the generator part), the general ladder in place.  The same inputs
+    with S2K_ECDSA_FORCE_WORKLIST: every lane through the complete kernel, same verdicts."""
+    from secp256k1_voi_amd.synth import synth_all_fallback_batch, synth_batch, synth_equal_points_batch
     n = 4096
     pub, e, r, s = synth_all_fallback_batch(eng, n, 64, seed=41)
     exp, st_auto, _ = _check_all_modes(eng, oracle, pub, e, r, s, expect_keyed=n)
-    assert st_auto["complete"] == n
+    assert st_auto["complete"] == 0
     assert not exp.any()                                          # R = infinity: the reference says false
+    assert not eng.ecdsa_verify_batch(pub, e, r, s, force_worklist=True).any() and eng.key_grouping_stats()["complete"] == n
+    # equal points; a few of them made VALID: r = x(2 u1 G) mod n, s = r / u2, e = u1 s with u1 = u2 d needs r first -
+    # take r from the point itself: R = 2 u2 d G
+    pub, e, r, s = (np.array(a) for a in synth_equal_points_batch(eng, n, 64, seed=42))
+    from secp256k1_voi_amd import OP_INV, OP_MUL
+    m = 256
+    u2inv, _ = eng.fn_op_batch(OP_INV, s[:m])                      # u2 = r / s
+    u2, _ = eng.fn_op_batch(OP_MUL, r[:m], u2inv)
+    u1 = np.zeros((m, 32), np.uint8)
+    for i in range(m):                                            # u1 = e / s
+        u1[i] = np.frombuffer(oracle.fn_mul(bytes(e[i]), oracle.fn_inv(bytes(s[i]))), np.uint8)
+    two_u1, _ = eng.fn_op_batch(2, u1, u1)                         # OP_ADD
+    Rp = eng.scalar_base_mult_batch(two_u1)
+    for i in range(m):
+        rn = int.from_bytes(bytes(Rp[i, 1:33]), "big") % R_N
+        r[i] = np.frombuffer(rn.to_bytes(32, "big"), np.uint8)
+        # keep u1 = u2 d and u2: s = r / u2, e = u1 s
+        s[i] = np.frombuffer(oracle.fn_mul(bytes(r[i]), oracle.fn_inv(bytes(u2[i]))), np.uint8)
+        e[i] = np.frombuffer(oracle.fn_mul(bytes(u1[i]), bytes(s[i])), np.uint8)
+    exp, st_auto, _ = _check_all_modes(eng, oracle, pub, e, r, s, expect_keyed=n)
+    assert exp[:m].all() and not exp[m:].any()
+    assert st_auto["complete"] == n                               # tagged worklist entries: R = 2 u1 G
+    assert np.array_equal(eng.ecdsa_verify_batch(pub, e, r, s, force_worklist=True), exp)
+    # a valid batch through the forced worklist
+    vb = synth_batch(eng, 2048, 32, seed=43)
+    assert eng.ecdsa_verify_batch(*vb, force_worklist=True).all() and eng.key_grouping_stats()["complete"] == 2048
 
 
 def test_chosen_scalars_on_tables(eng, oracle):
