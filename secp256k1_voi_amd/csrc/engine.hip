@@ -250,8 +250,10 @@ S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe
 }
 
 // A worklist entry of the ECDSA flows is the signature's index, plus (batches below 2^30) a tag in the top bits:
-// WL_DOUBLE_GEN = the fast ladder found u2 Q == u1 G, both finite, in its final addition: R = 2 u1 G.
-constexpr uint32_t WL_TAG_LIMIT = 1u << 30, WL_INDEX_MASK = WL_TAG_LIMIT - 1u, WL_DOUBLE_GEN = 1u << 30;
+// WL_DOUBLE_GEN = the fast ladder found u2 Q == u1 G, both finite, in its final addition: R = 2 u1 G;
+// WL_DOUBLE_LAST = the plain ladder (generator part inside the kernel) found its sum equal to the last generator-table
+// entry it was about to add: R = 2 T_last[top digit of u1].
+constexpr uint32_t WL_TAG_LIMIT = 1u << 30, WL_INDEX_MASK = WL_TAG_LIMIT - 1u, WL_DOUBLE_GEN = 1u << 30, WL_DOUBLE_LAST = 2u << 30;
 
 // (`key`: the 64 bytes X || Y of the signature's public key)
 S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, const uint8_t* __restrict__ dig,
@@ -307,6 +309,18 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, c
       apt g = gt_load(gt, w, gt_next_digit(u));
       acc = pt29_add_mixed(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
+    acc = pt29_double(acc);
+  } else if (tag == WL_DOUBLE_LAST) {
+    uint32_t u[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) u[w] = u1.v[w];
+    uint32_t digit = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < GT_WINDOWS; ++w) digit = gt_next_digit(u);
+    apt g = gt_load(gt, GT_WINDOWS - 1, digit);
+    acc.x = fe29_from_words(g.x.v);
+    acc.y = fe29_from_words(g.y.v);
+    acc.z = fe29_one();
     acc = pt29_double(acc);
   } else {
     acc = dsm_complete29(u1, u2, qx, qy, gt, qt, stride, lane);
@@ -787,7 +801,6 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
   // ---- generator part: u1*G from the resident tables ----
   // (final_only: Z was not 0 BEFORE the last addition and the addend is finite - then a zero after it arose in that addition,
   // and the verdict code below decides it instead of queueing the lane for the complete-formula kernel)
-  uint32_t last_digit = 0;
   bool final_only = false;
   if constexpr (GROUPED) {
     jpt29 q;                                            // computed by k_generator_part
@@ -801,12 +814,13 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
 #pragma unroll
     for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
 #pragma unroll 1
-    for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
-      last_digit = gt_next_digit(u);
-      apt g = gt_load(gt, w, last_digit);
-      if constexpr (ECDSA) {
-        if (w == GT_WINDOWS - 1) final_only = !fe29_is_zero(acc.z);
-      }
+    for (uint32_t w = 0; w + 1 < GT_WINDOWS; ++w) {
+      apt g = gt_load(gt, w, gt_next_digit(u));
+      acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
+    }
+    {   // the last addition apart: whether Z was 0 before it is what the verdict code needs to know
+      apt g = gt_load(gt, GT_WINDOWS - 1, gt_next_digit(u));
+      if constexpr (ECDSA) final_only = !fe29_is_zero(acc.z);
       acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
   }
@@ -822,10 +836,10 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
   // addition leaves X3 = I^2, I = Y1 - S2 (jacobian29.h), so X3 != 0 says OPPOSITE points: R is the identity and verify
   // rejects it (ecdsa.go:450).  That is what anyone who owns a key gets with r = -e/d in every lane, whatever the digests
   // (the signature need not be valid), and it used to send the whole batch through the complete-formula kernel: 3.4 x a
-  // normal step; now the lane is done.  X3 = 0 says EQUAL points (r = e/d): R is twice the last addend - computed here when
-  // that is a table entry, and by the worklist kernel as 2 u1 G (tag WL_DOUBLE_GEN: a twelfth of a full verification)
-  // in the grouped flows, whose keyed ladder has no registers to spare.  Zeros from INSIDE the ladder or the generator
-  // part (and u1 = 0: a digest that is 0 mod n) go to the worklist as before.
+  // normal step; now the lane is done.  X3 = 0 says EQUAL points (r = e/d): R is twice the last addend - left to the
+  // worklist kernel with a tag (WL_DOUBLE_GEN: 2 u1 G in the grouped flows, WL_DOUBLE_LAST: twice the last generator-table
+  // entry in the plain one; a twelfth of a full verification or less), since the keyed ladder has no registers to spare.
+  // Zeros from INSIDE the ladder or the generator part (and u1 = 0: a digest that is 0 mod n) go to the worklist as before.
   bool undecided = ok && fe29_is_zero(acc.z), is_identity = false;
   uint32_t wl_tag = 0;
   if constexpr (ECDSA) {
@@ -839,16 +853,8 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
       if (!fe29_is_zero(acc.x)) {
         undecided = false;
         is_identity = true;                              // P - P
-      } else if constexpr (GROUPED) {
-        if (n < WL_TAG_LIMIT) wl_tag = WL_DOUBLE_GEN;    // P + P, R = 2 u1 G
-      } else {
-        apt g = gt_load(gt, GT_WINDOWS - 1, last_digit);
-        jpt29 q;
-        q.x = fe29_from_words(g.x.v);
-        q.y = fe29_from_words(g.y.v);
-        q.z = fe29_one();
-        acc = jpt29_double(q);                           // P + P
-        undecided = false;
+      } else if (n < WL_TAG_LIMIT) {
+        wl_tag = GROUPED ? WL_DOUBLE_GEN : WL_DOUBLE_LAST;   // P + P: R = 2 u1 G, or twice the last table entry
       }
     }
   }

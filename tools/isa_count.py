@@ -4,10 +4,13 @@
     python tools/isa_count.py [path/to/libsecp256k1_voi_amd.so]      -> JSON on stdout
 
 The library's gfx950 code objects are unbundled with `llvm-objdump --offloading`, the kernel is disassembled with
-`llvm-objdump -d`, and the loops are recovered from the BACKWARD BRANCHES of the disassembly (a branch to a lower
-address closes a loop [target, branch]; nesting is containment).  Trip counts are those of the source:
+`llvm-objdump -d`, and the loops are recovered from the control-flow graph of the disassembly (basic blocks; a loop is a
+strongly connected component, the loops inside it are the components left when the edges into its entries are cut - the
+code layout does not matter, nor does a second entry into a loop).  Trip counts are
+those of the source:
 
-  k_verify_fast<ECDSA>        table forward 7 | table backward 7 | ladder 32 x (doubling loop 4, addition loop 2) | generator part GT_WINDOWS
+  k_verify_fast<ECDSA>        table forward 7 | table backward 7 | ladder 32 x (doubling loop 4, addition loop 2) | generator part GT_WINDOWS - 1
+                              (the last generator addition stands outside the loop)
   k_verify_fast<ECDSA_KEYED>  main loop of 4 rounds, entered past its first blocks (the change of form and the doubling loop
                               run between rounds only: 3 times; doubling loop 4 per time), chunk loop 8, addition loop 2
 
@@ -66,85 +69,177 @@ def disassemble(lib, mangled_prefix):
         subprocess.run(["rm", "-rf", tmp])
 
 
-def loops_of(ins):
-    """Loops as (lo, hi) offset intervals from backward branches, merged per header, sorted by lo."""
-    by_head = {}
-    for off, op, tgt in ins:
-        if tgt is not None and tgt <= off:
-            by_head[tgt] = max(by_head.get(tgt, 0), off)
-    lp = sorted(by_head.items())
-    # cold blocks laid out behind the kernel's end branch BACK into the straight-line code: such "loops" cross each
-    # other (overlap without containment), which loops proper never do
-    crossing = lambda a, b: a[0] < b[0] <= a[1] < b[1] or b[0] < a[0] <= b[1] < a[1]
-    return [l for l in lp if not any(crossing(l, o) for o in lp)]
+class Cfg:
+    """Basic blocks, dominators and natural loops of one kernel's disassembly."""
 
+    def __init__(self, ins):
+        self.ins = ins
+        offs = [o for o, _, _ in ins]
+        index = {o: i for i, o in enumerate(offs)}
+        leaders = {0}
+        for i, (off, op, tgt) in enumerate(ins):
+            if tgt is not None:
+                leaders.add(index[tgt])
+                if i + 1 < len(ins):
+                    leaders.add(i + 1)
+            elif op.startswith(("s_endpgm", "s_setpc", "s_swappc")) and i + 1 < len(ins):
+                leaders.add(i + 1)
+        starts = sorted(leaders)
+        self.blocks = [(starts[k], starts[k + 1] if k + 1 < len(starts) else len(ins)) for k in range(len(starts))]
+        self.block_of = {}
+        for b, (lo, hi) in enumerate(self.blocks):
+            for i in range(lo, hi):
+                self.block_of[i] = b
+        nb = len(self.blocks)
+        self.succ = [[] for _ in range(nb)]
+        for b, (lo, hi) in enumerate(self.blocks):
+            off, op, tgt = ins[hi - 1]
+            if tgt is not None:
+                self.succ[b].append(self.block_of[index[tgt]])
+            if not op.startswith(("s_branch", "s_endpgm", "s_setpc")) and hi < len(ins):
+                self.succ[b].append(self.block_of[hi])
+        self.pred = [[] for _ in range(nb)]
+        for b in range(nb):
+            for t in self.succ[b]:
+                self.pred[t].append(b)
+        # Loop forest from strongly connected components (works for loops with two entries too - the keyed ladder's round
+        # loop is entered past its first blocks AND, by a never-taken guard, at them): a nontrivial SCC is a loop; its
+        # entries are the blocks with a predecessor outside; with the edges into the entries cut, the SCCs inside are the
+        # nested loops.
+        self.loops = []                                   # dicts: blocks (set), entries (sorted list), parent (index or None)
+        self._nest(set(range(nb)), set(), None)
 
-def count(ins, weight_of):
-    valu = mad = 0
-    for off, op, _ in ins:
-        if op.startswith("v_"):
-            w = weight_of(off)
-            valu += w
-            mad += w if op.startswith("v_mad_u64_u32") else 0
-    return valu, mad
+    def _sccs(self, nodes, cut):
+        """nontrivial SCCs of the graph on `nodes` without the edges into `cut` (Tarjan, iterative)"""
+        idx, low, on, stack, out, counter = {}, {}, set(), [], [], [0]
+        for root in sorted(nodes):
+            if root in idx:
+                continue
+            work = [(root, iter([t for t in self.succ[root] if t in nodes and t not in cut]))]
+            idx[root] = low[root] = counter[0]
+            counter[0] += 1
+            stack.append(root)
+            on.add(root)
+            while work:
+                v, it = work[-1]
+                advanced = False
+                for t in it:
+                    if t not in idx:
+                        idx[t] = low[t] = counter[0]
+                        counter[0] += 1
+                        stack.append(t)
+                        on.add(t)
+                        work.append((t, iter([x for x in self.succ[t] if x in nodes and x not in cut])))
+                        advanced = True
+                        break
+                    elif t in on:
+                        low[v] = min(low[v], idx[t])
+                if advanced:
+                    continue
+                work.pop()
+                if work:
+                    low[work[-1][0]] = min(low[work[-1][0]], low[v])
+                if low[v] == idx[v]:
+                    comp = set()
+                    while True:
+                        x = stack.pop()
+                        on.discard(x)
+                        comp.add(x)
+                        if x == v:
+                            break
+                    if len(comp) > 1 or v in [t for t in self.succ[v] if t not in cut]:
+                        out.append(comp)
+        return out
+
+    def _nest(self, nodes, cut, parent):
+        for comp in sorted(self._sccs(nodes, cut), key=min):
+            entries = sorted(b for b in comp if b == 0 or any(p not in comp for p in self.pred[b]))
+            self.loops.append({"blocks": comp, "entries": entries, "parent": parent})
+            self._nest(comp, cut | set(entries), len(self.loops) - 1)
+
+    def children(self, k):
+        return [i for i, l in enumerate(self.loops) if l["parent"] == k]
+
+    def top_level(self):
+        return self.children(None)
+
+    def weights(self, trips, headers=None):
+        """block -> product of the trip counts of the loops around it.  A loop whose exit test sits in the middle (the blocks
+        behind the test run one time fewer) counts trip - 1 for the blocks reached from the exiting block's in-loop successor
+        before the loop's header comes round again.  `headers`: loop index -> header block, for loops with several entries."""
+        w = [1] * len(self.blocks)
+        for k, l in enumerate(self.loops):
+            body, t = l["blocks"], trips[k]
+            head = (headers or {}).get(k, l["entries"][0] if len(l["entries"]) == 1 else None)
+            assert head is not None, "loop with several entries and no header given"
+            exiting = [b for b in body if any(s not in body for s in self.succ[b])]
+            late = set()
+            if len(exiting) == 1:
+                stack = [s_ for s_ in self.succ[exiting[0]] if s_ in body and s_ != head]
+                while stack:
+                    x = stack.pop()
+                    if x in late or x == head:
+                        continue
+                    late.add(x)
+                    stack.extend(y for y in self.succ[x] if y in body)
+            for b in body:
+                w[b] *= (t - 1) if b in late else t
+        return w
+
+    def count(self, w, blocks=None):
+        valu = mad = 0
+        for b, (lo, hi) in enumerate(self.blocks):
+            if blocks is not None and b not in blocks:
+                continue
+            for i in range(lo, hi):
+                op = self.ins[i][1]
+                if op.startswith("v_"):
+                    valu += w[b]
+                    mad += w[b] if op.startswith("v_mad_u64_u32") else 0
+        return valu, mad
+
+    def valu_in(self, body):
+        return sum(1 for b in body for i in range(*self.blocks[b]) if self.ins[i][1].startswith("v_"))
 
 
 def general(lib, gt_windows=12):
-    ins = disassemble(lib, "_Z13k_verify_fastILi0EE")
-    lp = loops_of(ins)
-    outer = [l for l in lp if not any(o[0] <= l[0] and l[1] <= o[1] and o != l for o in lp)]
-    inner = [l for l in lp if l not in outer]
-    assert len(outer) == 4 and len(inner) == 2, ("unexpected loop structure of k_verify_fast<ECDSA>", outer, inner)
-    assert all(outer[2][0] <= l[0] and l[1] <= outer[2][1] for l in inner), "inner loops are not inside the ladder loop"
-    trips = {outer[0]: 7, outer[1]: 7, outer[2]: 32, outer[3]: gt_windows, inner[0]: 32 * 4, inner[1]: 32 * 2}
-
-    def weight(off):
-        for l in inner + outer:                       # innermost first
-            if l[0] <= off <= l[1]:
-                return trips[l]
-        return 1
-    valu, mad = count(ins, weight)
-    regions = {}
-    for name, l in (("table_fwd", outer[0]), ("table_bwd", outer[1]), ("doubling", inner[0]), ("addition", inner[1]), ("generator", outer[3])):
-        regions[name] = sum(1 for off, op, _ in ins if op.startswith("v_") and l[0] <= off <= l[1])
-    return {"valu_instr_static": valu, "mad_u64_u32_per_verify": mad, "valu_per_trip": regions, "instructions": len(ins)}
+    g = Cfg(disassemble(lib, "_Z13k_verify_fastILi0EE"))
+    top = g.top_level()
+    assert len(top) == 4, ("unexpected loop structure of k_verify_fast<ECDSA>", [g.loops[k]["entries"] for k in top])
+    inner = g.children(top[2])
+    assert len(inner) == 2 and not g.children(top[0]) and not g.children(top[1]) and not g.children(top[3]), ("unexpected inner loops", inner)
+    trips = {top[0]: 7, top[1]: 7, top[2]: 32, top[3]: gt_windows - 1, inner[0]: 4, inner[1]: 2}   # (the last generator addition stands apart)
+    assert len(trips) == len(g.loops), "loops without a trip count"
+    valu, mad = g.count(g.weights(trips))
+    regions = {name: g.valu_in(g.loops[k]["blocks"]) for name, k in (("table_fwd", top[0]), ("table_bwd", top[1]), ("doubling", inner[0]),
+                                                                      ("addition", inner[1]), ("generator", top[3]))}
+    return {"valu_instr_static": valu, "mad_u64_u32_per_verify": mad, "valu_per_trip": regions, "instructions": len(g.ins)}
 
 
 def keyed(lib):
-    ins = disassemble(lib, "_Z13k_verify_fastILi4EE")
-    lp = loops_of(ins)
-    outer = [l for l in lp if not any(o[0] <= l[0] and l[1] <= o[1] and o != l for o in lp)]
-    assert len(outer) == 1, ("unexpected loop structure of k_verify_fast<ECDSA_KEYED>", lp)
-    main = outer[0]
-    inside = [l for l in lp if l != main]
-    depth2 = [l for l in inside if not any(o[0] <= l[0] and l[1] <= o[1] and o != l for o in inside)]
-    depth3 = [l for l in inside if l not in depth2]
-    assert len(depth2) == 2 and len(depth3) == 1, ("unexpected loop structure of k_verify_fast<ECDSA_KEYED>", lp)
-    dbl, chunk = depth2
-    add = depth3[0]
-    assert chunk[0] <= add[0] and add[1] <= chunk[1], "the addition loop is not inside the chunk loop"
-    # the main loop is entered past its first blocks: the forward branch from before the loop into it names the header of
-    # a ROUND; what lies before that inside the loop (change of form, doubling loop, change back) runs between rounds only
-    # (a second branch from the prologue, to the change of form itself, is the compiler's copy of the `if (round)` test:
-    # never taken, the first round is round 0)
-    entry = sorted(set(tgt for off, op, tgt in ins if tgt is not None and off < main[0] and dbl[1] < tgt <= chunk[0]))
-    assert len(entry) == 1, ("main loop entry not found", entry, main, dbl, chunk)
-    entry = entry[0]
-
-    def weight(off):
-        if add[0] <= off <= add[1]:
-            return 64
-        if chunk[0] <= off <= chunk[1]:
-            return 32
-        if dbl[0] <= off <= dbl[1]:
-            return 12
-        if main[0] <= off <= main[1]:
-            return 3 if off < entry else 4
-        return 1
-    valu, mad = count(ins, weight)
-    per = lambda l: sum(1 for off, op, _ in ins if op.startswith("v_") and l[0] <= off <= l[1])
+    g = Cfg(disassemble(lib, "_Z13k_verify_fastILi4EE"))
+    top = g.top_level()
+    assert len(top) == 1, ("unexpected loop structure of k_verify_fast<ECDSA_KEYED>", [g.loops[k]["entries"] for k in top])
+    kids = g.children(top[0])
+    assert len(kids) == 2, ("unexpected loops inside the round loop", kids)
+    chunk = [k for k in kids if g.children(k)]
+    dbl = [k for k in kids if not g.children(k)]
+    assert len(chunk) == 1 and len(dbl) == 1, "cannot tell the doubling loop from the chunk loop"
+    add = g.children(chunk[0])
+    assert len(add) == 1 and not g.children(add[0])
+    trips = {top[0]: 4, dbl[0]: 4, chunk[0]: 8, add[0]: 2}
+    assert len(trips) == len(g.loops), "loops without a trip count"
+    # a ROUND starts where the chunk loop is entered from: the block in front of the chunk loop's header
+    ch = g.loops[chunk[0]]
+    round_head = [p for e in ch["entries"] for p in g.pred[e] if p not in ch["blocks"]]
+    assert len(set(round_head)) == 1, ("round header not found", round_head)
+    w = g.weights(trips, headers={top[0]: round_head[0]})
+    # the doubling loop runs between rounds only: 3 x 4
+    assert {w[b] for b in g.loops[dbl[0]]["blocks"]} == {12} and {w[b] for b in g.loops[add[0]]["blocks"]} == {64}, "trip weights are not the source's"
+    valu, mad = g.count(w)
     return {"valu_instr_static": valu, "mad_u64_u32_per_verify": mad,
-            "valu_per_trip": {"doubling": per(dbl), "addition": per(add)}, "instructions": len(ins)}
+            "valu_per_trip": {"doubling": g.valu_in(g.loops[dbl[0]]["blocks"]), "addition": g.valu_in(g.loops[add[0]]["blocks"])},
+            "instructions": len(g.ins)}
 
 
 def static_counts(lib=DEFAULT_LIB, gt_windows=12):
