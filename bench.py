@@ -66,8 +66,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe inclusive) measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip configs 3/4, K=N and the worst case (e.g. under a profiler)")
-    ap.add_argument("--key-grouping", choices=("auto", "off"), default="auto",
-                    help="off: every signature through the general ladder (profiling the K = N kernel; not the headline)")
+    ap.add_argument("--key-grouping", choices=("auto", "off", "keyset"), default="auto",
+                    help="off: every signature through the general ladder; keyset: the batch against a key set built before the "
+                         "timed region (both for profiling those kernels under the driver's settings; not the headline)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="test hook: allow more ranks than devices (rank r -> device r mod count, gloo collectives)")
     return ap.parse_args()
@@ -278,12 +279,21 @@ def worker(args):
     st = torch.cuda.current_stream().cuda_stream
     gather_scratch = {}
 
+    main_keyset = None
+    if args.key_grouping == "keyset":
+        ks_keys, ks_inv = np.unique(pub, axis=0, return_inverse=True)
+        main_keyset = (eng.keyset_create(ks_keys), torch.from_numpy(ks_inv.reshape(-1).astype(np.uint32).view(np.int32)).to(dev))
+
     def step(inputs=None):
         p, d, rr, ss = inputs or (d_pub, d_dig, d_r, d_s)
         # verdicts are cleared first, so a step that silently did nothing cannot pass the count check
         d_valid.zero_()
-        eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(),
-                                      d_valid.data_ptr(), 0, st)
+        if main_keyset is not None:
+            eng.ecdsa_verify_batch_keyset_device(main_keyset[0], n, main_keyset[1].data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(),
+                                                 d_valid.data_ptr(), 0, st)
+        else:
+            eng.ecdsa_verify_batch_device(n, p.data_ptr(), d.data_ptr(), rr.data_ptr(), ss.data_ptr(),
+                                          d_valid.data_ptr(), 0, st)
         # the only collective of the path: one all-gather of the valid bitmap shards, each with its rank's count behind it
         return gather_valid_device(d_valid, n * world, dist, engine=eng, bitmap=d_bitmap, count=d_count, scratch=gather_scratch)
 
@@ -376,10 +386,12 @@ def worker(args):
         fast_med = median(prof["fast_each"])
         calls = prof["calls"]
         keyed = grouping["keyed"] * 2 >= n                # which ladder is the dominant kernel of this run
+        if main_keyset is not None:
+            keyed = True
         clock_hz = prof["shader_mhz"] * 1e6
         value = n * world * args.steps / dt
         counts, counts_src = committed_counts()
-        kname = "k_verify_fast_keyed" if keyed else "k_verify_fast"
+        kname = "k_verify_fast_keyset" if main_keyset is not None else ("k_verify_fast_keyed" if keyed else "k_verify_fast")
         traffic, traffic_src = committed_traffic(kname)
         stages = {"grouping_by_key_ms": prof["group_ms"] / calls, "key_tables_ms": None, "ladder_ms": fast_ms,
                   "general_ladder_ms": prof["left_ms"] / calls, "complete_worklist_ms": prof["fallback_ms"] / calls}
@@ -391,7 +403,7 @@ def worker(args):
             stages["scalar_prep_ms"] = prof["prep_ms"] / calls
             stages.pop("grouping_by_key_ms")
             stages.pop("key_tables_ms")
-        roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>",
+        roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYSET>" if main_keyset is not None else ("k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>"),
                 "kernel_ms": fast_ms, "kernel_ms_median": fast_med, "stages_ms": stages,
                 "shader_clock_mhz": prof["shader_mhz"], "shader_clock_mhz_first_wave": prof["shader_mhz_first_wave"],
                 "shader_clock_mhz_last_round": prof["shader_mhz_last_round"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
@@ -401,7 +413,7 @@ def worker(args):
             counts = None
         if counts:
             ipv = counts[kname]["valu_instr_per_signature"]
-            st_ = counts.get("static_keyed" if keyed else "static", {})
+            st_ = counts.get("static_keyset" if main_keyset is not None else ("static_keyed" if keyed else "static"), {})
             lane_ops = ipv * n / (fast_ms * 1e-3)
             roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
                          "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src,
@@ -448,7 +460,7 @@ def worker(args):
                        "inputs": "resident in HBM", "collective": "one all-gather per step: bitmap shard + valid count of every rank",
                        "build": eng._lib.s2k_build_config().decode()},
             "roofline": roof,
-            "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)" if args.key_grouping == "auto" else "off (--key-grouping off)", "signatures_on_key_tables": grouping["keyed"],
+            "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)" if args.key_grouping == "auto" else "%s (--key-grouping %s)" % (args.key_grouping, args.key_grouping), "signatures_on_key_tables": grouping["keyed"],
                              "tables_built_per_step": grouping["tables"], "signatures_on_general_ladder": grouping["general"],
                              "note": "signatures are grouped by public key inside every step; keys with >= 4 signatures get a "
                                      "precomputed table (built inside the step) and their signatures a 12-doubling ladder"},
@@ -603,6 +615,31 @@ def general_roofline(kernel_ms, shader_mhz, n):
     return roof
 
 
+def keyset_roofline(eng, kernel_ms, shader_mhz, n):
+    """`roofline` of k_verify_fast<ECDSA_KEYSET> (64 table additions, no doubling): PMC count when the committed profile has
+    one (bench.py --key-grouping keyset under the counters), else the static recount of the loaded library."""
+    import secp256k1_voi_amd as S
+    counts, src = committed_counts()
+    roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYSET>", "kernel_ms": kernel_ms, "shader_clock_mhz": shader_mhz,
+            "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12}
+    ipv = None
+    if counts and "k_verify_fast_keyset" in counts:
+        ipv, roof["counts_from"] = counts["k_verify_fast_keyset"]["valu_instr_per_signature"], "profiles/" + src
+    else:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import isa_count
+            ipv, roof["counts_from"] = isa_count.keyset(S.LIB_PATH)["valu_instr_static"], "static recount of the loaded library (tools/isa_count.py)"
+        except Exception as e:
+            roof["recount_error"] = repr(e)[:200]
+    if ipv and kernel_ms > 0:
+        lane_ops = ipv * n / (kernel_ms * 1e-3)
+        roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS, "valu_instr_per_verify": ipv})
+        if shader_mhz > 0:
+            roof["frac_at_measured_clock"] = ipv * n / 64.0 * 4.0 / (SIMDS * kernel_ms * 1e-3 * shader_mhz * 1e6)
+    return roof
+
+
 def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_stage):
     """`roofline` object of BASELINE config 3 / 4: the dominant kernel's VALU instructions (PMC, committed profile of the
     same entry point at the same size, tools/collect_msm_profiles.sh) over its live duration (HIP events on the call's
@@ -678,10 +715,15 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
         def with_keyset():
             eng.ecdsa_verify_batch_keyset_device(ks, n, d_kidx.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_valid.data_ptr(), 0, st)
         d_valid.zero_()
+        with_keyset()
+        eng.profile(True)
         ms = timed(with_keyset, 10)
+        prk = eng.profile_read_stages(cap=16)
+        eng.profile(False)
         assert int(d_valid.sum().item()) == n, "key-set verification did not accept the synthetic batch"
         out["keyset_resident"] = {"keys": int(len(ks)), "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
                                   "keyset_device_bytes": ks.device_bytes(),
+                                  "roofline": keyset_roofline(eng, prk["fast_ms"] / max(prk["calls"], 1), prk["shader_mhz"], n),
                                   "note": "s2k_ecdsa_verify_batch_keyset_device: tables of the %d keys built once by s2k_keyset_create "
                                           "(not timed); per call: scalar preparation, generator part, sort by key index, ladder" % len(ks)}
         ks.close()

@@ -474,7 +474,7 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // ---------------------------------------------------------------------------------------
 
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
-       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7 };
+       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 constexpr uint32_t KVF_FORCE_WORKLIST = 0x80000000u;   // top bit of k_verify_fast's first argument (batches are below 2^31)
 
@@ -575,9 +575,10 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
               key_groups kg) {
-  constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED;
+  constexpr bool KEYSET = MODE == MODE_ECDSA_KEYSET;   // KEYED over a key set's 32-chunk tables: no doublings at all
+  constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED || KEYSET;
   constexpr bool GROUPED = KEYED || MODE == MODE_ECDSA_LEFT || MODE == MODE_SCHNORR_LEFT;
-  constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT;
+  constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT || KEYSET;
   const bool force_wl = (n_and_flags & KVF_FORCE_WORKLIST) != 0;
   const uint32_t n = n_and_flags & ~KVF_FORCE_WORKLIST;
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;         // lane: workspace column
@@ -731,9 +732,9 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
     // k = 16^32 + sum_i d_i 16^i with d_i = 2 nib_i - 15, i = 4c + j: round j (3 down to 0) adds
     // d_(4c+j) * 2^(16c) Q for the eight chunks c, with four doublings between rounds; the leading
     // 16^32 Q = 16^3 * 2^116 Q goes in first (for both halves at once: one table point, see below).
-    const uint4* kt = kg.ktab + (size_t)kg.ptab[idx] * (KT_SLOTS * 8);
-    digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);
-    const fe29 kw = ke_load(kt + (size_t)(KT_SCR + KT_W_SLOT / 3) * 8, KT_W_SLOT % 3);   // wanted at the very end: asked for early
+    using G = kt_geom<KEYSET ? KS_CHUNKS : KT_CHUNKS>;
+    const uint4* kt = kg.ktab + (size_t)kg.ptab[idx] * (G::SLOTS * 8);
+    const fe29 kw = ke_load(kt + (size_t)(G::SCR + G::W_SLOT / 3) * 8, G::W_SLOT % 3);   // wanted at the very end: asked for early
     // The 64 additions of this ladder run in XYZZ coordinates (xyzz29.h: 8 M + 2 S in 9 reductions against 8 M + 3 S in
     // 10 for the Jacobian mixed addition: 1 441 instead of 1 578 instructions); the 12 doublings stay Jacobian (7 products
     // against 9), so the accumulator changes form at the three round borders (3 M + 1 S each way together).  The
@@ -743,20 +744,28 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
     {
       // +-L +- phi(L): the table holds L + phi(L) and L - phi(L) (keyed.hip), the other two are their negatives
       fe29 lx, ly;
-      ke_load_xy(kt + (size_t)(neg1 == neg2 ? KT_LEAD : KT_LEAD + 1) * 8, false, lx, ly);
+      ke_load_xy(kt + (size_t)(neg1 == neg2 ? G::LEAD : G::LEAD + 1) * 8, false, lx, ly);
       xa = xyzz29_from_affine(lx, fe29_cond_negate1(ly, neg1));
     }
-#pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
-      if (round) {
-        jpt29 j4 = xyzz29_to_jacobian(xa);
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) j4 = jpt29_double(j4);
-        xa = xyzz29_from_jacobian(j4);
+    if constexpr (KEYSET) {
+      // Key sets: one chunk per digit, {1,3,..,15} * 16^i Q for i < 32 and L = 16^32 Q: k = 16^32 + sum d_i 16^i is 64
+      // table additions, in any order - bottom up, nibble i = bits 4i+1 .. 4i+4 of the odd half scalar (k >> 1, 128 bits).
+      uint32_t a[4], b[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a[w] = (k1.v[w] >> 1) | (k1.v[w + 1] << 31);
+        b[w] = (k2.v[w] >> 1) | (k2.v[w + 1] << 31);
       }
 #pragma unroll 1
-      for (int c = 0; c < KT_CHUNKS; ++c) {
-        uint32_t w1 = ds4_next(d1), w2 = ds4_next(d2);
+      for (int c = 0; c < KS_CHUNKS; ++c) {
+        const uint32_t w1 = a[0] & 15u, w2 = b[0] & 15u;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          a[w] = (a[w] >> 4) | (a[w + 1] << 28);
+          b[w] = (b[w] >> 4) | (b[w + 1] << 28);
+        }
+        a[3] >>= 4;
+        b[3] >>= 4;
 #pragma unroll 1
         for (int t = 0; t < 2; ++t) {
           uint32_t w = t ? w2 : w1;
@@ -765,6 +774,30 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           fe29 x, y;
           ke_load_xy(kt + (size_t)(c * 8 + entry) * 8, t != 0, x, y);
           xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, neg));
+        }
+      }
+    } else {
+      digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);
+#pragma unroll 1
+      for (int round = 0; round < 4; ++round) {
+        if (round) {
+          jpt29 j4 = xyzz29_to_jacobian(xa);
+#pragma unroll 1
+          for (int j = 0; j < 4; ++j) j4 = jpt29_double(j4);
+          xa = xyzz29_from_jacobian(j4);
+        }
+#pragma unroll 1
+        for (int c = 0; c < KT_CHUNKS; ++c) {
+          uint32_t w1 = ds4_next(d1), w2 = ds4_next(d2);
+#pragma unroll 1
+          for (int t = 0; t < 2; ++t) {
+            uint32_t w = t ? w2 : w1;
+            bool neg = (t ? neg2 : neg1) != (w < 8u);
+            uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+            fe29 x, y;
+            ke_load_xy(kt + (size_t)(c * 8 + entry) * 8, t != 0, x, y);
+            xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, neg));
+          }
         }
       }
     }
@@ -1575,7 +1608,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   delete[] ctx->prof_ev;
   for (hipEvent_t e : ctx->ev_copied)
     if (e) (void)hipEventDestroy(e);
-  if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+  if (ctx->s_copy && !ctx->s_copy_shared) (void)hipStreamDestroy(ctx->s_copy);
   if (ctx->s_comp) (void)hipStreamDestroy(ctx->s_comp);
   delete ctx;
 }
@@ -1882,6 +1915,9 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   // second stream: scalar preparation and generator part; caller's: the sort by key index
+  // (stage times, s2k_ctx_profile_read_stages: [0] + [1] the sort with the second stream's work beside it, [2] the ladder)
+  prof_mark(ctx, st, 0);
+  prof_mark(ctx, st, 1);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
   k_scalar_prep<<<(T + 63) / 64, 64, 0, ctx->s_aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s,
@@ -1896,13 +1932,18 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
     return rc;
   }
   kg.gp = gp;
-  k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
-                                                                 (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
+  uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
+  prof_mark(ctx, st, 2);
+  k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
+                                                                  (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+  prof_mark(ctx, st, 3);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback_keyset<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, ks->base + off[0], (const uint32_t*)d_key_index,
                                                                     (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s, flags,
                                                                     (uint8_t*)d_valid, ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
+  prof_mark(ctx, st, 4);
+  prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
 }
 
@@ -2322,8 +2363,12 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
     if (rc) pipe_note_failure(ctx, t, rc);           // (reported by s2k_wait on that ticket)
   }
   if (!sl.ctx) {
-    int rc = s2k_ctx_create(ctx->device, &sl.ctx);
+    int rc = ctx_streams(ctx);                        // (the parent's copy stream carries the transfers of all slots)
+    if (rc) return rc;
+    rc = s2k_ctx_create(ctx->device, &sl.ctx);
     if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
+    sl.ctx->s_copy = ctx->s_copy;
+    sl.ctx->s_copy_shared = true;
   }
   // the child verifies with the parent's settings of the moment
   sl.ctx->kg_mode = ctx->kg_mode;

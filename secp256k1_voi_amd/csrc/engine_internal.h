@@ -83,6 +83,9 @@ struct s2k_ctx {
   void* io = nullptr;
   size_t io_bytes = 0;
   hipStream_t s_copy = nullptr, s_comp = nullptr;
+  bool s_copy_shared = false;   // a child context of submit / wait: the copy stream is its parent's (all slots share one: their
+                                // transfers are in order anyway, and every stream fewer is one fewer to land on a compute stream's
+                                // hardware queue)
   hipEvent_t ev_copied[2] = {nullptr, nullptr};
   hipEvent_t ev_arrival[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pieces of a pinned batch on their way in
   int cu_count = 0;
@@ -243,10 +246,10 @@ bool s2k_internal_host_pinned(const void* p, size_t bytes);
 
 // copy / compute streams and the events chaining them, for the host-buffer entry points
 inline int ctx_streams(s2k_ctx* ctx) {
-  if (ctx->s_copy) return S2K_OK;
-  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
-  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
-  for (hipEvent_t& e : ctx->ev_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!ctx->s_copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));   // (a child context is given its parent's)
+  if (!ctx->s_comp) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
+  for (hipEvent_t& e : ctx->ev_copied)
+    if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return S2K_OK;
 }
 
@@ -276,12 +279,30 @@ inline int ctx_stage(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** ptr
 // 16-bit chunks c of a 128-bit half scalar the odd multiples {1,3,..,15} * 2^(16c) Q, and 2^116 Q for
 // the recoding's leading digit, all affine (one shared inversion per key) with their beta*x column.
 // A signature's ladder is then 12 doublings instead of 128 around the same 66 additions.
+// Two geometries.  CHUNKS = 8: what a verification call builds for itself (16-bit chunks, 12 doublings left per signature,
+// 9 KiB per key).  CHUNKS = 32: key sets (s2k_keyset_*), built once, so their size is free: one chunk per 4-bit digit,
+// {1,3,..,15} * 2^(4c) Q for c < 32 and the lead pair from L = 2^128 Q - a signature's ladder is 64 additions and NO
+// doubling (36 KiB per key).
+template <int CHUNKS>
+struct kt_geom {
+  static constexpr int DBL = 128 / CHUNKS;          // doublings from one chunk's base to the next (then 4 more to the lead point)
+  static constexpr int LEAD = CHUNKS * 8;           // entries of L + phi(L) and (LEAD + 1) L - phi(L): the two starting points of a ladder
+  static constexpr int ENTRIES = LEAD + 2;
+  static constexpr int SCR = ENTRIES;               // first scratch entry; three field elements per entry (keyed.hip: kt_scratch)
+  static constexpr int W_SLOT = CHUNKS + 1;         // scratch element that stays part of the table: W, the Z all entries of the key share
+  static constexpr int PRE_SLOT = CHUNKS + 2;       // (32 chunks) prefix products of the nine / 33 Z, CHUNKS + 1 of them
+  static constexpr int SCR_ELEMS = CHUNKS == 8 ? 18 : 2 * CHUNKS + 3;
+  static constexpr int SLOTS = CHUNKS == 8 ? 72 : ((ENTRIES + (SCR_ELEMS + 2) / 3 + 7) / 8 * 8);   // entries of 128 bytes reserved per key
+};
 constexpr int KT_CHUNKS = 8;
-constexpr int KT_LEAD = KT_CHUNKS * 8;          // entries of L + phi(L) and (KT_LEAD + 1) L - phi(L), L = 2^116 Q: the two starting points of a ladder
-constexpr int KT_ENTRIES = KT_LEAD + 2;
-constexpr int KT_SLOTS = 72;                    // entries of 128 bytes reserved per key: 66 + 6 of build scratch
-constexpr int KT_SCR = KT_ENTRIES;              // first scratch entry: 18 field elements, three per entry (keyed.hip: kt_scratch)
-constexpr int KT_W_SLOT = 9;                    // scratch element that stays part of the table: W, the Z all entries of the key share
+constexpr int KT_LEAD = kt_geom<8>::LEAD;
+constexpr int KT_ENTRIES = kt_geom<8>::ENTRIES;
+constexpr int KT_SLOTS = kt_geom<8>::SLOTS;     // 72: 66 + 6 of build scratch
+constexpr int KT_SCR = kt_geom<8>::SCR;
+constexpr int KT_W_SLOT = kt_geom<8>::W_SLOT;   // 9
+constexpr int KS_CHUNKS = 32;                   // key sets
+constexpr int KS_SLOTS = kt_geom<32>::SLOTS;    // 288
+static_assert(KT_SLOTS == 72 && KT_W_SLOT == 9 && kt_geom<32>::SLOTS == 288, "table geometry");
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
 constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grouping
@@ -299,6 +320,7 @@ struct key_groups {        // device pointers of one call
   const uint32_t* trep;    // per table: a signature that carries the key
   const uint32_t* gp;      // per signature: u1*G (Jacobian, three fin-format elements; k_generator_part)
   uint32_t max_tables;
+  int chunks;              // table geometry: 8 (built per call) or 32 (key sets); 0 means 8
   int key_bytes;           // 64: X || Y (ECDSA), 32: x-only (BIP-340)
   // two-part flow: part 0 = tables [0, counters[KG_SPLIT_T]) and lanes [0, counters[KG_SPLIT_LANE]), part 1 the
   // rest; nparts == 1: everything (kernels take these from the copy of the struct they are launched with)

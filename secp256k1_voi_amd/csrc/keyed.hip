@@ -298,18 +298,21 @@ k_key_place(uint32_t n, const uint32_t* __restrict__ slot_of, const uint32_t* __
 //                The ladder's formulas (a = 0, no curve constant) run on that curve unchanged and its result
 //                (X, Y, Z) is the secp256k1 point (X, Y, Z W): one product per signature.
 // Cost per key: 116 doublings, 8 * (1 doubling + 7 additions), 23 products, ~7 products per point.
-S2K_DEV uint4* kt_scratch(uint4* kt, int slot, int& which) {   // 18 field elements in the 6 scratch entries
+template <int CHUNKS>
+S2K_DEV uint4* kt_scratch(uint4* kt, int slot, int& which) {   // field elements in the scratch entries, three per entry
   which = slot % 3;
-  return kt + (size_t)(KT_SCR + slot / 3) * 8;
+  return kt + (size_t)(kt_geom<CHUNKS>::SCR + slot / 3) * 8;
 }
+template <int CHUNKS>
 S2K_DEV void scr_store(uint4* kt, int slot, const fe29& v) {
   int which;
-  uint4* e = kt_scratch(kt, slot, which);
+  uint4* e = kt_scratch<CHUNKS>(kt, slot, which);
   ke_store(e, which, v);
 }
+template <int CHUNKS>
 S2K_DEV fe29 scr_load(uint4* kt, int slot) {
   int which;
-  uint4* e = kt_scratch(kt, slot, which);
+  uint4* e = kt_scratch<CHUNKS>(kt, slot, which);
   return ke_load(e, which);
 }
 S2K_DEV uint32_t table_count(const uint32_t* __restrict__ counters, uint32_t max_tables) {
@@ -331,14 +334,15 @@ S2K_DEV void table_range(const uint32_t* __restrict__ counters, uint32_t max_tab
 
 // XONLY: the keys are 32-byte BIP-340 x-only keys, validated and lifted to the even-y point as
 // NewSchnorrPublicKey does (schnorr.go:257-275); otherwise 64-byte X || Y.
-template <bool XONLY>
+template <bool XONLY, int CHUNKS>
 __global__ void __launch_bounds__(64)
 k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const uint32_t* __restrict__ trep,
             const uint8_t* __restrict__ pub, uint4* __restrict__ ktab, uint8_t* __restrict__ tinfo) {
+  using G = kt_geom<CHUNKS>;
   uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= table_count(counters, max_tables)) return;
   const size_t sig = trep[t];
-  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+  uint4* kt = ktab + (size_t)t * (G::SLOTS * 8);
   bool ok;
   fe29 qx, qy;
   if constexpr (XONLY) {
@@ -389,11 +393,11 @@ k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const ui
   ke_store(kt, TB_Y, cur.y);
   ke_store(kt, TB_BX, cur.z);
 #pragma unroll 1
-  for (int c = 1; c <= KT_CHUNKS; ++c) {
-    const int nd = c < KT_CHUNKS ? 16 : 4;
+  for (int c = 1; c <= CHUNKS; ++c) {
+    const int nd = c < CHUNKS ? G::DBL : 4;   // (8 chunks: L = 2^116 Q, the ladder's 12 doublings make it 16^32 Q; 32 chunks: L = 2^128 Q)
 #pragma unroll 1
     for (int j = 0; j < nd; ++j) cur = jpt29_double(cur);
-    if (c == KT_CHUNKS) break;               // the lead point: below
+    if (c == CHUNKS) break;                  // the lead point: below
     uint4* e = kt + (size_t)(c * 8) * 8;
     ke_store(e, TB_X, cur.x);
     ke_store(e, TB_Y, cur.y);
@@ -418,19 +422,20 @@ k_key_chain(const uint32_t* __restrict__ counters, uint32_t max_tables, const ui
     // difference: Y2 - Y1 = -2 Y:  X3 = 4 Y^2 - B - C,  Y3 = -Y (B + C - 2 X3)
     const fe29 xd = fe29_normalize_weak(fe29_add(fe29_sqr(fe29_mul_int(yn, 2)), fe29_negate(bc, 2)));
     const fe29 yd = fe29_mul(fe29_negate(yn, 1), fe29_normalize_weak(fe29_add(bc, fe29_negate(fe29_mul_int(xd, 2), 2))));
-    uint4* e = kt + (size_t)KT_LEAD * 8;
+    uint4* e = kt + (size_t)G::LEAD * 8;
     ke_store3(e, xs, ys, z3);
     ke_store3(e + 8, xd, yd, z3);
   }
 }
 
+template <int CHUNKS>
 __global__ void __launch_bounds__(256)
 k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
   uint32_t id = blockIdx.x * 256 + threadIdx.x, lo, hi;
   table_range(counters, max_tables, part, nparts, lo, hi);
-  const uint32_t t = lo + id / KT_CHUNKS, c = id % KT_CHUNKS;
+  const uint32_t t = lo + id / CHUNKS, c = id % CHUNKS;
   if (t >= hi) return;
-  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+  uint4* kt = ktab + (size_t)t * (kt_geom<CHUNKS>::SLOTS * 8);
   uint4* e0 = kt + (size_t)(c * 8) * 8;
   jpt29 a0;
   a0.x = ke_load(e0, TB_X);
@@ -453,53 +458,84 @@ k_key_odd(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t p
     cur = jpt29_add_affine(cur, dx, dy, &h);
     ke_store3(e0 + (size_t)j * 8, cur.x, cur.y, h);
   }
-  scr_store(kt, (int)c, fe29_mul(fe29_mul(cur.z, d.z), zb));
+  scr_store<CHUNKS>(kt, (int)c, fe29_mul(fe29_mul(cur.z, d.z), zb));
 }
 
+template <int CHUNKS>
 __global__ void __launch_bounds__(64)
 k_key_cofactors(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
+  using G = kt_geom<CHUNKS>;
   uint32_t lo, hi;
   table_range(counters, max_tables, part, nparts, lo, hi);
   const uint32_t t = lo + blockIdx.x * 64 + threadIdx.x;
   if (t >= hi) return;
-  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
-  // everything this lane needs is loaded up front (nine independent loads: one memory latency)
-  fe29 z[KT_CHUNKS + 1], pre[KT_CHUNKS + 1];
+  uint4* kt = ktab + (size_t)t * (G::SLOTS * 8);
+  uint4* el = kt + (size_t)G::LEAD * 8;
+  if constexpr (CHUNKS == 8) {
+    // everything this lane needs is loaded up front (nine independent loads: one memory latency)
+    fe29 z[CHUNKS + 1], pre[CHUNKS + 1];
 #pragma unroll
-  for (int c = 0; c < KT_CHUNKS; ++c) z[c] = scr_load(kt, c);
-  uint4* el = kt + (size_t)KT_LEAD * 8;
-  fe29 lx, ly, dx, dy, dz;
-  ke_load3(el, lx, ly, z[KT_CHUNKS]);
-  ke_load3(el + 8, dx, dy, dz);                                               // (the two lead points share their Z)
-  pre[0] = z[0];
+    for (int c = 0; c < CHUNKS; ++c) z[c] = scr_load<CHUNKS>(kt, c);
+    fe29 lx, ly, dx, dy, dz;
+    ke_load3(el, lx, ly, z[CHUNKS]);
+    ke_load3(el + 8, dx, dy, dz);                                               // (the two lead points share their Z)
+    pre[0] = z[0];
 #pragma unroll
-  for (int c = 1; c <= KT_CHUNKS; ++c) pre[c] = fe29_mul(pre[c - 1], z[c]);   // z_0 ... z_c
-  scr_store(kt, KT_W_SLOT, pre[KT_CHUNKS]);                                    // W
-  fe29 suf = fe29_one();                                                       // z_(c+1) ... z_8
+    for (int c = 1; c <= CHUNKS; ++c) pre[c] = fe29_mul(pre[c - 1], z[c]);   // z_0 ... z_c
+    scr_store<CHUNKS>(kt, G::W_SLOT, pre[CHUNKS]);                            // W
+    fe29 suf = fe29_one();                                                       // z_(c+1) ... z_8
 #pragma unroll
-  for (int c = KT_CHUNKS; c >= 0; --c) {
-    const fe29 co = c == KT_CHUNKS ? pre[c - 1] : (c > 0 ? fe29_mul(pre[c - 1], suf) : suf);   // W / z_c
-    if (c == KT_CHUNKS) {   // the two lead points, finished here
-      const fe29 s2 = fe29_sqr(co), s3 = fe29_mul(s2, co);
+    for (int c = CHUNKS; c >= 0; --c) {
+      const fe29 co = c == CHUNKS ? pre[c - 1] : (c > 0 ? fe29_mul(pre[c - 1], suf) : suf);   // W / z_c
+      if (c == CHUNKS) {   // the two lead points, finished here
+        const fe29 s2 = fe29_sqr(co), s3 = fe29_mul(s2, co);
+        ke_store3(el, fe29_mul(lx, s2), fe29_mul(ly, s3), fe29_zero());
+        ke_store3(el + 8, fe29_mul(dx, s2), fe29_mul(dy, s3), fe29_zero());
+      } else {
+        scr_store<CHUNKS>(kt, c, co);
+      }
+      if (c > 0) suf = c == CHUNKS ? z[c] : fe29_mul(suf, z[c]);
+    }
+  } else {
+    // 33 Z do not fit in registers: the prefix products go through the key's scratch elements (built once per key set)
+    fe29 lx, ly, lz, dx, dy, dz;
+    ke_load3(el, lx, ly, lz);
+    ke_load3(el + 8, dx, dy, dz);
+    fe29 pre = scr_load<CHUNKS>(kt, 0);
+    scr_store<CHUNKS>(kt, G::PRE_SLOT, pre);
+#pragma unroll 1
+    for (int c = 1; c < CHUNKS; ++c) {
+      pre = fe29_mul(pre, scr_load<CHUNKS>(kt, c));
+      scr_store<CHUNKS>(kt, G::PRE_SLOT + c, pre);                              // z_0 ... z_c
+    }
+    scr_store<CHUNKS>(kt, G::W_SLOT, fe29_mul(pre, lz));                        // W
+    {   // the two lead points: cofactor z_0 ... z_(CHUNKS - 1)
+      const fe29 s2 = fe29_sqr(pre), s3 = fe29_mul(s2, pre);
       ke_store3(el, fe29_mul(lx, s2), fe29_mul(ly, s3), fe29_zero());
       ke_store3(el + 8, fe29_mul(dx, s2), fe29_mul(dy, s3), fe29_zero());
-    } else {
-      scr_store(kt, c, co);
     }
-    if (c > 0) suf = c == KT_CHUNKS ? z[c] : fe29_mul(suf, z[c]);
+    fe29 suf = lz;                                                               // z_(c+1) ... z_CHUNKS
+#pragma unroll 1
+    for (int c = CHUNKS - 1; c >= 0; --c) {
+      const fe29 zc = scr_load<CHUNKS>(kt, c);
+      const fe29 co = c > 0 ? fe29_mul(scr_load<CHUNKS>(kt, G::PRE_SLOT + c - 1), suf) : suf;   // W / z_c
+      scr_store<CHUNKS>(kt, c, co);
+      suf = fe29_mul(suf, zc);
+    }
   }
 }
 
+template <int CHUNKS>
 __global__ void __launch_bounds__(256)
 k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
   uint32_t id = blockIdx.x * 256 + threadIdx.x, lo, hi;
   table_range(counters, max_tables, part, nparts, lo, hi);
-  const uint32_t t = lo + id / KT_CHUNKS, c = id % KT_CHUNKS;
+  const uint32_t t = lo + id / CHUNKS, c = id % CHUNKS;
   if (t >= hi) return;
-  uint4* kt = ktab + (size_t)t * (KT_SLOTS * 8);
+  uint4* kt = ktab + (size_t)t * (kt_geom<CHUNKS>::SLOTS * 8);
   uint4* e0 = kt + (size_t)(c * 8) * 8;
   const fe29 beta = fe29_from_words(FE_BETA);
-  fe29 rr = scr_load(kt, (int)c);
+  fe29 rr = scr_load<CHUNKS>(kt, (int)c);
   // entry j - 1 is in flight while entry j is scaled (a lane walks its eight entries one after the other: with the
   // load at the top of each step the kernel waited for memory eight times per lane)
   fe29 ex, ey, eh;
@@ -674,6 +710,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   out->tinfo = tinfo;
   out->trep = trep;
   out->max_tables = (uint32_t)max_tables;
+  out->chunks = KT_CHUNKS;
   out->key_bytes = key_bytes;
   return S2K_OK;
 }
@@ -683,10 +720,12 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_chains(s2k_ctx* ctx, 
                                                                   const key_groups* g) {
   uint4* ktab = const_cast<uint4*>(g->ktab);     // (the context's table buffer, or a key set's own)
   const size_t max_tables = g->max_tables;
-  if (g->key_bytes == 64)
-    k_key_chain<false><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
+  if (g->chunks == KS_CHUNKS)
+    k_key_chain<false, KS_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
+  else if (g->key_bytes == 64)
+    k_key_chain<false, KT_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
   else
-    k_key_chain<true><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
+    k_key_chain<true, KT_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, g->trep, d_pub, ktab, (uint8_t*)g->tinfo);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
@@ -696,12 +735,22 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
                                                                   uint32_t nparts, hipEvent_t ev_after_odd) {
   uint4* ktab = const_cast<uint4*>(g->ktab);
   const size_t max_tables = g->max_tables;
-  k_key_odd<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+  if (g->chunks == KS_CHUNKS) {
+    k_key_odd<KS_CHUNKS><<<blocks_for(max_tables * KS_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
+    k_key_cofactors<KS_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+    HIP_TRY(ctx, hipGetLastError());
+    k_key_scale<KS_CHUNKS><<<blocks_for(max_tables * KS_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+    HIP_TRY(ctx, hipGetLastError());
+    return S2K_OK;
+  }
+  k_key_odd<KT_CHUNKS><<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
-  k_key_cofactors<<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+  k_key_cofactors<KT_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_scale<<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+  k_key_scale<KT_CHUNKS><<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }
@@ -757,7 +806,7 @@ __attribute__((visibility("hidden"))) size_t s2k_internal_keyset_bytes(size_t n,
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   off[0] = 0;
   off[1] = off[0] + al(n * 64);
-  off[2] = off[1] + al(n * (size_t)KT_SLOTS * 128);
+  off[2] = off[1] + al(n * (size_t)KS_SLOTS * 128);           // 36 KiB per key: the 32-chunk geometry (engine_internal.h)
   off[3] = off[2] + al(n + 64);
   off[4] = off[3] + al(n * 4);
   return off[4] + al(KG_COUNTERS * 4);
@@ -772,6 +821,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_keyset_build(s2k_ctx* ctx
   g.tinfo = base + off[2];
   g.trep = (const uint32_t*)(base + off[3]);          // table t is the key of "signature" t: the identity
   g.max_tables = (uint32_t)n;
+  g.chunks = KS_CHUNKS;
   g.key_bytes = 64;
   g.part = 0;
   g.nparts = 1;
@@ -825,6 +875,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_keyset_sort(s2k_ctx* ctx,
   out->tinfo = set_base + off[2];
   out->trep = (const uint32_t*)(set_base + off[3]);
   out->max_tables = (uint32_t)nkeys;
+  out->chunks = KS_CHUNKS;
   out->key_bytes = 64;
   out->part = 0;
   out->nparts = 1;

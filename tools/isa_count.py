@@ -242,8 +242,22 @@ def keyed(lib):
             "instructions": len(g.ins)}
 
 
+def keyset(lib):
+    """k_verify_fast<ECDSA_KEYSET>: the ladder over a key set's 32-chunk tables - one chunk loop (32) around the addition loop (2)"""
+    g = Cfg(disassemble(lib, "_Z13k_verify_fastILi8EE"))
+    top = g.top_level()
+    assert len(top) == 1, ("unexpected loop structure of k_verify_fast<ECDSA_KEYSET>", [g.loops[k]["entries"] for k in top])
+    add = g.children(top[0])
+    assert len(add) == 1 and not g.children(add[0])
+    trips = {top[0]: 32, add[0]: 2}
+    assert len(trips) == len(g.loops), "loops without a trip count"
+    valu, mad = g.count(g.weights(trips))
+    return {"valu_instr_static": valu, "mad_u64_u32_per_verify": mad, "valu_per_trip": {"addition": g.valu_in(g.loops[add[0]]["blocks"])},
+            "instructions": len(g.ins)}
+
+
 def static_counts(lib=DEFAULT_LIB, gt_windows=12):
-    return {"k_verify_fast": general(lib, gt_windows), "k_verify_fast_keyed": keyed(lib)}
+    return {"k_verify_fast": general(lib, gt_windows), "k_verify_fast_keyed": keyed(lib), "k_verify_fast_keyset": keyset(lib)}
 
 
 if __name__ == "__main__":
