@@ -1360,13 +1360,19 @@ static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
 template <class PrepFn>
 static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* d_keys, int key_bytes, uint32_t* prep,
                                 uint32_t* gp, size_t stride, PrepFn launch_prep, key_groups* kg, bool gp_in_prep) {
-  launch_prep(ctx->s_aux);
-  HIP_TRY(ctx, hipGetLastError());
+  // One stream (a child context of submit / wait): the grouping and the tables first - they need the keys only, which
+  // arrive first -, then the preparation and the generator part; other tickets' kernels fill the machine meanwhile.
+  const bool one_stream = ctx->s_aux == st;
   // gp_in_prep: the caller's launch_prep has enqueued the generator part as well (piecewise, as its inputs arrive)
-  const uint32_t n_first = gp_in_prep ? (uint32_t)n : (uint32_t)((n * (size_t)ctx->gp_first_percent / 100) & ~(size_t)255);
-  if (n_first && !gp_in_prep) {
-    k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gtable, gp, stride);
+  const uint32_t n_first = (gp_in_prep || one_stream) ? (gp_in_prep ? (uint32_t)n : 0u)
+                                                      : (uint32_t)((n * (size_t)ctx->gp_first_percent / 100) & ~(size_t)255);
+  if (!one_stream) {
+    launch_prep(ctx->s_aux);
     HIP_TRY(ctx, hipGetLastError());
+    if (n_first && !gp_in_prep) {
+      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gtable, gp, stride);
+      HIP_TRY(ctx, hipGetLastError());
+    }
   }
   int rc = s2k_internal_key_group(ctx, n, d_keys, key_bytes, st, kg);
   if (rc) return rc;
@@ -1390,7 +1396,12 @@ static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const ui
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_part1, ctx->s_aux2));
   }
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
+  if (one_stream) {
+    launch_prep(st);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
+  }
   if (n_first < n) {
     k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gtable, gp, stride);
     HIP_TRY(ctx, hipGetLastError());
@@ -1591,7 +1602,8 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->io) (void)hipFree(ctx->io);
   if (ctx->clk) (void)hipFree(ctx->clk);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
-  if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+  if (ctx->gate_record) (void)hipEventDestroy(ctx->gate_record);
+  if (ctx->s_aux && !ctx->s_aux_shared) (void)hipStreamDestroy(ctx->s_aux);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
@@ -1769,6 +1781,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                        },
                        &kg, /*gp_in_prep=*/arrivals != nullptr);
     if (rc) return rc;
+    if (ctx->gate_wait) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->gate_wait, 0));   // (submit / wait: the previous ticket's ladder and tail first)
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
                                                                    qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
@@ -1793,6 +1806,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
                                                 (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->gate_wait) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->gate_wait, 0));
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
@@ -1806,6 +1820,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                         ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
+  if (ctx->gate_record) HIP_TRY(ctx, hipEventRecord(ctx->gate_record, st));
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
 }
@@ -2241,7 +2256,10 @@ static int verify_batch_enqueue_inner(s2k_ctx* ctx, size_t n, const uint8_t* pub
   // preparation on the second stream waits for them).  From pageable memory a copy is staged by the runtime and the
   // same order measured slower than two independent halves (9.0 against 8.4-8.6 ms per 2^20), which stay the path there.
   const bool pinned = host_pinned(pub, n * 64) && host_pinned(dig, n * 32) && host_pinned(r, n * 32) && host_pinned(s, n * 32);
-  if (pinned && ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH) {
+  // (submit / wait, one_shot: no pieces - the other tickets' kernels are what the transfer hides behind, and the ticket runs
+  // one compute stream; measured 5.07 against 5.13 ms per 2^20 with the pieces.  S2K_SUBMIT_ARRIVALS=1: measurement knob)
+  static const bool submit_arrivals = [] { const char* v = getenv("S2K_SUBMIT_ARRIVALS"); return v && atoi(v) != 0; }();
+  if (pinned && ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH && (!one_shot || submit_arrivals)) {
     rc = ctx_arrival_events(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_pub, pub, n * 64, hipMemcpyHostToDevice, ctx->s_copy));
@@ -2369,6 +2387,22 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
     if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
     sl.ctx->s_copy = ctx->s_copy;
     sl.ctx->s_copy_shared = true;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ctx->gate_record, hipEventDisableTiming));
+    static const bool two_streams = [] { const char* v = getenv("S2K_SUBMIT_TWO_STREAMS"); return v && atoi(v) != 0; }();   // measurement knob
+    if (!two_streams) {
+      rc = ctx_streams(sl.ctx);
+      if (rc) return fail(ctx, rc, "%s", sl.ctx->err);
+      sl.ctx->s_aux = sl.ctx->s_comp;                 // one compute stream per ticket (engine_internal.h: s_aux_shared)
+      sl.ctx->s_aux_shared = true;
+      rc = ctx_aux_streams(sl.ctx);                   // (the fork / join events)
+      if (rc) return fail(ctx, rc, "%s", sl.ctx->err);
+    }
+  }
+  {
+    // chain the ladders: this ticket's ladder waits for the previous ticket's ladder and tail (if that one is still in flight)
+    static const bool no_gate = [] { const char* v = getenv("S2K_SUBMIT_NO_GATE"); return v && atoi(v) != 0; }();   // measurement knob
+    s2k_ctx::pipe_slot& prev = ctx->pipe[(ctx->pipe_next + s2k_ctx::PIPE_SLOTS - 1) % s2k_ctx::PIPE_SLOTS];
+    sl.ctx->gate_wait = (!no_gate && prev.ctx && prev.ticket && prev.ctx != sl.ctx) ? prev.ctx->gate_record : nullptr;
   }
   // the child verifies with the parent's settings of the moment
   sl.ctx->kg_mode = ctx->kg_mode;

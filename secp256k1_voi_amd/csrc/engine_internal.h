@@ -83,6 +83,19 @@ struct s2k_ctx {
   void* io = nullptr;
   size_t io_bytes = 0;
   hipStream_t s_copy = nullptr, s_comp = nullptr;
+  // submit / wait: the ladders of consecutive tickets are chained.  Ticket k+1's ladder is enqueued (on its own stream)
+  // while ticket k's is running; without a chain its 4096 workgroups take every register a retiring wave of ticket k frees,
+  // and ticket k's (normally empty) general-ladder and worklist launches behind its ladder - 161 VGPRs a wave against the
+  // keyed ladder's 126 - find no room until ticket k+1's ladder has been dispatched whole: 3.3 ms during which ticket k
+  // holds its slot for nothing (kernel trace, profiles/r04_pipeline_timeline.txt).  gate_wait: waited for before this
+  // context's ladder; gate_record: recorded behind its worklist kernel.
+  hipEvent_t gate_wait = nullptr, gate_record = nullptr;
+  // A child context runs ONE compute stream: its "second stream" is the first (s_aux == s_comp).  What the second stream
+  // buys a lone batch (preparation and generator part beside grouping and tables) the other tickets' kernels provide here,
+  // and every stream fewer matters: the runtime maps streams onto a handful of hardware queues, and two tickets whose
+  // streams share a queue run strictly one after the other (kernel trace of three tickets on nine streams: six streams with
+  // kernels on five queues, the grouping of one ticket queued behind the ladder of another).
+  bool s_aux_shared = false;
   bool s_copy_shared = false;   // a child context of submit / wait: the copy stream is its parent's (all slots share one: their
                                 // transfers are in order anyway, and every stream fewer is one fewer to land on a compute stream's
                                 // hardware queue)
@@ -205,13 +218,13 @@ static inline unsigned fallback_blocks(const s2k_ctx* ctx, size_t n) {
 
 // second / third stream of the grouped flows and of the BIP-340 whole-batch check, with the events that fork and join them
 inline int ctx_aux_streams(s2k_ctx* ctx) {
-  if (ctx->s_aux) return S2K_OK;
-  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+  if (ctx->ev_fork) return S2K_OK;
+  if (!ctx->s_aux) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));   // (a child context: its own compute stream)
   // The third stream only where it is used (the two-part flow, off by default): the runtime multiplexes a process's
   // streams onto four hardware queues, and with the caller's stream, the copy stream and the compute stream a fifth one
   // made two of them share a queue - when those were the copy and a compute stream, the host-buffer path lost its
   // overlap (2^20 verifications from pinned memory: 9.3 instead of 7.3 ms, in some processes and not in others).
-  if (ctx->kg_parts > 1) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux2, hipStreamNonBlocking));
+  if (ctx->kg_parts > 1 && !ctx->s_aux2) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux2, hipStreamNonBlocking));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
