@@ -533,8 +533,11 @@ def worker(args):
             pg_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 3]), 12) for _ in range(3)]
             line["pcie_inclusive"]["pipelined_pageable"] = {"value": n / (median(pg_ms) * 1e-3), "unit": "verifications/s",
                                                             "ms_per_batch": median(pg_ms), "ms_per_batch_each": pg_ms,
-                                                            "note": "the same from pageable memory (the runtime stages the copies; submit "
-                                                                    "blocks while it does, beside the other batches' kernels)"}
+                                                            "note": "the same from pageable memory: the runtime stages the copies and submit "
+                                                                    "blocks while it does - 3.1 ms in a bare process (5.2 ms per batch, "
+                                                                    "tools/boundary_probe.py), but this process has torch in it, where the "
+                                                                    "staging copy waits for the kernels in flight (8.6 ms per submit: "
+                                                                    "profiles/r04_pageable_submit_with_and_without_torch.txt)"}
             del pinned, pin3, outs3, pg3
             # the encoded boundary (SEC1 keys + DER signatures, what secec.PublicKey.Verify takes): bytes parsed on the device
             if not args.no_extras:
@@ -578,10 +581,21 @@ def encoded_measurement(eng, pub, digest, r, s, reps=3):
         if rep:
             ms.append((time.perf_counter() - t0) * 1e3)
         assert int(out.sum()) == n
+    # (page-locked copies of the blobs: from pageable memory a submit blocks while the runtime stages the copy - 3.1 ms in a
+    # bare process, but 8.6 ms in one that has torch in it, where the staging copy waits for the kernels in flight:
+    # profiles/r04_pageable_submit_with_and_without_torch.txt)
+    from secp256k1_voi_amd import pinned_array
+    pblobs = []
+    for blob, offs in ((pb, po), (db, do), (sb, so)):
+        qb, qo = pinned_array(blob.shape), pinned_array(offs.shape, np.uint64)
+        qb[...] = blob
+        qo[...] = offs
+        pblobs.append((qb, qo))
+
     def pipelined(nb, depth=3):
         tickets, t_0 = [], time.perf_counter()
         for k in range(nb):
-            tickets.append(eng.ecdsa_verify_encoded_batch_submit((pb, po), (db, do), (sb, so), digest_len=32))
+            tickets.append(eng.ecdsa_verify_encoded_batch_submit(*pblobs, digest_len=32))
             if len(tickets) >= depth:
                 assert int(tickets.pop(0).wait().sum()) == n
         for tk in tickets:
@@ -591,7 +605,7 @@ def encoded_measurement(eng, pub, digest, r, s, reps=3):
     pl = [pipelined(12) for _ in range(3)]
     return {"value": n / (median(ms) * 1e-3), "unit": "verifications/s", "ms_each": ms, "bytes_per_item": (len(pb) + len(db) + len(sb)) / n,
             "pipelined": {"value": n / (median(pl) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl), "ms_per_batch_each": pl,
-                          "note": "s2k_ecdsa_verify_encoded_batch_submit / s2k_wait, 12 batches, three in flight, pageable host memory"},
+                          "note": "s2k_ecdsa_verify_encoded_batch_submit / s2k_wait, 12 batches, three in flight, page-locked host memory"},
             "note": "s2k_ecdsa_verify_encoded_batch: 65-byte SEC1 keys, 32-byte digests, DER signatures from pageable host memory; "
                     "strict DER parsing and key decoding on the device, then the batch verifier"}
 

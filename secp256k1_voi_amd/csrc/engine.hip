@@ -566,8 +566,11 @@ template <int MODE>
 #ifdef S2K_FAST_MAX_WAVES   // experiment: cap the occupancy (leaves VGPRs for a kernel of another stream to run beside the ladder)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S2K_FAST_MAX_WAVES, S2K_FAST_MAX_WAVES)))
 #else
-// (the ladders over per-key tables hold no per-lane table state and fit four waves per SIMD - 123 VGPRs before the in-place
-// decision of the final addition was added, which the allocator, left alone, took as licence to use 152)
+// (The ladders over per-key tables hold no per-lane table state and come out at 126 VGPRs: four waves per SIMD.  That is
+// the allocator's doing under a bound of three, and it is fragile: a rare branch that kept the accumulator alive across the
+// final addition took 152, and asking for four waves outright spills - 26 VGPRs for <ECDSA_KEYED>, 28 for the key-set
+// ladder, which stays at 142 VGPRs and three waves.  tests/test_counts_cpu.py watches the instruction counts; the
+// resource usage is printed by tools/kernel_regs.sh.)
 __global__ void __launch_bounds__(256, S2K_FAST_WAVES)
 #endif
 k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,

@@ -31,6 +31,17 @@ rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc_g_$TAG -o run 
 cp $O/prof_g_$TAG/run_kernel_stats.csv $P/general/kernel_stats_bench_steps20_warmup5.csv
 python3 tools/collect_traffic.py $O/pmc_fetch_g_$TAG $O/pmc_write_g_$TAG > $P/general/hbm_traffic.json
 python3 tools/summarize_profiles_r02.py $O/prof_g_$TAG/run_kernel_trace.csv $O/pmc_g_$TAG $P/general
+# the key-set ladder (32-chunk tables, no doublings): kernel trace and the instruction counters
+K="$B --key-grouping keyset"
+mkdir -p $P/keyset
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k_$TAG -o run -- $K > $P/keyset/bench_under_kernel_trace.json 2> /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_k_$TAG -o run -- $K > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_k_$TAG -o run -- $K > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc_k_$TAG -o run -- $K > $P/keyset/bench_under_pmc.json 2> /dev/null
+cp $O/prof_k_$TAG/run_kernel_stats.csv $P/keyset/kernel_stats_bench_steps20_warmup5.csv
+python3 tools/collect_traffic.py $O/pmc_fetch_k_$TAG $O/pmc_write_k_$TAG > $P/keyset/hbm_traffic.json
+python3 tools/summarize_profiles_r02.py $O/prof_k_$TAG/run_kernel_trace.csv $O/pmc_k_$TAG $P/keyset
+$K > $P/keyset/bench_same_box_unprofiled.json 2>/dev/null
 # the unprofiled bench right after, same box: the lines the profiles have to reconcile with
 $B > $P/bench_same_box_unprofiled.json 2>/dev/null
 $G > $P/general/bench_same_box_unprofiled.json 2>/dev/null

@@ -33,13 +33,20 @@ def main():
     out["source"] = ("rocprofv3 --pmc of bench.py --steps 20 --warmup 5 (tools/collect_profiles_r04.sh): averages over the timed steps, 2^20 "
                      "signatures of 2^16 keys per dispatch; k_verify_fast (the general ladder) from the same passes with --key-grouping off")
     out["k_verify_fast"] = general["k_verify_fast"]
+    ks_path = os.path.join(src, "keyset", "valu_counts.json")
+    if os.path.exists(ks_path):
+        ks = json.load(open(ks_path))
+        if "k_verify_fast_keyset" in ks:
+            out["k_verify_fast_keyset"] = ks["k_verify_fast_keyset"]
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     out["head"] = head
     # whole step: every kernel of a grouped step, VALU instructions per verification
     whole = sum(v["valu_instr_per_signature"] for k, v in grouped.items()
                 if isinstance(v, dict) and "valu_instr_per_signature" in v and k.startswith("k_") and
                 k not in ("k_gen_gtable", "k_gen_gtable_bases", "k_fn_op", "k_point_op", "k_verify_fast"))
-    for key, kname in (("static", "k_verify_fast"), ("static_keyed", "k_verify_fast_keyed")):
+    for key, kname in (("static", "k_verify_fast"), ("static_keyed", "k_verify_fast_keyed"), ("static_keyset", "k_verify_fast_keyset")):
+        if kname not in static:
+            continue
         st = dict((prev or {}).get(key, {}))
         st["valu_instr_static"] = static[kname]["valu_instr_static"]
         st["mad_u64_u32_per_verify"] = static[kname]["mad_u64_u32_per_verify"]
@@ -52,12 +59,19 @@ def main():
     gtraffic = json.load(open(os.path.join(src, "general", "hbm_traffic.json")))
     if "k_verify_fast" in gtraffic:
         traffic["k_verify_fast"] = gtraffic["k_verify_fast"]
+    kt_path = os.path.join(src, "keyset", "hbm_traffic.json")
+    if os.path.exists(kt_path):
+        kt = json.load(open(kt_path))
+        if "k_verify_fast_keyset" in kt:
+            traffic["k_verify_fast_keyset"] = kt["k_verify_fast_keyset"]
     json.dump(traffic, open(os.path.join(prof, "%s_hbm_traffic.json" % rnd), "w"), indent=1)
     for a, b in (("kernel_time_summary.json", "%s_%s_kernel_time_summary.json"), ("kernel_stats_bench_steps20_warmup5.csv", "%s_%s_kernel_stats_bench_steps20_warmup5.csv"),
                  ("bench_same_box_unprofiled.json", "%s_%s_bench_same_box_unprofiled.json"), ("pmc_per_dispatch.txt", "%s_%s_pmc_per_dispatch.txt"),
                  ("general/kernel_time_summary.json", "%s_%s_general_kernel_time_summary.json"),
                  ("general/kernel_stats_bench_steps20_warmup5.csv", "%s_%s_general_kernel_stats_bench_steps20_warmup5.csv"),
-                 ("general/bench_same_box_unprofiled.json", "%s_%s_general_bench_same_box_unprofiled.json")):
+                 ("general/bench_same_box_unprofiled.json", "%s_%s_general_bench_same_box_unprofiled.json"),
+                 ("keyset/kernel_time_summary.json", "%s_%s_keyset_kernel_time_summary.json"),
+                 ("keyset/bench_same_box_unprofiled.json", "%s_%s_keyset_bench_same_box_unprofiled.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(prof, b % (rnd, letter)))
     print("wrote profiles/%s_valu_counts.json: keyed %.0f, general %.0f, whole step %.0f (head %s)" %
