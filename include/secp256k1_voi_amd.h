@@ -220,16 +220,15 @@ int s2k_host_unregister(void *p);
  * from pageable memory against 4.9 ms resident per 2^20 signatures).  s2k_ecdsa_verify_batch_submit returns as soon as
  * the batch is enqueued (from page-locked buffers: at once; from pageable ones: when the runtime has staged the copies)
  * and s2k_wait blocks until the verdicts of that ticket are in `valid`.  The context keeps up to THREE batches in flight on
- * internal child contexts (own workspaces and streams on the same device; the generator tables are shared): batch k+1's
- * transfer, grouping and per-key tables run beside batch k's ladder, so a caller that submits batch k+1 (better: k+2)
- * before it waits for batch k sees the resident rate.  A fourth submit first retires the oldest ticket (delivers its
+ * internal child contexts (own workspaces on the same device; the generator tables are shared): batch k+1 crosses PCIe
+ * while batch k's kernels run (the kernels of consecutive tickets follow each other on the context's streams), so a
+ * caller that submits batch k+1 (better: k+2) before it waits for batch k sees the resident rate.  A fourth submit first retires the oldest ticket (delivers its
  * verdicts; a later s2k_wait on it returns at once).  s2k_poll is s2k_wait without the blocking: S2K_PENDING while the
  * ticket is in flight.  Same verdicts as s2k_ecdsa_verify_batch, bit for bit; the inputs and `valid` must
  * stay untouched until the ticket has been waited for (or retired).  Submit, wait and the other calls of one context
  * must come from one thread at a time, like all calls on a context; the key-grouping settings are those the context
  * has at submit time.  s2k_wait_all retires everything in flight (oldest first; s2k_ctx_destroy does the same).
- * Each child holds what s2k_ctx_device_bytes reports minus the generator tables.  Set GPU_MAX_HW_QUEUES=8 in the
- * process environment: three batches in flight use nine streams. */
+ * Each child holds what s2k_ctx_device_bytes reports minus the generator tables. */
 typedef uint64_t s2k_ticket;
 int s2k_ecdsa_verify_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy, const uint8_t *digest32, const uint8_t *r,
                                   const uint8_t *s, uint32_t flags, uint8_t *valid, s2k_ticket *ticket);

@@ -1597,6 +1597,8 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
     }
     if (sl.h_valid) (void)hipHostFree(sl.h_valid);
     sl.h_valid = nullptr;
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    sl.done = nullptr;
   }
   if (ctx->gtable) gtable_release(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
@@ -1605,8 +1607,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->io) (void)hipFree(ctx->io);
   if (ctx->clk) (void)hipFree(ctx->clk);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
-  if (ctx->gate_record) (void)hipEventDestroy(ctx->gate_record);
-  if (ctx->s_aux && !ctx->s_aux_shared) (void)hipStreamDestroy(ctx->s_aux);
+  if (ctx->s_aux && !ctx->streams_shared) (void)hipStreamDestroy(ctx->s_aux);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
@@ -1623,8 +1624,8 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   delete[] ctx->prof_ev;
   for (hipEvent_t e : ctx->ev_copied)
     if (e) (void)hipEventDestroy(e);
-  if (ctx->s_copy && !ctx->s_copy_shared) (void)hipStreamDestroy(ctx->s_copy);
-  if (ctx->s_comp) (void)hipStreamDestroy(ctx->s_comp);
+  if (ctx->s_copy && !ctx->streams_shared) (void)hipStreamDestroy(ctx->s_copy);
+  if (ctx->s_comp && !ctx->streams_shared) (void)hipStreamDestroy(ctx->s_comp);
   delete ctx;
 }
 
@@ -1784,7 +1785,6 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                        },
                        &kg, /*gp_in_prep=*/arrivals != nullptr);
     if (rc) return rc;
-    if (ctx->gate_wait) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->gate_wait, 0));   // (submit / wait: the previous ticket's ladder and tail first)
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
                                                                    qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
@@ -1809,7 +1809,6 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
                                                 (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->gate_wait) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->gate_wait, 0));
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
@@ -1823,7 +1822,6 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
                                         ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->gate_record) HIP_TRY(ctx, hipEventRecord(ctx->gate_record, st));
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
 }
@@ -2346,13 +2344,18 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
 // ---------------------------------------------------------------------------------------
 // submit / wait: the host-pointer entry points without the wait at their end.  The reference's caller holds its data in
 // host memory (secec/ecdsa.go:171-228) and a synchronous call pays transfer and compute in series: 7.1 ms from pinned
-// memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns child
-// contexts ("slots": own workspaces, staging buffers and streams; the 3 GiB generator tables are shared per device)
-// that take the submitted batches in turn: batch k+1's 160 MiB cross PCIe (3.0 ms) and its grouping and per-key
-// tables run while batch k's ladder holds the multipliers.  Up to three batches are in flight (two keep the device busy;
-// the third takes the caller's turn-around time out of the rate: with two, batch k+1 has to be submitted the moment batch
-// k-1 ends, or its transfer no longer fits under batch k's ladder); a fourth submit first retires the oldest one (its
-// verdicts are delivered; a later s2k_wait on its ticket returns at once).
+// memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns child contexts
+// ("slots": own workspaces and staging buffers; the 3 GiB generator tables are shared per device) that take the submitted
+// batches in turn.  The children run on the PARENT's three streams: the kernels of consecutive tickets follow each other
+// in stream order, each ticket with the two-stream overlap of a resident call (grouping and tables beside preparation and
+// generator part), while ticket k+1's 160 MiB cross PCIe (3.0 ms) on the copy stream beside ticket k's kernels.  The
+// rate is the resident rate minus what the transfers cost the kernels (1.5 %: tools/dma_interference_probe.py).  Up to
+// three tickets are in flight (one computing, one arriving, one of slack for the caller's turn-around); a fourth submit
+// first retires the oldest one (its verdicts are delivered; a later s2k_wait on its ticket returns at once).
+// (Earlier forms gave every ticket streams of its own so that one ticket's grouping and tables could run beside another's
+// ladder.  They do not: the keyed ladder holds 4 x 128 of a SIMD's 512 VGPRs, so the other ticket's kernels crawl, its
+// empty tail launches - 161 VGPRs a wave - wait milliseconds for room, and nine streams on the runtime's hardware queues
+// serialise at random.  5.2-5.7 ms per batch against 4.9-5.0 this way; profiles/r04_pipeline_timeline.txt.)
 // ---------------------------------------------------------------------------------------
 }  // extern "C"
 static void pipe_note_failure(s2k_ctx* ctx, uint64_t ticket, int rc) {
@@ -2364,7 +2367,7 @@ static void pipe_note_failure(s2k_ctx* ctx, uint64_t ticket, int rc) {
 __attribute__((visibility("hidden"))) int s2k_internal_pipe_retire(s2k_ctx* ctx, s2k_ctx::pipe_slot& sl) {
   if (!sl.ticket) return S2K_OK;
   int rc = S2K_OK;
-  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(sl.ctx->s_comp) != hipSuccess) {
+  if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(sl.done) != hipSuccess) {
     rc = fail(ctx, S2K_ERR_HIP, "ticket %llu: the batch did not complete: %s", (unsigned long long)sl.ticket,
               hipGetErrorString(hipGetLastError()));
     s2k_internal_drain(sl.ctx);
@@ -2384,28 +2387,19 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
     if (rc) pipe_note_failure(ctx, t, rc);           // (reported by s2k_wait on that ticket)
   }
   if (!sl.ctx) {
-    int rc = ctx_streams(ctx);                        // (the parent's copy stream carries the transfers of all slots)
+    int rc = ctx_streams(ctx);                        // the parent's three streams carry every ticket
+    if (rc == S2K_OK) rc = ctx_aux_streams(ctx);
     if (rc) return rc;
     rc = s2k_ctx_create(ctx->device, &sl.ctx);
     if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
     sl.ctx->s_copy = ctx->s_copy;
-    sl.ctx->s_copy_shared = true;
-    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ctx->gate_record, hipEventDisableTiming));
-    static const bool two_streams = [] { const char* v = getenv("S2K_SUBMIT_TWO_STREAMS"); return v && atoi(v) != 0; }();   // measurement knob
-    if (!two_streams) {
-      rc = ctx_streams(sl.ctx);
-      if (rc) return fail(ctx, rc, "%s", sl.ctx->err);
-      sl.ctx->s_aux = sl.ctx->s_comp;                 // one compute stream per ticket (engine_internal.h: s_aux_shared)
-      sl.ctx->s_aux_shared = true;
-      rc = ctx_aux_streams(sl.ctx);                   // (the fork / join events)
-      if (rc) return fail(ctx, rc, "%s", sl.ctx->err);
-    }
-  }
-  {
-    // chain the ladders: this ticket's ladder waits for the previous ticket's ladder and tail (if that one is still in flight)
-    static const bool no_gate = [] { const char* v = getenv("S2K_SUBMIT_NO_GATE"); return v && atoi(v) != 0; }();   // measurement knob
-    s2k_ctx::pipe_slot& prev = ctx->pipe[(ctx->pipe_next + s2k_ctx::PIPE_SLOTS - 1) % s2k_ctx::PIPE_SLOTS];
-    sl.ctx->gate_wait = (!no_gate && prev.ctx && prev.ticket && prev.ctx != sl.ctx) ? prev.ctx->gate_record : nullptr;
+    sl.ctx->s_comp = ctx->s_comp;
+    sl.ctx->s_aux = ctx->s_aux;
+    sl.ctx->streams_shared = true;
+    rc = ctx_streams(sl.ctx);                         // (its events)
+    if (rc == S2K_OK) rc = ctx_aux_streams(sl.ctx);
+    if (rc) return fail(ctx, rc, "%s", sl.ctx->err);
+    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   }
   // the child verifies with the parent's settings of the moment
   sl.ctx->kg_mode = ctx->kg_mode;
@@ -2427,6 +2421,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   return S2K_OK;
 }
 __attribute__((visibility("hidden"))) void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, s2k_ticket* ticket) {
+  (void)hipEventRecord(sl->done, ctx->s_comp);        // behind the ticket's last operation
   sl->ticket = ctx->pipe_next++;
   *ticket = sl->ticket;
 }
@@ -2467,7 +2462,7 @@ int s2k_poll(s2k_ctx* ctx, s2k_ticket ticket) {
   for (s2k_ctx::pipe_slot& sl : ctx->pipe)
     if (sl.ticket == ticket) {
       HIP_TRY(ctx, hipSetDevice(ctx->device));
-      const hipError_t e = hipStreamQuery(sl.ctx->s_comp);
+      const hipError_t e = hipEventQuery(sl.done);
       if (e == hipErrorNotReady) {
         (void)hipGetLastError();
         return S2K_PENDING;

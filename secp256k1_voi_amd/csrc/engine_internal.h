@@ -83,22 +83,12 @@ struct s2k_ctx {
   void* io = nullptr;
   size_t io_bytes = 0;
   hipStream_t s_copy = nullptr, s_comp = nullptr;
-  // submit / wait: the ladders of consecutive tickets are chained.  Ticket k+1's ladder is enqueued (on its own stream)
-  // while ticket k's is running; without a chain its 4096 workgroups take every register a retiring wave of ticket k frees,
-  // and ticket k's (normally empty) general-ladder and worklist launches behind its ladder - 161 VGPRs a wave against the
-  // keyed ladder's 126 - find no room until ticket k+1's ladder has been dispatched whole: 3.3 ms during which ticket k
-  // holds its slot for nothing (kernel trace, profiles/r04_pipeline_timeline.txt).  gate_wait: waited for before this
-  // context's ladder; gate_record: recorded behind its worklist kernel.
-  hipEvent_t gate_wait = nullptr, gate_record = nullptr;
-  // A child context runs ONE compute stream: its "second stream" is the first (s_aux == s_comp).  What the second stream
-  // buys a lone batch (preparation and generator part beside grouping and tables) the other tickets' kernels provide here,
-  // and every stream fewer matters: the runtime maps streams onto a handful of hardware queues, and two tickets whose
-  // streams share a queue run strictly one after the other (kernel trace of three tickets on nine streams: six streams with
-  // kernels on five queues, the grouping of one ticket queued behind the ladder of another).
-  bool s_aux_shared = false;
-  bool s_copy_shared = false;   // a child context of submit / wait: the copy stream is its parent's (all slots share one: their
-                                // transfers are in order anyway, and every stream fewer is one fewer to land on a compute stream's
-                                // hardware queue)
+  // A child context of submit / wait owns buffers, not streams: its copy, compute and second stream are its parent's.
+  // Tickets therefore run their kernels strictly one after the other, each with the two-stream overlap of a resident call,
+  // and only the transfers run ahead (DESIGN.md section 4c for what was tried before: per-ticket streams let one ticket's
+  // front end run beside another's ladder, which holds every VGPR of the SIMDs - the front end crawls, empty tail launches
+  // of 161 VGPRs wait milliseconds for room, and streams beyond the hardware queues serialise at random).
+  bool streams_shared = false;
   hipEvent_t ev_copied[2] = {nullptr, nullptr};
   hipEvent_t ev_arrival[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pieces of a pinned batch on their way in
   int cu_count = 0;
@@ -143,13 +133,13 @@ struct s2k_ctx {
     uint64_t ticket = 0;           // ticket in flight on it (0: none)
     uint8_t* dst = nullptr;        // where its verdicts go (the caller's array)
     size_t n = 0;
+    hipEvent_t done = nullptr;     // recorded behind the ticket's last operation (the verdicts' copy out)
     uint8_t* h_valid = nullptr;    // page-locked landing buffer of the verdicts (when dst is pageable)
     size_t h_valid_bytes = 0;
     bool direct = false;           // dst is page-locked itself: the device-to-host copy lands there
   };
-  static constexpr unsigned PIPE_SLOTS = 3;   // batches in flight: with two, batch k+1 must be submitted the moment batch k-1
-                                              // ends or its transfer no longer fits under batch k's ladder; the third slot
-                                              // takes the caller's (and a group's thread hand-over) latency out of the rate
+  static constexpr unsigned PIPE_SLOTS = 3;   // batches in flight: one computing, one arriving, and a third that takes the
+                                              // caller's (and a group's thread hand-over) turn-around out of the rate
   pipe_slot pipe[PIPE_SLOTS];
   uint64_t pipe_next = 1;          // next ticket (ticket t runs on slot t mod PIPE_SLOTS)
   uint64_t pipe_failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tickets retired with an error (by a later submit), and their codes
@@ -219,7 +209,7 @@ static inline unsigned fallback_blocks(const s2k_ctx* ctx, size_t n) {
 // second / third stream of the grouped flows and of the BIP-340 whole-batch check, with the events that fork and join them
 inline int ctx_aux_streams(s2k_ctx* ctx) {
   if (ctx->ev_fork) return S2K_OK;
-  if (!ctx->s_aux) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));   // (a child context: its own compute stream)
+  if (!ctx->s_aux) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));   // (a child context is given its parent's)
   // The third stream only where it is used (the two-part flow, off by default): the runtime multiplexes a process's
   // streams onto four hardware queues, and with the caller's stream, the copy stream and the compute stream a fifth one
   // made two of them share a queue - when those were the copy and a compute stream, the host-buffer path lost its
@@ -259,7 +249,7 @@ bool s2k_internal_host_pinned(const void* p, size_t bytes);
 
 // copy / compute streams and the events chaining them, for the host-buffer entry points
 inline int ctx_streams(s2k_ctx* ctx) {
-  if (!ctx->s_copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));   // (a child context is given its parent's)
+  if (!ctx->s_copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));   // (a child context is given its parent's streams)
   if (!ctx->s_comp) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
   for (hipEvent_t& e : ctx->ev_copied)
     if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

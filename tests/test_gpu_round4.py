@@ -330,3 +330,49 @@ def test_compact_recoverable_options_and_edges(eng, oracle):
         eng.ecdsa_verify_encoded_batch(pubs[:4], digs[:4], sigs[:4], encoding=S.ENCODING_COMPACT_RECOVERABLE, bip0066=True)
     with pytest.raises(S.EngineError):
         eng.ecdsa_verify_encoded_batch(pubs[:4], digs[:4], sigs[:4], encoding=3)
+
+
+# ---- the table buffer degrades instead of failing -------------------------------------------------------
+def test_table_buffer_allocation_failure_degrades(oracle):
+    """S2K_TEST_TABLE_BYTES_LIMIT makes s2k_internal_key_reserve treat larger table buffers as unobtainable: the cap is
+    halved until the buffer fits (fewer, longer groups get tables), below 1024 tables the batch is verified without tables
+    - the verification call never fails, the verdicts never change."""
+    import secp256k1_voi_amd as S
+    eng = S.Engine(0)                                  # a context of its own: the cap it finds stays with it
+    n = 1 << 17
+    arrs = damaged_batch(eng, n, n // 32, 555)         # 32 signatures per key
+    ref = eng.ecdsa_verify_batch(*arrs)
+    st0 = eng.key_grouping_stats()
+    assert st0["tables"] == n // 32 and st0["keyed"] + st0["general"] == n
+    m = 2048
+    assert np.array_equal(ref[:m], oracle.ecdsa_verify_batch(*(a[:m] for a in arrs), nthreads=os.cpu_count() or 1))
+    try:
+        # default plan: n / 4 = 32768 tables of 9 KiB = 302 MB.  100 MB: the cap goes 32768 -> 16384 -> 8192 (75 MB),
+        # threshold 16 signatures per key: all 4096 keys still get their tables
+        eng2 = S.Engine(0)
+        os.environ["S2K_TEST_TABLE_BYTES_LIMIT"] = str(100 << 20)
+        assert np.array_equal(eng2.ecdsa_verify_batch(*arrs), ref)
+        st = eng2.key_grouping_stats()
+        assert st["tables"] == n // 32 and st["keyed"] + st["general"] == n
+        assert eng2.device_bytes(n) < eng.device_bytes(n)                       # the memory query follows the cap
+        # 20 MB: 2048 tables, threshold 64 per key: no key qualifies, everything on the general ladder
+        eng3 = S.Engine(0)
+        os.environ["S2K_TEST_TABLE_BYTES_LIMIT"] = str(20 << 20)
+        assert np.array_equal(eng3.ecdsa_verify_batch(*arrs), ref)
+        st = eng3.key_grouping_stats()
+        assert st["tables"] == 0 and st["general"] == n
+        # 1 MB: not even 1024 tables: verified without the grouping at all
+        eng4 = S.Engine(0)
+        os.environ["S2K_TEST_TABLE_BYTES_LIMIT"] = str(1 << 20)
+        assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref)
+        st = eng4.key_grouping_stats()
+        assert st["tables"] == 0 and st["keyed"] == 0
+        # BIP-340 takes the same way out
+        from secp256k1_voi_amd.synth import synth_schnorr_batch
+        pk, msgs, sig = synth_schnorr_batch(eng4, 4096, 64, seed=9)
+        assert eng4.schnorr_verify_batch(pk, msgs, sig).all()
+    finally:
+        os.environ.pop("S2K_TEST_TABLE_BYTES_LIMIT", None)
+    # the limit gone and the setting renewed: tables again
+    eng4.set_key_grouping(S.KEYS_AUTO)
+    assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref) and eng4.key_grouping_stats()["tables"] == n // 32

@@ -14,17 +14,23 @@ import secp256k1_voi_amd as S
 from secp256k1_voi_amd.synth import synth_batch
 
 
-def pipelined(submit, nb, depth=2):
-    """nb batches, `depth` in flight; ms per batch (the first `depth` submits are the ramp, all nb waits are timed)"""
-    tickets = []
-    t0 = time.perf_counter()
-    for k in range(nb):
+def pipelined(submit, nb, depth=2, lead=3):
+    """ms per batch in steady state: `lead` batches fill the pipeline (the first transfer has nothing to hide behind), then
+    the clock runs from the completion of batch `lead` to the completion of batch `lead + nb`; `depth` in flight."""
+    tickets, done, t0 = [], 0, None
+    for k in range(nb + lead):
         tickets.append(submit(k))
         if len(tickets) >= depth:
             tickets.pop(0).wait()
+            done += 1
+            if done == lead:
+                t0 = time.perf_counter()
     for t in tickets:
         t.wait()
-    return (time.perf_counter() - t0) * 1e3 / nb
+        done += 1
+        if done == lead:
+            t0 = time.perf_counter()
+    return (time.perf_counter() - t0) * 1e3 / (done - lead)
 
 
 def main():
