@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes the profiles/ files of a round from a tools/collect_profiles_r04.sh run.
 
-    python tools/merge_counts_r04.py gpurun_out/profiles_TAG r04 [letter]
+    python tools/merge_counts_r04.py gpurun_out/profiles_TAG r04 [letter] [commit the run was made at]
 
 profiles/<round>_valu_counts.json: the PMC counts of both ladders (grouped run: k_verify_fast_keyed and the kernels around
 it; grouping-off run: k_verify_fast), the static recount of the SAME library (tools/isa_count.py, run on the box), the
@@ -38,7 +38,7 @@ def main():
         ks = json.load(open(ks_path))
         if "k_verify_fast_keyset" in ks:
             out["k_verify_fast_keyset"] = ks["k_verify_fast_keyset"]
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    head = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     out["head"] = head
     # whole step: every kernel of a grouped step, VALU instructions per verification
     whole = sum(v["valu_instr_per_signature"] for k, v in grouped.items()
