@@ -123,17 +123,18 @@ def cpu_baseline(pub, digest, r, s, budget_s=15.0):
 
     m1 = min(1024, r.shape[0])
     single = rate(m1, 1)
-    best_th, best = 1, single
+    probes = {1: single}
     th = 2
     while th <= cores:
-        rt = rate(min(r.shape[0], 128 * th), th)
-        if rt > best:
-            best_th, best = th, rt
+        probes[th] = rate(min(r.shape[0], 512 * th), th)
         th *= 2
     if cores not in (1,) and cores & (cores - 1):
-        rt = rate(min(r.shape[0], 128 * cores), cores)
-        if rt > best:
-            best_th, best = cores, rt
+        probes[cores] = rate(min(r.shape[0], 512 * cores), cores)
+    # the SMALLEST thread count within 3 % of the best probe: on a box whose cgroup gives the process 16 CPUs, 64 threads are
+    # no faster than 16, and the figure to quote as `cores` is 16
+    top = max(probes.values())
+    best_th = min(t for t, v in probes.items() if v >= 0.97 * top)
+    best = probes[best_th]
     m = int(min(r.shape[0], max(1024, best * budget_s)))
     value = rate(m, best_th)
 
@@ -168,8 +169,9 @@ def cpu_baseline(pub, digest, r, s, budget_s=15.0):
                             "than the thread count",
             "config1_der_single_thread": {"value": config1, "unit": "verifications/s", "sample": f"{m1} DER signatures, "
                                           "single-signature verify incl. parsing"},
-            "sample": f"first {m} signatures of the rank-0 batch, {best_th} threads (best of 1..{cores} host cores, "
-                      f"static split); single-thread rate {single:.0f}/s",
+            "thread_probe": {str(t): round(v) for t, v in sorted(probes.items())},
+            "sample": f"first {m} signatures of the rank-0 batch, {best_th} threads (the smallest count within 3 % of the best "
+                      f"of 1..{cores}, static split); single-thread rate {single:.0f}/s",
             "reference_toolchain": "go: " + ("present" if shutil.which("go") else "absent - reference Go path not timed")}
 
 
@@ -844,6 +846,18 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     out["worst_case_equal_points"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s", "on_worklist": gs["complete"],
                                       "note": "u1*G = u2*Q in every lane (r = e/d): tagged worklist entries, R = 2 u1 G from the "
                                               "generator tables with complete formulas; all verdicts 0 (checked)"}
+    del inp
+    # one crafted value of u2 = r/s (no key needed: any r, s = r / u2) makes the LAST table addition of the keyed ladder add a
+    # point to itself; the lanes are then the worklist's.  Known and not yet closed.
+    from secp256k1_voi_amd.synth import synth_ladder_collision_batch
+    inp = tuple(torch.from_numpy(x).to(dev) for x in synth_ladder_collision_batch(eng, n, n_keys, seed=0xBAD3))
+    d_valid.fill_(1)
+    ms = timed(lambda: verify_on(inp), 2)
+    assert int(d_valid.sum().item()) == 0, "crafted u2 with random r must reject"
+    gs = eng.key_grouping_stats()
+    out["worst_case_ladder_collision"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s", "on_worklist": gs["complete"],
+                                          "note": "u2 = r/s = -26 * 16^28 * lambda in every lane: the keyed ladder's last table addition "
+                                                  "is P + P, every lane is re-done by the complete-formula kernel; all verdicts 0 (checked)"}
     del inp
     if resident is not None:
         dd, dr, ds = resident

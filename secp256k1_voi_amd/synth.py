@@ -94,6 +94,43 @@ def synth_equal_points_batch(eng, n, n_keys, seed):
     return np.ascontiguousarray(Q[key_idx]), e, r, s
 
 
+# u2 = r/s for which the LAST table addition of a ladder meets its own partial sum (P + P inside the ladder, Z = 0 from there on):
+# u2 = 2 d c with d the last signed digit of the lambda-half and c = lambda (general ladder: digit 0 is added last) or
+# 16^28 lambda (ladder over per-key tables: round 0, chunk 7 is added last); d = -13 is the self-consistent one.  Found by
+# integer simulation of the ladders' partial sums.  No key is needed to use them: any r, s = r / u2.
+U2_LAST_ADDITION_GENERAL = 0x87e0663476a3092f3a2127be2e21ceceb7763854dc6939d318220a5890470db5
+U2_LAST_ADDITION_KEYED = 0xcecf64212ab6eb5a5997b96cac25ca2bb234b7d1e5bd755372f392d91409e89f
+
+
+def synth_ladder_collision_batch(eng, n, n_keys, seed, u2_value=U2_LAST_ADDITION_KEYED, valid_every=0):
+    """Signatures with the SAME u2 = r/s in every item, chosen so that the last table addition of the ladder is exceptional:
+    the fast kernels cannot decide these lanes and the complete-formula worklist does.  r random, s = r / u2, random digests:
+    invalid (verdict 0) - except every `valid_every`-th item, which is made valid for its key (R = u1 G + u2 Q computed by the
+    engine, r = x(R) mod n; needs the key's d: u1 + u2 d = k)."""
+    rng = np.random.default_rng(seed)
+    d = _rand_scalars(rng, n_keys)
+    Q = eng.scalar_base_mult_batch(d)[:, 1:]
+    key_idx = np.arange(n) % n_keys
+    u2 = np.tile(np.frombuffer(int(u2_value).to_bytes(32, "big"), np.uint8), (n, 1))
+    u2inv, _ = eng.fn_op_batch(OP_INV, u2)
+    r = _rand_scalars(rng, n)
+    e = _rand_scalars(rng, n)
+    if valid_every:
+        idx = np.arange(0, n, valid_every)
+        k = _rand_scalars(rng, len(idx))                          # R = k G with k = u1 + u2 d  ->  u1 = k - u2 d
+        Rp = eng.scalar_base_mult_batch(k)
+        zero = np.zeros((len(idx), 32), np.uint8)
+        rv, _ = eng.fn_op_batch(OP_ADD, Rp[:, 1:33], zero)        # x(R) mod n
+        u2d, _ = eng.fn_op_batch(OP_MUL, u2[idx], d[key_idx[idx]])
+        nu2d, _ = eng.fn_op_batch(OP_NEG, u2d)
+        u1, _ = eng.fn_op_batch(OP_ADD, k, nu2d)
+        sv, _ = eng.fn_op_batch(OP_MUL, rv, u2inv[idx])           # s = r / u2
+        ev, _ = eng.fn_op_batch(OP_MUL, u1, sv)                   # e = u1 s
+        r[idx], e[idx] = rv, ev
+    s, _ = eng.fn_op_batch(OP_MUL, r, u2inv)
+    return np.ascontiguousarray(Q[key_idx]), e, r, s
+
+
 def synth_msm_terms(eng, n, seed):
     """n points with known discrete logarithms (P_i = d_i*G, 65-byte records) and scalars k_i
     (uniform plus a sprinkle of edge values: 0, 1, n-1, zero windows), and the expected sum's

@@ -376,3 +376,32 @@ def test_table_buffer_allocation_failure_degrades(oracle):
     # the limit gone and the setting renewed: tables again
     eng4.set_key_grouping(S.KEYS_AUTO)
     assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref) and eng4.key_grouping_stats()["tables"] == n // 32
+
+
+# ---- inputs that make the LAST ladder addition exceptional ---------------------------------------------------------
+def test_last_ladder_addition_collisions(eng, oracle):
+    """u2 = r/s = -26 lambda (general ladder) and -26 * 16^28 lambda (ladder over per-key tables): the last table addition of
+    the ladder adds a point to itself, Z is 0 from there on and the lane is the worklist's.  Every item of the batch carries
+    that u2 (no key needed to build them); verdicts - some items are made valid - must be the oracle's on every path, and
+    the lanes must be seen on the worklist of the ladder they were built for."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import U2_LAST_ADDITION_GENERAL, U2_LAST_ADDITION_KEYED, synth_ladder_collision_batch
+    n = 8192
+    for u2v, keyed_form in ((U2_LAST_ADDITION_KEYED, True), (U2_LAST_ADDITION_GENERAL, False)):
+        pub, e, r, s = synth_ladder_collision_batch(eng, n, 64, seed=77, u2_value=u2v, valid_every=5)
+        exp = oracle.ecdsa_verify_batch(pub, e, r, s, nthreads=os.cpu_count() or 1)
+        assert exp[::5].all() and int(exp.sum()) == len(range(0, n, 5))
+        for mode in (S.KEYS_AUTO, S.KEYS_OFF):
+            eng.set_key_grouping(mode)
+            try:
+                got = eng.ecdsa_verify_batch(pub, e, r, s)
+                st = eng.key_grouping_stats()
+            finally:
+                eng.set_key_grouping(S.KEYS_AUTO)
+            assert np.array_equal(got, exp), (hex(u2v), mode)
+            on_tables = mode == S.KEYS_AUTO
+            if on_tables == keyed_form:
+                assert st["complete"] == n, st              # every lane undecided by the ladder it was built for
+            else:
+                assert st["complete"] == 0, st              # the other ladder adds in another order: no collision
+        assert np.array_equal(eng.ecdsa_verify_batch(pub, e, r, s, force_complete=True), exp)
