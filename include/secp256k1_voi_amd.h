@@ -61,8 +61,9 @@ enum {
  * ~3.4x a normal step: the price of a batch in which every lane is such a case.  The exceptional cases a key owner can
  * force for given digests - u1 G = -u2 Q (r = -e/d: decided inside the ladder kernel) and u1 G = u2 Q (r = e/d: a short
  * form of the worklist kernel, 2 u1 G) - arise in the final addition and no longer cost this; u1 = 0 needs a digest that
- * is 0 mod n.  What still does: crafted values of u2 = r/s for which a late table addition of the ladder adds a point to
- * itself (one known value per ladder form; bench key worst_case_ladder_collision). */
+ * is 0 mod n.  One crafted value of u2 = r/s per ladder form used to make the ladder's last table addition add a point to
+ * itself; the odd GLV split avoids it now (bench key worst_case_ladder_collision).  No input is known
+ * that fills the worklist any more; the flag keeps the kernel measurable and tested. */
 #define S2K_ECDSA_FORCE_WORKLIST 0x40000000u
 
 /* bitcoin.VerifyASN1 (secec/bitcoin/ecdsa_shitcoin.go:29): BIP-0066 shape check, sighash byte

@@ -333,8 +333,44 @@ S2K_DEV void sc_split_glv_odd(const sc& k, sc& k1, bool& neg1, sc& k2, bool& neg
   uint32_t m1[5] = {k1.v[0], k1.v[1], k1.v[2], k1.v[3], 0u}, m2[5] = {k2.v[0], k2.v[1], k2.v[2], k2.v[3], 0u};
   const bool odd1 = m1[0] & 1u, odd2 = m2[0] & 1u;
   if (!odd1 && !odd2) {            // + v1 = (a1, b1), b1 < 0
+    // The natural halves (k1, k2), kept for the rule below (magnitude in n2, sign in n2neg)
+    const bool k1_zero = (m1[0] | m1[1] | m1[2] | m1[3]) == 0u;
+    const uint32_t n2[4] = {m2[0], m2[1], m2[2], m2[3]};
+    const bool n2neg = neg2;
     sm160_add(m1, neg1, GLV_A1, false);
     sm160_add(m2, neg2, GLV_NB1, true);
+    if (k1_zero) {
+      // k = k2 * lambda with a SMALL even k2: the first half has collapsed and the halves the ladders see are (a1, k2 + b1).
+      // If k2 = 2 s d w - s the sign of the second half, d its signed digit at the position a ladder adds LAST, w that
+      // position's weight (digit 0, weight 1: the general ladder; digit 28, weight 16^28: the ladder over per-key tables) -
+      // then everything but the last addend sums to the last addend, the last table addition of the ladder is P + P, and
+      // the lane ends on the complete-formula worklist.  One value of k2 does that for each ladder (-26 and -26 * 16^28:
+      // found by simulating the ladders on integers, tests/test_glv_odd_model.py), and anyone can put it into every lane of
+      // a batch (any r, s = r / (k2 lambda)): 3.4 x a step.  - v1 is as good a vector as + v1 (same bound), has other
+      // digits, and does not collide (same test): take it when + v1 would.
+      bool hit = false;
+#pragma unroll
+      for (int form = 0; form < 2; ++form) {
+        const uint32_t nib = form ? (m2[3] >> 17) & 15u : (m2[0] >> 1) & 15u;       // digit 28 / digit 0: bits 4i+1 .. 4i+4
+        const int d = 2 * (int)nib - 15, sd = neg2 ? -d : d;                          // the addend's sign times its digit
+        const uint32_t mag = 2u * (uint32_t)(sd < 0 ? -sd : sd);
+        const bool same_mag = form ? (n2[3] == (mag << 16) && (n2[0] | n2[1] | n2[2]) == 0u)
+                                   : (n2[0] == mag && (n2[1] | n2[2] | n2[3]) == 0u);
+        hit = hit || (same_mag && n2neg == (sd < 0));
+      }
+      if (hit) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          m1[i] = 0u;
+          m2[i] = n2[i];
+        }
+        m1[4] = m2[4] = 0u;
+        neg1 = false;
+        neg2 = n2neg;
+        sm160_add(m1, neg1, GLV_A1, true);      // - v1
+        sm160_add(m2, neg2, GLV_NB1, false);
+      }
+    }
   } else if (odd1 && !odd2) {      // -+ v2 = (a2, b2), b2 = a1: against the sign of k1
     const bool cneg = !neg1;
     sm160_add(m1, neg1, GLV_A2, cneg);

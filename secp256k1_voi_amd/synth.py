@@ -94,7 +94,8 @@ def synth_equal_points_batch(eng, n, n_keys, seed):
     return np.ascontiguousarray(Q[key_idx]), e, r, s
 
 
-# u2 = r/s for which the LAST table addition of a ladder meets its own partial sum (P + P inside the ladder, Z = 0 from there on):
+# u2 = r/s for which - with the PLAIN odd split - the LAST table addition of a ladder meets its own partial sum (P + P inside the
+# ladder, Z = 0 from there on; sc_split_glv_odd takes the other lattice vector for them since round 4):
 # u2 = 2 d c with d the last signed digit of the lambda-half and c = lambda (general ladder: digit 0 is added last) or
 # 16^28 lambda (ladder over per-key tables: round 0, chunk 7 is added last); d = -13 is the self-consistent one.  Found by
 # integer simulation of the ladders' partial sums.  No key is needed to use them: any r, s = r / u2.
@@ -103,8 +104,8 @@ U2_LAST_ADDITION_KEYED = 0xcecf64212ab6eb5a5997b96cac25ca2bb234b7d1e5bd755372f39
 
 
 def synth_ladder_collision_batch(eng, n, n_keys, seed, u2_value=U2_LAST_ADDITION_KEYED, valid_every=0):
-    """Signatures with the SAME u2 = r/s in every item, chosen so that the last table addition of the ladder is exceptional:
-    the fast kernels cannot decide these lanes and the complete-formula worklist does.  r random, s = r / u2, random digests:
+    """Signatures with the SAME u2 = r/s in every item, chosen so that the last table addition of the ladder would be
+    exceptional under the plain odd split (the fast kernels then cannot decide these lanes and the worklist does).  r random, s = r / u2, random digests:
     invalid (verdict 0) - except every `valid_every`-th item, which is made valid for its key (R = u1 G + u2 Q computed by the
     engine, r = x(R) mod n; needs the key's d: u1 + u2 d = k)."""
     rng = np.random.default_rng(seed)

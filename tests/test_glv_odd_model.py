@@ -28,13 +28,25 @@ def split_reference(k):
     return k1, k2
 
 
-def make_odd(k1, k2):
+def signed_digit(k, pos):
+    """digit `pos` of the ladders' recoding of an odd |k| < 2^129: 2 * (bits 4 pos + 1 .. 4 pos + 4) - 15"""
+    return 2 * ((abs(k) >> (4 * pos + 1)) & 15) - 15
+
+
+def make_odd(k1, k2, avoid_last_addition=True):
     """the device rule: magnitudes and signs in, magnitudes and signs out"""
     p = (k1 & 1, k2 & 1)
     if p == (1, 1):
         return k1, k2
     if p == (0, 0):
-        return k1 + A1, k2 + B1
+        c1, c2 = k1 + A1, k2 + B1
+        if avoid_last_addition and k1 == 0:
+            # k = k2 lambda with k2 = 2 s d w (d the digit the ladder adds last, w its weight): + v1 would make that last
+            # addition P + P; - v1 does not (test_no_last_addition_collisions)
+            s2 = 1 if c2 > 0 else -1
+            if k2 == 2 * s2 * signed_digit(c2, 0) or k2 == 2 * s2 * signed_digit(c2, 28) * 16 ** 28:
+                c1, c2 = k1 - A1, k2 - B1
+        return c1, c2
     if p == (1, 0):
         s = -1 if k1 >= 0 else 1
         return k1 + s * A2, k2 + s * B2
@@ -94,3 +106,69 @@ def test_lattice_form_split_is_the_reference_split():
     for k in ks:
         assert split_lattice_form(k) == split_reference(k), hex(k)
         assert ((k * G1 + (1 << 383)) >> 384) < (1 << 128) and ((k * G2 + (1 << 383)) >> 384) < (1 << 128)
+
+
+def ladder_events(u2, keyed, avoid_last_addition=True):
+    """Integer simulation of the two ladders' partial sums a Q + b lambda Q over the odd split of u2: the positions at which
+    an addition would meet an operand at infinity, P + P or P - P (what makes Z = 0 in the incomplete formulas)."""
+    k1, k2 = make_odd(*split_reference(u2), avoid_last_addition=avoid_last_addition)
+    assert (k1 + k2 * LAM - u2) % N == 0 and k1 & 1 and k2 & 1 and abs(k1) < (1 << 129) and abs(k2) < (1 << 129)
+    s1, s2 = (1 if k1 > 0 else -1), (1 if k2 > 0 else -1)
+    d1, d2 = [signed_digit(k1, i) for i in range(32)], [signed_digit(k2, i) for i in range(32)]
+    ev = []
+
+    def add(a, b, da, db, where):
+        v, w = (a + b * LAM) % N, (da + db * LAM) % N
+        if v == 0 or w == 0 or v == w or v == (N - w) % N:
+            ev.append(where)
+        return a + da, b + db
+    if keyed:       # k_verify_fast<ECDSA_KEYED>: start +-2^116 Q +- 2^116 lambda Q, four rounds of eight chunks, four doublings between rounds
+        a, b = s1 << 116, s2 << 116
+        for rnd in range(4):
+            j = 3 - rnd
+            if rnd:
+                a, b = 16 * a, 16 * b
+            for c in range(8):
+                i = 4 * c + j
+                a, b = add(a, b, s1 * d1[i] * 16 ** (4 * c), 0, ("k1", i))
+                a, b = add(a, b, 0, s2 * d2[i] * 16 ** (4 * c), ("k2", i))
+    else:           # k_verify_fast<ECDSA>: start +-Q +- lambda Q, 32 windows of (four doublings, two additions)
+        a, b = s1, 0
+        a, b = add(a, b, 0, s2, "start")
+        for i in range(31, -1, -1):
+            a, b = 16 * a, 16 * b
+            a, b = add(a, b, s1 * d1[i], 0, ("k1", i))
+            a, b = add(a, b, 0, s2 * d2[i], ("k2", i))
+    assert (a + b * LAM - u2) % N == 0
+    return ev
+
+
+def test_no_last_addition_collisions():
+    """Scalars with SMALL natural halves at the weights where the ladders' additions sit (u2 = a w + b w lambda, |a|, |b| <= 40,
+    w in {1, 16^4, 16^27, 16^28, 16^31}: 32 800 of them) through both ladders.  With the plain rule exactly two of them make
+    the LAST table addition of a ladder add a point to itself (u2 = -26 lambda: general ladder; -26 * 16^28 lambda: the
+    ladder over per-key tables); with the rule the device uses, none meets any exceptional addition."""
+    plain, fixed = [], []
+    for w in (1, 16 ** 4, 16 ** 27, 16 ** 28, 16 ** 31):
+        for a in range(-40, 41):
+            for b in range(-40, 41):
+                u2 = (a * w + b * w * LAM) % N
+                if u2 == 0:
+                    continue
+                for keyed in (False, True):
+                    if ladder_events(u2, keyed, avoid_last_addition=False):
+                        plain.append((a, b, w.bit_length(), keyed))
+                    if ladder_events(u2, keyed):
+                        fixed.append((a, b, w.bit_length(), keyed))
+    assert sorted(plain) == [(0, -26, 1, False), (0, -26, 113, True)]
+    assert fixed == []
+    # the two values by name (secp256k1_voi_amd/synth.py quotes them)
+    assert (-26 * LAM) % N == 0x87e0663476a3092f3a2127be2e21ceceb7763854dc6939d318220a5890470db5
+    assert (-26 * 16 ** 28 * LAM) % N == 0xcecf64212ab6eb5a5997b96cac25ca2bb234b7d1e5bd755372f392d91409e89f
+
+
+def test_random_scalars_meet_no_exceptional_addition():
+    rnd = random.Random(77)
+    for _ in range(3000):
+        u2 = rnd.randrange(1, N)
+        assert not ladder_events(u2, False) and not ladder_events(u2, True)
