@@ -887,6 +887,11 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     want = eng.scalar_base_mult_batch([tot.to_bytes(32, "big")])[0].tobytes()
     assert dout[:65].cpu().numpy().tobytes() == want, "2^20-term MSM differs from (sum k_i d_i) G"
     out["msm_2p20"] = {"terms": m, "ms": ms, "terms_per_s": m / (ms * 1e-3),
+                       "method": "Pippenger over signed 16-bit windows of the endomorphism-split scalars: two-level counting sort of the "
+                                 "(window, digit) keys assembled in LDS, then a bucket pass over EQUAL RANGES OF THE SORTED LIST (one lane per "
+                                 "range, incomplete XYZZ additions in registers, pieces stitched per bucket) - LDS is used by the sort, the "
+                                 "bucket accumulation itself runs in registers over the sorted list (DESIGN.md 7a); BASELINE config 3 says "
+                                 "'LDS bucket accumulation'",
                        "check": "full sum == (sum k_i d_i mod n) * G (big-int on the host, base mult on the device)",
                        "roofline": multiscalar_roofline(eng, "msm", ms, stages, {
                            # every input is two 128-bit terms (endomorphism), 8 signed 16-bit windows each: one bucket

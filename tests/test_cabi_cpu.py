@@ -97,3 +97,32 @@ def test_host_register_refuses_heap_blocks():
         assert "page" in str(e)
     else:
         raise AssertionError("heap array accepted")
+
+
+def test_group_and_tickets_without_a_device():
+    """The streaming / multi-device entry points on a box without a GPU: no device is counted, a group cannot be made
+    (S2K_ERR_NO_DEVICE, no CPU fallback), null arguments are refused - and nothing crashes."""
+    import ctypes as C
+
+    import torch
+
+    import secp256k1_voi_amd as S
+    if torch.cuda.device_count() > 0:
+        import pytest
+        pytest.skip("box has GPUs")
+    lib = S.load_library()
+    assert lib.s2k_device_count() == 0 and S.device_count() == 0
+    g = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.s2k_group_create(devs, 2, C.byref(g)) == -1 and not g.value          # S2K_ERR_NO_DEVICE
+    assert lib.s2k_group_create(None, 2, C.byref(g)) == -3                          # S2K_ERR_ARG
+    assert lib.s2k_group_create(devs, 0, C.byref(g)) == -3
+    assert lib.s2k_group_size(None) == 0
+    assert lib.s2k_group_wait(None, 1) == -3
+    lib.s2k_group_destroy(None)
+    t = C.c_uint64(0)
+    assert lib.s2k_ecdsa_verify_batch_submit(None, 0, None, None, None, None, 0, None, C.byref(t)) == -3
+    assert lib.s2k_wait(None, 1) == -3 and lib.s2k_poll(None, 1) == -3 and lib.s2k_wait_all(None) == -3
+    import pytest
+    with pytest.raises(S.EngineError):
+        S.Group([0])

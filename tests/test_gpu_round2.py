@@ -42,6 +42,13 @@ def test_bench_two_ranks_one_device():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert "2^16 in total" in d["config"]["workload"]
     assert d["roofline"]["bound"] == "valu" and d["roofline"]["kernel_ms"] > 0
+    # what a first run on N devices needs to tell a straggler from a slow collective (round 4)
+    mr = d["multi_rank"]
+    assert mr["group_world_size"] == 2 and mr["backend"] == "gloo"
+    for key in ("per_rank_ms", "per_rank_local_ms", "collective_ms", "per_rank_step_ms_diagnostic_pass"):
+        assert len(mr[key]) == 2 and all(x > 0 for x in mr[key]), key
+    assert max(mr["per_rank_ms"]) <= d["ms_per_step"] * 1.001 and mr["value_without_collective"] > 0
+    assert d["roofline"]["counts_stale"] is False
 
 
 def test_worst_case_all_fallback(eng, oracle):
