@@ -506,10 +506,10 @@ def worker(args):
             line["pcie_inclusive"]["pinned"] = {"value": n / (median(pin_ms) * 1e-3), "unit": "verifications/s", "ms_each": pin_ms,
                                                 "note": "the same call from s2k_host_alloc buffers; 160 MiB over PCIe take 3.0 ms on their "
                                                         "own (55 GB/s), the keys' 64 MiB of it are exposed"}
-            # submit / wait: three batches in flight on the context's child contexts, a new one submitted whenever one
+            # submit / wait: four batches in flight on the context's child contexts (two lanes), a new one submitted whenever one
             # is done - what a caller that streams batches gets (s2k_ecdsa_verify_batch_submit / s2k_wait); the verdict
             # arrays are page-locked too
-            def pipelined(submit, nb, depth=3, lead=3):
+            def pipelined(submit, nb, depth=4, lead=4):
                 # steady state: `lead` batches fill the pipeline (the first transfer has nothing to hide behind), the clock
                 # runs from the completion of batch `lead` to the completion of batch `lead + nb`
                 tickets, done, t_0 = [], 0, None
@@ -526,22 +526,22 @@ def worker(args):
                     if done == lead:
                         t_0 = time.perf_counter()
                 return (time.perf_counter() - t_0) * 1e3 / (done - lead)
-            pin3 = [pinned] + [[pinned_array(a.shape) for a in pinned] for _ in range(2)]
+            pin3 = [pinned] + [[pinned_array(a.shape) for a in pinned] for _ in range(3)]
             for q in pin3[1:]:
                 for dst, src in zip(q, pinned):
                     dst[...] = src
-            outs3 = [pinned_array((n,)) for _ in range(3)]
-            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 3], out=outs3[k % 3]), 6)
-            pl_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 3], out=outs3[k % 3]), 12) for _ in range(3)]
+            outs3 = [pinned_array((n,)) for _ in range(4)]
+            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 4], out=outs3[k % 4]), 8)
+            pl_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 4], out=outs3[k % 4]), 12) for _ in range(3)]
             line["pcie_inclusive"]["pipelined"] = {"value": n / (median(pl_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl_ms),
-                                                   "ms_per_batch_each": pl_ms, "batches": 12, "in_flight": 3,
+                                                   "ms_per_batch_each": pl_ms, "batches": 12, "in_flight": 4,
                                                    "fraction_of_resident_value": (n / (median(pl_ms) * 1e-3)) / value,
                                                    "note": "s2k_ecdsa_verify_batch_submit / s2k_wait from page-locked buffers, batches of 2^%d, "
-                                                           "three in flight, host bytes to host verdicts; steady state: 3 batches fill "
-                                                           "the pipeline, then 12 are timed completion to completion" % batch_log2}
-            pg3 = [(pub, digest, r, s)] + [tuple(a.copy() for a in (pub, digest, r, s)) for _ in range(2)]
-            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 3]), 4)
-            pg_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 3]), 12) for _ in range(3)]
+                                                           "four in flight (two lanes of two), host bytes to host verdicts; steady state: 4 batches "
+                                                           "fill the pipeline, then 12 are timed completion to completion" % batch_log2}
+            pg3 = [(pub, digest, r, s)] + [tuple(a.copy() for a in (pub, digest, r, s)) for _ in range(3)]
+            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 4]), 4)
+            pg_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 4]), 12) for _ in range(3)]
             line["pcie_inclusive"]["pipelined_pageable"] = {"value": n / (median(pg_ms) * 1e-3), "unit": "verifications/s",
                                                             "ms_per_batch": median(pg_ms), "ms_per_batch_each": pg_ms,
                                                             "note": "the same from pageable memory: the runtime stages the copies and submit "
@@ -603,7 +603,7 @@ def encoded_measurement(eng, pub, digest, r, s, reps=3):
         qo[...] = offs
         pblobs.append((qb, qo))
 
-    def pipelined(nb, depth=3, lead=3):
+    def pipelined(nb, depth=4, lead=4):
         tickets, done, t_0 = [], 0, None
         for k in range(nb + lead):
             tickets.append(eng.ecdsa_verify_encoded_batch_submit(*pblobs, digest_len=32))
@@ -622,8 +622,8 @@ def encoded_measurement(eng, pub, digest, r, s, reps=3):
     pl = [pipelined(12) for _ in range(3)]
     return {"value": n / (median(ms) * 1e-3), "unit": "verifications/s", "ms_each": ms, "bytes_per_item": (len(pb) + len(db) + len(sb)) / n,
             "pipelined": {"value": n / (median(pl) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl), "ms_per_batch_each": pl,
-                          "note": "s2k_ecdsa_verify_encoded_batch_submit / s2k_wait, three in flight, page-locked host memory; steady state "
-                                  "(3 batches fill the pipeline, 12 timed completion to completion)"},
+                          "note": "s2k_ecdsa_verify_encoded_batch_submit / s2k_wait, four in flight, page-locked host memory; steady state "
+                                  "(4 batches fill the pipeline, 12 timed completion to completion)"},
             "note": "s2k_ecdsa_verify_encoded_batch: 65-byte SEC1 keys, 32-byte digests, DER signatures from pageable host memory; "
                     "strict DER parsing and key decoding on the device, then the batch verifier"}
 

@@ -221,11 +221,12 @@ int s2k_host_unregister(void *p);
  * it into s2k_ecdsa_verify_batch, which pays the PCIe transfer and the kernels in series (7.1 ms from pinned, 8.2 ms
  * from pageable memory against 4.9 ms resident per 2^20 signatures).  s2k_ecdsa_verify_batch_submit returns as soon as
  * the batch is enqueued (from page-locked buffers: at once; from pageable ones: when the runtime has staged the copies)
- * and s2k_wait blocks until the verdicts of that ticket are in `valid`.  The context keeps up to THREE batches in flight on
- * internal child contexts (own workspaces on the same device; the generator tables are shared): batch k+1 crosses PCIe
- * while batch k's kernels run (the kernels of consecutive tickets follow each other on the context's streams), so a
- * caller that submits batch k+1 (better: k+2) before it waits for batch k sees the resident rate.  A fourth submit first retires the oldest ticket (delivers its
- * verdicts; a later s2k_wait on it returns at once).  s2k_poll is s2k_wait without the blocking: S2K_PENDING while the
+ * and s2k_wait blocks until the verdicts of that ticket are in `valid`.  The context keeps up to FOUR batches in flight on
+ * internal child contexts (own workspaces on the same device; the generator tables are shared), in two lanes: even and odd
+ * tickets run on two sets of streams beside each other, within a lane the kernels of consecutive tickets follow each other,
+ * and a ticket crosses PCIe while its lane's previous ticket computes - a caller that keeps three or four batches
+ * submitted sees a little more than the resident rate of a single stream.  A fifth submit first retires the oldest ticket
+ * (delivers its verdicts; a later s2k_wait on it returns at once).  s2k_poll is s2k_wait without the blocking: S2K_PENDING while the
  * ticket is in flight.  Same verdicts as s2k_ecdsa_verify_batch, bit for bit; the inputs and `valid` must
  * stay untouched until the ticket has been waited for (or retired).  Submit, wait and the other calls of one context
  * must come from one thread at a time, like all calls on a context; the key-grouping settings are those the context
@@ -251,8 +252,9 @@ int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t 
  * up to rounding to 256), every member runs s2k_ecdsa_verify_batch_submit / s2k_wait on its shard from its own thread,
  * and the verdicts land in the caller's `valid` at the shard's offset - the "all-gather" is the host array itself.
  * Verdicts are those of s2k_ecdsa_verify_batch on the whole batch, bit for bit (signatures are independent; only the
- * grouping by key is per shard).  s2k_group_ecdsa_verify_batch = submit + wait.  Up to three group batches are in flight
- * per member (a fourth submit blocks until the oldest is done).  Group calls may come from any ONE thread at a time.
+ * grouping by key is per shard).  s2k_group_ecdsa_verify_batch = submit + wait.  Up to four group batches are in flight
+ * per member (a fifth submit blocks until the oldest is done).  Listing a device twice is for tests: two members then run
+ * four lanes on it, which is slower than one member's two.  Group calls may come from any ONE thread at a time.
  * s2k_device_count: devices visible to the runtime (0 when there is none). */
 typedef struct s2k_group s2k_group;
 int s2k_device_count(void);

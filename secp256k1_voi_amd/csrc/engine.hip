@@ -1624,6 +1624,8 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   delete[] ctx->prof_ev;
   for (hipEvent_t e : ctx->ev_copied)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->lane1_comp) (void)hipStreamDestroy(ctx->lane1_comp);
+  if (ctx->lane1_aux) (void)hipStreamDestroy(ctx->lane1_aux);
   if (ctx->s_copy && !ctx->streams_shared) (void)hipStreamDestroy(ctx->s_copy);
   if (ctx->s_comp && !ctx->streams_shared) (void)hipStreamDestroy(ctx->s_comp);
   delete ctx;
@@ -2346,16 +2348,17 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
 // host memory (secec/ecdsa.go:171-228) and a synchronous call pays transfer and compute in series: 7.1 ms from pinned
 // memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns child contexts
 // ("slots": own workspaces and staging buffers; the 3 GiB generator tables are shared per device) that take the submitted
-// batches in turn.  The children run on the PARENT's three streams: the kernels of consecutive tickets follow each other
-// in stream order, each ticket with the two-stream overlap of a resident call (grouping and tables beside preparation and
-// generator part), while ticket k+1's 160 MiB cross PCIe (3.0 ms) on the copy stream beside ticket k's kernels.  The
-// rate is the resident rate minus what the transfers cost the kernels (1.5 %: tools/dma_interference_probe.py).  Up to
-// three tickets are in flight (one computing, one arriving, one of slack for the caller's turn-around); a fourth submit
-// first retires the oldest one (its verdicts are delivered; a later s2k_wait on its ticket returns at once).
+// batches in turn.  The children run on the PARENT's streams, in two lanes: even tickets on the parent's own two compute
+// streams, odd tickets on a second pair, one copy stream for all.  Within a lane the kernels of consecutive tickets follow
+// each other in stream order, each ticket with the two-stream overlap of a resident call (grouping and tables beside
+// preparation and generator part); the lanes run beside each other as two resident contexts do (worth 3 %); a ticket's
+// 160 MiB cross PCIe (3.0 ms) on the copy stream beside the kernels of the tickets before it.  Up to four tickets are in
+// flight (per lane one computing, one arriving); a fifth submit first retires the oldest one (its verdicts are delivered;
+// a later s2k_wait on its ticket returns at once).
 // (Earlier forms gave every ticket streams of its own so that one ticket's grouping and tables could run beside another's
 // ladder.  They do not: the keyed ladder holds 4 x 128 of a SIMD's 512 VGPRs, so the other ticket's kernels crawl, its
 // empty tail launches - 161 VGPRs a wave - wait milliseconds for room, and nine streams on the runtime's hardware queues
-// serialise at random.  5.2-5.7 ms per batch against 4.9-5.0 this way; profiles/r04_pipeline_timeline.txt.)
+// serialise at random.  5.2-5.7 ms per batch against 4.7-4.9 this way; profiles/r04_pipeline_timeline.txt.)
 // ---------------------------------------------------------------------------------------
 }  // extern "C"
 static void pipe_note_failure(s2k_ctx* ctx, uint64_t ticket, int rc) {
@@ -2392,9 +2395,15 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
     if (rc) return rc;
     rc = s2k_ctx_create(ctx->device, &sl.ctx);
     if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
+    const bool odd_lane = (ctx->pipe_next & 1u) != 0;   // (PIPE_SLOTS is even: a slot always serves the same lane)
+    static const bool one_lane = [] { const char* v = getenv("S2K_SUBMIT_ONE_LANE"); return v && atoi(v) != 0; }();   // measurement knob
+    if (odd_lane && !one_lane && !ctx->lane1_comp) {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane1_comp, hipStreamNonBlocking));
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane1_aux, hipStreamNonBlocking));
+    }
     sl.ctx->s_copy = ctx->s_copy;
-    sl.ctx->s_comp = ctx->s_comp;
-    sl.ctx->s_aux = ctx->s_aux;
+    sl.ctx->s_comp = (odd_lane && !one_lane) ? ctx->lane1_comp : ctx->s_comp;
+    sl.ctx->s_aux = (odd_lane && !one_lane) ? ctx->lane1_aux : ctx->s_aux;
     sl.ctx->streams_shared = true;
     rc = ctx_streams(sl.ctx);                         // (its events)
     if (rc == S2K_OK) rc = ctx_aux_streams(sl.ctx);
@@ -2421,7 +2430,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   return S2K_OK;
 }
 __attribute__((visibility("hidden"))) void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, s2k_ticket* ticket) {
-  (void)hipEventRecord(sl->done, ctx->s_comp);        // behind the ticket's last operation
+  (void)hipEventRecord(sl->done, sl->ctx->s_comp);    // behind the ticket's last operation (on its lane's stream)
   sl->ticket = ctx->pipe_next++;
   *ticket = sl->ticket;
 }

@@ -83,11 +83,12 @@ struct s2k_ctx {
   void* io = nullptr;
   size_t io_bytes = 0;
   hipStream_t s_copy = nullptr, s_comp = nullptr;
-  // A child context of submit / wait owns buffers, not streams: its copy, compute and second stream are its parent's.
-  // Tickets therefore run their kernels strictly one after the other, each with the two-stream overlap of a resident call,
-  // and only the transfers run ahead (DESIGN.md section 4c for what was tried before: per-ticket streams let one ticket's
-  // front end run beside another's ladder, which holds every VGPR of the SIMDs - the front end crawls, empty tail launches
-  // of 161 VGPRs wait milliseconds for room, and streams beyond the hardware queues serialise at random).
+  // A child context of submit / wait owns buffers, not streams: its copy stream is its parent's, its two compute streams
+  // those of its LANE (even tickets: the parent's own; odd tickets: a second pair).  Within a lane tickets run their kernels
+  // strictly one after the other, each with the two-stream overlap of a resident call; the two lanes run beside each other
+  // like two contexts (worth 3 %), and the transfers run ahead of both (also for what was tried
+  // before: a stream set per ticket - the front ends crawl beside three ladders, empty tail launches of 161 VGPRs wait
+  // milliseconds for room, and streams beyond the hardware queues serialise at random).
   bool streams_shared = false;
   hipEvent_t ev_copied[2] = {nullptr, nullptr};
   hipEvent_t ev_arrival[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pieces of a pinned batch on their way in
@@ -138,9 +139,10 @@ struct s2k_ctx {
     size_t h_valid_bytes = 0;
     bool direct = false;           // dst is page-locked itself: the device-to-host copy lands there
   };
-  static constexpr unsigned PIPE_SLOTS = 3;   // batches in flight: one computing, one arriving, and a third that takes the
-                                              // caller's (and a group's thread hand-over) turn-around out of the rate
+  static constexpr unsigned PIPE_SLOTS = 4;   // batches in flight: two LANES (even and odd tickets), each with one batch
+                                              // computing and one arriving
   pipe_slot pipe[PIPE_SLOTS];
+  hipStream_t lane1_comp = nullptr, lane1_aux = nullptr;   // the compute streams of the odd tickets (the even ones: s_comp, s_aux)
   uint64_t pipe_next = 1;          // next ticket (ticket t runs on slot t mod PIPE_SLOTS)
   uint64_t pipe_failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tickets retired with an error (by a later submit), and their codes
   int pipe_failed_rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -118,7 +118,7 @@ void member_main(member* me) {
   // preferred over waiting: the oldest shard in flight is POLLED (s2k_poll) between looks at the queue, so a shard that
   // arrives while one is being waited for is submitted within ~0.1 ms - its transfer has to fit under the ladder of the
   // shard before it.
-  constexpr size_t MAX_IN_FLIGHT = 3;
+  constexpr size_t MAX_IN_FLIGHT = 4;
   struct flying {
     shard_job job;
     s2k_ticket ticket;
@@ -135,19 +135,30 @@ void member_main(member* me) {
   for (;;) {
     shard_job job;
     bool have_job = false;
+    bool block_on_oldest = false;
     {
       std::unique_lock<std::mutex> lock(me->m);
       if (inflight.empty())
         me->cv.wait(lock, [&] { return me->stop || !me->q.empty(); });
-      else if (me->q.empty())
-        me->cv.wait_for(lock, std::chrono::microseconds(100), [&] { return !me->q.empty(); });
-      if (!me->q.empty()) {
+      else if (me->q.empty()) {
+        // nothing new to submit.  With three or more shards in flight both lanes of the context have work beyond the oldest one: wait for that
+        // one in the runtime (a new shard that arrives meanwhile is submitted when it is done - the device is not idle);
+        // with one or two in flight a new one must not wait for it: poll (polling at 10 kHz all the time cost 2-7 % of the
+        // rate: every query goes through the runtime)
+        if (inflight.size() >= 3) block_on_oldest = true;
+        else me->cv.wait_for(lock, std::chrono::microseconds(100), [&] { return !me->q.empty(); });
+      }
+      if (!block_on_oldest && !me->q.empty()) {
         job = me->q.front();
         me->q.pop_front();
         have_job = true;
       } else if (inflight.empty() && me->stop) {
         break;
       }
+    }
+    if (block_on_oldest) {
+      (void)finish_oldest(true);
+      continue;
     }
     if (have_job) {
       while (inflight.size() >= MAX_IN_FLIGHT) (void)finish_oldest(true);
@@ -261,11 +272,11 @@ int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* p
   uint64_t t;
   {
     std::unique_lock<std::mutex> lock(g->m);
-    // at most three group batches in flight: every member keeps up to three shards on its device
+    // at most four group batches in flight: every member keeps up to four shards on its device
     g->cv.wait(lock, [&] {
       int busy = 0;
       for (auto& kv : g->pend) busy += kv.second.remaining ? 1 : 0;
-      return busy < 3;
+      return busy < 4;
     });
     t = g->next_ticket++;
     while (g->pend.size() > 16 && g->pend.begin()->second.remaining == 0) g->pend.erase(g->pend.begin());   // old results

@@ -40,11 +40,11 @@ def main():
     n = 1 << lg
     eng = S.Engine(0)
     base = [np.array(x) for x in synth_batch(eng, n, min(n, 1 << kl), seed=0x5EC9)]
-    pin = [[S.pinned_array(a.shape) for a in base] for _ in range(3)]
+    pin = [[S.pinned_array(a.shape) for a in base] for _ in range(4)]
     for pb in pin:
         for d, a in zip(pb, base):
             d[...] = a
-    outs = [S.pinned_array((n,)) for _ in range(3)]
+    outs = [S.pinned_array((n,)) for _ in range(4)]
     res = {"n_log2": lg, "keys_log2": kl, "batches": nb, "queues": os.environ.get("GPU_MAX_HW_QUEUES")}
 
     def sync_ms(arrs, reps=4):
@@ -60,15 +60,15 @@ def main():
     res["sync_pinned_ms"] = sync_ms(pin[0])
     res["sync_pageable_ms"] = sync_ms(base)
     # submit / wait
-    for name, bufs, o in (("pinned", pin, outs), ("pageable", [base, [a.copy() for a in base], [a.copy() for a in base]], [None, None, None])):
-        pipelined(lambda k: eng.ecdsa_verify_batch_submit(*bufs[k % 3], out=o[k % 3]), 6, 3)      # creates the slots
-        for depth in (2, 3):
-            ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*bufs[k % 3], out=o[k % 3]), nb, depth) for _ in range(3)]
+    for name, bufs, o in (("pinned", pin, outs), ("pageable", [base] + [[a.copy() for a in base] for _ in range(3)], [None] * 4)):
+        pipelined(lambda k: eng.ecdsa_verify_batch_submit(*bufs[k % 4], out=o[k % 4]), 8, 4)      # creates the slots
+        for depth in (2, 3, 4):
+            ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*bufs[k % 4], out=o[k % 4]), nb, depth) for _ in range(3)]
             res["pipelined_%s_depth%d_ms" % (name, depth)] = sorted(ms)[1]
             res["pipelined_%s_depth%d_ms_all" % (name, depth)] = ms
     assert int(outs[0].sum()) == n and int(outs[1].sum()) == n
     # depth 1 = submit immediately followed by wait (the synchronous call on a child context)
-    res["submit_wait_depth1_pinned_ms"] = pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin[k % 3], out=outs[k % 3]), nb, depth=1)
+    res["submit_wait_depth1_pinned_ms"] = pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin[k % 4], out=outs[k % 4]), nb, depth=1)
     # encoded
     if len(sys.argv) <= 4:
         def der_int(b):
@@ -92,7 +92,7 @@ def main():
             t0 = time.perf_counter()
             v = eng.ecdsa_verify_encoded_batch_submit(*c, digest_len=32).wait()
             assert int(v.sum()) == n
-            for depth in (2, 3):
+            for depth in (2, 4):
                 ms = [pipelined(lambda k: eng.ecdsa_verify_encoded_batch_submit(*c, digest_len=32), nb, depth) for _ in range(3)]
                 res["encoded_pipelined_%s_depth%d_ms" % (name, depth)] = sorted(ms)[1]
         out = np.zeros(n, np.uint8)
@@ -108,14 +108,14 @@ def main():
     for members in (1, 2):
         g = S.Group([0] * members)
         big = [np.concatenate([a] * members) for a in base] if members > 1 else base
-        pb = [[S.pinned_array(a.shape) for a in big] for _ in range(3)]
+        pb = [[S.pinned_array(a.shape) for a in big] for _ in range(4)]
         for q in pb:
             for d, a in zip(q, big):
                 d[...] = a
-        po = [S.pinned_array((n * members,)) for _ in range(3)]
-        pipelined(lambda k: g.ecdsa_verify_batch_submit(*pb[k % 3], out=po[k % 3]), 6, 3)
-        for depth in (2, 3):
-            ms = [pipelined(lambda k: g.ecdsa_verify_batch_submit(*pb[k % 3], out=po[k % 3]), nb, depth) for _ in range(3)]
+        po = [S.pinned_array((n * members,)) for _ in range(4)]
+        pipelined(lambda k: g.ecdsa_verify_batch_submit(*pb[k % 4], out=po[k % 4]), 8, 4)
+        for depth in (2, 4):
+            ms = [pipelined(lambda k: g.ecdsa_verify_batch_submit(*pb[k % 4], out=po[k % 4]), nb, depth) for _ in range(3)]
             res["group_%d_member_pipelined_depth%d_ms_per_2p%d" % (members, depth, lg)] = sorted(ms)[1] / members
         assert int(po[0].sum()) == n * members
         res["group_%d_member_stats" % members] = g.member_stats()
