@@ -761,6 +761,38 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
         ks.close()
         del d_kidx
 
+    # ---- two contexts on two streams taking resident batches alternately: one batch's grouping and tables beside the other's
+    # ladder.  What a device-resident caller with two batches at hand gets; `value` stays the single-stream figure ----
+    if resident is not None and host_pub is not None:
+        import secp256k1_voi_amd as S2
+        eng_b = S2.Engine(dev.index or 0)
+        streams2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        valid2 = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_pub2 = torch.from_numpy(host_pub).to(dev)
+        dd, dr, ds = resident
+
+        def two_ctx(reps):
+            for k_ in range(reps):
+                j = k_ & 1
+                with torch.cuda.stream(streams2[j]):
+                    (eng, eng_b)[j].ecdsa_verify_batch_device(n, d_pub2.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(),
+                                                              valid2[j].data_ptr(), 0, streams2[j].cuda_stream)
+        for s_ in streams2:
+            s_.wait_stream(torch.cuda.current_stream())
+        two_ctx(4)
+        torch.cuda.synchronize()
+        reps2 = 20
+        t_0 = time.perf_counter()
+        two_ctx(reps2)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t_0) * 1e3 / reps2
+        assert all(int(v.sum().item()) == n for v in valid2), "two-context verification lost verdicts"
+        out["resident_two_contexts"] = {"ms": ms2, "value": n / (ms2 * 1e-3), "unit": "verifications/s",
+                                        "note": "two contexts on two streams, %d resident batches alternately (no bitmap exchange): the "
+                                                "overlap the submit / wait lanes are built on; never `value`" % reps2}
+        eng_b.close()
+        del d_pub2, valid2
+
     # ---- the same batch with key grouping off: every signature as if its key were new (the reference's way) ----
     from secp256k1_voi_amd import KEYS_AUTO, KEYS_OFF
     if n_keys < n:
