@@ -268,6 +268,15 @@ int s2k_group_ecdsa_verify_batch(s2k_group *g, size_t n, const uint8_t *pub_xy, 
 int s2k_group_ecdsa_verify_batch_submit(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32,
                                         const uint8_t *r, const uint8_t *s, uint32_t flags, uint8_t *valid, s2k_ticket *ticket);
 int s2k_group_wait(s2k_group *g, s2k_ticket ticket);
+/* s2k_ecdsa_verify_encoded_batch (below) across the group: the three blobs are shared, every member takes a contiguous range of
+ * ITEMS (its slice of the offset arrays; the offsets stay absolute). */
+int s2k_group_ecdsa_verify_encoded_batch(s2k_group *g, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
+                                         const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,
+                                         const uint64_t *sig_off, int encoding, size_t digest_len, uint32_t flags, uint8_t *valid);
+int s2k_group_ecdsa_verify_encoded_batch_submit(s2k_group *g, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
+                                                const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,
+                                                const uint64_t *sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                                uint8_t *valid, s2k_ticket *ticket);
 /* stats[m * 4 + 0..3] for member m, of its last finished shard: signatures, first index, milliseconds from the member's
  * submit to its verdicts (host clock), device index. */
 int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);

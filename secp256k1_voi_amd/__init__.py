@@ -264,6 +264,8 @@ def load_library() -> C.CDLL:
     lib.s2k_group_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_group_ecdsa_verify_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, C.POINTER(u64)]
     lib.s2k_group_wait.argtypes = [vp, u64]
+    lib.s2k_group_ecdsa_verify_encoded_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, ci, sz, u32, vp]
+    lib.s2k_group_ecdsa_verify_encoded_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, ci, sz, u32, vp, C.POINTER(u64)]
     lib.s2k_group_member_stats.argtypes = [vp, vp]
     lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
@@ -308,6 +310,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ecdsa_verify_batch_submit", "s2k_ecdsa_verify_encoded_batch_submit", "s2k_wait", "s2k_poll", "s2k_wait_all",
     "s2k_device_count", "s2k_group_create", "s2k_group_destroy", "s2k_group_size", "s2k_group_last_error",
     "s2k_group_set_key_grouping", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
+    "s2k_group_ecdsa_verify_encoded_batch", "s2k_group_ecdsa_verify_encoded_batch_submit",
     "s2k_group_member_stats",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
@@ -909,6 +912,23 @@ class Group:
 
     def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
         return self.ecdsa_verify_batch_submit(pub_xy, digest32, r, s, reject_malleable=reject_malleable).wait()
+
+    def ecdsa_verify_encoded_batch_submit(self, pubs, digests, sigs, encoding=ENCODING_ASN1, digest_len=0,
+                                          reject_malleable=False, bip0066=False) -> Ticket:
+        """s2k_group_ecdsa_verify_encoded_batch_submit for lists of byte strings (or pre-built (blob, offsets) pairs)."""
+        def cat(x):
+            return x if isinstance(x, tuple) else _concat(list(x))
+        (pb, po), (db, do), (sb, so) = cat(pubs), cat(digests), cat(sigs)
+        n = len(po) - 1
+        if len(do) - 1 != n or len(so) - 1 != n:
+            raise ValueError("length mismatch")
+        out = np.zeros(n, dtype=np.uint8)
+        flags = (REJECT_MALLEABLE if reject_malleable else 0) | (BIP0066 if bip0066 else 0)
+        t = C.c_uint64(0)
+        self._check(self._lib.s2k_group_ecdsa_verify_encoded_batch_submit(self._h, n, pb.ctypes.data, po.ctypes.data, db.ctypes.data,
+                                                                          do.ctypes.data, sb.ctypes.data, so.ctypes.data, encoding,
+                                                                          digest_len, flags, out.ctypes.data, C.byref(t)))
+        return Ticket(self, int(t.value), out, [pb, po, db, do, sb, so])
 
     def member_stats(self):
         """Per member, of its last finished shard: dict(n, first, ms, device)."""

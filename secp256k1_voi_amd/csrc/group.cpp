@@ -28,7 +28,10 @@ namespace {
 struct shard_job {
   uint64_t ticket = 0;
   size_t lo = 0, n = 0;            // the member's shard of the batch
-  const uint8_t *pub = nullptr, *dig = nullptr, *r = nullptr, *s = nullptr;
+  const uint8_t *pub = nullptr, *dig = nullptr, *r = nullptr, *s = nullptr;   // packed arrays; encoded: pub / dig / s = the three blobs
+  const uint64_t *pub_off = nullptr, *dig_off = nullptr, *sig_off = nullptr;    // encoded form only (pub_off != nullptr)
+  int encoding = 0;
+  size_t digest_len = 0;
   uint32_t flags = 0;
   uint8_t* valid = nullptr;
   std::chrono::steady_clock::time_point t0;
@@ -164,7 +167,10 @@ void member_main(member* me) {
       while (inflight.size() >= MAX_IN_FLIGHT) (void)finish_oldest(true);
       s2k_ticket t = 0;
       int rc = S2K_OK;
-      if (job.n)
+      if (job.n && job.pub_off)   // encoded items: the offsets are absolute, so a shard is the same blobs with shifted offset arrays
+        rc = s2k_ecdsa_verify_encoded_batch_submit(me->ctx, job.n, job.pub, job.pub_off + job.lo, job.dig, job.dig_off + job.lo, job.s,
+                                                   job.sig_off + job.lo, job.encoding, job.digest_len, job.flags, job.valid + job.lo, &t);
+      else if (job.n)
         rc = s2k_ecdsa_verify_batch_submit(me->ctx, job.n, job.pub + job.lo * 64, job.dig + job.lo * 32, job.r + job.lo * 32,
                                            job.s + job.lo * 32, job.flags, job.valid + job.lo, &t);
       if (rc || !job.n) {
@@ -259,11 +265,7 @@ int s2k_group_set_key_grouping(s2k_group* g, int mode, uint32_t min_group, uint3
   return S2K_OK;
 }
 
-int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
-                                        const uint8_t* s, uint32_t flags, uint8_t* valid, s2k_ticket* ticket) {
-  if (!g || !ticket) return S2K_ERR_ARG;
-  *ticket = 0;
-  if (n && (!pub || !dig || !r || !s || !valid)) return gfail(g, S2K_ERR_ARG, "null buffer");
+static int group_submit(s2k_group* g, size_t n, const shard_job& proto, s2k_ticket* ticket) {
   const size_t D = g->members.size();
   // contiguous index shards, rounded up to whole workgroups so that no member gets a ragged tail but the last
   size_t per = (n + D - 1) / D;
@@ -287,16 +289,10 @@ int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* p
   const auto now = std::chrono::steady_clock::now();
   for (size_t i = 0; i < D; ++i) {
     member* me = g->members[i];
-    shard_job job;
+    shard_job job = proto;
     job.ticket = t;
     job.lo = i * per < n ? i * per : n;
     job.n = job.lo + per <= n ? per : n - job.lo;
-    job.pub = pub;
-    job.dig = dig;
-    job.r = r;
-    job.s = s;
-    job.flags = flags;
-    job.valid = valid;
     job.t0 = now;
     {
       std::lock_guard<std::mutex> lock(me->m);
@@ -306,6 +302,55 @@ int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* p
   }
   *ticket = t;
   return S2K_OK;
+}
+
+int s2k_group_ecdsa_verify_batch_submit(s2k_group* g, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r,
+                                        const uint8_t* s, uint32_t flags, uint8_t* valid, s2k_ticket* ticket) {
+  if (!g || !ticket) return S2K_ERR_ARG;
+  *ticket = 0;
+  if (n && (!pub || !dig || !r || !s || !valid)) return gfail(g, S2K_ERR_ARG, "null buffer");
+  shard_job proto;
+  proto.pub = pub;
+  proto.dig = dig;
+  proto.r = r;
+  proto.s = s;
+  proto.flags = flags;
+  proto.valid = valid;
+  return group_submit(g, n, proto, ticket);
+}
+
+// PublicKey.Verify(digest, sig, opts) on encoded items (s2k_ecdsa_verify_encoded_batch) across the group: the blobs are
+// shared, every member takes a contiguous range of ITEMS (its slice of the three offset arrays)
+int s2k_group_ecdsa_verify_encoded_batch_submit(s2k_group* g, size_t n, const uint8_t* pubs, const uint64_t* pub_off,
+                                                const uint8_t* digests, const uint64_t* dig_off, const uint8_t* sigs,
+                                                const uint64_t* sig_off, int encoding, size_t digest_len, uint32_t flags,
+                                                uint8_t* valid, s2k_ticket* ticket) {
+  if (!g || !ticket) return S2K_ERR_ARG;
+  *ticket = 0;
+  if (n && (!pubs || !pub_off || !digests || !dig_off || !sigs || !sig_off || !valid)) return gfail(g, S2K_ERR_ARG, "null buffer");
+  shard_job proto;
+  proto.pub = pubs;
+  proto.dig = digests;
+  proto.s = sigs;
+  proto.pub_off = pub_off;
+  proto.dig_off = dig_off;
+  proto.sig_off = sig_off;
+  proto.encoding = encoding;
+  proto.digest_len = digest_len;
+  proto.flags = flags;
+  proto.valid = valid;
+  if (n == 0) proto.pub_off = nullptr;
+  return group_submit(g, n, proto, ticket);
+}
+
+int s2k_group_ecdsa_verify_encoded_batch(s2k_group* g, size_t n, const uint8_t* pubs, const uint64_t* pub_off, const uint8_t* digests,
+                                         const uint64_t* dig_off, const uint8_t* sigs, const uint64_t* sig_off, int encoding,
+                                         size_t digest_len, uint32_t flags, uint8_t* valid) {
+  s2k_ticket t = 0;
+  const int rc = s2k_group_ecdsa_verify_encoded_batch_submit(g, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, digest_len,
+                                                             flags, valid, &t);
+  if (rc) return rc;
+  return s2k_group_wait(g, t);
 }
 
 int s2k_group_wait(s2k_group* g, s2k_ticket ticket) {

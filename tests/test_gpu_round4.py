@@ -214,6 +214,19 @@ def test_group_two_members_one_device(eng, oracle):
         assert np.array_equal(g.ecdsa_verify_batch(*a, reject_malleable=True), eng.ecdsa_verify_batch(*a, reject_malleable=True))
         with pytest.raises(S.EngineError):
             g._wait(10 ** 6)
+        # encoded items across the group: shared blobs, item ranges per member; DER, compact and recoverable forms
+        n = 20001
+        arrs = damaged_batch(eng, n, 300, 991)
+        ref = eng.ecdsa_verify_batch(*arrs)
+        pubs = [b"\x04" + bytes(q) if i % 3 else oracle.point_compressed(b"\x04" + bytes(q)) if oracle.point_on_curve_xy(bytes(q[:32]), bytes(q[32:])) else b"\x04" + bytes(q)
+                for i, q in enumerate(arrs[0])]
+        digs = [bytes(d) for d in arrs[1]]
+        compact = [bytes(r) + bytes(s_) for r, s_ in zip(arrs[2], arrs[3])]
+        assert np.array_equal(g.ecdsa_verify_encoded_batch_submit(pubs, digs, compact, encoding=S.ENCODING_COMPACT).wait(), ref)
+        assert np.array_equal(eng.ecdsa_verify_encoded_batch(pubs, digs, compact, encoding=S.ENCODING_COMPACT), ref)
+        rec = [c + bytes([i & 3]) for i, c in enumerate(compact)]
+        assert np.array_equal(g.ecdsa_verify_encoded_batch_submit(pubs, digs, rec, encoding=S.ENCODING_COMPACT_RECOVERABLE).wait(),
+                              eng.ecdsa_verify_encoded_batch(pubs, digs, rec, encoding=S.ENCODING_COMPACT_RECOVERABLE))
     finally:
         g.close()
     with pytest.raises(S.EngineError):
