@@ -428,3 +428,13 @@ def test_last_ladder_addition_collisions(eng, oracle):
             assert st["complete"] == 0, st                  # decided by the ladders themselves
         assert np.array_equal(eng.ecdsa_verify_batch(pub, e, r, s, force_complete=True), exp)
         assert np.array_equal(eng.ecdsa_verify_batch(pub, e, r, s, force_worklist=True), exp)
+
+
+def test_streaming_boundary_randomised_stress():
+    """tools/stress_pipeline.py: random batches, sizes, grouping modes, flags, pinned / pageable buffers, depths and waiting
+    orders through submit / wait on one context and through a two-member group, synchronous calls in between; every ticket
+    against the synchronous call, samples against the oracle."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_pipeline.py"), "25", "404"], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and "ok:" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
