@@ -438,3 +438,16 @@ def test_streaming_boundary_randomised_stress():
     import sys
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_pipeline.py"), "25", "404"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "ok:" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_group_bench_tool_one_device():
+    """tools/group_bench.py (the single-process route to all GPUs of a node) on the one device this box has: runs, checks every
+    batch's verdict pattern itself, prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "group_bench.py"), "--devices", "0", "--batch-log2", "16", "--batches", "6"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-1500:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["member_stats_last_shard"][0]["n"] == 1 << 16

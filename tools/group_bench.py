@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""All GPUs of a node from ONE process through the C-ABI's device group (s2k_group_*): what a cgo host gets.
+
+    python tools/group_bench.py [--devices 0,1,...] [--batch-log2 20] [--keys-log2 16] [--batches 16]
+
+Every listed device gets 2^batch_log2 signatures per group batch (weak scaling, like bench.py --gpus N: 2^21 per GPU is BASELINE
+config 5's shape); the packed arrays live in page-locked host memory, four group batches are kept in flight, and the clock runs
+from the completion of the fourth batch to the completion of the last (steady state).  Prints ONE JSON line: whole-node
+verifications/s host to host, per-member times of the last shards, and the verdict check (every batch carries a seeded
+pattern of damaged signatures that must come back as exactly that pattern).  No torch, no RCCL.  On this pool only one device
+per box exists; `--devices 0` is what has been run."""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import secp256k1_voi_amd as S
+from secp256k1_voi_amd.synth import synth_batch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--devices", default=None)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--keys-log2", type=int, default=16)
+    ap.add_argument("--batches", type=int, default=16)
+    a = ap.parse_args()
+    ndev = S.device_count()
+    devices = [int(x) for x in a.devices.split(",")] if a.devices else list(range(ndev))
+    if not devices:
+        print("group_bench.py: no GPU", file=sys.stderr)
+        return 2
+    per = 1 << a.batch_log2
+    n = per * len(devices)
+    # one shard's worth of signatures is synthesised (on device 0, by a temporary engine) and tiled: every member gets the same
+    # keys, which is what per-shard key grouping sees anyway
+    eng = S.Engine(devices[0])
+    base = [np.array(x) for x in synth_batch(eng, per, min(per, 1 << a.keys_log2), seed=0x5EC9)]
+    eng.close()
+    del eng
+    lead, depth = 4, 4
+    bufs, outs, masks = [], [], []
+    for k in range(depth):
+        pb = [S.pinned_array((n, x.shape[1])) for x in base]
+        for d, x in zip(pb, base):
+            for m in range(len(devices)):
+                d[m * per:(m + 1) * per] = x
+        i = np.arange(n, dtype=np.uint64)
+        bad = ((i * np.uint64(2654435761) + np.uint64(k * 7919 + 5)) % np.uint64(61)) == 0
+        pb[3][bad, 31] ^= 1
+        bufs.append(pb)
+        masks.append((~bad).astype(np.uint8))
+        outs.append(S.pinned_array((n,)))
+    g = S.Group(devices)
+    tickets, done, t0 = [], 0, None
+    total = a.batches + lead
+    for k in range(total):
+        outs[k % depth][...] = 9
+        tickets.append((k, g.ecdsa_verify_batch_submit(*bufs[k % depth], out=outs[k % depth])))
+        if len(tickets) >= depth:
+            j, t = tickets.pop(0)
+            assert np.array_equal(t.wait(), masks[j % depth]), "group verdicts differ from the damage pattern (batch %d)" % j
+            done += 1
+            if done == lead:
+                t0 = time.perf_counter()
+    for j, t in tickets:
+        assert np.array_equal(t.wait(), masks[j % depth]), "group verdicts differ from the damage pattern (batch %d)" % j
+        done += 1
+        if done == lead:
+            t0 = time.perf_counter()
+    dt = time.perf_counter() - t0
+    ms = dt * 1e3 / (done - lead)
+    line = {"metric": "secp256k1 ECDSA verifications/sec, host to host, one process, s2k_group over %d device(s)" % len(devices),
+            "value": n / (ms * 1e-3), "unit": "verifications/s", "n_gpus": len(devices), "devices": devices,
+            "ms_per_group_batch": ms, "signatures_per_group_batch": n, "per_gpu_value": per / (ms * 1e-3),
+            "batches_timed": done - lead, "in_flight": depth, "scaling": "weak", "data": "synthetic, page-locked host memory",
+            "member_stats_last_shard": g.member_stats(),
+            "check": "every batch's verdicts equal its seeded damage pattern (one bit of s flipped in every 61st signature)"}
+    g.close()
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
