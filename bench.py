@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe inclusive) measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip configs 3/4, K=N and the worst case (e.g. under a profiler)")
-    ap.add_argument("--key-grouping", choices=("auto", "off", "keyset"), default="auto",
+    ap.add_argument("--key-grouping", choices=("auto", "off", "keyset", "keyset-chunks"), default="auto",
                     help="off: every signature through the general ladder; keyset: the batch against a key set built before the "
                          "timed region (both for profiling those kernels under the driver's settings; not the headline)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -282,9 +282,10 @@ def worker(args):
     gather_scratch = {}
 
     main_keyset = None
-    if args.key_grouping == "keyset":
+    if args.key_grouping in ("keyset", "keyset-chunks"):
         ks_keys, ks_inv = np.unique(pub, axis=0, return_inverse=True)
-        main_keyset = (eng.keyset_create(ks_keys), torch.from_numpy(ks_inv.reshape(-1).astype(np.uint32).view(np.int32)).to(dev))
+        main_keyset = (eng.keyset_create(ks_keys, S.KEYSET_JOINT if args.key_grouping == "keyset" else S.KEYSET_CHUNKS),
+                       torch.from_numpy(ks_inv.reshape(-1).astype(np.uint32).view(np.int32)).to(dev))
 
     def step(inputs=None):
         p, d, rr, ss = inputs or (d_pub, d_dig, d_r, d_s)
@@ -393,7 +394,8 @@ def worker(args):
         clock_hz = prof["shader_mhz"] * 1e6
         value = n * world * args.steps / dt
         counts, counts_src = committed_counts()
-        kname = "k_verify_fast_keyset" if main_keyset is not None else ("k_verify_fast_keyed" if keyed else "k_verify_fast")
+        kname = ("k_verify_fast_keyset_joint" if args.key_grouping == "keyset" else "k_verify_fast_keyset") if main_keyset is not None else \
+            ("k_verify_fast_keyed" if keyed else "k_verify_fast")
         traffic, traffic_src = committed_traffic(kname)
         stages = {"grouping_by_key_ms": prof["group_ms"] / calls, "key_tables_ms": None, "ladder_ms": fast_ms,
                   "general_ladder_ms": prof["left_ms"] / calls, "complete_worklist_ms": prof["fallback_ms"] / calls}
@@ -405,7 +407,7 @@ def worker(args):
             stages["scalar_prep_ms"] = prof["prep_ms"] / calls
             stages.pop("grouping_by_key_ms")
             stages.pop("key_tables_ms")
-        roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYSET>" if main_keyset is not None else ("k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>"),
+        roof = {"bound": "valu", "kernel": ("k_verify_fast<ECDSA_KEYSET_JOINT>" if args.key_grouping == "keyset" else "k_verify_fast<ECDSA_KEYSET>") if main_keyset is not None else ("k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>"),
                 "kernel_ms": fast_ms, "kernel_ms_median": fast_med, "stages_ms": stages,
                 "shader_clock_mhz": prof["shader_mhz"], "shader_clock_mhz_first_wave": prof["shader_mhz_first_wave"],
                 "shader_clock_mhz_last_round": prof["shader_mhz_last_round"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
@@ -415,7 +417,8 @@ def worker(args):
             counts = None
         if counts:
             ipv = counts[kname]["valu_instr_per_signature"]
-            st_ = counts.get("static_keyset" if main_keyset is not None else ("static_keyed" if keyed else "static"), {})
+            st_ = counts.get(("static_keyset_joint" if args.key_grouping == "keyset" else "static_keyset") if main_keyset is not None else
+                             ("static_keyed" if keyed else "static"), {})
             lane_ops = ipv * n / (fast_ms * 1e-3)
             roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
                          "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src,
@@ -647,21 +650,24 @@ def general_roofline(kernel_ms, shader_mhz, n):
     return roof
 
 
-def keyset_roofline(eng, kernel_ms, shader_mhz, n):
-    """`roofline` of k_verify_fast<ECDSA_KEYSET> (64 table additions, no doubling): PMC count when the committed profile has
-    one (bench.py --key-grouping keyset under the counters), else the static recount of the loaded library."""
+def keyset_roofline(eng, kernel_ms, shader_mhz, n, joint=False):
+    """`roofline` of k_verify_fast<ECDSA_KEYSET> (64 table additions, no doubling) or <ECDSA_KEYSET_JOINT> (32): PMC count when
+    the committed profile has one (bench.py --key-grouping keyset / keyset-chunks under the counters), else the static recount
+    of the loaded library."""
     import secp256k1_voi_amd as S
     counts, src = committed_counts()
-    roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYSET>", "kernel_ms": kernel_ms, "shader_clock_mhz": shader_mhz,
-            "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12}
+    kname = "k_verify_fast_keyset_joint" if joint else "k_verify_fast_keyset"
+    roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYSET_JOINT>" if joint else "k_verify_fast<ECDSA_KEYSET>", "kernel_ms": kernel_ms,
+            "shader_clock_mhz": shader_mhz, "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12}
     ipv = None
-    if counts and "k_verify_fast_keyset" in counts:
-        ipv, roof["counts_from"] = counts["k_verify_fast_keyset"]["valu_instr_per_signature"], "profiles/" + src
+    if counts and kname in counts:
+        ipv, roof["counts_from"] = counts[kname]["valu_instr_per_signature"], "profiles/" + src
     else:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import isa_count
-            ipv, roof["counts_from"] = isa_count.keyset(S.LIB_PATH)["valu_instr_static"], "static recount of the loaded library (tools/isa_count.py)"
+            ipv = (isa_count.keyset_joint(S.LIB_PATH) if joint else isa_count.keyset(S.LIB_PATH))["valu_instr_static"]
+            roof["counts_from"] = "static recount of the loaded library (tools/isa_count.py)"
         except Exception as e:
             roof["recount_error"] = repr(e)[:200]
     if ipv and kernel_ms > 0:
@@ -740,25 +746,30 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     # inside every step. ----
     if host_pub is not None and resident is not None and n_keys < n:
         keys, inv = np.unique(host_pub, axis=0, return_inverse=True)
-        ks = eng.keyset_create(keys)
         d_kidx = torch.from_numpy(inv.astype(np.uint32).view(np.int32)).to(dev)
         dd, dr, ds = resident
+        from secp256k1_voi_amd import KEYSET_CHUNKS, KEYSET_JOINT
+        for layout, key in ((KEYSET_JOINT, "keyset_resident"), (KEYSET_CHUNKS, "keyset_resident_chunk_tables")):
+            ks = eng.keyset_create(keys, layout)
 
-        def with_keyset():
-            eng.ecdsa_verify_batch_keyset_device(ks, n, d_kidx.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_valid.data_ptr(), 0, st)
-        d_valid.zero_()
-        with_keyset()
-        eng.profile(True)
-        ms = timed(with_keyset, 10)
-        prk = eng.profile_read_stages(cap=16)
-        eng.profile(False)
-        assert int(d_valid.sum().item()) == n, "key-set verification did not accept the synthetic batch"
-        out["keyset_resident"] = {"keys": int(len(ks)), "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
-                                  "keyset_device_bytes": ks.device_bytes(),
-                                  "roofline": keyset_roofline(eng, prk["fast_ms"] / max(prk["calls"], 1), prk["shader_mhz"], n),
-                                  "note": "s2k_ecdsa_verify_batch_keyset_device: tables of the %d keys built once by s2k_keyset_create "
-                                          "(not timed); per call: scalar preparation, generator part, sort by key index, ladder" % len(ks)}
-        ks.close()
+            def with_keyset():
+                eng.ecdsa_verify_batch_keyset_device(ks, n, d_kidx.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_valid.data_ptr(), 0, st)
+            d_valid.zero_()
+            with_keyset()
+            eng.profile(True)
+            ms = timed(with_keyset, 10)
+            prk = eng.profile_read_stages(cap=16)
+            eng.profile(False)
+            assert int(d_valid.sum().item()) == n, "key-set verification did not accept the synthetic batch"
+            joint = layout == KEYSET_JOINT
+            out[key] = {"keys": int(len(ks)), "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
+                        "layout": "joint tables (S2K_KEYSET_JOINT): one table addition per digit position, 32 per signature" if joint else
+                                  "chunk tables (S2K_KEYSET_CHUNKS): 64 table additions per signature",
+                        "keyset_device_bytes": ks.device_bytes(),
+                        "roofline": keyset_roofline(eng, prk["fast_ms"] / max(prk["calls"], 1), prk["shader_mhz"], n, joint),
+                        "note": "s2k_ecdsa_verify_batch_keyset_device: tables of the %d keys built once by s2k_keyset_create_ex "
+                                "(not timed); per call: scalar preparation, generator part, sort by key index, ladder" % len(ks)}
+            ks.close()
         del d_kidx
 
     # ---- two contexts on two streams taking resident batches alternately: one batch's grouping and tables beside the other's

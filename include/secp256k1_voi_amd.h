@@ -188,6 +188,20 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx *ctx, size_t n, const void *d_digest3
  * while a call that uses the set is in progress on another thread. */
 typedef struct s2k_keyset s2k_keyset;
 int s2k_keyset_create(s2k_ctx *ctx, size_t n_keys, const uint8_t *pub_xy /* n_keys*64, host */, s2k_keyset **out);
+/* The same with the table layout named.  A key set is built once, so its tables can be large:
+ *   S2K_KEYSET_CHUNKS  one 8-entry chunk per 4-bit digit of a half scalar (36 KiB per key): a signature's ladder is 64 table
+ *                      additions and no doubling;
+ *   S2K_KEYSET_JOINT   on top of that, per digit position the sums E_a + s phi(E_b) of the chunk's entries and their images
+ *                      under the endomorphism (320 KiB per key more): the two half scalars' digits at a position are ONE table
+ *                      addition, 32 per signature;
+ *   S2K_KEYSET_AUTO    (s2k_keyset_create) joint tables when they take no more than a quarter of the device memory free at
+ *                      the time, else chunks.
+ * Verdicts are identical in every layout.  s2k_keyset_layout tells which one a set has. */
+#define S2K_KEYSET_AUTO 0
+#define S2K_KEYSET_CHUNKS 1
+#define S2K_KEYSET_JOINT 2
+int s2k_keyset_create_ex(s2k_ctx *ctx, size_t n_keys, const uint8_t *pub_xy, int layout, s2k_keyset **out);
+int s2k_keyset_layout(const s2k_keyset *ks);
 void s2k_keyset_destroy(s2k_keyset *ks);
 size_t s2k_keyset_size(const s2k_keyset *ks);
 size_t s2k_keyset_device_bytes(const s2k_keyset *ks);

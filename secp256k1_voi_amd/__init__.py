@@ -46,6 +46,7 @@ ENCODING_ASN1, ENCODING_COMPACT, ENCODING_COMPACT_RECOVERABLE = 0, 1, 2
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 IMPL_COMPLETE, IMPL_FAST = 0, 1
 KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS = 0, 1, 2     # s2k_ctx_set_key_grouping
+KEYSET_AUTO, KEYSET_CHUNKS, KEYSET_JOINT = 0, 1, 2   # s2k_keyset_create_ex
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
  HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
  HP_PT29_ADD_MIXED, HP_INV_GCD, HP_JADD_FULL, HP_PT29Q_DBL, HP_PT29Q_ADD, HP_XYZZ_ADD, HP_XYZZ_ROUND) = range(27)
@@ -223,6 +224,8 @@ def load_library() -> C.CDLL:
     lib.s2k_ecdsa_recover_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp, vp]
     lib.s2k_pack_valid_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.s2k_keyset_create.argtypes = [vp, sz, vp, C.POINTER(vp)]
+    lib.s2k_keyset_create_ex.argtypes = [vp, sz, vp, ci, C.POINTER(vp)]
+    lib.s2k_keyset_layout.argtypes = [vp]
     lib.s2k_keyset_destroy.argtypes = [vp]
     lib.s2k_keyset_destroy.restype = None
     lib.s2k_keyset_size.argtypes = [vp]
@@ -302,7 +305,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages", "s2k_ctx_profile_msm", "s2k_ctx_profile_read_msm",
     "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
-    "s2k_keyset_create", "s2k_keyset_destroy", "s2k_keyset_size", "s2k_keyset_device_bytes", "s2k_keyset_valid_keys",
+    "s2k_keyset_create", "s2k_keyset_create_ex", "s2k_keyset_layout", "s2k_keyset_destroy", "s2k_keyset_size", "s2k_keyset_device_bytes", "s2k_keyset_valid_keys",
     "s2k_ecdsa_verify_batch_keyset", "s2k_ecdsa_verify_batch_keyset_device",
     "s2k_pack_valid_device", "s2k_host_alloc", "s2k_host_free", "s2k_host_register", "s2k_host_unregister", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
@@ -497,9 +500,10 @@ class Engine:
         self._check(self._lib.s2k_wait_all(self._h))
 
     # ---- key sets ----------------------------------------------------------------------
-    def keyset_create(self, pub_xy) -> "KeySet":
-        """Per-key tables of a fixed list of public keys (n_keys x 64 bytes), built once (s2k_keyset_create)."""
-        return KeySet(self, pub_xy)
+    def keyset_create(self, pub_xy, layout: int = 0) -> "KeySet":
+        """Per-key tables of a fixed list of public keys (n_keys x 64 bytes), built once (s2k_keyset_create[_ex]);
+        layout: KEYSET_AUTO (0), KEYSET_CHUNKS (1), KEYSET_JOINT (2)."""
+        return KeySet(self, pub_xy, layout)
 
     def ecdsa_verify_batch_keyset(self, keyset, key_index, digest32, r, s, reject_malleable: bool = False,
                                   force_worklist: bool = False) -> np.ndarray:
@@ -941,12 +945,16 @@ class Group:
 class KeySet:
     """Handle of s2k_keyset_*: the per-key tables of a fixed key list on the engine's device."""
 
-    def __init__(self, engine: "Engine", pub_xy):
+    def __init__(self, engine: "Engine", pub_xy, layout: int = 0):
         pub_xy = _arr(pub_xy, 64)
         self._eng = engine
         k = C.c_void_p()
-        engine._check(engine._lib.s2k_keyset_create(engine._h, pub_xy.shape[0], pub_xy.ctypes.data, C.byref(k)))
+        engine._check(engine._lib.s2k_keyset_create_ex(engine._h, pub_xy.shape[0], pub_xy.ctypes.data, int(layout), C.byref(k)))
         self._k = k
+
+    def layout(self) -> int:
+        """KEYSET_CHUNKS or KEYSET_JOINT (s2k_keyset_layout)."""
+        return int(self._eng._lib.s2k_keyset_layout(self._k))
 
     def __len__(self):
         return int(self._eng._lib.s2k_keyset_size(self._k))

@@ -474,7 +474,7 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // ---------------------------------------------------------------------------------------
 
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
-       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8 };
+       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8, MODE_ECDSA_KEYSET_JOINT = 9 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 constexpr uint32_t KVF_FORCE_WORKLIST = 0x80000000u;   // top bit of k_verify_fast's first argument (batches are below 2^31)
 
@@ -578,7 +578,8 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
               key_groups kg) {
-  constexpr bool KEYSET = MODE == MODE_ECDSA_KEYSET;   // KEYED over a key set's 32-chunk tables: no doublings at all
+  constexpr bool JOINT = MODE == MODE_ECDSA_KEYSET_JOINT;   // ... over its joint tables: one addition per digit position
+  constexpr bool KEYSET = MODE == MODE_ECDSA_KEYSET || JOINT;   // KEYED over a key set's 32-chunk tables: no doublings at all
   constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED || KEYSET;
   constexpr bool GROUPED = KEYED || MODE == MODE_ECDSA_LEFT || MODE == MODE_SCHNORR_LEFT;
   constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT || KEYSET;
@@ -753,12 +754,15 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
     if constexpr (KEYSET) {
       // Key sets: one chunk per digit, {1,3,..,15} * 16^i Q for i < 32 and L = 16^32 Q: k = 16^32 + sum d_i 16^i is 64
       // table additions, in any order - bottom up, nibble i = bits 4i+1 .. 4i+4 of the odd half scalar (k >> 1, 128 bits).
+      // JOINT tables hold, per position, E_a + s phi(E_b) for all pairs of odd multiples and both signs: the two halves'
+      // digits d1 = +-(2a+1), d2 = +-(2b+1) are ONE addition of +-(E_a + s phi(E_b)), s = the product of their signs.
       uint32_t a[4], b[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         a[w] = (k1.v[w] >> 1) | (k1.v[w + 1] << 31);
         b[w] = (k2.v[w] >> 1) | (k2.v[w + 1] << 31);
       }
+      [[maybe_unused]] const uint4* jt = JOINT ? kg.jtab + (size_t)kg.ptab[idx] * KJ_KEY_QUADS : nullptr;
 #pragma unroll 1
       for (int c = 0; c < KS_CHUNKS; ++c) {
         const uint32_t w1 = a[0] & 15u, w2 = b[0] & 15u;
@@ -769,14 +773,23 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
         }
         a[3] >>= 4;
         b[3] >>= 4;
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-          uint32_t w = t ? w2 : w1;
-          bool neg = (t ? neg2 : neg1) != (w < 8u);
-          uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+        if constexpr (JOINT) {
+          const bool n1 = neg1 != (w1 < 8u), n2 = neg2 != (w2 < 8u);          // signs of the two signed digits
+          const uint32_t ea = (w1 < 8u) ? (7u - w1) : (w1 - 8u), eb = (w2 < 8u) ? (7u - w2) : (w2 - 8u);
+          const uint32_t j = (((uint32_t)c * 8u + ea) * 8u + eb) * 2u + (n1 != n2 ? 1u : 0u);
           fe29 x, y;
-          ke_load_xy(kt + (size_t)(c * 8 + entry) * 8, t != 0, x, y);
-          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, neg));
+          je_load(jt + (size_t)j * KJ_ENTRY_QUADS, x, y);
+          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
+        } else {
+#pragma unroll 1
+          for (int t = 0; t < 2; ++t) {
+            uint32_t w = t ? w2 : w1;
+            bool neg = (t ? neg2 : neg1) != (w < 8u);
+            uint32_t entry = (w < 8u) ? (7u - w) : (w - 8u);
+            fe29 x, y;
+            ke_load_xy(kt + (size_t)(c * 8 + entry) * 8, t != 0, x, y);
+            xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, neg));
+          }
         }
       }
     } else {
@@ -1840,10 +1853,16 @@ struct s2k_keyset {
   size_t n;
   uint8_t* base;      // device: keys | tables | validity | identity | counters (s2k_internal_keyset_bytes)
   size_t bytes;
+  uint4* joint;       // device: the joint tables (320 KiB per key), or null: the ladder over the 32-chunk tables
+  size_t joint_bytes;
 };
 
 int s2k_keyset_create(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, s2k_keyset** out) {
+  return s2k_keyset_create_ex(ctx, n_keys, pub_xy, S2K_KEYSET_AUTO, out);
+}
+int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int layout, s2k_keyset** out) {
   if (!ctx || !out) return fail(ctx, S2K_ERR_ARG, "null argument");
+  if (layout != S2K_KEYSET_AUTO && layout != S2K_KEYSET_CHUNKS && layout != S2K_KEYSET_JOINT) return fail(ctx, S2K_ERR_ARG, "unknown key-set layout");
   *out = nullptr;
   if (n_keys == 0 || !pub_xy) return fail(ctx, S2K_ERR_ARG, "empty key set");
   if (n_keys > 0x0fffffffu) return fail(ctx, S2K_ERR_ARG, "key set too large");
@@ -1868,9 +1887,31 @@ int s2k_keyset_create(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, s2k_ke
   if (rc == S2K_OK && hipMemcpyAsync(ks->base + off[0], pub_xy, n_keys * 64, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(ctx, S2K_ERR_HIP, "copy of the keys failed");
   if (rc == S2K_OK) rc = s2k_internal_keyset_build(ctx, ks->base, n_keys, st);
+  // joint tables (one table addition per digit position instead of two; 320 KiB per key on top): when asked for, or -
+  // S2K_KEYSET_AUTO - when they take no more than a quarter of the device memory that is free now
+  ks->joint = nullptr;
+  ks->joint_bytes = 0;
+  if (rc == S2K_OK && layout != S2K_KEYSET_CHUNKS) {
+    const size_t want = n_keys * KJ_KEY_QUADS * sizeof(uint4);
+    size_t free_b = 0, total_b = 0;
+    bool take = layout == S2K_KEYSET_JOINT;
+    if (!take && hipMemGetInfo(&free_b, &total_b) == hipSuccess) take = want <= free_b / 4;
+    if (take) {
+      const hipError_t e2 = hipMalloc((void**)&ks->joint, want);
+      if (e2 == hipSuccess) {
+        ks->joint_bytes = want;
+        rc = s2k_internal_keyset_build_joint(ctx, ks->base, n_keys, ks->joint, st);
+      } else {
+        (void)hipGetLastError();
+        ks->joint = nullptr;
+        if (layout == S2K_KEYSET_JOINT) rc = fail(ctx, S2K_ERR_HIP, "joint tables of %zu keys (%zu bytes): %s", n_keys, want, hipGetErrorString(e2));
+      }
+    }
+  }
   if (rc == S2K_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "key set build failed");
   ctx->have_last = false;
   if (rc) {
+    if (ks->joint) (void)hipFree(ks->joint);
     (void)hipFree(ks->base);
     delete ks;
     return rc;
@@ -1882,11 +1923,13 @@ void s2k_keyset_destroy(s2k_keyset* ks) {
   if (!ks) return;
   (void)hipSetDevice(ks->device);
   (void)hipDeviceSynchronize();
+  if (ks->joint) (void)hipFree(ks->joint);
   (void)hipFree(ks->base);
   delete ks;
 }
 size_t s2k_keyset_size(const s2k_keyset* ks) { return ks ? ks->n : 0; }
-size_t s2k_keyset_device_bytes(const s2k_keyset* ks) { return ks ? ks->bytes : 0; }
+size_t s2k_keyset_device_bytes(const s2k_keyset* ks) { return ks ? ks->bytes + ks->joint_bytes : 0; }
+int s2k_keyset_layout(const s2k_keyset* ks) { return !ks ? 0 : (ks->joint ? S2K_KEYSET_JOINT : S2K_KEYSET_CHUNKS); }
 int s2k_keyset_valid_keys(s2k_keyset* ks, uint8_t* valid) {
   if (!ks || !valid) return fail(nullptr, S2K_ERR_ARG, "null argument");
   size_t off[5];
@@ -1951,9 +1994,14 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   }
   kg.gp = gp;
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
+  kg.jtab = ks->joint;
   prof_mark(ctx, st, 2);
-  k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
-                                                                  (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+  if (ks->joint)
+    k_verify_fast<MODE_ECDSA_KEYSET_JOINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
+                                                                          ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+  else
+    k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
+                                                                    (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   prof_mark(ctx, st, 3);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback_keyset<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, ks->base + off[0], (const uint32_t*)d_key_index,

@@ -307,6 +307,13 @@ constexpr int KT_SCR = kt_geom<8>::SCR;
 constexpr int KT_W_SLOT = kt_geom<8>::W_SLOT;   // 9
 constexpr int KS_CHUNKS = 32;                   // key sets
 constexpr int KS_SLOTS = kt_geom<32>::SLOTS;    // 288
+// Key sets, JOINT tables: for every digit position c the sums E_a + s phi(E_b) of the chunk's odd multiples (a, b < 8, s = +-),
+// so that the two half scalars' digits at a position cost ONE table addition: 32 additions per signature instead of 64.
+// 128 entries per position, 80 bytes each (x and y of an affine point of the key's isomorphic curve: five quads
+// [x 0-3][x 4-7][y 0-3][y 4-7][x8, y8, -, -]), 4096 entries = 320 KiB per key, built once from the 32-chunk table.
+constexpr int KJ_ENTRY_QUADS = 5;
+constexpr int KJ_PER_CHUNK = 128;
+constexpr size_t KJ_KEY_QUADS = (size_t)KS_CHUNKS * KJ_PER_CHUNK * KJ_ENTRY_QUADS;   // 20480 quads = 320 KiB
 static_assert(KT_SLOTS == 72 && KT_W_SLOT == 9 && kt_geom<32>::SLOTS == 288, "table geometry");
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
@@ -321,6 +328,7 @@ struct key_groups {        // device pointers of one call
   uint32_t* ptab;          // keyed lane -> table
   uint32_t* left;          // dense lane of the general kernel -> signature
   const uint4* ktab;       // tables, KT_SLOTS * 8 quads each
+  const uint4* jtab;       // key sets with joint tables: KJ_KEY_QUADS quads per key (else null)
   const uint8_t* tinfo;    // per table: 1 if the key is a valid public key
   const uint32_t* trep;    // per table: a signature that carries the key
   const uint32_t* gp;      // per signature: u1*G (Jacobian, three fin-format elements; k_generator_part)
@@ -355,6 +363,7 @@ int s2k_internal_key_reserve32(s2k_ctx* ctx, size_t n);
 // key sets (s2k_keyset_*): buffer layout, table build, scratch reservation, sort of a batch by key index
 size_t s2k_internal_keyset_bytes(size_t n, size_t off[5]);
 int s2k_internal_keyset_build(s2k_ctx* ctx, uint8_t* base, size_t n, hipStream_t st);
+int s2k_internal_keyset_build_joint(s2k_ctx* ctx, const uint8_t* base, size_t n, uint4* joint, hipStream_t st);   // from the 32-chunk tables
 int s2k_internal_keyset_reserve(s2k_ctx* ctx, size_t nkeys, size_t n);
 int s2k_internal_keyset_sort(s2k_ctx* ctx, const uint8_t* set_base, size_t nkeys, size_t n, const uint32_t* d_kidx, hipStream_t st,
                              key_groups* out);

@@ -707,6 +707,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   out->ptab = ptab;
   out->left = left;
   out->ktab = (const uint4*)ctx->ktab;
+  out->jtab = nullptr;
   out->tinfo = tinfo;
   out->trep = trep;
   out->max_tables = (uint32_t)max_tables;
@@ -799,6 +800,54 @@ __global__ void __launch_bounds__(256) k_ks_iota(uint32_t n, uint32_t* __restric
   if (i < n) a[i] = i;
   if (i == 0) counters[KG_NTAB] = n;
 }
+
+// Joint tables of a key set (engine_internal.h: KJ_*), one lane per (key, digit position).  The position's eight odd
+// multiples E_0 .. E_7 are affine points of the key's isomorphic curve (k_key_scale), and so are their images under the
+// endomorphism, phi(E_b) = (beta x_b, y_b).  For every pair (a, b): J[a][b][0] = E_a + phi(E_b), J[a][b][1] = E_a - phi(E_b),
+// by the AFFINE addition law (lambda = (y2 - y1) / (x2 - x1): it contains no curve constant, so it holds on the isomorphic
+// curve), the 64 denominators beta x_b - x_a - the same for both signs - inverted together (Montgomery's trick, one safegcd
+// inversion per lane; the prefix products are parked in the entries' own slots).  x2 = x1 would need (2a+1) = +-(2b+1) lambda
+// mod n: never.  Cost per lane: 64 * 9 products and an inversion; once per key set.
+__global__ void __launch_bounds__(64)
+k_ks_joint(uint32_t nkeys, const uint4* __restrict__ ktab, uint4* __restrict__ jtab) {
+  const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t t = id / KS_CHUNKS, c = id % KS_CHUNKS;
+  if (t >= nkeys) return;
+  const uint4* e0 = ktab + (size_t)t * (KS_SLOTS * 8) + (size_t)(c * 8) * 8;
+  uint4* j0 = jtab + (size_t)t * KJ_KEY_QUADS + (size_t)c * KJ_PER_CHUNK * KJ_ENTRY_QUADS;
+  fe29 pre = fe29_one();
+#pragma unroll 1
+  for (int k = 0; k < 64; ++k) {
+    const int a = k >> 3, b = k & 7;
+    const fe29 xa = ke_load(e0 + (size_t)a * 8, TB_X), bxb = ke_load(e0 + (size_t)b * 8, TB_BX);
+    const fe29 d = fe29_add(bxb, fe29_negate(xa, 1));                            // x2 - x1 [3]
+    pre = fe29_mul(pre, d);
+    je_store1(j0 + (size_t)(2 * k) * KJ_ENTRY_QUADS, pre);
+  }
+  fe29 inv = fe29_inv_gcd(pre);
+#pragma unroll 1
+  for (int k = 63; k >= 0; --k) {
+    const int a = k >> 3, b = k & 7;
+    fe29 xa, ya, bxa, xb, yb, bxb;
+    ke_load3(e0 + (size_t)a * 8, xa, ya, bxa);
+    ke_load3(e0 + (size_t)b * 8, xb, yb, bxb);
+    const fe29 d = fe29_add(bxb, fe29_negate(xa, 1));
+    const fe29 prev = k ? je_load1(j0 + (size_t)(2 * (k - 1)) * KJ_ENTRY_QUADS) : fe29_one();
+    const fe29 di = fe29_mul(inv, prev);                                         // 1 / (x2 - x1)
+    inv = fe29_mul(inv, d);
+    const fe29 nxs = fe29_negate(fe29_add(xa, bxb), 2);                          // -(x1 + x2) [3]
+    const fe29 nya = fe29_negate(ya, 1);                                         // -y1 [2]
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      // y2 - y1 with y2 = +-y_b
+      const fe29 dy = s_ ? fe29_negate(fe29_add(yb, ya), 2) : fe29_add(yb, nya);   // [3]
+      const fe29 lam = fe29_mul(dy, di);                                         // [1]
+      const fe29 x3 = fe29_sqr_plus(lam, nxs);                                   // lambda^2 - x1 - x2 [1]
+      const fe29 y3 = fe29_mul_plus(lam, fe29_add(xa, fe29_negate(x3, 1)), nya); // lambda (x1 - x3) - y1 [1]
+      je_store(j0 + (size_t)(2 * k + s_) * KJ_ENTRY_QUADS, x3, y3);
+    }
+  }
+}
 }  // namespace
 
 // device memory of a key set of n keys: keys | tables | validity | identity | counters
@@ -831,6 +880,15 @@ __attribute__((visibility("hidden"))) int s2k_internal_keyset_build(s2k_ctx* ctx
   int rc = s2k_internal_key_chains(ctx, base + off[0], st, &g);
   if (rc) return rc;
   return s2k_internal_key_tables(ctx, st, &g, 0, 1, nullptr);
+}
+// the joint tables of a key set whose 32-chunk tables are built (same stream, behind them)
+__attribute__((visibility("hidden"))) int s2k_internal_keyset_build_joint(s2k_ctx* ctx, const uint8_t* base, size_t n, uint4* joint,
+                                                                         hipStream_t st) {
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(n, off);
+  k_ks_joint<<<(unsigned)((n * KS_CHUNKS + 63) / 64), 64, 0, st>>>((uint32_t)n, (const uint4*)(base + off[1]), joint);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
 }
 // scratch of the sort below, in the context's grouping arrays: counters | cnt, base [nkeys] | slot_of, pos_of, perm, ptab, left [n]
 __attribute__((visibility("hidden"))) int s2k_internal_keyset_reserve(s2k_ctx* ctx, size_t nkeys, size_t n) {
@@ -872,6 +930,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_keyset_sort(s2k_ctx* ctx,
   out->ptab = ptab;
   out->left = left;
   out->ktab = (const uint4*)(set_base + off[1]);
+  out->jtab = nullptr;
   out->tinfo = set_base + off[2];
   out->trep = (const uint32_t*)(set_base + off[3]);
   out->max_tables = (uint32_t)nkeys;

@@ -119,4 +119,33 @@ S2K_DEV void ke_load_xy(const uint4* __restrict__ e, bool lam, fe29& x, fe29& y)
   y.n[8] = t.y;
 }
 
+// joint entries of a key set (engine_internal.h: KJ_*): x and y in five quads
+S2K_DEV void je_store(uint4* __restrict__ e, const fe29& x, const fe29& y) {
+  e[0] = make_uint4(x.n[0], x.n[1], x.n[2], x.n[3]);
+  e[1] = make_uint4(x.n[4], x.n[5], x.n[6], x.n[7]);
+  e[2] = make_uint4(y.n[0], y.n[1], y.n[2], y.n[3]);
+  e[3] = make_uint4(y.n[4], y.n[5], y.n[6], y.n[7]);
+  e[4] = make_uint4(x.n[8], y.n[8], 0u, 0u);
+}
+S2K_DEV void je_load(const uint4* __restrict__ e, fe29& x, fe29& y) {
+  const uint4 a = e[0], b = e[1], c = e[2], d = e[3], t = e[4];
+  x.n[0] = a.x; x.n[1] = a.y; x.n[2] = a.z; x.n[3] = a.w; x.n[4] = b.x; x.n[5] = b.y; x.n[6] = b.z; x.n[7] = b.w;
+  y.n[0] = c.x; y.n[1] = c.y; y.n[2] = c.z; y.n[3] = c.w; y.n[4] = d.x; y.n[5] = d.y; y.n[6] = d.z; y.n[7] = d.w;
+  x.n[8] = t.x;
+  y.n[8] = t.y;
+}
+// one field element parked in the first three quads of a joint entry's slot (the build's prefix products)
+S2K_DEV void je_store1(uint4* __restrict__ e, const fe29& v) {
+  e[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
+  e[1] = make_uint4(v.n[4], v.n[5], v.n[6], v.n[7]);
+  e[2] = make_uint4(v.n[8], 0u, 0u, 0u);
+}
+S2K_DEV fe29 je_load1(const uint4* __restrict__ e) {
+  const uint4 a = e[0], b = e[1], c = e[2];
+  fe29 r;
+  r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w; r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
+  r.n[8] = c.x;
+  return r;
+}
+
 }  // namespace s2k

@@ -242,7 +242,8 @@ def test_synthetic_signatures_against_libcrypto(eng):
     assert int(got.sum()) >= n - n // 5 - 1 and int(got.sum()) < n
 
 
-def test_keyset_matches_batch_verifier(eng, oracle):
+@pytest.mark.parametrize("layout", [1, 2])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT
+def test_keyset_matches_batch_verifier(eng, oracle, layout):
     """s2k_keyset_*: tables of a fixed key list built once, signatures name their key by index.  Same verdicts as
     s2k_ecdsa_verify_batch on the expanded key array and as the oracle: valid and damaged signatures, keys that are no
     public keys (off the curve, coordinate >= p, all zero: every signature under them false), key indices outside the set
@@ -265,8 +266,9 @@ def test_keyset_matches_batch_verifier(eng, oracle):
         a[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
     kidx[11] = len(keys)                                               # outside the set
     kidx[12] = 0xFFFFFFFF
-    ks = eng.keyset_create(keys)
-    assert len(ks) == len(keys) and ks.device_bytes() >= len(keys) * 9216
+    ks = eng.keyset_create(keys, layout)
+    assert ks.layout() == layout
+    assert len(ks) == len(keys) and ks.device_bytes() >= len(keys) * (36864 if layout == 1 else 36864 + 327680)
     vk = ks.valid_keys()
     assert [k for k in range(len(keys)) if not vk[k]] == sorted(bad_keys)
     got = eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s)
@@ -294,7 +296,8 @@ def test_keyset_matches_batch_verifier(eng, oracle):
     ks.close()
 
 
-def test_keyset_worklist_and_full_size(eng):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_keyset_worklist_and_full_size(eng, layout):
     """Key set at BASELINE size: 2^20 signatures of 2^16 keys against the batch verifier (grouping on), and an adversarial
     batch whose every lane ends on the complete-formula worklist (u1 G + u2 Q = infinity), which must reach the worklist
     kernel's key-set form and come back all false."""
@@ -302,7 +305,7 @@ def test_keyset_worklist_and_full_size(eng):
     n, nk = 1 << 20, 1 << 16
     pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, nk, seed=4))
     keys, inv = np.unique(pub, axis=0, return_inverse=True)
-    ks = eng.keyset_create(keys)
+    ks = eng.keyset_create(keys, layout)
     r[::9, 3] ^= 4
     got = eng.ecdsa_verify_batch_keyset(ks, inv.astype(np.uint32), dig, r, s)
     assert np.array_equal(got, eng.ecdsa_verify_batch(pub, dig, r, s))
@@ -311,7 +314,7 @@ def test_keyset_worklist_and_full_size(eng):
     m = 1 << 14
     pub, dig, r, s = (np.array(a) for a in synth_all_fallback_batch(eng, m, 64, seed=6))
     keys, inv = np.unique(pub, axis=0, return_inverse=True)
-    ks = eng.keyset_create(keys)
+    ks = eng.keyset_create(keys, layout)
     got = eng.ecdsa_verify_batch_keyset(ks, inv.astype(np.uint32), dig, r, s)
     assert not got.any() and eng.key_grouping_stats()["complete"] == 0     # (decided in the ladder's final addition since round 4)
     got = eng.ecdsa_verify_batch_keyset(ks, inv.astype(np.uint32), dig, r, s, force_worklist=True)

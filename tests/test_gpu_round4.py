@@ -451,3 +451,44 @@ def test_group_bench_tool_one_device():
     assert p.returncode == 0, p.stderr[-1500:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["member_stats_last_shard"][0]["n"] == 1 << 16
+
+
+# ---- key sets with joint tables -------------------------------------------------------------------------------------------
+def test_keyset_joint_tables_edge_scalars(eng, oracle):
+    """S2K_KEYSET_JOINT: per digit position the sums E_a + s phi(E_b) of the chunk's entries, one table addition for both half
+    scalars.  VALID signatures with chosen u2 = r/s around the recoding's corners (every digit pair (d1, d2) must pick the right
+    entry and sign: tiny values, all-ones and alternating nibbles, lambda and its neighbours, n - small, values whose halves
+    have opposite signs) under a few keys, plus damaged ones: verdicts of the joint layout, the chunk layout and the batch
+    verifier must agree with the oracle; S2K_KEYSET_AUTO picks the joint layout for a small set."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(909)
+    ds = [rnd.randrange(1, R.N) for _ in range(5)]
+    Q = [oracle.scalar_base_mult_vartime(b32(d)) for d in ds]
+    u2s = [1, 2, 3, 15, 16, 17, 255, 256, R.N - 1, R.N - 2, R.N - 16, R.LAMBDA, R.LAMBDA + 1, R.LAMBDA - 1, R.N - R.LAMBDA, 2 * R.LAMBDA % R.N,
+           (1 << 128) - 1, 1 << 128, (1 << 128) + 1, (1 << 127), int("8" * 64, 16) % R.N, int("7" * 64, 16) % R.N, int("f0" * 32, 16) % R.N,
+           int("0f" * 32, 16) % R.N, int("a5" * 32, 16) % R.N, (-26 * R.LAMBDA) % R.N, (-26 * 16 ** 28 * R.LAMBDA) % R.N]
+    u2s += [rnd.randrange(1, R.N) for _ in range(300)] + [(rnd.randrange(1, 1 << 20) << (4 * rnd.randrange(0, 60))) % R.N or 1 for _ in range(200)]
+    pub, dig, rr, ss, kidx = [], [], [], [], []
+    for i, u2 in enumerate(u2s):
+        ki = i % len(ds)
+        k = rnd.randrange(1, R.N)                               # R = k G, k = u1 + u2 d
+        Rp = oracle.scalar_base_mult_vartime(b32(k))
+        r = int.from_bytes(Rp[1:33], "big") % R.N
+        if r == 0:
+            continue
+        u1 = (k - u2 * ds[ki]) % R.N
+        s = r * pow(u2, -1, R.N) % R.N
+        e = u1 * s % R.N
+        if i % 9 == 8:
+            e = (e + 1) % R.N                                   # damaged
+        pub.append(Q[ki][1:]); dig.append(b32(e)); rr.append(b32(r)); ss.append(b32(s)); kidx.append(ki)
+    exp = oracle.ecdsa_verify_batch(b"".join(pub), b"".join(dig), b"".join(rr), b"".join(ss), nthreads=os.cpu_count() or 1)
+    assert 0.8 * len(exp) < int(exp.sum()) < len(exp)
+    keys = np.frombuffer(b"".join(q[1:] for q in Q), np.uint8).reshape(-1, 64)
+    for layout in (S.KEYSET_JOINT, S.KEYSET_CHUNKS, S.KEYSET_AUTO):
+        ks = eng.keyset_create(keys, layout)
+        assert ks.layout() == (S.KEYSET_CHUNKS if layout == S.KEYSET_CHUNKS else S.KEYSET_JOINT)
+        got = eng.ecdsa_verify_batch_keyset(ks, np.array(kidx, np.uint32), dig, rr, ss)
+        assert np.array_equal(got, exp), (layout, np.nonzero(got != exp)[0][:10])
+        ks.close()
+    assert np.array_equal(eng.ecdsa_verify_batch(pub, dig, rr, ss), exp)

@@ -42,6 +42,15 @@ cp $O/prof_k_$TAG/run_kernel_stats.csv $P/keyset/kernel_stats_bench_steps20_warm
 python3 tools/collect_traffic.py $O/pmc_fetch_k_$TAG $O/pmc_write_k_$TAG > $P/keyset/hbm_traffic.json
 python3 tools/summarize_profiles_r02.py $O/prof_k_$TAG/run_kernel_trace.csv $O/pmc_k_$TAG $P/keyset
 $K > $P/keyset/bench_same_box_unprofiled.json 2>/dev/null
+# the key-set ladder over chunk tables (64 additions): the instruction counters only
+C="$B --key-grouping keyset-chunks"
+mkdir -p $P/keyset_chunks
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c_$TAG -o run -- $C > $P/keyset_chunks/bench_under_kernel_trace.json 2> /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_c_$TAG -o run -- $C > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_c_$TAG -o run -- $C > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc_c_$TAG -o run -- $C > /dev/null 2>&1
+python3 tools/collect_traffic.py $O/pmc_fetch_c_$TAG $O/pmc_write_c_$TAG > $P/keyset_chunks/hbm_traffic.json
+python3 tools/summarize_profiles_r02.py $O/prof_c_$TAG/run_kernel_trace.csv $O/pmc_c_$TAG $P/keyset_chunks
 # the unprofiled bench right after, same box: the lines the profiles have to reconcile with
 $B > $P/bench_same_box_unprofiled.json 2>/dev/null
 $G > $P/general/bench_same_box_unprofiled.json 2>/dev/null

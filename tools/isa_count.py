@@ -256,8 +256,19 @@ def keyset(lib):
             "instructions": len(g.ins)}
 
 
+def keyset_joint(lib):
+    """k_verify_fast<ECDSA_KEYSET_JOINT>: one loop over the 32 digit positions, one table addition each"""
+    g = Cfg(disassemble(lib, "_Z13k_verify_fastILi9EE"))
+    top = g.top_level()
+    assert len(top) == 1 and not g.children(top[0]), ("unexpected loop structure of k_verify_fast<ECDSA_KEYSET_JOINT>", [g.loops[k]["entries"] for k in top])
+    valu, mad = g.count(g.weights({top[0]: 32}))
+    return {"valu_instr_static": valu, "mad_u64_u32_per_verify": mad, "valu_per_trip": {"addition": g.valu_in(g.loops[top[0]]["blocks"])},
+            "instructions": len(g.ins)}
+
+
 def static_counts(lib=DEFAULT_LIB, gt_windows=12):
-    return {"k_verify_fast": general(lib, gt_windows), "k_verify_fast_keyed": keyed(lib), "k_verify_fast_keyset": keyset(lib)}
+    return {"k_verify_fast": general(lib, gt_windows), "k_verify_fast_keyed": keyed(lib), "k_verify_fast_keyset": keyset(lib),
+            "k_verify_fast_keyset_joint": keyset_joint(lib)}
 
 
 if __name__ == "__main__":

@@ -33,18 +33,21 @@ def main():
     out["source"] = ("rocprofv3 --pmc of bench.py --steps 20 --warmup 5 (tools/collect_profiles_r04.sh): averages over the timed steps, 2^20 "
                      "signatures of 2^16 keys per dispatch; k_verify_fast (the general ladder) from the same passes with --key-grouping off")
     out["k_verify_fast"] = general["k_verify_fast"]
-    ks_path = os.path.join(src, "keyset", "valu_counts.json")
-    if os.path.exists(ks_path):
-        ks = json.load(open(ks_path))
-        if "k_verify_fast_keyset" in ks:
-            out["k_verify_fast_keyset"] = ks["k_verify_fast_keyset"]
+    for sub in ("keyset", "keyset_chunks"):
+        ks_path = os.path.join(src, sub, "valu_counts.json")
+        if os.path.exists(ks_path):
+            ks = json.load(open(ks_path))
+            for kn in ("k_verify_fast_keyset", "k_verify_fast_keyset_joint"):
+                if kn in ks:
+                    out[kn] = ks[kn]
     head = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     out["head"] = head
     # whole step: every kernel of a grouped step, VALU instructions per verification
     whole = sum(v["valu_instr_per_signature"] for k, v in grouped.items()
                 if isinstance(v, dict) and "valu_instr_per_signature" in v and k.startswith("k_") and
                 k not in ("k_gen_gtable", "k_gen_gtable_bases", "k_fn_op", "k_point_op", "k_verify_fast"))
-    for key, kname in (("static", "k_verify_fast"), ("static_keyed", "k_verify_fast_keyed"), ("static_keyset", "k_verify_fast_keyset")):
+    for key, kname in (("static", "k_verify_fast"), ("static_keyed", "k_verify_fast_keyed"), ("static_keyset", "k_verify_fast_keyset"),
+                       ("static_keyset_joint", "k_verify_fast_keyset_joint")):
         if kname not in static:
             continue
         st = dict((prev or {}).get(key, {}))
@@ -59,11 +62,13 @@ def main():
     gtraffic = json.load(open(os.path.join(src, "general", "hbm_traffic.json")))
     if "k_verify_fast" in gtraffic:
         traffic["k_verify_fast"] = gtraffic["k_verify_fast"]
-    kt_path = os.path.join(src, "keyset", "hbm_traffic.json")
-    if os.path.exists(kt_path):
-        kt = json.load(open(kt_path))
-        if "k_verify_fast_keyset" in kt:
-            traffic["k_verify_fast_keyset"] = kt["k_verify_fast_keyset"]
+    for sub in ("keyset", "keyset_chunks"):
+        kt_path = os.path.join(src, sub, "hbm_traffic.json")
+        if os.path.exists(kt_path):
+            kt = json.load(open(kt_path))
+            for kn in ("k_verify_fast_keyset", "k_verify_fast_keyset_joint"):
+                if kn in kt:
+                    traffic[kn] = kt[kn]
     json.dump(traffic, open(os.path.join(prof, "%s_hbm_traffic.json" % rnd), "w"), indent=1)
     for a, b in (("kernel_time_summary.json", "%s_%s_kernel_time_summary.json"), ("kernel_stats_bench_steps20_warmup5.csv", "%s_%s_kernel_stats_bench_steps20_warmup5.csv"),
                  ("bench_same_box_unprofiled.json", "%s_%s_bench_same_box_unprofiled.json"), ("pmc_per_dispatch.txt", "%s_%s_pmc_per_dispatch.txt"),

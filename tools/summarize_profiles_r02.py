@@ -58,7 +58,7 @@ def main():
         return sum(v) / len(v) if v else None
     res = {"source": "rocprofv3 --pmc (tools/collect_profiles_r02.sh), averages over the last %d dispatches, 2^20 signatures per dispatch" % TIMED}
     # the ladder kernels: template instance <0> = general, <4> = over per-key tables (all 2^20 lanes live in the bench)
-    for inst, key in (("k_verify_fast<0>", "k_verify_fast"), ("k_verify_fast<4>", "k_verify_fast_keyed"), ("k_verify_fast<8>", "k_verify_fast_keyset")):
+    for inst, key in (("k_verify_fast<0>", "k_verify_fast"), ("k_verify_fast<4>", "k_verify_fast_keyed"), ("k_verify_fast<8>", "k_verify_fast_keyset"), ("k_verify_fast<9>", "k_verify_fast_keyset_joint")):
         fast = next((k for k in set(k for k, _ in acc) if k.startswith(inst)), None)
         if not fast:
             continue
@@ -73,7 +73,7 @@ def main():
     # the other kernels of a step: VALU instructions per signature of the batch (wave counts differ per kernel)
     # (a kernel launched several times per step - the generator part runs in two pieces - counts with all its launches:
     # launches per step = its dispatches / the ladder's dispatches, averaged over the last TIMED steps' worth of them)
-    steps_total = max((len(acc[(k, "SQ_INSTS_VALU")]) for k in set(k for k, _ in acc) if k.startswith("k_verify_fast<4>") or k.startswith("k_verify_fast<0>") or k.startswith("k_verify_fast<8>")), default=0)
+    steps_total = max((len(acc[(k, "SQ_INSTS_VALU")]) for k in set(k for k, _ in acc) if k.startswith("k_verify_fast<4>") or k.startswith("k_verify_fast<0>") or k.startswith("k_verify_fast<8>") or k.startswith("k_verify_fast<9>")), default=0)
     for k in sorted(set(k for k, _ in acc)):
         if k.startswith("k_verify_fast") or not k.startswith("k_"):
             continue
