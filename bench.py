@@ -465,7 +465,7 @@ def worker(args):
                        "inputs": "resident in HBM", "collective": "one all-gather per step: bitmap shard + valid count of every rank",
                        "build": eng._lib.s2k_build_config().decode()},
             "roofline": roof,
-            "key_grouping": {"mode": "auto (s2k_ctx_set_key_grouping default)" if args.key_grouping == "auto" else "%s (--key-grouping %s)" % (args.key_grouping, args.key_grouping), "signatures_on_key_tables": grouping["keyed"],
+            "key_grouping": {"mode": "adaptive (s2k_ctx_set_key_grouping default: looks for repeated keys until two large batches in a row have none)" if args.key_grouping == "auto" else "%s (--key-grouping %s)" % (args.key_grouping, args.key_grouping), "signatures_on_key_tables": grouping["keyed"],
                              "tables_built_per_step": grouping["tables"], "signatures_on_general_ladder": grouping["general"],
                              "note": "signatures are grouped by public key inside every step; keys with >= 4 signatures get a "
                                      "precomputed table (built inside the step) and their signatures a 12-doubling ladder"},
@@ -805,7 +805,7 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
         del d_pub2, valid2
 
     # ---- the same batch with key grouping off: every signature as if its key were new (the reference's way) ----
-    from secp256k1_voi_amd import KEYS_AUTO, KEYS_OFF
+    from secp256k1_voi_amd import KEYS_ADAPTIVE, KEYS_AUTO, KEYS_OFF
     if n_keys < n:
         eng.set_key_grouping(KEYS_OFF)
         try:
@@ -818,7 +818,7 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
             assert int(cnt.item()) == n, "general path lost verdicts"
         finally:
             eng.profile(False)
-            eng.set_key_grouping(KEYS_AUTO)
+            eng.set_key_grouping(KEYS_ADAPTIVE)
         out["general_path_same_batch"] = {"ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
                                           "kernel": "k_verify_fast<ECDSA>", "kernel_ms": pr["fast_ms"] / pr["calls"],
                                           "shader_clock_mhz": pr["shader_mhz"],
@@ -828,13 +828,25 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
         out["general_path_same_batch"]["roofline"] = general_roofline(general_ms, pr["shader_mhz"], n)
 
     # ---- K = N: every signature under its own key (SURVEY 8d "also report K = N").  The grouping finds nothing to share
-    # and must cost (next to) nothing: auto and off are measured ALTERNATELY, five rounds of five calls each, medians - the
-    # clock drifts by more than the difference between two consecutive blocks of calls ----
+    # and must cost (next to) nothing.  Three settings measured ALTERNATELY, five rounds of five calls each, medians - the
+    # clock drifts by more than the difference between two consecutive blocks of calls: the context's default
+    # (S2K_KEYS_ADAPTIVE: after two observed batches without a repeated key it verifies fifteen batches without looking,
+    # looks again in one, ...), S2K_KEYS_AUTO (looks in every call) and S2K_KEYS_OFF ----
     if n_keys < n:
         inp = tuple(torch.from_numpy(x).to(dev) for x in synth_batch(eng, n, n, seed=0xD157))
-        ms_auto, ms_off, kern = [], [], None
+        ms_adp, ms_auto, ms_off, kern = [], [], [], None
         try:
+            eng.set_key_grouping(KEYS_ADAPTIVE)
+            eng.key_grouping_adaptive(reset=True)
+            ad0 = eng.key_grouping_adaptive()
+            for _ in range(3):               # what a caller's first batches of such a workload are: looked at, and noted
+                verify_on(inp)
+                torch.cuda.synchronize()
             for rnd_ in range(5):
+                eng.set_key_grouping(KEYS_ADAPTIVE)
+                d_valid.zero_()
+                ms_adp.append(timed(lambda: verify_on(inp), 5))
+                assert int(d_valid.sum().item()) == n, "K = N batch did not verify (adaptive)"
                 eng.set_key_grouping(KEYS_AUTO)
                 d_valid.zero_()
                 ms_auto.append(timed(lambda: verify_on(inp), 5))
@@ -849,18 +861,26 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
                 assert int(d_valid.sum().item()) == n, "K = N batch did not verify (grouping off)"
             pr2 = eng.profile_read_stages(cap=8)
             kern = (pr2["fast_ms"] / pr2["calls"], pr2["shader_mhz"])
+            ad1 = eng.key_grouping_adaptive()
         finally:
             eng.profile(False)
-            eng.set_key_grouping(KEYS_AUTO)
-        ms, ms_off_med = median(ms_auto), median(ms_off)
+            eng.set_key_grouping(KEYS_ADAPTIVE)
+            eng.key_grouping_adaptive(reset=True)
+        ms, ms_auto_med, ms_off_med = median(ms_adp), median(ms_auto), median(ms_off)
         out["distinct_keys"] = {"keys": n, "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
                                 "ms_with_key_grouping_off": ms_off_med, "grouping_overhead": ms / ms_off_med - 1.0,
-                                "ms_rounds_auto": ms_auto, "ms_rounds_off": ms_off,
+                                "ms_with_key_grouping_in_every_call": ms_auto_med,
+                                "grouping_overhead_in_every_call": ms_auto_med / ms_off_med - 1.0,
+                                "adaptive_calls": {"verified_without_looking": ad1["skipped"] - ad0["skipped"],
+                                                   "looked_again": ad1["probes"] - ad0["probes"],
+                                                   "of": 3 + 5 * 6},
+                                "ms_rounds": ms_adp, "ms_rounds_every_call": ms_auto, "ms_rounds_off": ms_off,
                                 "roofline": general_roofline(kern[0], kern[1], n),
                                 "note": "every signature under its own key: the grouping finds nothing to share and all "
-                                        "signatures take the general ladder; the same call with the grouping off measured "
-                                        "alternately with it (5 x 5 calls each, medians); roofline: k_verify_fast<ECDSA> of the "
-                                        "grouping-off calls"}
+                                        "signatures take the general ladder.  `ms`: the context's default setting "
+                                        "(S2K_KEYS_ADAPTIVE) after three such batches, the calls with the grouping in every "
+                                        "call (S2K_KEYS_AUTO) and off measured alternately with it (5 x 5 calls each, medians); "
+                                        "roofline: k_verify_fast<ECDSA> of the grouping-off calls"}
         del inp
 
     # ---- adversarial inputs.  What a key owner can force for GIVEN digests are the two exceptional cases of the final

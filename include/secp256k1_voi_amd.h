@@ -141,8 +141,17 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
  * built inside the call, after which each of its signatures costs 12 point doublings instead of 128;
  * the other signatures take the general kernel.  Verdicts are the same either way.
  *   mode        S2K_KEYS_OFF: every signature through the general kernel (the round-1/2 path)
- *               S2K_KEYS_AUTO (default): as described
+ *               S2K_KEYS_AUTO: as described, in every call
  *               S2K_KEYS_ALWAYS: tables even for keys with a single signature (tests)
+ *               S2K_KEYS_ADAPTIVE (default): S2K_KEYS_AUTO that stops looking when there is nothing to find.  A batch
+ *               whose keys never repeat pays 1-2 % for the grouping that finds nothing; the context therefore notes what
+ *               each grouped call of at least 2^16 signatures found (one word written by the device into page-locked host
+ *               memory, read by later calls: no synchronisation), and after two consecutive observed calls in which no
+ *               key reached the threshold it verifies the next 15 such batches as S2K_KEYS_OFF does, looks again in
+ *               one, and so on; the first observed call that finds a group ends the skipping.  A workload that turns
+ *               from distinct keys to repeated ones is therefore verified at the general ladder's rate for up to 15
+ *               calls (plus the calls already enqueued) before its tables come back.  What has been learned belongs to
+ *               the context and survives mode changes; verdicts do not depend on it (s2k_ctx_key_grouping_adaptive)
  *   min_group   0 = default (4): measured break-even between 3 and 4 signatures per key
  *   hash_bits   0 = default (slots >= 2n); smaller values force probe chains (tests)
  *   max_tables  0 = default (2^22 tables of 9 KiB; the buffer is sized by the batch: n / min_group tables).  The threshold is raised until n / threshold tables
@@ -153,11 +162,16 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
 #define S2K_KEYS_OFF 0
 #define S2K_KEYS_AUTO 1
 #define S2K_KEYS_ALWAYS 2
+#define S2K_KEYS_ADAPTIVE 3
 int s2k_ctx_set_key_grouping(s2k_ctx *ctx, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables);
 /* After the last s2k_ecdsa_verify_batch_device call has finished (synchronises the device):
  * stats[0] signatures verified from per-key tables, [1] tables built, [2] signatures through the
  * general kernel, [3] signatures re-done by the complete-formula kernel. */
 int s2k_ctx_key_grouping_stats(s2k_ctx *ctx, uint32_t stats[4]);
+/* State of S2K_KEYS_ADAPTIVE, without synchronising: out[0] consecutive observed calls that found no group, [1] calls
+ * still to be verified without looking, [2] calls verified without looking so far, [3] calls that looked again after a
+ * run of skipped ones, [4] grouped calls whose result has been observed.  reset != 0: forget what was learned. */
+int s2k_ctx_key_grouping_adaptive(s2k_ctx *ctx, uint32_t out[5], int reset);
 
 /* ---- batch public-key recovery ------------------------------------------------------------ */
 /* For each i < n: secec.RecoverPublicKey(digest, r, s, recovery_id) (ecdsa.go:244-282):

@@ -45,7 +45,7 @@ ENCODING_ASN1, ENCODING_COMPACT, ENCODING_COMPACT_RECOVERABLE = 0, 1, 2
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 IMPL_COMPLETE, IMPL_FAST = 0, 1
-KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS = 0, 1, 2     # s2k_ctx_set_key_grouping
+KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS, KEYS_ADAPTIVE = 0, 1, 2, 3     # s2k_ctx_set_key_grouping (a new context: KEYS_ADAPTIVE)
 KEYSET_AUTO, KEYSET_CHUNKS, KEYSET_JOINT = 0, 1, 2   # s2k_keyset_create_ex
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
  HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
@@ -218,6 +218,7 @@ def load_library() -> C.CDLL:
     lib.s2k_ctx_profile_read_msm.argtypes = [vp, vp, vp]
     lib.s2k_ctx_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
     lib.s2k_ctx_key_grouping_stats.argtypes = [vp, vp]
+    lib.s2k_ctx_key_grouping_adaptive.argtypes = [vp, vp, ci]
     lib.s2k_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_ecdsa_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, vp]
@@ -303,7 +304,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "s2k_ctx_create", "s2k_ctx_destroy", "s2k_last_error", "s2k_version", "s2k_build_config",
     "s2k_ctx_profile", "s2k_ctx_profile_read", "s2k_ctx_profile_read_stages", "s2k_ctx_profile_msm", "s2k_ctx_profile_read_msm",
-    "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats",
+    "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats", "s2k_ctx_key_grouping_adaptive",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
     "s2k_keyset_create", "s2k_keyset_create_ex", "s2k_keyset_layout", "s2k_keyset_destroy", "s2k_keyset_size", "s2k_keyset_device_bytes", "s2k_keyset_valid_keys",
     "s2k_ecdsa_verify_batch_keyset", "s2k_ecdsa_verify_batch_keyset_device",
@@ -691,8 +692,10 @@ class Engine:
 
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         """How ecdsa_verify_batch[_device] treats signatures that share a public key (s2k_ctx_set_key_grouping):
-        KEYS_OFF = every signature through the general kernel, KEYS_AUTO (default) = keys with at least
-        `min_group` (default 4, the measured break-even) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does."""
+        KEYS_OFF = every signature through the general kernel, KEYS_AUTO = keys with at least `min_group` (default 4, the
+        measured break-even) signatures in the batch get a per-key table, KEYS_ALWAYS = every key does, KEYS_ADAPTIVE (what a
+        new engine starts with) = KEYS_AUTO that stops looking for repeated keys after two large batches without any and looks
+        again every sixteenth batch (key_grouping_adaptive)."""
         self._check(self._lib.s2k_ctx_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
 
     def key_grouping_stats(self):
@@ -700,6 +703,13 @@ class Engine:
         st = (C.c_uint32 * 4)()
         self._check(self._lib.s2k_ctx_key_grouping_stats(self._h, st))
         return {"keyed": int(st[0]), "tables": int(st[1]), "general": int(st[2]), "complete": int(st[3])}
+
+    def key_grouping_adaptive(self, reset: bool = False):
+        """State of KEYS_ADAPTIVE, without synchronising -> dict(miss_streak, skip_left, skipped, probes, observed)."""
+        st = (C.c_uint32 * 5)()
+        self._check(self._lib.s2k_ctx_key_grouping_adaptive(self._h, st, 1 if reset else 0))
+        return {"miss_streak": int(st[0]), "skip_left": int(st[1]), "skipped": int(st[2]), "probes": int(st[3]),
+                "observed": int(st[4])}
 
     def workspace_bytes(self, n):
         return self._lib.s2k_ecdsa_workspace_bytes(int(n))

@@ -1373,6 +1373,58 @@ static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
 // the multipliers busy) is through.  Returns with the caller's stream waiting for the second.
 // Stage times (s2k_ctx_profile_read_stages): [0] grouping, [1] tables and whatever is left of the second
 // stream's work.
+// S2K_KEYS_ADAPTIVE (engine_internal.h: kga_*): takes in the notes that have arrived, decides whether this call looks for
+// repeated keys, and if it does, where its k_key_counts leaves its note.  No device call that waits.
+static bool kg_adaptive_decide(s2k_ctx* ctx) {
+  s2k_ctx* own = ctx->kga_owner ? ctx->kga_owner : ctx;
+  if (!own->kga_note) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, KG_ADAPT_SLOTS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return true;                                     // no note, no learning: S2K_KEYS_AUTO
+    }
+    memset(p, 0, KG_ADAPT_SLOTS * sizeof(unsigned long long));
+    own->kga_note = (unsigned long long*)p;
+  }
+  for (;;) {                                           // notes in the order of their numbers; a slot overwritten by a later call: that one
+    unsigned long long next = 0;
+    for (uint32_t i = 0; i < KG_ADAPT_SLOTS; ++i) {
+      const unsigned long long v = __atomic_load_n(&own->kga_note[i], __ATOMIC_ACQUIRE);
+      const uint32_t sq = (uint32_t)(v >> 32);
+      if (v && (int32_t)(sq - own->kga_seen) > 0 && (!next || (int32_t)(sq - (uint32_t)(next >> 32)) < 0)) next = v;
+    }
+    if (!next) break;
+    own->kga_seen = (uint32_t)(next >> 32);
+    ++own->kga_observed;
+    if ((uint32_t)next == 0) {
+      ++own->kga_miss_streak;
+    } else {
+      own->kga_miss_streak = 0;
+      own->kga_skip_left = 0;
+      own->kga_skipping = false;
+    }
+  }
+  if (own->kga_miss_streak >= KG_ADAPT_MISSES) {
+    if (!own->kga_skipping) {
+      own->kga_skipping = true;
+      own->kga_skip_left = KG_ADAPT_SKIP;
+    }
+    if (own->kga_skip_left) {
+      --own->kga_skip_left;
+      ++own->kga_skipped;
+      return false;
+    }
+    own->kga_skip_left = KG_ADAPT_SKIP;                // this call looks again; the next ones do not, unless it finds something
+    ++own->kga_probes;
+  } else {
+    own->kga_skipping = false;
+  }
+  if (++own->kga_seq == 0) own->kga_seq = 1;           // (0 marks an empty slot)
+  ctx->kg_note_seq = own->kga_seq;
+  ctx->kg_note_dst = own->kga_note + own->kga_seq % KG_ADAPT_SLOTS;
+  return true;
+}
+
 template <class PrepFn>
 static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* d_keys, int key_bytes, uint32_t* prep,
                                 uint32_t* gp, size_t stride, PrepFn launch_prep, key_groups* kg, bool gp_in_prep) {
@@ -1613,6 +1665,10 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     sl.done = nullptr;
   }
+  if (ctx->kga_note) {                                // (a kernel still in flight may hold the address)
+    (void)hipDeviceSynchronize();
+    (void)hipHostFree(ctx->kga_note);
+  }
   if (ctx->gtable) gtable_release(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
@@ -1766,6 +1822,8 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
   bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  ctx->kg_note_dst = nullptr;
+  if (grouped && ctx->kg_mode == S2K_KEYS_ADAPTIVE && n >= KG_ADAPT_MIN_BATCH) grouped = kg_adaptive_decide(ctx);
   if (grouped) {
     // the grouping arrays and the table buffer, before anything of this call is in flight; a device without room for the
     // tables verifies without them
@@ -2042,7 +2100,7 @@ int s2k_ecdsa_verify_batch_keyset(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, 
 
 int s2k_ctx_set_key_grouping(s2k_ctx* ctx, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
-  if (mode != S2K_KEYS_OFF && mode != S2K_KEYS_AUTO && mode != S2K_KEYS_ALWAYS)
+  if (mode != S2K_KEYS_OFF && mode != S2K_KEYS_AUTO && mode != S2K_KEYS_ALWAYS && mode != S2K_KEYS_ADAPTIVE)
     return fail(ctx, S2K_ERR_ARG, "key grouping mode %d", mode);
   if (hash_bits > 30) return fail(ctx, S2K_ERR_ARG, "hash_bits %u > 30", hash_bits);
   ctx->kg_mode = mode;
@@ -2066,6 +2124,23 @@ int s2k_ctx_key_grouping_stats(s2k_ctx* ctx, uint32_t* stats) {
     stats[2] = c[KG_NLEFT];
   }
   if (ctx->last_wl_count) HIP_TRY(ctx, hipMemcpy(&stats[3], ctx->last_wl_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return S2K_OK;
+}
+
+int s2k_ctx_key_grouping_adaptive(s2k_ctx* ctx, uint32_t* out, int reset) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (out) {
+    out[0] = ctx->kga_miss_streak;
+    out[1] = ctx->kga_miss_streak >= KG_ADAPT_MISSES ? ctx->kga_skip_left : 0;
+    out[2] = ctx->kga_skipped;
+    out[3] = ctx->kga_probes;
+    out[4] = ctx->kga_observed;
+  }
+  if (reset) {
+    ctx->kga_miss_streak = ctx->kga_skip_left = 0;
+    ctx->kga_skipping = false;
+    ctx->kga_seen = ctx->kga_seq;                      // notes still on their way are not taken
+  }
   return S2K_OK;
 }
 
@@ -2460,6 +2535,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   }
   // the child verifies with the parent's settings of the moment
   sl.ctx->kg_mode = ctx->kg_mode;
+  sl.ctx->kga_owner = ctx;
   sl.ctx->kg_min_group = ctx->kg_min_group;
   sl.ctx->kg_hash_bits = ctx->kg_hash_bits;
   sl.ctx->kg_max_tables = ctx->kg_max_tables;

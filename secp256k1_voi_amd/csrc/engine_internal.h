@@ -110,7 +110,7 @@ struct s2k_ctx {
   size_t msm_prof_cap = 0, msm_prof_used = 0;
   bool msm_prof_on = false;
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
-  int kg_mode = S2K_KEYS_AUTO;
+  int kg_mode = S2K_KEYS_ADAPTIVE;
   uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = KG_MAX_TABLES_DEFAULT;
   uint32_t kg_table_cap = 0;         // 0: none; else the table count the device had memory for (s2k_internal_key_reserve)
   uint64_t kg_seed = 0;              // hash seed of the key grouping (operating-system randomness, per context)
@@ -126,6 +126,21 @@ struct s2k_ctx {
   uint32_t* kg_counters = nullptr;   // device, KG_COUNTERS words (of the last call; null: it did not group)
   uint32_t kg_last_max_tables = 0;   // table cap of that call (the device counter of tables is not clamped)
   uint32_t* last_wl_count = nullptr; // device: the last verification call's complete-formula worklist length
+  // S2K_KEYS_ADAPTIVE (the default): what the grouping of recent calls found, learned WITHOUT synchronising.  k_key_counts of
+  // a grouped call stores (sequence number << 32 | signatures that got a table) into a slot of `kga_note` (page-locked host
+  // memory, eight slots); the next calls read the slots that have arrived.  After KG_ADAPT_MISSES consecutive observed
+  // batches (of at least KG_ADAPT_MIN_BATCH signatures) in which no key reached the threshold, the next KG_ADAPT_SKIP such
+  // batches are verified without looking (the general ladder, exactly as S2K_KEYS_OFF), then one batch looks again; the first
+  // observed batch that does find a group ends the skipping.  Children of submit / wait use their parent's state (kga_owner).
+  s2k_ctx* kga_owner = nullptr;
+  unsigned long long* kga_note = nullptr;   // host, page-locked, KG_ADAPT_SLOTS entries
+  uint32_t kga_seq = 0;                     // sequence number of the last grouped call that was asked to leave a note
+  uint32_t kga_seen = 0;                    // ... of the last note taken into account
+  uint32_t kga_miss_streak = 0, kga_skip_left = 0;
+  bool kga_skipping = false;
+  uint32_t kga_skipped = 0, kga_probes = 0, kga_observed = 0;   // totals (s2k_ctx_key_grouping_adaptive)
+  unsigned long long* kg_note_dst = nullptr;   // where THIS call's k_key_counts leaves its note (null: nowhere), and its number
+  uint32_t kg_note_seq = 0;
   // submit / wait (s2k_ecdsa_verify_batch_submit, s2k_wait): child contexts on the same device take the submitted
   // batches in turn, so that one batch's transfer, grouping and tables run beside another's ladder.  A child owns
   // its own workspaces, staging and streams (the generator tables are shared per device); `pipe` is empty in a child.
@@ -318,6 +333,9 @@ static_assert(KT_SLOTS == 72 && KT_W_SLOT == 9 && kt_geom<32>::SLOTS == 288, "ta
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
 constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grouping
+// S2K_KEYS_ADAPTIVE (s2k_ctx above): batches it learns from and applies to, misses before it stops looking, batches it then skips
+constexpr size_t KG_ADAPT_MIN_BATCH = (size_t)1 << 16;
+constexpr uint32_t KG_ADAPT_MISSES = 2, KG_ADAPT_SKIP = 15, KG_ADAPT_SLOTS = 8;
 // Signatures per key from which a table pays, measured (MI355X, 2^20 signatures, ms with tables / without):
 // 4 per key 7.94 / 8.02, 5 per key 8.08 / 8.01 (the table kernels do not scale linearly and the clock sags),
 // 6 per key 6.65 / 7.93, 8 per key 6.02 / 7.96, 16 per key 5.1 / 8.0

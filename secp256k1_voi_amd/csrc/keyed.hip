@@ -233,9 +233,12 @@ k_key_alloc(uint32_t slots, uint32_t min_group, const uint32_t* __restrict__ rep
 // the counts where their readers expect them, and the split of the two-part flow: tables [0, split) are
 // built first and their signatures verified while the rest of the tables is being built.  Few tables: no split.
 constexpr uint32_t KG_SPLIT_MIN_TABLES = 4096;
-__global__ void k_key_counts(uint32_t* __restrict__ tbase, uint32_t* __restrict__ counters) {
+// note (S2K_KEYS_ADAPTIVE, engine_internal.h): page-locked host memory; the call's number and how many signatures got a table
+__global__ void k_key_counts(uint32_t* __restrict__ tbase, uint32_t* __restrict__ counters, unsigned long long* __restrict__ note,
+                             uint32_t note_seq) {
   const unsigned long long both = *reinterpret_cast<const unsigned long long*>(&counters[KG_ALLOC64]);
   const uint32_t T = (uint32_t)(both >> 32), nk = (uint32_t)both;
+  if (note) __hip_atomic_store(note, ((unsigned long long)note_seq << 32) | nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   counters[KG_NTAB] = T;
   counters[KG_NKEYED] = nk;
   tbase[T] = nk;
@@ -698,7 +701,8 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_group(s2k_ctx* ctx, s
   HIP_TRY(ctx, hipGetLastError());
   k_key_alloc<<<(unsigned)((slots + 256 * ALLOC_ITEMS - 1) / (256 * ALLOC_ITEMS)), 256, 0, st>>>((uint32_t)slots, min_group, rep, cnt, tix, trep, tbase, counters);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_counts<<<1, 1, 0, st>>>(tbase, counters);
+  k_key_counts<<<1, 1, 0, st>>>(tbase, counters, ctx->kg_note_dst, ctx->kg_note_seq);
+  ctx->kg_note_dst = nullptr;            // (the note of THIS call: other callers of the grouping leave none)
   HIP_TRY(ctx, hipGetLastError());
   k_key_place<<<(unsigned)((n + 256 * PLACE_ITEMS - 1) / (256 * PLACE_ITEMS)), 256, 0, st>>>((uint32_t)n, slot_of, pos_of, tbase, true, tix, perm, ptab, left, counters);
   HIP_TRY(ctx, hipGetLastError());

@@ -391,6 +391,69 @@ def test_table_buffer_allocation_failure_degrades(oracle):
     assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref) and eng4.key_grouping_stats()["tables"] == n // 32
 
 
+# ---- S2K_KEYS_ADAPTIVE: the grouping that stops looking when there is nothing to find ------------------------------------
+def test_adaptive_key_grouping(oracle):
+    """The default setting of a new context.  Two observed batches (>= 2^16 signatures) without a repeated key, and the next
+    15 are verified without looking (no grouping ran: the statistics of the call are empty), whatever their keys; the 16th
+    looks again, finds the groups of a batch that has them, and the one after it builds tables as if nothing had been
+    learned.  Verdicts never depend on any of it; S2K_KEYS_AUTO looks in every call; submit / wait children share the
+    state of their parent; reset forgets."""
+    import secp256k1_voi_amd as S
+    eng = S.Engine(0)
+    n = 1 << 16
+    lone = damaged_batch(eng, n, n, 71)                 # every signature under its own key
+    shared = damaged_batch(eng, n, n // 16, 72)         # 16 per key
+    eng.set_key_grouping(S.KEYS_OFF)
+    ref_lone, ref_shared = eng.ecdsa_verify_batch(*lone), eng.ecdsa_verify_batch(*shared)
+    m = 2048
+    for arrs, ref in ((lone, ref_lone), (shared, ref_shared)):
+        assert np.array_equal(ref[:m], oracle.ecdsa_verify_batch(*(a[:m] for a in arrs), nthreads=os.cpu_count() or 1))
+        assert 0 < int(ref.sum()) < n
+    eng.set_key_grouping(S.KEYS_ADAPTIVE)
+    a0 = eng.key_grouping_adaptive()
+    assert a0["skipped"] == 0 and a0["miss_streak"] == 0
+    for k in range(2):                                  # looked at, nothing found
+        assert np.array_equal(eng.ecdsa_verify_batch(*lone), ref_lone)
+        st = eng.key_grouping_stats()
+        assert st["keyed"] == 0 and st["general"] == n, (k, st)
+    idx = np.arange(n).reshape(16, n // 16)[:, :256].reshape(-1)      # (key of signature i: i mod n / 16) 256 keys, 16 each
+    small = [np.ascontiguousarray(a[idx]) for a in shared]            # below 2^16: neither learned from nor skipped
+    assert np.array_equal(eng.ecdsa_verify_batch(*small), ref_shared[idx]) and eng.key_grouping_stats()["tables"] == 256
+    for k in range(15):                                 # not looked at - even where there would be something to find
+        arrs, ref = (lone, ref_lone) if k < 8 else (shared, ref_shared)
+        assert np.array_equal(eng.ecdsa_verify_batch(*arrs), ref)
+        st = eng.key_grouping_stats()
+        assert st["keyed"] == 0 and st["tables"] == 0 and st["general"] == 0, (k, st)
+        ad = eng.key_grouping_adaptive()
+        assert ad["skipped"] == k + 1 and ad["skip_left"] == 14 - k and ad["observed"] == 2, (k, ad)
+    assert np.array_equal(eng.ecdsa_verify_batch(*shared), ref_shared)      # the sixteenth looks again
+    st = eng.key_grouping_stats()
+    assert st["tables"] == n // 16 and st["keyed"] + st["general"] == n and st["keyed"] > n * 9 // 10, st   # (damaged keys stand alone)
+    assert eng.key_grouping_adaptive()["probes"] == 1
+    assert np.array_equal(eng.ecdsa_verify_batch(*shared), ref_shared)      # ... and what it found ends the skipping
+    assert eng.key_grouping_stats()["tables"] == n // 16
+    ad = eng.key_grouping_adaptive()
+    assert ad["miss_streak"] == 0 and ad["skip_left"] == 0 and ad["skipped"] == 15 and ad["observed"] == 3, ad
+    # learn again, then S2K_KEYS_AUTO: looks in every call whatever was learned; the learned state is kept for later
+    for k in range(3):
+        assert np.array_equal(eng.ecdsa_verify_batch(*lone), ref_lone)
+    assert eng.key_grouping_adaptive()["skipped"] == 16
+    eng.set_key_grouping(S.KEYS_AUTO)
+    assert np.array_equal(eng.ecdsa_verify_batch(*shared), ref_shared) and eng.key_grouping_stats()["tables"] == n // 16
+    eng.set_key_grouping(S.KEYS_ADAPTIVE)
+    assert np.array_equal(eng.ecdsa_verify_batch(*shared), ref_shared) and eng.key_grouping_stats()["tables"] == 0
+    assert eng.key_grouping_adaptive(reset=True)["skipped"] == 17
+    assert np.array_equal(eng.ecdsa_verify_batch(*shared), ref_shared) and eng.key_grouping_stats()["tables"] == n // 16
+    # submit / wait: the children's calls are the parent's observations
+    eng2 = S.Engine(0)
+    for k in range(6):
+        assert np.array_equal(eng2.ecdsa_verify_batch_submit(*lone).wait(), ref_lone)
+    ad = eng2.key_grouping_adaptive()
+    assert ad["observed"] == 2 and ad["skipped"] == 4, ad
+    eng2.close()
+    eng.close()
+
+
 # ---- inputs that would make the LAST ladder addition exceptional ----------------------------------------------------
 def test_last_ladder_addition_collisions(eng, oracle):
     """u2 = r/s = -26 lambda (general ladder) and -26 * 16^28 lambda (ladder over per-key tables): with the plain odd split the
