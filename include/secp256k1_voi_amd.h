@@ -266,6 +266,12 @@ int s2k_ecdsa_verify_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy,
 int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
+/* s2k_ecdsa_verify_batch_keyset in the same form: signatures that name their key by its index in a key set of this context
+ * (100 bytes per signature cross PCIe instead of 160, and no table is built).  Tickets of all submit entry points share
+ * the context's four slots and may be mixed. */
+int s2k_ecdsa_verify_batch_keyset_submit(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const uint32_t *key_index,
+                                         const uint8_t *digest32, const uint8_t *r, const uint8_t *s, uint32_t flags,
+                                         uint8_t *valid, s2k_ticket *ticket);
 /* s2k_ecdsa_verify_encoded_batch (below) in the same form */
 int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pubs, const uint64_t *pub_off,
                                           const uint8_t *digests, const uint64_t *dig_off, const uint8_t *sigs,

@@ -236,6 +236,7 @@ def load_library() -> C.CDLL:
     lib.s2k_keyset_valid_keys.argtypes = [vp, vp]
     lib.s2k_ecdsa_verify_batch_keyset.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_ecdsa_verify_batch_keyset_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp, vp]
+    lib.s2k_ecdsa_verify_batch_keyset_submit.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_host_alloc.argtypes = [sz]
     lib.s2k_host_alloc.restype = vp
     lib.s2k_host_free.argtypes = [vp]
@@ -307,7 +308,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ctx_set_key_grouping", "s2k_ctx_key_grouping_stats", "s2k_ctx_key_grouping_adaptive",
     "s2k_ecdsa_verify_batch", "s2k_ecdsa_verify_batch_device", "s2k_ecdsa_workspace_bytes", "s2k_ctx_device_bytes",
     "s2k_keyset_create", "s2k_keyset_create_ex", "s2k_keyset_layout", "s2k_keyset_destroy", "s2k_keyset_size", "s2k_keyset_device_bytes", "s2k_keyset_valid_keys",
-    "s2k_ecdsa_verify_batch_keyset", "s2k_ecdsa_verify_batch_keyset_device",
+    "s2k_ecdsa_verify_batch_keyset", "s2k_ecdsa_verify_batch_keyset_device", "s2k_ecdsa_verify_batch_keyset_submit",
     "s2k_pack_valid_device", "s2k_host_alloc", "s2k_host_free", "s2k_host_register", "s2k_host_unregister", "s2k_ecdsa_recover_batch", "s2k_ecdsa_recover_batch_device",
     "s2k_parse_asn1_signature", "s2k_parse_compact_signature", "s2k_is_valid_signature_encoding_bip0066",
     "s2k_ecdsa_verify_encoded_batch",
@@ -521,6 +522,32 @@ class Engine:
                                                             (REJECT_MALLEABLE if reject_malleable else 0) |
                                                             (FORCE_WORKLIST if force_worklist else 0), out.ctypes.data))
         return out
+
+    def ecdsa_verify_batch_keyset_submit(self, keyset, key_index, digest32, r, s, out=None, reject_malleable: bool = False) -> "Ticket":
+        """s2k_ecdsa_verify_batch_keyset_submit: as ecdsa_verify_batch_submit, the keys named by their index in `keyset`
+        (contiguous arrays are used as they are - uint32 indices, uint8 rows - and kept alive by the ticket)."""
+        ki = key_index if (isinstance(key_index, np.ndarray) and key_index.dtype == np.uint32 and key_index.flags["C_CONTIGUOUS"]) \
+            else np.ascontiguousarray(key_index, dtype=np.uint32)
+        ki = ki.reshape(-1)
+        n = ki.shape[0]
+        arrs = [ki]
+        for a in (digest32, r, s):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]):
+                a = _arr(a, 32)
+            a = a.reshape(-1, 32)
+            if a.shape[0] != n:
+                raise ValueError(f"length mismatch: expected {n} items, got {a.shape[0]}")
+            arrs.append(a)
+        if out is None:
+            out = np.zeros(n, dtype=np.uint8)
+        elif out.shape != (n,) or out.dtype != np.uint8:
+            raise ValueError("out must be a uint8 array of n items")
+        t = C.c_uint64(0)
+        self._check(self._lib.s2k_ecdsa_verify_batch_keyset_submit(self._h, keyset._k, n, arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                                                   arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                                                   REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data,
+                                                                   C.byref(t)))
+        return Ticket(self, int(t.value), out, arrs + [keyset])
 
     def ecdsa_verify_batch_keyset_device(self, keyset, n, d_key_index, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):
         self._check(self._lib.s2k_ecdsa_verify_batch_keyset_device(self._h, keyset._k, int(n), d_key_index, d_digest32, d_r, d_s,

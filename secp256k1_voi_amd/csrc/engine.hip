@@ -1376,7 +1376,7 @@ static inline void prof_mark(s2k_ctx* ctx, hipStream_t st, int slot) {
 // S2K_KEYS_ADAPTIVE (engine_internal.h: kga_*): takes in the notes that have arrived, decides whether this call looks for
 // repeated keys, and if it does, where its k_key_counts leaves its note.  No device call that waits.
 static bool kg_adaptive_decide(s2k_ctx* ctx) {
-  s2k_ctx* own = ctx->kga_owner ? ctx->kga_owner : ctx;
+  s2k_ctx* own = ctx->parent ? ctx->parent : ctx;
   if (!own->kga_note) {
     void* p = nullptr;
     if (hipHostMalloc(&p, KG_ADAPT_SLOTS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
@@ -2000,7 +2000,9 @@ int s2k_keyset_valid_keys(s2k_keyset* ks, uint8_t* valid) {
 int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const void* d_key_index, const void* d_dig,
                                          const void* d_r, const void* d_s, uint32_t flags, void* d_valid, void* hip_stream) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
-  if (!ks || ks->ctx != ctx || ks->generation != ctx->generation || ks->device != ctx->device)
+  // (a child context of submit / wait verifies over its parent's key sets: the tables are only read)
+  const s2k_ctx* owner = ctx->parent ? ctx->parent : ctx;
+  if (!ks || ks->ctx != owner || ks->generation != owner->generation || ks->device != ctx->device)
     return fail(ctx, S2K_ERR_ARG, "key set of another context");
   if (n == 0) return S2K_OK;
   if (!d_key_index || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
@@ -2535,7 +2537,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   }
   // the child verifies with the parent's settings of the moment
   sl.ctx->kg_mode = ctx->kg_mode;
-  sl.ctx->kga_owner = ctx;
+  sl.ctx->parent = ctx;
   sl.ctx->kg_min_group = ctx->kg_min_group;
   sl.ctx->kg_hash_bits = ctx->kg_hash_bits;
   sl.ctx->kg_max_tables = ctx->kg_max_tables;
@@ -2573,6 +2575,50 @@ int s2k_ecdsa_verify_batch_submit(s2k_ctx* ctx, size_t n, const uint8_t* pub, co
   if (n) {
     rc = verify_batch_enqueue(sl->ctx, n, pub, dig, r, s, flags, sl->direct ? valid : sl->h_valid, /*one_shot=*/true);
     if (rc) return fail(ctx, rc, "%s", sl->ctx->err);
+  }
+  s2k_internal_pipe_issue(ctx, sl, ticket);
+  return S2K_OK;
+}
+
+// s2k_ecdsa_verify_batch_keyset without the wait at its end: the ticket's index, digest and signature arrays (100 bytes per
+// signature) cross PCIe on the copy stream beside the kernels of the tickets before it; the child context verifies over
+// the parent's key set.
+int s2k_ecdsa_verify_batch_keyset_submit(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const uint32_t* key_index, const uint8_t* dig,
+                                         const uint8_t* r, const uint8_t* s, uint32_t flags, uint8_t* valid, s2k_ticket* ticket) {
+  if (!ctx || !ticket) return fail(ctx, S2K_ERR_ARG, "null argument");
+  *ticket = 0;
+  if (!ks || ks->ctx != ctx || ks->generation != ctx->generation || ks->device != ctx->device)
+    return fail(ctx, S2K_ERR_ARG, "key set of another context");
+  if (n && (!key_index || !dig || !r || !s || !valid)) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (flags & S2K_ECDSA_FORCE_COMPLETE) return fail(ctx, S2K_ERR_ARG, "S2K_ECDSA_FORCE_COMPLETE does not apply to key sets");
+  s2k_ctx::pipe_slot* sl = nullptr;
+  int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
+  if (rc) return rc;
+  if (n) {
+    s2k_ctx* c = sl->ctx;
+    uint8_t* h_out = sl->direct ? valid : sl->h_valid;
+    auto enqueue = [&]() -> int {
+      const size_t sizes[5] = {n * 4, n * 32, n * 32, n * 32, n};
+      uint8_t* d[5];
+      int rc2 = ctx_stage(c, sizes, 5, d);
+      if (rc2) return rc2;
+      HIP_TRY(c, hipMemcpyAsync(d[0], key_index, n * 4, hipMemcpyHostToDevice, c->s_copy));
+      HIP_TRY(c, hipMemcpyAsync(d[1], dig, n * 32, hipMemcpyHostToDevice, c->s_copy));
+      HIP_TRY(c, hipMemcpyAsync(d[2], r, n * 32, hipMemcpyHostToDevice, c->s_copy));
+      HIP_TRY(c, hipMemcpyAsync(d[3], s, n * 32, hipMemcpyHostToDevice, c->s_copy));
+      HIP_TRY(c, hipEventRecord(c->ev_copied[0], c->s_copy));
+      HIP_TRY(c, hipStreamWaitEvent(c->s_comp, c->ev_copied[0], 0));
+      rc2 = s2k_ecdsa_verify_batch_keyset_device(c, ks, n, d[0], d[1], d[2], d[3], flags, d[4], c->s_comp);
+      if (rc2) return rc2;
+      HIP_TRY(c, hipMemcpyAsync(h_out, d[4], n, hipMemcpyDeviceToHost, c->s_comp));
+      return S2K_OK;
+    };
+    rc = enqueue();
+    if (rc) {
+      s2k_internal_drain(c);
+      return fail(ctx, rc, "%s", c->err);
+    }
   }
   s2k_internal_pipe_issue(ctx, sl, ticket);
   return S2K_OK;

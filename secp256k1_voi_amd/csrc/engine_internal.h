@@ -131,8 +131,8 @@ struct s2k_ctx {
   // memory, eight slots); the next calls read the slots that have arrived.  After KG_ADAPT_MISSES consecutive observed
   // batches (of at least KG_ADAPT_MIN_BATCH signatures) in which no key reached the threshold, the next KG_ADAPT_SKIP such
   // batches are verified without looking (the general ladder, exactly as S2K_KEYS_OFF), then one batch looks again; the first
-  // observed batch that does find a group ends the skipping.  Children of submit / wait use their parent's state (kga_owner).
-  s2k_ctx* kga_owner = nullptr;
+  // observed batch that does find a group ends the skipping.  Children of submit / wait use their parent's state (parent).
+  s2k_ctx* parent = nullptr;                // of a child context of submit / wait (else null)
   unsigned long long* kga_note = nullptr;   // host, page-locked, KG_ADAPT_SLOTS entries
   uint32_t kga_seq = 0;                     // sequence number of the last grouped call that was asked to leave a note
   uint32_t kga_seen = 0;                    // ... of the last note taken into account

@@ -391,6 +391,75 @@ def test_table_buffer_allocation_failure_degrades(oracle):
     assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref) and eng4.key_grouping_stats()["tables"] == n // 32
 
 
+# ---- key sets through submit / wait ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [1, 2])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT
+def test_keyset_submit_wait(eng, oracle, layout):
+    """s2k_ecdsa_verify_batch_keyset_submit: six batches (ragged sizes, one empty, pageable and page-locked buffers, indices
+    outside the set, keys that are no public keys) with four in flight, mixed with tickets of the plain submit: every ticket's
+    verdicts equal the synchronous key-set call's, the batch verifier's on the expanded keys and the oracle's; a key set of
+    another context is refused."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    nk = 500
+    sizes = [30011, 0, 70000, 257, 131072, 5000]
+    rng = np.random.default_rng(91)
+    total = sum(sizes)
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, total, nk, seed=17))     # one synthetic batch, cut into the six
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)
+    keys = keys.copy()
+    kidx_all = inv.reshape(-1).astype(np.uint32)
+    keys[3, 40] ^= 4                                                   # no public key
+    ks = eng.keyset_create(keys, layout)
+    for i in range(0, total, 9):
+        a = (dig, r, s)[int(rng.integers(0, 3))]
+        a[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+    batches, lo = [], 0
+    for n in sizes:
+        kidx = kidx_all[lo:lo + n].copy()
+        if n > 20:
+            kidx[7] = len(keys)
+            kidx[13] = 0xFFFFFFFF
+        full = np.zeros((n, 64), np.uint8)
+        inside = kidx < len(keys)
+        full[inside] = keys[kidx[inside]]
+        batches.append((kidx, dig[lo:lo + n].copy(), r[lo:lo + n].copy(), s[lo:lo + n].copy(), full))
+        lo += n
+    refs = [eng.ecdsa_verify_batch_keyset(ks, b[0], b[1], b[2], b[3]) if len(b[0]) else np.zeros(0, np.uint8) for b in batches]
+    for b, ref in zip(batches, refs):
+        if len(b[0]):
+            assert np.array_equal(ref, eng.ecdsa_verify_batch(b[4], b[1], b[2], b[3]))
+            m = min(len(b[0]), 1500)
+            assert np.array_equal(ref[:m], oracle.ecdsa_verify_batch(b[4][:m], b[1][:m], b[2][:m], b[3][:m], nthreads=os.cpu_count() or 1))
+            assert 0 < int(ref.sum()) < len(ref)
+    src = []
+    for bi, b in enumerate(batches):                                   # every other batch from page-locked memory
+        if bi % 2 == 0 and len(b[0]):
+            pk = [S.pinned_array(a.shape, a.dtype) for a in b[:4]]
+            for d, a in zip(pk, b[:4]):
+                d[...] = a
+            src.append(pk)
+        else:
+            src.append(list(b[:4]))
+    tickets = []
+    for bi, q in enumerate(src):
+        tickets.append(eng.ecdsa_verify_batch_keyset_submit(ks, *q))
+        if bi == 2:                                                    # a ticket of the plain submit between them
+            plain = eng.ecdsa_verify_batch_submit(batches[0][4], *batches[0][1:4])
+    assert np.array_equal(plain.wait(), refs[0])
+    for tk, ref in zip(tickets, refs):
+        assert np.array_equal(tk.wait(), ref)
+    # low-s rule through the flag
+    b = batches[0]
+    t1 = eng.ecdsa_verify_batch_keyset_submit(ks, *b[:4], reject_malleable=True)
+    assert np.array_equal(t1.wait(), eng.ecdsa_verify_batch_keyset(ks, *b[:4], reject_malleable=True))
+    other = S.Engine(0)
+    with pytest.raises(S.EngineError):
+        other.ecdsa_verify_batch_keyset_submit(ks, *b[:4])
+    other.close()
+    eng.wait_all()
+    ks.close()
+
+
 # ---- S2K_KEYS_ADAPTIVE: the grouping that stops looking when there is nothing to find ------------------------------------
 def test_adaptive_key_grouping(oracle):
     """The default setting of a new context.  Two observed batches (>= 2^16 signatures) without a repeated key, and the next
