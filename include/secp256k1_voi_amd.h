@@ -314,6 +314,25 @@ int s2k_group_ecdsa_verify_encoded_batch_submit(s2k_group *g, size_t n, const ui
 /* stats[m * 4 + 0..3] for member m, of its last finished shard: signatures, first index, milliseconds from the member's
  * submit to its verdicts (host clock), device index. */
 int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
+/* Key sets across a group: every member builds the tables of all n_keys keys on its own device (side by side; the
+ * tables are replicated per device like the generator tables: s2k_group_keyset_device_bytes per member), and
+ * s2k_group_ecdsa_verify_batch_keyset[_submit] shards a batch of (key index, digest, r, s) items like any other group
+ * call, each member verifying its shard over its own copy (s2k_ecdsa_verify_batch_keyset_submit).  Same verdicts as
+ * s2k_ecdsa_verify_batch_keyset on one device.  The set belongs to its group and is destroyed before it; tickets are those
+ * of s2k_group_wait.  What secec.PublicKey caches per key (secec/secec.go:80-85), for a stable key set, on every GPU of the node. */
+typedef struct s2k_group_keyset s2k_group_keyset;
+int s2k_group_keyset_create(s2k_group *g, size_t n_keys, const uint8_t *pub_xy /* n_keys*64, host */, int layout,
+                            s2k_group_keyset **out);
+void s2k_group_keyset_destroy(s2k_group_keyset *gks);
+size_t s2k_group_keyset_size(const s2k_group_keyset *gks);
+int s2k_group_keyset_layout(const s2k_group_keyset *gks);
+size_t s2k_group_keyset_device_bytes(const s2k_group_keyset *gks);
+int s2k_group_ecdsa_verify_batch_keyset(s2k_group *g, const s2k_group_keyset *gks, size_t n, const uint32_t *key_index,
+                                        const uint8_t *digest32, const uint8_t *r, const uint8_t *s, uint32_t flags,
+                                        uint8_t *valid);
+int s2k_group_ecdsa_verify_batch_keyset_submit(s2k_group *g, const s2k_group_keyset *gks, size_t n, const uint32_t *key_index,
+                                               const uint8_t *digest32, const uint8_t *r, const uint8_t *s, uint32_t flags,
+                                               uint8_t *valid, s2k_ticket *ticket);
 
 /* Packs valid[n] (0/1 bytes, device) into a bitmap (bit i of byte i/8, LSB first; (n+7)/8
  * bytes, device) and writes the number of valid items to *d_count (uint64, device).  This is

@@ -266,6 +266,16 @@ def load_library() -> C.CDLL:
     lib.s2k_group_last_error.argtypes = [vp]
     lib.s2k_group_last_error.restype = C.c_char_p
     lib.s2k_group_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
+    lib.s2k_group_keyset_create.argtypes = [vp, sz, vp, ci, vp]
+    lib.s2k_group_keyset_destroy.argtypes = [vp]
+    lib.s2k_group_keyset_destroy.restype = None
+    lib.s2k_group_keyset_size.argtypes = [vp]
+    lib.s2k_group_keyset_size.restype = sz
+    lib.s2k_group_keyset_layout.argtypes = [vp]
+    lib.s2k_group_keyset_device_bytes.argtypes = [vp]
+    lib.s2k_group_keyset_device_bytes.restype = sz
+    lib.s2k_group_ecdsa_verify_batch_keyset.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp]
+    lib.s2k_group_ecdsa_verify_batch_keyset_submit.argtypes = [vp, vp, sz, vp, vp, vp, vp, u32, vp, vp]
     lib.s2k_group_ecdsa_verify_batch.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp]
     lib.s2k_group_ecdsa_verify_batch_submit.argtypes = [vp, sz, vp, vp, vp, vp, u32, vp, C.POINTER(u64)]
     lib.s2k_group_wait.argtypes = [vp, u64]
@@ -317,6 +327,8 @@ EXPORTED_SYMBOLS = [
     "s2k_group_set_key_grouping", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
     "s2k_group_ecdsa_verify_encoded_batch", "s2k_group_ecdsa_verify_encoded_batch_submit",
     "s2k_group_member_stats",
+    "s2k_group_keyset_create", "s2k_group_keyset_destroy", "s2k_group_keyset_size", "s2k_group_keyset_layout", "s2k_group_keyset_device_bytes",
+    "s2k_group_ecdsa_verify_batch_keyset", "s2k_group_ecdsa_verify_batch_keyset_submit",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_schnorr_verify_batch_bisect", "s2k_schnorr_verify_batch_bisect_device",
@@ -971,12 +983,67 @@ class Group:
                                                                           digest_len, flags, out.ctypes.data, C.byref(t)))
         return Ticket(self, int(t.value), out, [pb, po, db, do, sb, so])
 
+    def keyset_create(self, pub_xy, layout: int = 0) -> "GroupKeySet":
+        """The tables of a fixed list of public keys on every member's device (s2k_group_keyset_create)."""
+        return GroupKeySet(self, pub_xy, layout)
+
+    def ecdsa_verify_batch_keyset_submit(self, keyset, key_index, digest32, r, s, out=None, reject_malleable: bool = False) -> Ticket:
+        ki = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
+        n = ki.shape[0]
+        arrs = [ki] + [(_arr(a, 32) if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]) else a.reshape(-1, 32))
+                       for a in (digest32, r, s)]
+        if any(a.shape[0] != n for a in arrs):
+            raise ValueError("length mismatch")
+        if out is None:
+            out = np.zeros(n, dtype=np.uint8)
+        t = C.c_uint64(0)
+        self._check(self._lib.s2k_group_ecdsa_verify_batch_keyset_submit(self._h, keyset._k, n, arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                                                         arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                                                         REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data,
+                                                                         C.byref(t)))
+        return Ticket(self, int(t.value), out, arrs + [keyset])
+
+    def ecdsa_verify_batch_keyset(self, keyset, key_index, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
+        return self.ecdsa_verify_batch_keyset_submit(keyset, key_index, digest32, r, s, reject_malleable=reject_malleable).wait()
+
     def member_stats(self):
         """Per member, of its last finished shard: dict(n, first, ms, device)."""
         st = (C.c_double * (4 * len(self)))()
         self._check(self._lib.s2k_group_member_stats(self._h, st))
         return [{"n": int(st[4 * i]), "first": int(st[4 * i + 1]), "ms": float(st[4 * i + 2]), "device": int(st[4 * i + 3])}
                 for i in range(len(self))]
+
+
+class GroupKeySet:
+    """Handle of s2k_group_keyset_*: the per-key tables of a fixed key list on every device of a group."""
+
+    def __init__(self, group: "Group", pub_xy, layout: int = 0):
+        pub_xy = _arr(pub_xy, 64)
+        self._grp = group
+        k = C.c_void_p()
+        group._check(group._lib.s2k_group_keyset_create(group._h, pub_xy.shape[0], pub_xy.ctypes.data, int(layout), C.byref(k)))
+        self._k = k
+
+    def layout(self) -> int:
+        return int(self._grp._lib.s2k_group_keyset_layout(self._k))
+
+    def __len__(self):
+        return int(self._grp._lib.s2k_group_keyset_size(self._k))
+
+    def device_bytes(self):
+        """per member"""
+        return int(self._grp._lib.s2k_group_keyset_device_bytes(self._k))
+
+    def close(self):
+        if self._k:
+            self._grp._lib.s2k_group_keyset_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class KeySet:

@@ -29,6 +29,8 @@ struct shard_job {
   uint64_t ticket = 0;
   size_t lo = 0, n = 0;            // the member's shard of the batch
   const uint8_t *pub = nullptr, *dig = nullptr, *r = nullptr, *s = nullptr;   // packed arrays; encoded: pub / dig / s = the three blobs
+  const s2k_group_keyset* gks = nullptr;       // key-set form: the keys named by index (kidx) into the group's key set
+  const uint32_t* kidx = nullptr;
   const uint64_t *pub_off = nullptr, *dig_off = nullptr, *sig_off = nullptr;    // encoded form only (pub_off != nullptr)
   int encoding = 0;
   size_t digest_len = 0;
@@ -39,6 +41,7 @@ struct shard_job {
 
 struct member {
   s2k_group* group = nullptr;
+  size_t index = 0;                // position in the group (its key set in a s2k_group_keyset)
   int device = -1;
   s2k_ctx* ctx = nullptr;
   int create_rc = S2K_OK;
@@ -59,6 +62,13 @@ struct pending {
 };
 
 }  // namespace
+
+// a key set on every member's context (the tables are replicated per device, like the generator tables)
+struct s2k_group_keyset {
+  s2k_group* group = nullptr;
+  std::vector<s2k_keyset*> sets;
+  size_t n_keys = 0;
+};
 
 struct s2k_group {
   std::vector<member*> members;
@@ -170,6 +180,9 @@ void member_main(member* me) {
       if (job.n && job.pub_off)   // encoded items: the offsets are absolute, so a shard is the same blobs with shifted offset arrays
         rc = s2k_ecdsa_verify_encoded_batch_submit(me->ctx, job.n, job.pub, job.pub_off + job.lo, job.dig, job.dig_off + job.lo, job.s,
                                                    job.sig_off + job.lo, job.encoding, job.digest_len, job.flags, job.valid + job.lo, &t);
+      else if (job.n && job.gks)
+        rc = s2k_ecdsa_verify_batch_keyset_submit(me->ctx, job.gks->sets[me->index], job.n, job.kidx + job.lo, job.dig + job.lo * 32,
+                                                  job.r + job.lo * 32, job.s + job.lo * 32, job.flags, job.valid + job.lo, &t);
       else if (job.n)
         rc = s2k_ecdsa_verify_batch_submit(me->ctx, job.n, job.pub + job.lo * 64, job.dig + job.lo * 32, job.r + job.lo * 32,
                                            job.s + job.lo * 32, job.flags, job.valid + job.lo, &t);
@@ -206,6 +219,7 @@ int s2k_group_create(const int* devices, size_t n_devices, s2k_group** out) {
       return S2K_ERR_NOMEM;
     }
     me->group = g;
+    me->index = i;
     me->device = devices[i];
     g->members.push_back(me);
     me->th = std::thread(member_main, me);
@@ -349,6 +363,73 @@ int s2k_group_ecdsa_verify_encoded_batch(s2k_group* g, size_t n, const uint8_t* 
   s2k_ticket t = 0;
   const int rc = s2k_group_ecdsa_verify_encoded_batch_submit(g, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, digest_len,
                                                              flags, valid, &t);
+  if (rc) return rc;
+  return s2k_group_wait(g, t);
+}
+
+// Key sets across the group (s2k_keyset_*, engine.hip): every member builds the tables of ALL the keys on its own device -
+// a shard may name any key - side by side, one host thread each; a verification call is sharded like any other, the
+// members' shards go through s2k_ecdsa_verify_batch_keyset_submit over their own copy.
+int s2k_group_keyset_create(s2k_group* g, size_t n_keys, const uint8_t* pub_xy, int layout, s2k_group_keyset** out) {
+  if (!g || !out) return S2K_ERR_ARG;
+  *out = nullptr;
+  if (!pub_xy || n_keys == 0) return gfail(g, S2K_ERR_ARG, "empty key set");
+  group_wait_idle(g);                              // the members' threads are parked: their contexts may be used from other threads
+  s2k_group_keyset* gks = new (std::nothrow) s2k_group_keyset();
+  if (!gks) return gfail(g, S2K_ERR_NOMEM, "out of host memory");
+  gks->group = g;
+  gks->n_keys = n_keys;
+  const size_t D = g->members.size();
+  gks->sets.assign(D, nullptr);
+  std::vector<int> rcs(D, S2K_OK);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < D; ++i)
+    th.emplace_back([&, i] { rcs[i] = s2k_keyset_create_ex(g->members[i]->ctx, n_keys, pub_xy, layout, &gks->sets[i]); });
+  for (std::thread& t : th) t.join();
+  for (size_t i = 0; i < D; ++i)
+    if (rcs[i]) {
+      const int rc = gfail(g, rcs[i], "key set on device %d: %s", g->members[i]->device, s2k_last_error(g->members[i]->ctx));
+      s2k_group_keyset_destroy(gks);
+      return rc;
+    }
+  *out = gks;
+  return S2K_OK;
+}
+
+void s2k_group_keyset_destroy(s2k_group_keyset* gks) {
+  if (!gks) return;
+  group_wait_idle(gks->group);
+  for (s2k_keyset* ks : gks->sets) s2k_keyset_destroy(ks);
+  delete gks;
+}
+size_t s2k_group_keyset_size(const s2k_group_keyset* gks) { return gks ? gks->n_keys : 0; }
+// layout and device memory of the set on the group's first member (the members hold the same set; with S2K_KEYSET_AUTO a
+// member short of memory may have fallen back to chunk tables on its own)
+int s2k_group_keyset_layout(const s2k_group_keyset* gks) { return gks && !gks->sets.empty() ? s2k_keyset_layout(gks->sets[0]) : 0; }
+size_t s2k_group_keyset_device_bytes(const s2k_group_keyset* gks) { return gks && !gks->sets.empty() ? s2k_keyset_device_bytes(gks->sets[0]) : 0; }
+
+int s2k_group_ecdsa_verify_batch_keyset_submit(s2k_group* g, const s2k_group_keyset* gks, size_t n, const uint32_t* key_index,
+                                               const uint8_t* dig, const uint8_t* r, const uint8_t* s, uint32_t flags, uint8_t* valid,
+                                               s2k_ticket* ticket) {
+  if (!g || !ticket) return S2K_ERR_ARG;
+  *ticket = 0;
+  if (!gks || gks->group != g) return gfail(g, S2K_ERR_ARG, "key set of another group");
+  if (n && (!key_index || !dig || !r || !s || !valid)) return gfail(g, S2K_ERR_ARG, "null buffer");
+  shard_job proto;
+  proto.gks = gks;
+  proto.kidx = key_index;
+  proto.dig = dig;
+  proto.r = r;
+  proto.s = s;
+  proto.flags = flags;
+  proto.valid = valid;
+  return group_submit(g, n, proto, ticket);
+}
+
+int s2k_group_ecdsa_verify_batch_keyset(s2k_group* g, const s2k_group_keyset* gks, size_t n, const uint32_t* key_index,
+                                        const uint8_t* dig, const uint8_t* r, const uint8_t* s, uint32_t flags, uint8_t* valid) {
+  s2k_ticket t = 0;
+  const int rc = s2k_group_ecdsa_verify_batch_keyset_submit(g, gks, n, key_index, dig, r, s, flags, valid, &t);
   if (rc) return rc;
   return s2k_group_wait(g, t);
 }

@@ -233,6 +233,63 @@ def test_group_two_members_one_device(eng, oracle):
         S.Group([S.device_count()])            # no such device
 
 
+@pytest.mark.parametrize("layout", [1, 2])
+def test_group_keyset_two_members_one_device(eng, oracle, layout):
+    """s2k_group_keyset_*: the key set on both members, batches of (key index, digest, r, s) sharded across them; verdicts
+    equal the single-context key-set call's, the batch verifier's on the expanded keys and the oracle's - ragged sizes,
+    sizes below the member count, an empty batch, three batches in flight, the low-s rule, a set of another group."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    nk, total = 700, 150000
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, total, nk, seed=23))
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)
+    keys = keys.copy()
+    keys[9, 1] ^= 0x10                                                 # no public key
+    kidx = inv.reshape(-1).astype(np.uint32)
+    rng = np.random.default_rng(5)
+    for i in range(0, total, 8):
+        a = (dig, r, s)[int(rng.integers(0, 3))]
+        a[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+    kidx[5] = len(keys)
+    full = np.zeros((total, 64), np.uint8)
+    inside = kidx < len(keys)
+    full[inside] = keys[kidx[inside]]
+    ks1 = eng.keyset_create(keys, layout)
+    ref = eng.ecdsa_verify_batch_keyset(ks1, kidx, dig, r, s)
+    assert np.array_equal(ref, eng.ecdsa_verify_batch(full, dig, r, s))
+    m = 2048
+    assert np.array_equal(ref[:m], oracle.ecdsa_verify_batch(full[:m], dig[:m], r[:m], s[:m], nthreads=os.cpu_count() or 1))
+    assert 0 < int(ref.sum()) < total and not ref[5]
+    g = S.Group([0, 0])
+    try:
+        gks = g.keyset_create(keys, layout)
+        assert len(gks) == len(keys) and gks.layout() == layout and gks.device_bytes() == ks1.device_bytes()
+        for lo, n in ((0, total), (7, 100001), (11, 1), (0, 0), (300, 513)):
+            got = g.ecdsa_verify_batch_keyset(gks, kidx[lo:lo + n], dig[lo:lo + n], r[lo:lo + n], s[lo:lo + n])
+            assert np.array_equal(got, ref[lo:lo + n]), (lo, n)
+            if n > 1:
+                st = g.member_stats()
+                assert sum(x["n"] for x in st) == n and st[1]["first"] == st[0]["n"]
+        cuts = [(0, 50000), (50000, 50001), (100001, 49999)]
+        tickets = [g.ecdsa_verify_batch_keyset_submit(gks, kidx[a:a + n], dig[a:a + n], r[a:a + n], s[a:a + n]) for a, n in cuts]
+        plain = g.ecdsa_verify_batch_submit(full[:30000], dig[:30000], r[:30000], s[:30000])       # and a plain one among them
+        for t, (a, n) in zip(tickets, cuts):
+            assert np.array_equal(t.wait(), ref[a:a + n])
+        assert np.array_equal(plain.wait(), ref[:30000])
+        assert np.array_equal(g.ecdsa_verify_batch_keyset(gks, kidx[:20000], dig[:20000], r[:20000], s[:20000], reject_malleable=True),
+                              eng.ecdsa_verify_batch_keyset(ks1, kidx[:20000], dig[:20000], r[:20000], s[:20000], reject_malleable=True))
+        g2 = S.Group([0])
+        try:
+            with pytest.raises(S.EngineError):
+                g2.ecdsa_verify_batch_keyset(gks, kidx[:100], dig[:100], r[:100], s[:100])
+        finally:
+            g2.close()
+        gks.close()
+    finally:
+        g.close()
+        ks1.close()
+
+
 # ---- EncodingCompactRecoverable -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fn", ["wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"])
 def test_wycheproof_compact_recoverable(eng, oracle, fn):
