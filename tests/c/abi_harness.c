@@ -228,6 +228,39 @@ static int group_part(void) {
   CHECK(s2k_group_member_stats(grp, st) == S2K_OK && st[0] + st[4] == N - 100 * (B - 1) && st[1] == 0 && st[5] == st[0], "member statistics");
   CHECK(s2k_group_ecdsa_verify_batch(grp, N, pub[0], dig[0], r[0], s[0], 0, grouped[0]) == S2K_OK, "synchronous group call");
   CHECK(good > 0 && good < B * N, "mixed verdicts");
+  /* key sets: the 97 keys of batch 0 built once - on the context, and on every member of the group; the batch names them
+   * by index and goes through the ticket forms */
+  {
+    const int n0 = N;
+    uint8_t* keys = malloc(97 * 64);
+    uint32_t* kidx = s2k_host_alloc(n0 * sizeof(uint32_t));
+    uint8_t* ksv = malloc(n0);
+    CHECK(keys && kidx && ksv, "allocation");
+    memcpy(keys, pub[0], 97 * 64);                      /* (signature i was made with key i mod 97) */
+    for (int i = 0; i < n0; ++i) kidx[i] = (uint32_t)(i % 97);
+    s2k_keyset* ks = NULL;
+    s2k_group_keyset* gks = NULL;
+    CHECK(s2k_keyset_create_ex(ctx, 97, keys, S2K_KEYSET_JOINT, &ks) == S2K_OK && s2k_keyset_size(ks) == 97 &&
+              s2k_keyset_layout(ks) == S2K_KEYSET_JOINT, "s2k_keyset_create_ex");
+    CHECK(s2k_group_keyset_create(grp, 97, keys, S2K_KEYSET_JOINT, &gks) == S2K_OK && s2k_group_keyset_size(gks) == 97, "s2k_group_keyset_create");
+    s2k_ticket kt = 0, kgt = 0;
+    memset(ksv, 9, n0);
+    CHECK(s2k_ecdsa_verify_batch_keyset_submit(ctx, ks, n0, kidx, dig[0], r[0], s[0], S2K_ECDSA_REJECT_MALLEABLE, ksv, &kt) == S2K_OK, "key-set submit");
+    CHECK(s2k_wait(ctx, kt) == S2K_OK && memcmp(ksv, sync[0], n0) == 0, "key-set submit / wait verdicts");
+    memset(ksv, 9, n0);
+    CHECK(s2k_group_ecdsa_verify_batch_keyset_submit(grp, gks, n0, kidx, dig[0], r[0], s[0], S2K_ECDSA_REJECT_MALLEABLE, ksv, &kgt) == S2K_OK,
+          "group key-set submit");
+    CHECK(s2k_group_wait(grp, kgt) == S2K_OK && memcmp(ksv, sync[0], n0) == 0, "group key-set verdicts");
+    kidx[5] = 97;                                       /* names no key: invalid */
+    CHECK(s2k_group_ecdsa_verify_batch_keyset(grp, gks, n0, kidx, dig[0], r[0], s[0], S2K_ECDSA_REJECT_MALLEABLE, ksv) == S2K_OK && ksv[5] == 0 &&
+              memcmp(ksv + 6, sync[0] + 6, n0 - 6) == 0, "index outside the set");
+    CHECK(s2k_ecdsa_verify_batch_keyset_submit(ctx, NULL, n0, kidx, dig[0], r[0], s[0], 0, ksv, &kt) == S2K_ERR_ARG, "null key set refused");
+    s2k_group_keyset_destroy(gks);
+    s2k_keyset_destroy(ks);
+    s2k_host_free(kidx);
+    free(keys);
+    free(ksv);
+  }
   const int bad_dev[1] = {s2k_device_count()};
   s2k_group* none = NULL;
   CHECK(s2k_group_create(bad_dev, 1, &none) == S2K_ERR_ARG && none == NULL, "unknown device refused");

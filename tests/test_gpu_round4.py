@@ -635,11 +635,13 @@ def test_group_bench_tool_one_device():
     import json
     import subprocess
     import sys
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "group_bench.py"), "--devices", "0", "--batch-log2", "16", "--batches", "6"],
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-1500:]
-    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["member_stats_last_shard"][0]["n"] == 1 << 16
+    for extra in ([], ["--keyset"]):                  # the second run: key set on the member, batches naming keys by index
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "group_bench.py"), "--devices", "0", "--batch-log2", "16", "--batches", "6",
+                            "--keys-log2", "10"] + extra, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-1500:]
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["member_stats_last_shard"][0]["n"] == 1 << 16
+        assert (d["keyset"] is not None and d["keyset"]["keys"] == 1 << 10) if extra else d["keyset"] is None
 
 
 # ---- key sets with joint tables -------------------------------------------------------------------------------------------

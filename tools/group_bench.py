@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """All GPUs of a node from ONE process through the C-ABI's device group (s2k_group_*): what a cgo host gets.
 
-    python tools/group_bench.py [--devices 0,1,...] [--batch-log2 20] [--keys-log2 16] [--batches 16]
+    python tools/group_bench.py [--devices 0,1,...] [--batch-log2 20] [--keys-log2 16] [--batches 16] [--keyset]
 
 Every listed device gets 2^batch_log2 signatures per group batch (weak scaling, like bench.py --gpus N: 2^21 per GPU is BASELINE
 config 5's shape); the packed arrays live in page-locked host memory, four group batches are kept in flight, and the clock runs
 from the completion of the fourth batch to the completion of the last (steady state).  Prints ONE JSON line: whole-node
 verifications/s host to host, per-member times of the last shards, and the verdict check (every batch carries a seeded
-pattern of damaged signatures that must come back as exactly that pattern).  No torch, no RCCL.  On this pool only one device
+pattern of damaged signatures that must come back as exactly that pattern).  --keyset: the keys' tables are built once on
+every device (s2k_group_keyset_create, joint tables; not timed) and the batches name their keys by index
+(s2k_group_ecdsa_verify_batch_keyset_submit).  No torch, no RCCL.  On this pool only one device
 per box exists; `--devices 0` is what has been run."""
 import argparse
 import json
@@ -30,6 +32,7 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--keys-log2", type=int, default=16)
     ap.add_argument("--batches", type=int, default=16)
+    ap.add_argument("--keyset", action="store_true")
     a = ap.parse_args()
     ndev = S.device_count()
     devices = [int(x) for x in a.devices.split(",")] if a.devices else list(range(ndev))
@@ -58,11 +61,23 @@ def main():
         masks.append((~bad).astype(np.uint8))
         outs.append(S.pinned_array((n,)))
     g = S.Group(devices)
+    gks = None
+    if a.keyset:
+        keys, inv = np.unique(base[0], axis=0, return_inverse=True)
+        gks = g.keyset_create(keys, S.KEYSET_JOINT)
+        kx = S.pinned_array((n,), np.uint32)
+        for m in range(len(devices)):
+            kx[m * per:(m + 1) * per] = inv.reshape(-1).astype(np.uint32)
+
+    def submit(k):
+        if gks is not None:
+            return g.ecdsa_verify_batch_keyset_submit(gks, kx, bufs[k % depth][1], bufs[k % depth][2], bufs[k % depth][3], out=outs[k % depth])
+        return g.ecdsa_verify_batch_submit(*bufs[k % depth], out=outs[k % depth])
     tickets, done, t0 = [], 0, None
     total = a.batches + lead
     for k in range(total):
         outs[k % depth][...] = 9
-        tickets.append((k, g.ecdsa_verify_batch_submit(*bufs[k % depth], out=outs[k % depth])))
+        tickets.append((k, submit(k)))
         if len(tickets) >= depth:
             j, t = tickets.pop(0)
             assert np.array_equal(t.wait(), masks[j % depth]), "group verdicts differ from the damage pattern (batch %d)" % j
@@ -81,7 +96,10 @@ def main():
             "ms_per_group_batch": ms, "signatures_per_group_batch": n, "per_gpu_value": per / (ms * 1e-3),
             "batches_timed": done - lead, "in_flight": depth, "scaling": "weak", "data": "synthetic, page-locked host memory",
             "member_stats_last_shard": g.member_stats(),
+            "keyset": None if gks is None else {"keys": len(gks), "device_bytes_per_member": gks.device_bytes(), "layout": "joint tables"},
             "check": "every batch's verdicts equal its seeded damage pattern (one bit of s flipped in every 61st signature)"}
+    if gks is not None:
+        gks.close()
     g.close()
     print(json.dumps(line), flush=True)
     return 0
