@@ -473,6 +473,12 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 // "fin" elements.
 // ---------------------------------------------------------------------------------------
 
+// Waves per SIMD the joint-table key-set ladder is built for.  Measured (tools/gpu_joint_waves.sh, same box, two runs each):
+// 3 waves (150 VGPRs, no spills) 1.743 / 1.746 ms, 4 waves (128 VGPRs, 21 spilled) 1.733 / 1.743 ms - the kernel is at the
+// clock the chip gives it (1.89-2.02 GHz under 8 GB of table fetches per launch) either way; 3 stays.
+#ifndef S2K_JOINT_WAVES
+#define S2K_JOINT_WAVES 3
+#endif
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
        MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8, MODE_ECDSA_KEYSET_JOINT = 9 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
@@ -571,7 +577,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S2K_FA
 // final addition took 152, and asking for four waves outright spills - 26 VGPRs for <ECDSA_KEYED>, 28 for the key-set
 // ladder, which stays at 142 VGPRs and three waves.  tests/test_counts_cpu.py watches the instruction counts; the
 // resource usage is printed by tools/kernel_regs.sh.)
-__global__ void __launch_bounds__(256, S2K_FAST_WAVES)
+__global__ void __launch_bounds__(256, MODE == MODE_ECDSA_KEYSET_JOINT ? S2K_JOINT_WAVES : S2K_FAST_WAVES)
 #endif
 k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
