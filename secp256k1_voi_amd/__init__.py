@@ -923,9 +923,13 @@ class Group:
             raise EngineError(f"s2k_group_create failed ({rc})")
         self._h = h
         self.devices = list(devices)
+        import weakref
+        self._keysets = weakref.WeakSet()     # key sets go before their group (s2k_group_keyset_destroy follows the group pointer)
 
     def close(self):
         if getattr(self, "_h", None):
+            for ks in list(self._keysets):
+                ks.close()
             self._lib.s2k_group_destroy(self._h)
             self._h = None
 
@@ -1023,6 +1027,7 @@ class GroupKeySet:
         k = C.c_void_p()
         group._check(group._lib.s2k_group_keyset_create(group._h, pub_xy.shape[0], pub_xy.ctypes.data, int(layout), C.byref(k)))
         self._k = k
+        group._keysets.add(self)
 
     def layout(self) -> int:
         return int(self._grp._lib.s2k_group_keyset_layout(self._k))
@@ -1035,9 +1040,9 @@ class GroupKeySet:
         return int(self._grp._lib.s2k_group_keyset_device_bytes(self._k))
 
     def close(self):
-        if self._k:
+        if self._k and self._grp._h:
             self._grp._lib.s2k_group_keyset_destroy(self._k)
-            self._k = None
+        self._k = None
 
     def __del__(self):
         try:
