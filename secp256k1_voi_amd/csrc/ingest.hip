@@ -17,26 +17,88 @@
 
 namespace {
 
-// one lane per item: bytes -> pub X||Y (64), digest (32), r (32), s (32), all big-endian as the
-// verification entry point takes them.  Items that fail any pre-check get r = 0, which the
-// verifier's range check rejects.
+// A big-endian byte string of n <= 32 bytes, right-aligned in 32 bytes, as the eight 32-bit words the output arrays hold
+// (word k = bytes 4k .. 4k + 3 of the 32-byte string, first byte in the low bits: what a 16-byte store puts back in
+// order).  Branch-free over n: every output byte is one conditional byte read.
+S2K_DEV void be_string_words(uint32_t w[8], const uint8_t* p, uint32_t n) {
+  const uint32_t pad = 32u - n;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t idx = 4 * k + j;
+      const uint32_t b = idx >= pad ? (uint32_t)p[idx - pad] : 0u;
+      v |= b << (8 * j);
+    }
+    w[k] = v;
+  }
+}
+// bytesToCanonicalScalar (s11n.go:203-218) with the callers' IsZero test, on such words: 0 < value < n
+S2K_DEV bool words_canonical_nonzero(const uint32_t w[8]) {
+  const uint32_t order[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xfffffffeu, 0xbaaedce6u, 0xaf48a03bu, 0xbfd25e8cu, 0xd0364141u};
+  int cmp = 0;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t v = __builtin_bswap32(w[k]);          // most significant word first
+    if (cmp == 0 && v != order[k]) cmp = v < order[k] ? -1 : 1;
+    acc |= v;
+  }
+  return cmp < 0 && acc != 0;
+}
+S2K_DEV void store32(uint8_t* dst, const uint32_t w[8], bool keep) {
+  uint4* o = reinterpret_cast<uint4*>(dst);                // (the output arrays are 256-byte aligned, items 32 or 64 bytes)
+  o[0] = keep ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+  o[1] = keep ? make_uint4(w[4], w[5], w[6], w[7]) : make_uint4(0u, 0u, 0u, 0u);
+}
+
+// 256 items per workgroup: bytes -> pub X||Y (64), digest (32), r (32), s (32), all big-endian as the verification entry
+// point takes them.  Items that fail any pre-check get r = 0, which the verifier's range check rejects.
+// The items of a workgroup are contiguous in each of the three blobs, so the workgroup first copies its stretch of every
+// blob into LDS with aligned 16-byte loads (coalesced; up to 15 bytes before and after the stretch ride along: the staging
+// buffers are padded) and the lanes parse from there; outputs leave as 16-byte stores.  (The first version read and wrote
+// single bytes from and to global memory - 170 byte loads and 160 byte stores per item, every one of them a scattered
+// access of its own: 0.84 ms per 2^20 items, a sixth of the verification behind it.)  A stretch that does not fit - keys,
+// digests or signatures far longer than any valid ones - is read from global memory as before.
+constexpr uint32_t PE_PUB_CAP = 256 * 65 + 64, PE_DIG_CAP = 256 * 64 + 64, PE_SIG_CAP = 256 * 80 + 64;   // bytes of LDS per blob
+S2K_DEV bool pe_stage(const uint8_t* __restrict__ blob, uint64_t lo, uint64_t hi, uint8_t* lds, uint32_t cap, uint64_t& a) {
+  a = lo & ~(uint64_t)15;
+  const uint64_t bytes = hi - a;
+  if (bytes + 16 > cap) return false;
+  for (uint32_t t = threadIdx.x * 16; t < (uint32_t)bytes; t += 256 * 16)
+    *reinterpret_cast<uint4*>(lds + t) = *reinterpret_cast<const uint4*>(blob + a + t);
+  return true;
+}
 __global__ void __launch_bounds__(256)
 k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, const uint64_t* __restrict__ pub_off,
                 const uint8_t* __restrict__ digests, const uint64_t* __restrict__ dig_off, const uint8_t* __restrict__ sigs,
                 const uint64_t* __restrict__ sig_off, int encoding, uint32_t digest_len, int bip66, int low_s, uint8_t* __restrict__ xy,
                 uint8_t* __restrict__ dg, uint8_t* __restrict__ rr, uint8_t* __restrict__ ss, uint8_t* __restrict__ recid) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  i += first;                                            // items [first, first + n) of the batch
-  const uint8_t* pk = pubs + pub_off[i];
-  size_t pk_len = (size_t)(pub_off[i + 1] - pub_off[i]);
-  const uint8_t* d = digests + dig_off[i];
-  size_t d_len = (size_t)(dig_off[i + 1] - dig_off[i]);
-  const uint8_t* sg = sigs + sig_off[i];
-  size_t sg_len = (size_t)(sig_off[i + 1] - sig_off[i]);
-  uint8_t r[32], s[32], q[64];
-  for (int j = 0; j < 32; ++j) r[j] = s[j] = 0;
-  for (int j = 0; j < 64; ++j) q[j] = 0;
+  __shared__ uint4 lds_pub[PE_PUB_CAP / 16], lds_dig[PE_DIG_CAP / 16], lds_sig[PE_SIG_CAP / 16];
+  const uint32_t b0 = blockIdx.x * 256;
+  if (b0 >= n) return;
+  const uint32_t cnt = n - b0 < 256u ? n - b0 : 256u;
+  const size_t i0 = (size_t)first + b0;                  // items [first, first + n) of the batch
+  uint64_t a_pub, a_dig, a_sig;
+  const bool st_pub = pe_stage(pubs, pub_off[i0], pub_off[i0 + cnt], reinterpret_cast<uint8_t*>(lds_pub), PE_PUB_CAP, a_pub);
+  const bool st_dig = pe_stage(digests, dig_off[i0], dig_off[i0 + cnt], reinterpret_cast<uint8_t*>(lds_dig), PE_DIG_CAP, a_dig);
+  const bool st_sig = pe_stage(sigs, sig_off[i0], sig_off[i0 + cnt], reinterpret_cast<uint8_t*>(lds_sig), PE_SIG_CAP, a_sig);
+  __syncthreads();
+  if (threadIdx.x >= cnt) return;
+  const size_t i = i0 + threadIdx.x;
+  const uint64_t po = pub_off[i], dof = dig_off[i], so = sig_off[i];
+  const uint8_t* pk = st_pub ? reinterpret_cast<const uint8_t*>(lds_pub) + (po - a_pub) : pubs + po;
+  const size_t pk_len = (size_t)(pub_off[i + 1] - po);
+  const uint8_t* d = st_dig ? reinterpret_cast<const uint8_t*>(lds_dig) + (dof - a_dig) : digests + dof;
+  const size_t d_len = (size_t)(dig_off[i + 1] - dof);
+  const uint8_t* sg = st_sig ? reinterpret_cast<const uint8_t*>(lds_sig) + (so - a_sig) : sigs + so;
+  size_t sg_len = (size_t)(sig_off[i + 1] - so);
+  uint32_t rw[8], sw[8], qw[16], dw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rw[j] = sw[j] = dw[j] = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) qw[j] = 0;
   bool ok = !(digest_len && d_len != digest_len);        // ecdsa.go:186-188
   ok = ok && d_len >= 32;                                // hashToScalar, ecdsa.go:478-480
   if (ok && bip66) {
@@ -45,34 +107,53 @@ k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, co
   }
   uint8_t v = 0;
   if (ok) {
-    int rc;
+    // 0 ok, 1 malformed encoding, 2 scalar out of range or zero (der.h: parse_asn1_signature / parse_compact_signature,
+    // the same structure checks; the scalars come out as words)
+    int rc = 1;
     if (encoding == S2K_ENCODING_ASN1) {
-      rc = s2k_der::parse_asn1_signature(sg, sg_len, r, s);
-    } else if (encoding == S2K_ENCODING_COMPACT) {
-      rc = s2k_der::parse_compact_signature(sg, sg_len, r, s);
-    } else {   // ParseCompactRecoverableSignature (s11n.go:156-168): [R | S | V], 65 bytes
-      rc = sg_len == 65 ? s2k_der::parse_compact_signature(sg, 64, r, s) : 1;
-      if (rc == 0) v = sg[64];
-      // the recovery path takes no options: the low-s rule of Verify (ecdsa.go:212) is applied here
-      if (rc == 0 && low_s) {
-        // (n - 1) / 2, big-endian (scalar.go:190 IsGreaterThanHalfN)
-        const uint8_t half[32] = {0x7f, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
-                                  0x5d, 0x57, 0x6e, 0x73, 0x57, 0xa4, 0x50, 0x1d, 0xdf, 0xe9, 0x2f, 0x46, 0x68, 0x1b, 0x20, 0xa0};
-        int cmp = 0;
-        for (int j = 0; j < 32; ++j)
-          if (cmp == 0 && s[j] != half[j]) cmp = s[j] < half[j] ? -1 : 1;
-        if (cmp > 0) rc = 2;
+      s2k_der::cb_str in{sg, sg_len}, inner, rb, sb;
+      if (s2k_der::cb_read_asn1(in, inner, 0x30) && in.n == 0 && s2k_der::cb_read_asn1_integer(inner, rb) &&
+          s2k_der::cb_read_asn1_integer(inner, sb) && inner.n == 0) {      // else errInvalidAsn1Sig
+        rc = 2;                                                           // errInvalidScalar unless both are canonical
+        if (rb.n <= 32 && sb.n <= 32) {                                  // (never 0: ReadASN1Integer refuses empty integers)
+          be_string_words(rw, rb.p, (uint32_t)rb.n);
+          be_string_words(sw, sb.p, (uint32_t)sb.n);
+          if (words_canonical_nonzero(rw) && words_canonical_nonzero(sw)) rc = 0;
+        }
+      }
+    } else if ((encoding == S2K_ENCODING_COMPACT && sg_len == 64) || (encoding != S2K_ENCODING_COMPACT && sg_len == 65)) {
+      // ParseCompactSignature (s11n.go:129-144); ParseCompactRecoverableSignature (s11n.go:156-168): [R | S | V], 65 bytes
+      be_string_words(rw, sg, 32);
+      be_string_words(sw, sg + 32, 32);
+      rc = (words_canonical_nonzero(rw) && words_canonical_nonzero(sw)) ? 0 : 2;
+      if (encoding != S2K_ENCODING_COMPACT && rc == 0) {
+        v = sg[64];
+        // the recovery path takes no options: the low-s rule of Verify (ecdsa.go:212) is applied here
+        if (low_s) {
+          // (n - 1) / 2 (scalar.go:190 IsGreaterThanHalfN)
+          const uint32_t half[8] = {0x7fffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x5d576e73u, 0x57a4501du, 0xdfe92f46u, 0x681b20a0u};
+          int cmp = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t sv = __builtin_bswap32(sw[j]);
+            if (cmp == 0 && sv != half[j]) cmp = sv < half[j] ? -1 : 1;
+          }
+          if (cmp > 0) rc = 2;
+        }
       }
     }
     ok = rc == 0;
   }
   if (ok) {
     if (pk_len == 65 && pk[0] == 0x04) {
-      for (int j = 0; j < 64; ++j) q[j] = pk[1 + j];     // canonical coordinates and the curve equation: k_verify_fast
+      be_string_words(qw, pk + 1, 32);                   // canonical coordinates and the curve equation: k_verify_fast
+      be_string_words(qw + 8, pk + 33, 32);
     } else if (pk_len == 33 && (pk[0] == 0x02 || pk[0] == 0x03)) {
       // SetCompressedBytes (point_s11n.go:140-176)
-      uint32_t xw[8];
-      load_be32_unaligned(xw, pk + 1);
+      uint32_t xb[8], xw[8];
+      be_string_words(xb, pk + 1, 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xw[j] = __builtin_bswap32(xb[7 - j]);   // little-endian words of the value
       ok = fe_is_canonical_raw(xw);
       if (ok) {
         fe29 x = fe29_from_words(xw);
@@ -85,20 +166,22 @@ k_parse_encoded(uint32_t first, uint32_t n, const uint8_t* __restrict__ pubs, co
         y = fe29_normalize(fe29_select(((y.n[0] & 1u) != 0) != want_odd, y, fe29_negate(y, 1)));
         uint32_t yw[8];
         fe29_to_words(yw, y);
-        for (int j = 0; j < 32; ++j) q[j] = pk[1 + j];
-        store_be32_unaligned(q + 32, yw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          qw[j] = xb[j];
+          qw[8 + j] = __builtin_bswap32(yw[7 - j]);
+        }
       }
     } else {
       ok = false;                                        // bad length / prefix, or the identity (secec.go:206-209)
     }
   }
-  uint8_t* oq = xy + i * 64;
-  for (int j = 0; j < 64; ++j) oq[j] = q[j];
-  for (int j = 0; j < 32; ++j) {
-    dg[i * 32 + j] = (ok && d_len >= 32) ? d[j] : 0;
-    rr[i * 32 + j] = ok ? r[j] : 0;
-    ss[i * 32 + j] = ok ? s[j] : 0;
-  }
+  if (ok) be_string_words(dw, d, 32);                    // the leftmost 32 bytes (d_len >= 32 was checked)
+  store32(xy + i * 64, qw, true);                        // (a key that failed to decode: whatever was decoded, or zeros - r = 0 rejects the item)
+  store32(xy + i * 64 + 32, qw + 8, true);
+  store32(dg + i * 32, dw, ok);
+  store32(rr + i * 32, rw, ok);
+  store32(ss + i * 32, sw, ok);
   if (recid) recid[i] = ok ? v : 0xff;                   // (0xff: no recovery id, RecoverPublicKey refuses it)
 }
 

@@ -402,6 +402,67 @@ def test_compact_recoverable_options_and_edges(eng, oracle):
         eng.ecdsa_verify_encoded_batch(pubs[:4], digs[:4], sigs[:4], encoding=3)
 
 
+# ---- the parse kernel's two ways to its bytes ---------------------------------------------------------------------------
+def test_encoded_parse_staging_paths(eng, oracle):
+    """k_parse_encoded copies a workgroup's stretch of every blob into LDS and parses from there; a stretch that does not fit
+    (digests, keys or signatures far longer than valid ones) is read from global memory instead.  3 000 items - DER signatures
+    with leading-zero and short integers, compressed and uncompressed keys at every alignment, damaged items - in five
+    shapes: as they are; with 64-byte digests (staged); with 200-byte digests (not staged: the leftmost 32 bytes count);
+    with one 5 000-byte signature and one 5 000-byte key in the middle of a workgroup (that workgroup unstaged, the items
+    false); compact and recoverable forms.  Every verdict against per-item host parsing + the raw verifier, a sample
+    against the oracle."""
+    import secp256k1_voi_amd as S
+    n = 3000
+    arrs = damaged_batch(eng, n, 200, 4141)
+    pub, dig, r, s = arrs
+    for i in range(0, n, 50):                            # short scalars: leading zero bytes are stripped in DER
+        r[i, :3] = 0
+        s[i, 0] = 0
+    raw = eng.ecdsa_verify_batch(pub, dig, r, s)
+    m = 1024
+    assert np.array_equal(raw[:m], oracle.ecdsa_verify_batch(pub[:m], dig[:m], r[:m], s[:m], nthreads=os.cpu_count() or 1))
+
+    def der(rb, sb):
+        body = b""
+        for x in (int.from_bytes(bytes(rb), "big"), int.from_bytes(bytes(sb), "big")):
+            bb = x.to_bytes((x.bit_length() + 8) // 8 or 1, "big")
+            body += b"\x02" + bytes([len(bb)]) + bb
+        return b"\x30" + bytes([len(body)]) + body
+    sigs = [der(r[i], s[i]) for i in range(n)]
+    pubs = []
+    for i in range(n):
+        q = bytes(pub[i])
+        full = b"\x04" + q
+        pubs.append(oracle.point_compressed(full) if (i % 3 == 0 and oracle.point_on_curve_xy(q[:32], q[32:])) else full)
+    digs = [bytes(d) for d in dig]
+    exp = raw.copy()
+    for i in range(n):                                   # what the host parser says: a zero or out-of-range scalar is errInvalidScalar
+        if oracle.parse_asn1_signature(sigs[i]) is None:
+            exp[i] = 0
+    assert 0 < int(exp.sum()) < n
+    assert np.array_equal(eng.ecdsa_verify_encoded_batch(pubs, digs, sigs), exp)
+    # longer digests: the leftmost 32 bytes are the scalar (hashToScalar, ecdsa.go:477-486)
+    for extra in (32, 168):
+        assert np.array_equal(eng.ecdsa_verify_encoded_batch(pubs, [d + bytes(extra) for d in digs], sigs), exp), extra
+        assert not eng.ecdsa_verify_encoded_batch(pubs[:600], [d + bytes(extra) for d in digs[:600]], sigs[:600], digest_len=32).any()
+    # one oversized signature and one oversized key inside a workgroup: those two false, their neighbours untouched
+    sig2, pub2, exp2 = list(sigs), list(pubs), exp.copy()
+    sig2[700] = b"\x30\x82\x13\x84" + bytes(4996)
+    pub2[1800] = b"\x04" + bytes(4999)
+    exp2[700] = exp2[1800] = 0
+    assert np.array_equal(eng.ecdsa_verify_encoded_batch(pub2, digs, sig2), exp2)
+    # compact and recoverable forms of the same items
+    compact = [bytes(r[i]) + bytes(s[i]) for i in range(n)]
+    exp_c = raw                                          # (ParseCompactSignature's range checks are the raw verifier's)
+    assert np.array_equal(eng.ecdsa_verify_encoded_batch(pubs, digs, compact, encoding=S.ENCODING_COMPACT), exp_c)
+    rec = [c + bytes([i & 3]) for i, c in enumerate(compact)]
+    got_r = eng.ecdsa_verify_encoded_batch(pubs, digs, rec, encoding=S.ENCODING_COMPACT_RECOVERABLE)
+    assert np.array_equal(got_r, eng.ecdsa_verify_encoded_batch(pubs, digs, rec, encoding=S.ENCODING_COMPACT_RECOVERABLE, force_complete=True))
+    assert not got_r[exp_c == 0].any() and 0 < int(got_r.sum()) < int(exp_c.sum())      # a valid item verifies under ONE recovery id
+    # through the ticket form too
+    assert np.array_equal(eng.ecdsa_verify_encoded_batch_submit(pub2, digs, sig2).wait(), exp2)
+
+
 # ---- the table buffer degrades instead of failing (ADVICE r03) -------------------------------------------------------
 def test_table_buffer_allocation_failure_degrades(oracle):
     """S2K_TEST_TABLE_BYTES_LIMIT makes s2k_internal_key_reserve treat larger table buffers as unobtainable: the cap is
