@@ -882,10 +882,8 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
 
   // ---- verdict ----
   uint8_t verdict = 0;
-  if constexpr (MODE == MODE_RECOVER || MODE == MODE_POINT) {
-    uint8_t* rec = out_pts + idx * 65;
-    for (int i = 0; i < 65; ++i) rec[i] = 0;
-  }
+  // (MODE_RECOVER / MODE_POINT: the 65-byte records start as zeros - one fill of the output array by the caller; the loop of
+  // 65 single-byte stores per lane that used to stand here cost the recovery ladder a tenth of its time)
   // Z = 0: infinity, or an exceptional case of the incomplete formulas somewhere on the way.  Where the zero first appears
   // in the FINAL addition of two finite points (Z3 = Z1 Z2 H = 0: equal x) the answer is at hand.  With H = 0 the mixed
   // addition leaves X3 = I^2, I = Y1 - S2 (jacobian29.h), so X3 != 0 says OPPOSITE points: R is the identity and verify
@@ -2185,6 +2183,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));      // items without a key keep the zero record
   k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, ctx->gtable,
                                                              (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, nullptr,
                                                              key_groups{});
@@ -2746,6 +2745,7 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
     HIP_TRY(ctx, hipGetLastError());
   } else {
     HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(io + o_out, 0, n * 65, st));   // (the ladder kernel leaves the records of undecided lanes alone)
     k_hot_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_pub, prep, stride, wl_count, wl,
                                               status);
     HIP_TRY(ctx, hipGetLastError());
