@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe inclusive) measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip configs 3/4, K=N and the worst case (e.g. under a profiler)")
-    ap.add_argument("--key-grouping", choices=("auto", "off", "keyset", "keyset-chunks"), default="auto",
+    ap.add_argument("--key-grouping", choices=("auto", "off", "keyset", "keyset-chunks", "keyset5", "keyset6"), default="auto",
                     help="off: every signature through the general ladder; keyset: the batch against a key set built before the "
                          "timed region (both for profiling those kernels under the driver's settings; not the headline)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -282,9 +282,9 @@ def worker(args):
     gather_scratch = {}
 
     main_keyset = None
-    if args.key_grouping in ("keyset", "keyset-chunks"):
+    if args.key_grouping in KEYSET_OPTIONS:
         ks_keys, ks_inv = np.unique(pub, axis=0, return_inverse=True)
-        main_keyset = (eng.keyset_create(ks_keys, S.KEYSET_JOINT if args.key_grouping == "keyset" else S.KEYSET_CHUNKS),
+        main_keyset = (eng.keyset_create(ks_keys, KEYSET_OPTIONS[args.key_grouping][0]),
                        torch.from_numpy(ks_inv.reshape(-1).astype(np.uint32).view(np.int32)).to(dev))
 
     def step(inputs=None):
@@ -394,8 +394,7 @@ def worker(args):
         clock_hz = prof["shader_mhz"] * 1e6
         value = n * world * args.steps / dt
         counts, counts_src = committed_counts()
-        kname = ("k_verify_fast_keyset_joint" if args.key_grouping == "keyset" else "k_verify_fast_keyset") if main_keyset is not None else \
-            ("k_verify_fast_keyed" if keyed else "k_verify_fast")
+        kname = KEYSET_OPTIONS[args.key_grouping][1] if main_keyset is not None else ("k_verify_fast_keyed" if keyed else "k_verify_fast")
         traffic, traffic_src = committed_traffic(kname)
         stages = {"grouping_by_key_ms": prof["group_ms"] / calls, "key_tables_ms": None, "ladder_ms": fast_ms,
                   "general_ladder_ms": prof["left_ms"] / calls, "complete_worklist_ms": prof["fallback_ms"] / calls}
@@ -407,18 +406,26 @@ def worker(args):
             stages["scalar_prep_ms"] = prof["prep_ms"] / calls
             stages.pop("grouping_by_key_ms")
             stages.pop("key_tables_ms")
-        roof = {"bound": "valu", "kernel": ("k_verify_fast<ECDSA_KEYSET_JOINT>" if args.key_grouping == "keyset" else "k_verify_fast<ECDSA_KEYSET>") if main_keyset is not None else ("k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>"),
+        roof = {"bound": "valu", "kernel": KEYSET_OPTIONS[args.key_grouping][2] if main_keyset is not None else ("k_verify_fast<ECDSA_KEYED>" if keyed else "k_verify_fast<ECDSA>"),
                 "kernel_ms": fast_ms, "kernel_ms_median": fast_med, "stages_ms": stages,
                 "shader_clock_mhz": prof["shader_mhz"], "shader_clock_mhz_first_wave": prof["shader_mhz_first_wave"],
                 "shader_clock_mhz_last_round": prof["shader_mhz_last_round"], "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
                 "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
         counts_all = counts
         if counts and kname not in counts:
-            counts = None
+            # a ladder the committed profile has no PMC entry for (yet): priced with the static recount of the loaded library
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import isa_count
+                sc_ = isa_count.static_counts(S.LIB_PATH)[kname]
+                counts = {kname: {"valu_instr_per_signature": sc_["valu_instr_static"]},
+                          (KEYSET_OPTIONS[args.key_grouping][3] if main_keyset is not None else "static"): sc_}
+                counts_src = "(none: static recount of the loaded library, tools/isa_count.py)"
+            except Exception:
+                counts = None
         if counts:
             ipv = counts[kname]["valu_instr_per_signature"]
-            st_ = counts.get(("static_keyset_joint" if args.key_grouping == "keyset" else "static_keyset") if main_keyset is not None else
-                             ("static_keyed" if keyed else "static"), {})
+            st_ = counts.get(KEYSET_OPTIONS[args.key_grouping][3] if main_keyset is not None else ("static_keyed" if keyed else "static"), {})
             lane_ops = ipv * n / (fast_ms * 1e-3)
             roof.update({"achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
                          "valu_instr_per_verify": ipv, "counts_from": "profiles/" + counts_src,
@@ -544,9 +551,9 @@ def worker(args):
                                                            "fill the pipeline, then 12 are timed completion to completion" % batch_log2}
             # the same through a key set (s2k_ecdsa_verify_batch_keyset_submit): the keys named by index, tables built once
             if n_keys < n and not args.no_extras:
-                from secp256k1_voi_amd import KEYSET_JOINT
+                from secp256k1_voi_amd import KEYSET_JOINT5
                 ks_keys, ks_inv = np.unique(pub, axis=0, return_inverse=True)
-                ks = eng.keyset_create(ks_keys, KEYSET_JOINT)
+                ks = eng.keyset_create(ks_keys, KEYSET_JOINT5)
                 kx3 = []
                 for q in pin3:
                     kx = pinned_array((n,), np.uint32)
@@ -559,7 +566,7 @@ def worker(args):
                     "value": n / (median(pk_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pk_ms), "ms_per_batch_each": pk_ms,
                     "keys": int(len(ks)), "keyset_device_bytes": ks.device_bytes(), "batches": 12, "in_flight": 4,
                     "note": "s2k_ecdsa_verify_batch_keyset_submit / s2k_wait: key indices, digests and signatures (100 bytes per "
-                            "signature) from page-locked buffers to host verdicts, joint tables of the keys built once (not timed); "
+                            "signature) from page-locked buffers to host verdicts, 5-bit joint tables of the keys built once (not timed); "
                             "never `value`"}
                 ks.close()
                 del kx3
@@ -671,14 +678,21 @@ def general_roofline(kernel_ms, shader_mhz, n):
     return roof
 
 
-def keyset_roofline(eng, kernel_ms, shader_mhz, n, joint=False):
+# --key-grouping value -> (s2k_keyset_create_ex layout, name of the ladder in the committed counts, kernel, its static entry)
+KEYSET_OPTIONS = {"keyset-chunks": (1, "k_verify_fast_keyset", "k_verify_fast<ECDSA_KEYSET>", "static_keyset"),
+                  "keyset": (2, "k_verify_fast_keyset_joint", "k_verify_fast<ECDSA_KEYSET_JOINT>", "static_keyset_joint"),
+                  "keyset5": (3, "k_verify_fast_keyset_joint5", "k_verify_fast<ECDSA_KEYSET_JOINT5>", "static_keyset_joint5"),
+                  "keyset6": (4, "k_verify_fast_keyset_joint6", "k_verify_fast<ECDSA_KEYSET_JOINT6>", "static_keyset_joint6")}
+
+
+def keyset_roofline(eng, kernel_ms, shader_mhz, n, option):
     """`roofline` of k_verify_fast<ECDSA_KEYSET> (64 table additions, no doubling) or <ECDSA_KEYSET_JOINT> (32): PMC count when
     the committed profile has one (bench.py --key-grouping keyset / keyset-chunks under the counters), else the static recount
     of the loaded library."""
     import secp256k1_voi_amd as S
     counts, src = committed_counts()
-    kname = "k_verify_fast_keyset_joint" if joint else "k_verify_fast_keyset"
-    roof = {"bound": "valu", "kernel": "k_verify_fast<ECDSA_KEYSET_JOINT>" if joint else "k_verify_fast<ECDSA_KEYSET>", "kernel_ms": kernel_ms,
+    kname, klabel = KEYSET_OPTIONS[option][1], KEYSET_OPTIONS[option][2]
+    roof = {"bound": "valu", "kernel": klabel, "kernel_ms": kernel_ms,
             "shader_clock_mhz": shader_mhz, "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12}
     ipv = None
     if counts and kname in counts:
@@ -687,7 +701,7 @@ def keyset_roofline(eng, kernel_ms, shader_mhz, n, joint=False):
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import isa_count
-            ipv = (isa_count.keyset_joint(S.LIB_PATH) if joint else isa_count.keyset(S.LIB_PATH))["valu_instr_static"]
+            ipv = isa_count.static_counts(S.LIB_PATH)[kname]["valu_instr_static"]
             roof["counts_from"] = "static recount of the loaded library (tools/isa_count.py)"
         except Exception as e:
             roof["recount_error"] = repr(e)[:200]
@@ -769,9 +783,14 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
         keys, inv = np.unique(host_pub, axis=0, return_inverse=True)
         d_kidx = torch.from_numpy(inv.astype(np.uint32).view(np.int32)).to(dev)
         dd, dr, ds = resident
-        from secp256k1_voi_amd import KEYSET_CHUNKS, KEYSET_JOINT
-        for layout, key in ((KEYSET_JOINT, "keyset_resident"), (KEYSET_CHUNKS, "keyset_resident_chunk_tables")):
-            ks = eng.keyset_create(keys, layout)
+        import time as _time
+        layouts = {"keyset5": "5-bit joint tables (S2K_KEYSET_JOINT5): 26 digit positions, one table addition each",
+                   "keyset": "joint tables (S2K_KEYSET_JOINT): one table addition per 4-bit digit position, 32 per signature",
+                   "keyset-chunks": "chunk tables (S2K_KEYSET_CHUNKS): 64 table additions per signature"}
+        for option, key in (("keyset5", "keyset_resident"), ("keyset", "keyset_resident_joint_tables_4bit"), ("keyset-chunks", "keyset_resident_chunk_tables")):
+            t_b = _time.perf_counter()
+            ks = eng.keyset_create(keys, KEYSET_OPTIONS[option][0])
+            build_s = _time.perf_counter() - t_b
 
             def with_keyset():
                 eng.ecdsa_verify_batch_keyset_device(ks, n, d_kidx.data_ptr(), dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_valid.data_ptr(), 0, st)
@@ -782,14 +801,12 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
             prk = eng.profile_read_stages(cap=16)
             eng.profile(False)
             assert int(d_valid.sum().item()) == n, "key-set verification did not accept the synthetic batch"
-            joint = layout == KEYSET_JOINT
             out[key] = {"keys": int(len(ks)), "ms": ms, "value": n / (ms * 1e-3), "unit": "verifications/s",
-                        "layout": "joint tables (S2K_KEYSET_JOINT): one table addition per digit position, 32 per signature" if joint else
-                                  "chunk tables (S2K_KEYSET_CHUNKS): 64 table additions per signature",
-                        "keyset_device_bytes": ks.device_bytes(),
-                        "roofline": keyset_roofline(eng, prk["fast_ms"] / max(prk["calls"], 1), prk["shader_mhz"], n, joint),
+                        "layout": layouts[option], "keyset_device_bytes": ks.device_bytes(), "keyset_build_s": build_s,
+                        "roofline": keyset_roofline(eng, prk["fast_ms"] / max(prk["calls"], 1), prk["shader_mhz"], n, option),
                         "note": "s2k_ecdsa_verify_batch_keyset_device: tables of the %d keys built once by s2k_keyset_create_ex "
-                                "(not timed); per call: scalar preparation, generator part, sort by key index, ladder" % len(ks)}
+                                "(not timed: keyset_build_s, host clock around the call); per call: scalar preparation, generator part, "
+                                "sort by key index, ladder" % len(ks)}
             ks.close()
         del d_kidx
 

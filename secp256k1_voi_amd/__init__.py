@@ -46,7 +46,7 @@ ENCODING_ASN1, ENCODING_COMPACT, ENCODING_COMPACT_RECOVERABLE = 0, 1, 2
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 IMPL_COMPLETE, IMPL_FAST = 0, 1
 KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS, KEYS_ADAPTIVE = 0, 1, 2, 3     # s2k_ctx_set_key_grouping (a new context: KEYS_ADAPTIVE)
-KEYSET_AUTO, KEYSET_CHUNKS, KEYSET_JOINT = 0, 1, 2   # s2k_keyset_create_ex
+KEYSET_AUTO, KEYSET_CHUNKS, KEYSET_JOINT, KEYSET_JOINT5, KEYSET_JOINT6 = 0, 1, 2, 3, 4   # s2k_keyset_create_ex
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
  HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
  HP_PT29_ADD_MIXED, HP_INV_GCD, HP_JADD_FULL, HP_PT29Q_DBL, HP_PT29Q_ADD, HP_XYZZ_ADD, HP_XYZZ_ROUND) = range(27)

@@ -480,7 +480,8 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 #define S2K_JOINT_WAVES 3
 #endif
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
-       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8, MODE_ECDSA_KEYSET_JOINT = 9 };
+       MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8, MODE_ECDSA_KEYSET_JOINT = 9,
+       MODE_ECDSA_KEYSET_JOINT5 = 10, MODE_ECDSA_KEYSET_JOINT6 = 11 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 constexpr uint32_t KVF_FORCE_WORKLIST = 0x80000000u;   // top bit of k_verify_fast's first argument (batches are below 2^31)
 
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S2K_FA
 // final addition took 152, and asking for four waves outright spills - 26 VGPRs for <ECDSA_KEYED>, 28 for the key-set
 // ladder, which stays at 142 VGPRs and three waves.  tests/test_counts_cpu.py watches the instruction counts; the
 // resource usage is printed by tools/kernel_regs.sh.)
-__global__ void __launch_bounds__(256, MODE == MODE_ECDSA_KEYSET_JOINT ? S2K_JOINT_WAVES : S2K_FAST_WAVES)
+__global__ void __launch_bounds__(256, (MODE == MODE_ECDSA_KEYSET_JOINT || MODE == MODE_ECDSA_KEYSET_JOINT5 || MODE == MODE_ECDSA_KEYSET_JOINT6) ? S2K_JOINT_WAVES : S2K_FAST_WAVES)
 #endif
 k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
@@ -585,7 +586,9 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
               key_groups kg) {
   constexpr bool JOINT = MODE == MODE_ECDSA_KEYSET_JOINT;   // ... over its joint tables: one addition per digit position
-  constexpr bool KEYSET = MODE == MODE_ECDSA_KEYSET || JOINT;   // KEYED over a key set's 32-chunk tables: no doublings at all
+  constexpr int JW = MODE == MODE_ECDSA_KEYSET_JOINT5 ? 5 : MODE == MODE_ECDSA_KEYSET_JOINT6 ? 6 : 4;
+  constexpr bool JOINTW = JW > 4;                            // ... over joint tables of 5- or 6-bit digits (kjw_geom: 26 / 22 positions)
+  constexpr bool KEYSET = MODE == MODE_ECDSA_KEYSET || JOINT || JOINTW;   // KEYED over a key set's 32-chunk tables: no doublings at all
   constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED || KEYSET;
   constexpr bool GROUPED = KEYED || MODE == MODE_ECDSA_LEFT || MODE == MODE_SCHNORR_LEFT;
   constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT || KEYSET;
@@ -753,8 +756,12 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
     xyzz29 xa;
     {
       // +-L +- phi(L): the table holds L + phi(L) and L - phi(L) (keyed.hip), the other two are their negatives
+      // (wide joint tables: L = 2^(W POS) Q, the pair behind the positions of the key's joint table)
       fe29 lx, ly;
-      ke_load_xy(kt + (size_t)(neg1 == neg2 ? G::LEAD : G::LEAD + 1) * 8, false, lx, ly);
+      if constexpr (JOINTW)
+        je_load(kg.jtab + (size_t)kg.ptab[idx] * kjw_geom<JW>::KEY_QUADS + (kjw_geom<JW>::LEAD + (neg1 == neg2 ? 0 : 1)) * KJ_ENTRY_QUADS, lx, ly);
+      else
+        ke_load_xy(kt + (size_t)(neg1 == neg2 ? G::LEAD : G::LEAD + 1) * 8, false, lx, ly);
       xa = xyzz29_from_affine(lx, fe29_cond_negate1(ly, neg1));
     }
     if constexpr (KEYSET) {
@@ -768,7 +775,31 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
         a[w] = (k1.v[w] >> 1) | (k1.v[w + 1] << 31);
         b[w] = (k2.v[w] >> 1) | (k2.v[w + 1] << 31);
       }
-      [[maybe_unused]] const uint4* jt = JOINT ? kg.jtab + (size_t)kg.ptab[idx] * KJ_KEY_QUADS : nullptr;
+      [[maybe_unused]] const uint4* jt = JOINT ? kg.jtab + (size_t)kg.ptab[idx] * KJ_KEY_QUADS
+                                        : JOINTW ? kg.jtab + (size_t)kg.ptab[idx] * kjw_geom<JW>::KEY_QUADS : nullptr;
+      if constexpr (JOINTW) {
+        // W-bit digits: w_i = bits W i .. W i + W - 1 of (k - 1) / 2, d_i = 2 w_i - (2^W - 1): below 2^(W-1) negative with
+        // magnitude 2 (NE - 1 - w) + 1, else positive with magnitude 2 (w - NE) + 1
+        using J = kjw_geom<JW>;
+        constexpr uint32_t WM = (1u << JW) - 1u, NE = (uint32_t)J::NE;
+#pragma unroll 1
+        for (int c = 0; c < J::POS; ++c) {
+          const uint32_t w1 = a[0] & WM, w2 = b[0] & WM;
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            a[w] = (a[w] >> JW) | (a[w + 1] << (32 - JW));
+            b[w] = (b[w] >> JW) | (b[w + 1] << (32 - JW));
+          }
+          a[3] >>= JW;
+          b[3] >>= JW;
+          const bool n1 = neg1 != (w1 < NE), n2 = neg2 != (w2 < NE);
+          const uint32_t ea = (w1 < NE) ? (NE - 1u - w1) : (w1 - NE), eb = (w2 < NE) ? (NE - 1u - w2) : (w2 - NE);
+          const uint32_t j = (((uint32_t)c * NE + ea) * NE + eb) * 2u + (n1 != n2 ? 1u : 0u);
+          fe29 x, y;
+          je_load(jt + (size_t)j * KJ_ENTRY_QUADS, x, y);
+          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
+        }
+      } else {
 #pragma unroll 1
       for (int c = 0; c < KS_CHUNKS; ++c) {
         const uint32_t w1 = a[0] & 15u, w2 = b[0] & 15u;
@@ -797,6 +828,7 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
             xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, neg));
           }
         }
+      }
       }
     } else {
       digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);
@@ -1915,8 +1947,9 @@ struct s2k_keyset {
   size_t n;
   uint8_t* base;      // device: keys | tables | validity | identity | counters (s2k_internal_keyset_bytes)
   size_t bytes;
-  uint4* joint;       // device: the joint tables (320 KiB per key), or null: the ladder over the 32-chunk tables
+  uint4* joint;       // device: the joint tables (320 KiB per key; 1.04 / 3.6 MiB at 5- / 6-bit digits), or null: the ladder over the 32-chunk tables
   size_t joint_bytes;
+  int jw;             // digit width of the joint tables: 4, 5 or 6 (0: none)
 };
 
 int s2k_keyset_create(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, s2k_keyset** out) {
@@ -1924,7 +1957,9 @@ int s2k_keyset_create(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, s2k_ke
 }
 int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int layout, s2k_keyset** out) {
   if (!ctx || !out) return fail(ctx, S2K_ERR_ARG, "null argument");
-  if (layout != S2K_KEYSET_AUTO && layout != S2K_KEYSET_CHUNKS && layout != S2K_KEYSET_JOINT) return fail(ctx, S2K_ERR_ARG, "unknown key-set layout");
+  if (layout != S2K_KEYSET_AUTO && layout != S2K_KEYSET_CHUNKS && layout != S2K_KEYSET_JOINT && layout != S2K_KEYSET_JOINT5 &&
+      layout != S2K_KEYSET_JOINT6)
+    return fail(ctx, S2K_ERR_ARG, "unknown key-set layout");
   *out = nullptr;
   if (n_keys == 0 || !pub_xy) return fail(ctx, S2K_ERR_ARG, "empty key set");
   if (n_keys > 0x0fffffffu) return fail(ctx, S2K_ERR_ARG, "key set too large");
@@ -1949,28 +1984,44 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
   if (rc == S2K_OK && hipMemcpyAsync(ks->base + off[0], pub_xy, n_keys * 64, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(ctx, S2K_ERR_HIP, "copy of the keys failed");
   if (rc == S2K_OK) rc = s2k_internal_keyset_build(ctx, ks->base, n_keys, st);
-  // joint tables (one table addition per digit position instead of two; 320 KiB per key on top): when asked for, or -
-  // S2K_KEYSET_AUTO - when they take no more than a quarter of the device memory that is free now
+  // joint tables (one table addition per digit position instead of two; 320 KiB per key on top, 1.04 MiB at 5-bit digits: 26
+  // positions, 3.6 MiB at 6-bit digits: 22): the layout asked for, or - S2K_KEYSET_AUTO - the widest of 5 and 4 bits that takes no
+  // more than a quarter of the device memory that is free now
   ks->joint = nullptr;
   ks->joint_bytes = 0;
+  ks->jw = 0;
+  uint4* scratch = nullptr;
   if (rc == S2K_OK && layout != S2K_KEYSET_CHUNKS) {
-    const size_t want = n_keys * KJ_KEY_QUADS * sizeof(uint4);
-    size_t free_b = 0, total_b = 0;
-    bool take = layout == S2K_KEYSET_JOINT;
-    if (!take && hipMemGetInfo(&free_b, &total_b) == hipSuccess) take = want <= free_b / 4;
-    if (take) {
-      const hipError_t e2 = hipMalloc((void**)&ks->joint, want);
+    int w = layout == S2K_KEYSET_JOINT6 ? 6 : layout == S2K_KEYSET_JOINT5 ? 5 : layout == S2K_KEYSET_JOINT ? 4 : 0;
+    if (w == 0) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        if (s2k_internal_keyset_joint_bytes(n_keys, 5) + s2k_internal_keyset_joint_scratch_bytes(n_keys, 5) <= free_b / 4) w = 5;
+        else if (s2k_internal_keyset_joint_bytes(n_keys, 4) <= free_b / 4) w = 4;
+      }
+    }
+    if (w) {
+      const size_t want = s2k_internal_keyset_joint_bytes(n_keys, w), want_scr = s2k_internal_keyset_joint_scratch_bytes(n_keys, w);
+      hipError_t e2 = hipMalloc((void**)&ks->joint, want);
+      if (e2 == hipSuccess && want_scr) e2 = hipMalloc((void**)&scratch, want_scr);
       if (e2 == hipSuccess) {
         ks->joint_bytes = want;
-        rc = s2k_internal_keyset_build_joint(ctx, ks->base, n_keys, ks->joint, st);
+        ks->jw = w;
+        rc = w == 4 ? s2k_internal_keyset_build_joint(ctx, ks->base, n_keys, ks->joint, st)
+                    : s2k_internal_keyset_build_joint_wide(ctx, ks->base, n_keys, w, ks->joint, scratch, st);
       } else {
         (void)hipGetLastError();
+        if (ks->joint) (void)hipFree(ks->joint);
         ks->joint = nullptr;
-        if (layout == S2K_KEYSET_JOINT) rc = fail(ctx, S2K_ERR_HIP, "joint tables of %zu keys (%zu bytes): %s", n_keys, want, hipGetErrorString(e2));
+        if (layout != S2K_KEYSET_AUTO) rc = fail(ctx, S2K_ERR_HIP, "joint tables of %zu keys (%zu bytes): %s", n_keys, want + want_scr, hipGetErrorString(e2));
       }
     }
   }
   if (rc == S2K_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "key set build failed");
+  if (scratch) {
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+  }
   ctx->have_last = false;
   if (rc) {
     if (ks->joint) (void)hipFree(ks->joint);
@@ -1991,7 +2042,9 @@ void s2k_keyset_destroy(s2k_keyset* ks) {
 }
 size_t s2k_keyset_size(const s2k_keyset* ks) { return ks ? ks->n : 0; }
 size_t s2k_keyset_device_bytes(const s2k_keyset* ks) { return ks ? ks->bytes + ks->joint_bytes : 0; }
-int s2k_keyset_layout(const s2k_keyset* ks) { return !ks ? 0 : (ks->joint ? S2K_KEYSET_JOINT : S2K_KEYSET_CHUNKS); }
+int s2k_keyset_layout(const s2k_keyset* ks) {
+  return !ks ? 0 : !ks->joint ? S2K_KEYSET_CHUNKS : ks->jw == 6 ? S2K_KEYSET_JOINT6 : ks->jw == 5 ? S2K_KEYSET_JOINT5 : S2K_KEYSET_JOINT;
+}
 int s2k_keyset_valid_keys(s2k_keyset* ks, uint8_t* valid) {
   if (!ks || !valid) return fail(nullptr, S2K_ERR_ARG, "null argument");
   size_t off[5];
@@ -2060,7 +2113,13 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
   kg.jtab = ks->joint;
   prof_mark(ctx, st, 2);
-  if (ks->joint)
+  if (ks->joint && ks->jw == 6)
+    k_verify_fast<MODE_ECDSA_KEYSET_JOINT6><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
+                                                                           ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+  else if (ks->joint && ks->jw == 5)
+    k_verify_fast<MODE_ECDSA_KEYSET_JOINT5><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
+                                                                           ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+  else if (ks->joint)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
                                                                           ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else

@@ -329,7 +329,23 @@ constexpr int KS_SLOTS = kt_geom<32>::SLOTS;    // 288
 constexpr int KJ_ENTRY_QUADS = 5;
 constexpr int KJ_PER_CHUNK = 128;
 constexpr size_t KJ_KEY_QUADS = (size_t)KS_CHUNKS * KJ_PER_CHUNK * KJ_ENTRY_QUADS;   // 20480 quads = 320 KiB
+// Wider joint tables (S2K_KEYSET_JOINT5 / S2K_KEYSET_JOINT6): the same idea on W-bit digits.  A half scalar k (odd, < 2^129) is
+// k = 2^(W POS) + sum_i d_i 2^(W i), d_i = 2 w_i - (2^W - 1), w_i the W-bit windows of (k - 1) / 2, POS = ceil(128 / W) of them;
+// per position the sums (2a + 1) B_i + s phi((2b + 1) B_i), a, b < 2^(W-1), s = +-, B_i = 2^(W i) Q: POS additions per signature
+// instead of 32 (26 at W = 5, 22 at W = 6) for 2^(2W - 1) entries per position (1.04 MiB / 3.6 MiB per key).  The points are
+// derived from the key's 32-chunk table by affine doublings and additions, so they live on the same isomorphic curve (same W
+// factor at the end of the ladder).  The ladder's two starting points, 2^(W POS) Q +- phi(2^(W POS) Q), follow the positions.
+template <int W>
+struct kjw_geom {
+  static constexpr int NE = 1 << (W - 1);                        // odd multiples per position
+  static constexpr int POS = (128 + W - 1) / W;                  // digit positions
+  static constexpr int PER_POS = NE * NE * 2;                    // joint entries per position
+  static constexpr size_t LEAD = (size_t)POS * PER_POS;          // entries LEAD, LEAD + 1: the lead pair
+  static constexpr size_t KEY_QUADS = (LEAD + 2) * KJ_ENTRY_QUADS;
+  static constexpr int LEAD_SHIFT = W * POS - 128;               // doublings from the chunk table's L = 2^128 Q to 2^(W POS) Q
+};
 static_assert(KT_SLOTS == 72 && KT_W_SLOT == 9 && kt_geom<32>::SLOTS == 288, "table geometry");
+static_assert(kjw_geom<5>::POS == 26 && kjw_geom<5>::LEAD_SHIFT == 2 && kjw_geom<6>::POS == 22 && kjw_geom<6>::LEAD_SHIFT == 4, "joint geometry");
 enum { KG_NKEYED = 0, KG_NTAB = 1, KG_NLEFT = 2, KG_SPLIT_T = 3, KG_SPLIT_LANE = 4, KG_ALLOC64 = 6 /* and 7 */, KG_COUNTERS = 16 };
 constexpr uint32_t KG_NONE = 0xffffffffu;
 constexpr size_t KG_MIN_BATCH = 256;            // smaller batches skip the grouping
@@ -382,6 +398,9 @@ int s2k_internal_key_reserve32(s2k_ctx* ctx, size_t n);
 size_t s2k_internal_keyset_bytes(size_t n, size_t off[5]);
 int s2k_internal_keyset_build(s2k_ctx* ctx, uint8_t* base, size_t n, hipStream_t st);
 int s2k_internal_keyset_build_joint(s2k_ctx* ctx, const uint8_t* base, size_t n, uint4* joint, hipStream_t st);   // from the 32-chunk tables
+size_t s2k_internal_keyset_joint_bytes(size_t n, int w);                  // joint tables of n keys at digit width w (4, 5, 6)
+size_t s2k_internal_keyset_joint_scratch_bytes(size_t n, int w);          // build scratch of the wide layouts (0 at w = 4)
+int s2k_internal_keyset_build_joint_wide(s2k_ctx* ctx, const uint8_t* base, size_t n, int w, uint4* joint, uint4* scratch, hipStream_t st);
 int s2k_internal_keyset_reserve(s2k_ctx* ctx, size_t nkeys, size_t n);
 int s2k_internal_keyset_sort(s2k_ctx* ctx, const uint8_t* set_base, size_t nkeys, size_t n, const uint32_t* d_kidx, hipStream_t st,
                              key_groups* out);

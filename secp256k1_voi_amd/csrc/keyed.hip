@@ -852,6 +852,116 @@ k_ks_joint(uint32_t nkeys, const uint4* __restrict__ ktab, uint4* __restrict__ j
     }
   }
 }
+
+// ---- wide joint tables (kjw_geom<W>, engine_internal.h), built once per key set: inversions are affordable here ----
+// affine doubling and addition on y^2 = x^3 + b for any b (the formulas contain no curve constant: they hold on the key's
+// isomorphic curve), one safegcd inversion each; operands and results with 1 unit
+S2K_DEV void aff_double(fe29& x, fe29& y) {
+  const fe29 inv = fe29_inv_gcd(fe29_add(y, y));                                        // 1 / 2y
+  const fe29 lam = fe29_mul(fe29_mul_int(fe29_sqr(x), 3), inv);                          // 3 x^2 / 2y  ([3] x [1])
+  const fe29 x3 = fe29_sqr_plus(lam, fe29_negate(fe29_add(x, x), 2));                    // lambda^2 - 2x
+  y = fe29_mul_plus(lam, fe29_add(x, fe29_negate(x3, 1)), fe29_negate(y, 1));            // lambda (x - x3) - y
+  x = x3;
+}
+S2K_DEV void aff_add(const fe29& x1, const fe29& y1, const fe29& x2, const fe29& y2, fe29& x3, fe29& y3) {
+  const fe29 di = fe29_inv_gcd(fe29_add(x2, fe29_negate(x1, 1)));                        // 1 / (x2 - x1)
+  const fe29 nya = fe29_negate(y1, 1);
+  const fe29 lam = fe29_mul(fe29_add(y2, nya), di);                                      // ([3] x [1])
+  x3 = fe29_sqr_plus(lam, fe29_negate(fe29_add(x1, x2), 2));                             // lambda^2 - x1 - x2
+  y3 = fe29_mul_plus(lam, fe29_add(x1, fe29_negate(x3, 1)), nya);                        // lambda (x1 - x3) - y1
+}
+// One lane per (key, position i): B_i = 2^(W i) Q from the 32-chunk table's entry 16^c Q, c = W i / 4, by W i mod 4 doublings;
+// then the odd multiples (2a + 1) B_i, a < NE, by repeated addition of 2 B_i.  (x2 = x1 would need 2a + 1 = +-2 mod n.)
+template <int W>
+__global__ void __launch_bounds__(64)
+k_ksw_odd(uint32_t nkeys, const uint4* __restrict__ ktab, uint4* __restrict__ odd) {
+  using G = kjw_geom<W>;
+  const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t t = id / G::POS, i = id % G::POS;
+  if (t >= nkeys) return;
+  const uint32_t bit = (uint32_t)W * i, c = bit >> 2, r = bit & 3u;
+  fe29 x, y;
+  ke_load_xy(ktab + (size_t)t * (KS_SLOTS * 8) + (size_t)(c * 8) * 8, false, x, y);
+#pragma unroll 1
+  for (uint32_t k = 0; k < r; ++k) aff_double(x, y);
+  uint4* o = odd + ((size_t)t * G::POS + i) * G::NE * KJ_ENTRY_QUADS;
+  je_store(o, x, y);
+  fe29 dx = x, dy = y;
+  aff_double(dx, dy);                                                                   // 2 B_i
+#pragma unroll 1
+  for (int a = 1; a < G::NE; ++a) {
+    fe29 nx, ny;
+    aff_add(x, y, dx, dy, nx, ny);
+    x = nx;
+    y = ny;
+    je_store(o + (size_t)a * KJ_ENTRY_QUADS, x, y);
+  }
+}
+// One lane per (key, position): the NE * NE * 2 joint entries, exactly as k_ks_joint does for 8 * 8 * 2 (one inversion for all
+// the denominators beta x_b - x_a; the prefix products parked in the entries' own slots); the beta x column is computed here
+template <int W>
+__global__ void __launch_bounds__(64)
+k_ksw_joint(uint32_t nkeys, const uint4* __restrict__ odd, uint4* __restrict__ jtab) {
+  using G = kjw_geom<W>;
+  const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t t = id / G::POS, c = id % G::POS;
+  if (t >= nkeys) return;
+  const uint4* e0 = odd + ((size_t)t * G::POS + c) * G::NE * KJ_ENTRY_QUADS;
+  uint4* j0 = jtab + (size_t)t * G::KEY_QUADS + (size_t)c * G::PER_POS * KJ_ENTRY_QUADS;
+  const fe29 beta = fe29_from_words(FE_BETA);
+  constexpr int PAIRS = G::NE * G::NE;
+  fe29 pre = fe29_one();
+#pragma unroll 1
+  for (int k = 0; k < PAIRS; ++k) {
+    const int a = k / G::NE, b = k % G::NE;
+    fe29 xa, ya, xb, yb;
+    je_load(e0 + (size_t)a * KJ_ENTRY_QUADS, xa, ya);
+    je_load(e0 + (size_t)b * KJ_ENTRY_QUADS, xb, yb);
+    const fe29 d = fe29_add(fe29_mul(xb, beta), fe29_negate(xa, 1));              // x2 - x1 [3]
+    pre = fe29_mul(pre, d);
+    je_store1(j0 + (size_t)(2 * k) * KJ_ENTRY_QUADS, pre);
+  }
+  fe29 inv = fe29_inv_gcd(pre);
+#pragma unroll 1
+  for (int k = PAIRS - 1; k >= 0; --k) {
+    const int a = k / G::NE, b = k % G::NE;
+    fe29 xa, ya, xb, yb;
+    je_load(e0 + (size_t)a * KJ_ENTRY_QUADS, xa, ya);
+    je_load(e0 + (size_t)b * KJ_ENTRY_QUADS, xb, yb);
+    const fe29 bxb = fe29_mul(xb, beta);
+    const fe29 d = fe29_add(bxb, fe29_negate(xa, 1));
+    const fe29 prev = k ? je_load1(j0 + (size_t)(2 * (k - 1)) * KJ_ENTRY_QUADS) : fe29_one();
+    const fe29 di = fe29_mul(inv, prev);                                         // 1 / (x2 - x1)
+    inv = fe29_mul(inv, d);
+    const fe29 nxs = fe29_negate(fe29_add(xa, bxb), 2);                          // -(x1 + x2) [3]
+    const fe29 nya = fe29_negate(ya, 1);                                         // -y1 [2]
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const fe29 dy = s_ ? fe29_negate(fe29_add(yb, ya), 2) : fe29_add(yb, nya);   // y2 - y1 with y2 = +-y_b [3]
+      const fe29 lam = fe29_mul(dy, di);
+      const fe29 x3 = fe29_sqr_plus(lam, nxs);
+      const fe29 y3 = fe29_mul_plus(lam, fe29_add(xa, fe29_negate(x3, 1)), nya);
+      je_store(j0 + (size_t)(2 * k + s_) * KJ_ENTRY_QUADS, x3, y3);
+    }
+  }
+}
+// One lane per key: the ladder's two starting points, 2^(W POS) Q +- phi(2^(W POS) Q) = 2^LEAD_SHIFT (L +- phi(L)) from the
+// chunk table's lead pair (doubling commutes with phi)
+template <int W>
+__global__ void __launch_bounds__(64)
+k_ksw_lead(uint32_t nkeys, const uint4* __restrict__ ktab, uint4* __restrict__ jtab) {
+  using G = kjw_geom<W>;
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= nkeys) return;
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    fe29 x, y;
+    ke_load_xy(ktab + (size_t)t * (KS_SLOTS * 8) + (size_t)(kt_geom<KS_CHUNKS>::LEAD + k) * 8, false, x, y);
+#pragma unroll 1
+    for (int d = 0; d < G::LEAD_SHIFT; ++d) aff_double(x, y);
+    je_store(jtab + (size_t)t * G::KEY_QUADS + (G::LEAD + k) * KJ_ENTRY_QUADS, x, y);
+  }
+}
 }  // namespace
 
 // device memory of a key set of n keys: keys | tables | validity | identity | counters
@@ -893,6 +1003,37 @@ __attribute__((visibility("hidden"))) int s2k_internal_keyset_build_joint(s2k_ct
   k_ks_joint<<<(unsigned)((n * KS_CHUNKS + 63) / 64), 64, 0, st>>>((uint32_t)n, (const uint4*)(base + off[1]), joint);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
+}
+// the wide layouts: bytes of the joint tables and of the build's scratch (the odd multiples per position), and the build itself
+__attribute__((visibility("hidden"))) size_t s2k_internal_keyset_joint_bytes(size_t n, int w) {
+  const size_t quads = w == 6 ? kjw_geom<6>::KEY_QUADS : w == 5 ? kjw_geom<5>::KEY_QUADS : KJ_KEY_QUADS;
+  return n * quads * sizeof(uint4);
+}
+__attribute__((visibility("hidden"))) size_t s2k_internal_keyset_joint_scratch_bytes(size_t n, int w) {
+  if (w != 5 && w != 6) return 0;
+  const size_t per_key = w == 6 ? (size_t)kjw_geom<6>::POS * kjw_geom<6>::NE : (size_t)kjw_geom<5>::POS * kjw_geom<5>::NE;
+  return n * per_key * KJ_ENTRY_QUADS * sizeof(uint4);
+}
+template <int W>
+static int keyset_build_joint_wide(s2k_ctx* ctx, const uint4* ktab, size_t n, uint4* joint, uint4* scratch, hipStream_t st) {
+  using G = kjw_geom<W>;
+  const unsigned lanes_blocks = (unsigned)((n * G::POS + 63) / 64);
+  k_ksw_odd<W><<<lanes_blocks, 64, 0, st>>>((uint32_t)n, ktab, scratch);
+  HIP_TRY(ctx, hipGetLastError());
+  k_ksw_joint<W><<<lanes_blocks, 64, 0, st>>>((uint32_t)n, scratch, joint);
+  HIP_TRY(ctx, hipGetLastError());
+  k_ksw_lead<W><<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, ktab, joint);
+  HIP_TRY(ctx, hipGetLastError());
+  return S2K_OK;
+}
+__attribute__((visibility("hidden"))) int s2k_internal_keyset_build_joint_wide(s2k_ctx* ctx, const uint8_t* base, size_t n, int w, uint4* joint,
+                                                                              uint4* scratch, hipStream_t st) {
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(n, off);
+  const uint4* ktab = (const uint4*)(base + off[1]);
+  if (w == 5) return keyset_build_joint_wide<5>(ctx, ktab, n, joint, scratch, st);
+  if (w == 6) return keyset_build_joint_wide<6>(ctx, ktab, n, joint, scratch, st);
+  return fail(ctx, S2K_ERR_ARG, "joint tables of digit width %d", w);
 }
 // scratch of the sort below, in the context's grouping arrays: counters | cnt, base [nkeys] | slot_of, pos_of, perm, ptab, left [n]
 __attribute__((visibility("hidden"))) int s2k_internal_keyset_reserve(s2k_ctx* ctx, size_t nkeys, size_t n) {

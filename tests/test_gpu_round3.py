@@ -242,7 +242,7 @@ def test_synthetic_signatures_against_libcrypto(eng):
     assert int(got.sum()) >= n - n // 5 - 1 and int(got.sum()) < n
 
 
-@pytest.mark.parametrize("layout", [1, 2])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT, S2K_KEYSET_JOINT5, S2K_KEYSET_JOINT6
 def test_keyset_matches_batch_verifier(eng, oracle, layout):
     """s2k_keyset_*: tables of a fixed key list built once, signatures name their key by index.  Same verdicts as
     s2k_ecdsa_verify_batch on the expanded key array and as the oracle: valid and damaged signatures, keys that are no
@@ -268,7 +268,8 @@ def test_keyset_matches_batch_verifier(eng, oracle, layout):
     kidx[12] = 0xFFFFFFFF
     ks = eng.keyset_create(keys, layout)
     assert ks.layout() == layout
-    assert len(ks) == len(keys) and ks.device_bytes() >= len(keys) * (36864 if layout == 1 else 36864 + 327680)
+    joint_bytes = {1: 0, 2: 32 * 128 * 80, 3: (26 * 512 + 2) * 80, 4: (22 * 2048 + 2) * 80}[layout]
+    assert len(ks) == len(keys) and len(keys) * (36864 + joint_bytes) <= ks.device_bytes() <= len(keys) * (36864 + joint_bytes) + (1 << 20)
     vk = ks.valid_keys()
     assert [k for k in range(len(keys)) if not vk[k]] == sorted(bad_keys)
     got = eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s)
@@ -296,13 +297,13 @@ def test_keyset_matches_batch_verifier(eng, oracle, layout):
     ks.close()
 
 
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])
 def test_keyset_worklist_and_full_size(eng, layout):
     """Key set at BASELINE size: 2^20 signatures of 2^16 keys against the batch verifier (grouping on), and an adversarial
     batch whose every lane ends on the complete-formula worklist (u1 G + u2 Q = infinity), which must reach the worklist
     kernel's key-set form and come back all false."""
     from secp256k1_voi_amd.synth import synth_all_fallback_batch, synth_batch
-    n, nk = 1 << 20, 1 << 16
+    n, nk = 1 << 20, (1 << 16 if layout != 4 else 1 << 13)      # (6-bit joint tables: 3.6 MiB per key)
     pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, nk, seed=4))
     keys, inv = np.unique(pub, axis=0, return_inverse=True)
     ks = eng.keyset_create(keys, layout)

@@ -233,7 +233,7 @@ def test_group_two_members_one_device(eng, oracle):
         S.Group([S.device_count()])            # no such device
 
 
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("layout", [1, 2, 3])
 def test_group_keyset_two_members_one_device(eng, oracle, layout):
     """s2k_group_keyset_*: the key set on both members, batches of (key index, digest, r, s) sharded across them; verdicts
     equal the single-context key-set call's, the batch verifier's on the expanded keys and the oracle's - ragged sizes,
@@ -510,7 +510,7 @@ def test_table_buffer_allocation_failure_degrades(oracle):
 
 
 # ---- key sets through submit / wait ------------------------------------------------------------------------------------
-@pytest.mark.parametrize("layout", [1, 2])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT, S2K_KEYSET_JOINT5, S2K_KEYSET_JOINT6
 def test_keyset_submit_wait(eng, oracle, layout):
     """s2k_ecdsa_verify_batch_keyset_submit: six batches (ragged sizes, one empty, pageable and page-locked buffers, indices
     outside the set, keys that are no public keys) with four in flight, mixed with tickets of the plain submit: every ticket's
@@ -711,7 +711,8 @@ def test_keyset_joint_tables_edge_scalars(eng, oracle):
     scalars.  VALID signatures with chosen u2 = r/s around the recoding's corners (every digit pair (d1, d2) must pick the right
     entry and sign: tiny values, all-ones and alternating nibbles, lambda and its neighbours, n - small, values whose halves
     have opposite signs) under a few keys, plus damaged ones: verdicts of the joint layout, the chunk layout and the batch
-    verifier must agree with the oracle; S2K_KEYSET_AUTO picks the joint layout for a small set."""
+    verifier must agree with the oracle - the same for the 5- and 6-bit layouts (S2K_KEYSET_JOINT5 / JOINT6: 26 / 22 positions),
+    with single digits at every one of their positions; S2K_KEYSET_AUTO picks the 5-bit joint layout for a small set."""
     import secp256k1_voi_amd as S
     rnd = random.Random(909)
     ds = [rnd.randrange(1, R.N) for _ in range(5)]
@@ -720,6 +721,10 @@ def test_keyset_joint_tables_edge_scalars(eng, oracle):
            (1 << 128) - 1, 1 << 128, (1 << 128) + 1, (1 << 127), int("8" * 64, 16) % R.N, int("7" * 64, 16) % R.N, int("f0" * 32, 16) % R.N,
            int("0f" * 32, 16) % R.N, int("a5" * 32, 16) % R.N, (-26 * R.LAMBDA) % R.N, (-26 * 16 ** 28 * R.LAMBDA) % R.N]
     u2s += [rnd.randrange(1, R.N) for _ in range(300)] + [(rnd.randrange(1, 1 << 20) << (4 * rnd.randrange(0, 60))) % R.N or 1 for _ in range(200)]
+    # the wider layouts' corners: single 5- and 6-bit digits at every position, all-ones and alternating windows, next to lambda too
+    u2s += [(d << (5 * i)) % R.N or 1 for i in range(26) for d in (1, 15, 16, 17, 31)] + [(d << (6 * i)) % R.N or 1 for i in range(22) for d in (1, 31, 32, 33, 63)]
+    u2s += [int("1" * 128, 2), int("10" * 64, 2), int("01" * 64, 2), int("11111" * 25 + "0" * 3, 2) % R.N, int("100000" * 21, 2),
+            (R.LAMBDA * 31) % R.N, (R.LAMBDA * 63 + 31) % R.N, (R.LAMBDA << 5) % R.N, (R.LAMBDA << 6) % R.N]
     pub, dig, rr, ss, kidx = [], [], [], [], []
     for i, u2 in enumerate(u2s):
         ki = i % len(ds)
@@ -737,9 +742,9 @@ def test_keyset_joint_tables_edge_scalars(eng, oracle):
     exp = oracle.ecdsa_verify_batch(b"".join(pub), b"".join(dig), b"".join(rr), b"".join(ss), nthreads=os.cpu_count() or 1)
     assert 0.8 * len(exp) < int(exp.sum()) < len(exp)
     keys = np.frombuffer(b"".join(q[1:] for q in Q), np.uint8).reshape(-1, 64)
-    for layout in (S.KEYSET_JOINT, S.KEYSET_CHUNKS, S.KEYSET_AUTO):
+    for layout in (S.KEYSET_JOINT, S.KEYSET_JOINT5, S.KEYSET_JOINT6, S.KEYSET_CHUNKS, S.KEYSET_AUTO):
         ks = eng.keyset_create(keys, layout)
-        assert ks.layout() == (S.KEYSET_CHUNKS if layout == S.KEYSET_CHUNKS else S.KEYSET_JOINT)
+        assert ks.layout() == (S.KEYSET_JOINT5 if layout == S.KEYSET_AUTO else layout)      # (AUTO: the widest layout a small set has room for)
         got = eng.ecdsa_verify_batch_keyset(ks, np.array(kidx, np.uint32), dig, rr, ss)
         assert np.array_equal(got, exp), (layout, np.nonzero(got != exp)[0][:10])
         ks.close()

@@ -51,6 +51,16 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_c_
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc_c_$TAG -o run -- $C > /dev/null 2>&1
 python3 tools/collect_traffic.py $O/pmc_fetch_c_$TAG $O/pmc_write_c_$TAG > $P/keyset_chunks/hbm_traffic.json
 python3 tools/summarize_profiles_r02.py $O/prof_c_$TAG/run_kernel_trace.csv $O/pmc_c_$TAG $P/keyset_chunks
+# the key-set ladder over 5-bit joint tables (26 additions): kernel trace, counters, traffic
+W5="$B --key-grouping keyset5"
+mkdir -p $P/keyset5
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_w_$TAG -o run -- $W5 > $P/keyset5/bench_under_kernel_trace.json 2> /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_w_$TAG -o run -- $W5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_w_$TAG -o run -- $W5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc_w_$TAG -o run -- $W5 > /dev/null 2>&1
+python3 tools/collect_traffic.py $O/pmc_fetch_w_$TAG $O/pmc_write_w_$TAG > $P/keyset5/hbm_traffic.json
+python3 tools/summarize_profiles_r02.py $O/prof_w_$TAG/run_kernel_trace.csv $O/pmc_w_$TAG $P/keyset5
+$W5 > $P/keyset5/bench_same_box_unprofiled.json 2>/dev/null
 # the unprofiled bench right after, same box: the lines the profiles have to reconcile with
 $B > $P/bench_same_box_unprofiled.json 2>/dev/null
 $G > $P/general/bench_same_box_unprofiled.json 2>/dev/null

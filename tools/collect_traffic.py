@@ -27,7 +27,7 @@ def per_kernel(dirname, counter):
                 if name.startswith("k_key_"):
                     name = name.split("<")[0]
                 # ladder instances: <0> general, <4> over per-key tables, <5> general over the ungrouped rest
-                name = name.replace("k_verify_fast<4>", "k_verify_fast_keyed").replace("k_verify_fast<5>", "k_verify_fast_left").replace("k_verify_fast<8>", "k_verify_fast_keyset").replace("k_verify_fast<9>", "k_verify_fast_keyset_joint")
+                name = name.replace("k_verify_fast<4>", "k_verify_fast_keyed").replace("k_verify_fast<5>", "k_verify_fast_left").replace("k_verify_fast<8>", "k_verify_fast_keyset").replace("k_verify_fast<9>", "k_verify_fast_keyset_joint").replace("k_verify_fast<10>", "k_verify_fast_keyset_joint5").replace("k_verify_fast<11>", "k_verify_fast_keyset_joint6")
                 name = name.split("<")[0]          # the other template instances (k_verify_fast<0>) share an entry
                 acc[name].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}

@@ -266,9 +266,20 @@ def keyset_joint(lib):
             "instructions": len(g.ins)}
 
 
+def keyset_joint_wide(lib, w):
+    """k_verify_fast<ECDSA_KEYSET_JOINT5 / JOINT6>: one loop over the 26 / 22 digit positions, one table addition each"""
+    g = Cfg(disassemble(lib, "_Z13k_verify_fastILi%dEE" % (10 if w == 5 else 11)))
+    top = g.top_level()
+    assert len(top) == 1 and not g.children(top[0]), ("unexpected loop structure of the wide joint ladder", [g.loops[k]["entries"] for k in top])
+    valu, mad = g.count(g.weights({top[0]: (128 + w - 1) // w}))
+    return {"valu_instr_static": valu, "mad_u64_u32_per_verify": mad, "valu_per_trip": {"addition": g.valu_in(g.loops[top[0]]["blocks"])},
+            "instructions": len(g.ins)}
+
+
 def static_counts(lib=DEFAULT_LIB, gt_windows=12):
     return {"k_verify_fast": general(lib, gt_windows), "k_verify_fast_keyed": keyed(lib), "k_verify_fast_keyset": keyset(lib),
-            "k_verify_fast_keyset_joint": keyset_joint(lib)}
+            "k_verify_fast_keyset_joint": keyset_joint(lib), "k_verify_fast_keyset_joint5": keyset_joint_wide(lib, 5),
+            "k_verify_fast_keyset_joint6": keyset_joint_wide(lib, 6)}
 
 
 if __name__ == "__main__":

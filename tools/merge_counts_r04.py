@@ -33,11 +33,11 @@ def main():
     out["source"] = ("rocprofv3 --pmc of bench.py --steps 20 --warmup 5 (tools/collect_profiles_r04.sh): averages over the timed steps, 2^20 "
                      "signatures of 2^16 keys per dispatch; k_verify_fast (the general ladder) from the same passes with --key-grouping off")
     out["k_verify_fast"] = general["k_verify_fast"]
-    for sub in ("keyset", "keyset_chunks"):
+    for sub in ("keyset", "keyset_chunks", "keyset5"):
         ks_path = os.path.join(src, sub, "valu_counts.json")
         if os.path.exists(ks_path):
             ks = json.load(open(ks_path))
-            for kn in ("k_verify_fast_keyset", "k_verify_fast_keyset_joint"):
+            for kn in ("k_verify_fast_keyset", "k_verify_fast_keyset_joint", "k_verify_fast_keyset_joint5", "k_verify_fast_keyset_joint6"):
                 if kn in ks:
                     out[kn] = ks[kn]
     head = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -47,7 +47,8 @@ def main():
                 if isinstance(v, dict) and "valu_instr_per_signature" in v and k.startswith("k_") and
                 k not in ("k_gen_gtable", "k_gen_gtable_bases", "k_fn_op", "k_point_op", "k_verify_fast"))
     for key, kname in (("static", "k_verify_fast"), ("static_keyed", "k_verify_fast_keyed"), ("static_keyset", "k_verify_fast_keyset"),
-                       ("static_keyset_joint", "k_verify_fast_keyset_joint")):
+                       ("static_keyset_joint", "k_verify_fast_keyset_joint"), ("static_keyset_joint5", "k_verify_fast_keyset_joint5"),
+                       ("static_keyset_joint6", "k_verify_fast_keyset_joint6")):
         if kname not in static:
             continue
         st = dict((prev or {}).get(key, {}))
@@ -62,11 +63,11 @@ def main():
     gtraffic = json.load(open(os.path.join(src, "general", "hbm_traffic.json")))
     if "k_verify_fast" in gtraffic:
         traffic["k_verify_fast"] = gtraffic["k_verify_fast"]
-    for sub in ("keyset", "keyset_chunks"):
+    for sub in ("keyset", "keyset_chunks", "keyset5"):
         kt_path = os.path.join(src, sub, "hbm_traffic.json")
         if os.path.exists(kt_path):
             kt = json.load(open(kt_path))
-            for kn in ("k_verify_fast_keyset", "k_verify_fast_keyset_joint"):
+            for kn in ("k_verify_fast_keyset", "k_verify_fast_keyset_joint", "k_verify_fast_keyset_joint5", "k_verify_fast_keyset_joint6"):
                 if kn in kt:
                     traffic[kn] = kt[kn]
     json.dump(traffic, open(os.path.join(prof, "%s_hbm_traffic.json" % rnd), "w"), indent=1)
@@ -76,7 +77,9 @@ def main():
                  ("general/kernel_stats_bench_steps20_warmup5.csv", "%s_%s_general_kernel_stats_bench_steps20_warmup5.csv"),
                  ("general/bench_same_box_unprofiled.json", "%s_%s_general_bench_same_box_unprofiled.json"),
                  ("keyset/kernel_time_summary.json", "%s_%s_keyset_kernel_time_summary.json"),
-                 ("keyset/bench_same_box_unprofiled.json", "%s_%s_keyset_bench_same_box_unprofiled.json")):
+                 ("keyset/bench_same_box_unprofiled.json", "%s_%s_keyset_bench_same_box_unprofiled.json"),
+                 ("keyset5/kernel_time_summary.json", "%s_%s_keyset5_kernel_time_summary.json"),
+                 ("keyset5/bench_same_box_unprofiled.json", "%s_%s_keyset5_bench_same_box_unprofiled.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(prof, b % (rnd, letter)))
     print("wrote profiles/%s_valu_counts.json: keyed %.0f, general %.0f, whole step %.0f (head %s)" %

@@ -58,7 +58,8 @@ def main():
         return sum(v) / len(v) if v else None
     res = {"source": "rocprofv3 --pmc (tools/collect_profiles_r02.sh), averages over the last %d dispatches, 2^20 signatures per dispatch" % TIMED}
     # the ladder kernels: template instance <0> = general, <4> = over per-key tables (all 2^20 lanes live in the bench)
-    for inst, key in (("k_verify_fast<0>", "k_verify_fast"), ("k_verify_fast<4>", "k_verify_fast_keyed"), ("k_verify_fast<8>", "k_verify_fast_keyset"), ("k_verify_fast<9>", "k_verify_fast_keyset_joint")):
+    for inst, key in (("k_verify_fast<0>", "k_verify_fast"), ("k_verify_fast<4>", "k_verify_fast_keyed"), ("k_verify_fast<8>", "k_verify_fast_keyset"), ("k_verify_fast<9>", "k_verify_fast_keyset_joint"),
+                      ("k_verify_fast<10>", "k_verify_fast_keyset_joint5"), ("k_verify_fast<11>", "k_verify_fast_keyset_joint6")):
         fast = next((k for k in set(k for k, _ in acc) if k.startswith(inst)), None)
         if not fast:
             continue
