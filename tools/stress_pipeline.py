@@ -75,7 +75,8 @@ def main():
             inv = inv.reshape(-1).astype(np.uint32)
             cuts = np.cumsum([0] + sizes)
             kidx = [np.ascontiguousarray(inv[cuts[k]:cuts[k + 1]]) for k in range(nb)]
-            layout = int(rng.integers(1, 3)) if len(keys) <= 20000 else 1      # (joint tables: 356 KiB per key, three copies here)
+            # (joint tables: 356 KiB per key at 4-bit digits, 1.04 MiB at 5, 3.6 MiB at 6; three copies of the set here)
+            layout = int(rng.integers(1, 5)) if len(keys) <= 4000 else int(rng.integers(1, 4)) if len(keys) <= 20000 else 1
             ks_ctx, ks_grp = eng.keyset_create(keys, layout), grp.keyset_create(keys, layout)
         if pinned:
             src = []
@@ -118,8 +119,9 @@ def main():
             ks_ctx.close()
             ks_grp.close()
         total += sum(sizes)
-        print("iteration %d: %d batches %s%s, mode %d, low_s %d, pinned %d, key set %d, adaptive %s" %
-              (it, nb, sizes, " (no repeated keys)" if lone else "", mode, low_s, pinned, use_ks, eng.key_grouping_adaptive()), flush=True)
+        print("iteration %d: %d batches %s%s, mode %d, low_s %d, pinned %d, key set %s, adaptive %s" %
+              (it, nb, sizes, " (no repeated keys)" if lone else "", mode, low_s, pinned, ("layout %d of %d keys" % (layout, len(keys))) if use_ks else "-",
+               eng.key_grouping_adaptive()), flush=True)
     eng.set_key_grouping(S.KEYS_ADAPTIVE)
     grp.close()
     print("ok: %d iterations, %d signatures through submit / wait and the group" % (iters, total))
