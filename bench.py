@@ -487,106 +487,120 @@ def worker(args):
             except AssertionError as e:      # a failed guard must be visible, and must fail the run
                 line["extras_error"] = str(e) or "assertion failed"
                 rc = 1
+            except Exception as e:           # an infrastructure error in a side measurement: the line is printed all the same
+                line["extras_error"] = "%s: %s" % (type(e).__name__, e)
+                rc = 1
         # host-buffer entry point (chunked H2D overlapped with the kernels, D2H); reported, never `value`.
         # One untimed call first: it creates the context's staging buffers and streams.
         if not args.no_pcie and world == 1:
-            eng.ecdsa_verify_batch(pub, digest, r, s)
-            host_ms = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                hv = eng.ecdsa_verify_batch(pub, digest, r, s)
-                host_ms.append((time.perf_counter() - t1) * 1e3)
-                assert int(hv.sum()) == n
-            line["pcie_inclusive"] = {"value": n / (median(host_ms) * 1e-3), "unit": "verifications/s", "ms_each": host_ms,
-                                      "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch per call, "
-                                              "median of 3 calls after one that creates the staging buffers" % batch_log2}
-            # the same from page-locked buffers (s2k_host_alloc): asynchronous copies, one grouped call whose table phase
-            # overlaps the transfer of the digests and signatures
-            from secp256k1_voi_amd import pinned_array
-            pinned = [pinned_array(a.shape) for a in (pub, digest, r, s)]
-            for dst, src in zip(pinned, (pub, digest, r, s)):
-                dst[...] = src
-            eng.ecdsa_verify_batch(*pinned)
-            pin_ms = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                hv = eng.ecdsa_verify_batch(*pinned)
-                pin_ms.append((time.perf_counter() - t1) * 1e3)
-                assert int(hv.sum()) == n
-            line["pcie_inclusive"]["pinned"] = {"value": n / (median(pin_ms) * 1e-3), "unit": "verifications/s", "ms_each": pin_ms,
-                                                "note": "the same call from s2k_host_alloc buffers; 160 MiB over PCIe take 3.0 ms on their "
-                                                        "own (55 GB/s), the keys' 64 MiB of it are exposed"}
-            # submit / wait: four batches in flight on the context's child contexts (two lanes), a new one submitted whenever one
-            # is done - what a caller that streams batches gets (s2k_ecdsa_verify_batch_submit / s2k_wait); the verdict
-            # arrays are page-locked too
-            def pipelined(submit, nb, depth=4, lead=4):
-                # steady state: `lead` batches fill the pipeline (the first transfer has nothing to hide behind), the clock
-                # runs from the completion of batch `lead` to the completion of batch `lead + nb`
-                tickets, done, t_0 = [], 0, None
-                for k in range(nb + lead):
-                    tickets.append(submit(k))
-                    if len(tickets) >= depth:
-                        assert int(tickets.pop(0).wait().sum()) == n
+            try:
+                eng.ecdsa_verify_batch(pub, digest, r, s)
+                host_ms = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    hv = eng.ecdsa_verify_batch(pub, digest, r, s)
+                    host_ms.append((time.perf_counter() - t1) * 1e3)
+                    assert int(hv.sum()) == n
+                line["pcie_inclusive"] = {"value": n / (median(host_ms) * 1e-3), "unit": "verifications/s", "ms_each": host_ms,
+                                          "note": "s2k_ecdsa_verify_batch from pageable host buffers, one 2^%d batch per call, "
+                                                  "median of 3 calls after one that creates the staging buffers" % batch_log2}
+                # the same from page-locked buffers (s2k_host_alloc): asynchronous copies, one grouped call whose table phase
+                # overlaps the transfer of the digests and signatures
+                from secp256k1_voi_amd import pinned_array
+                pinned = [pinned_array(a.shape) for a in (pub, digest, r, s)]
+                for dst, src in zip(pinned, (pub, digest, r, s)):
+                    dst[...] = src
+                eng.ecdsa_verify_batch(*pinned)
+                pin_ms = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    hv = eng.ecdsa_verify_batch(*pinned)
+                    pin_ms.append((time.perf_counter() - t1) * 1e3)
+                    assert int(hv.sum()) == n
+                line["pcie_inclusive"]["pinned"] = {"value": n / (median(pin_ms) * 1e-3), "unit": "verifications/s", "ms_each": pin_ms,
+                                                    "note": "the same call from s2k_host_alloc buffers; 160 MiB over PCIe take 3.0 ms on their "
+                                                            "own (55 GB/s), the keys' 64 MiB of it are exposed"}
+                # submit / wait: four batches in flight on the context's child contexts (two lanes), a new one submitted whenever one
+                # is done - what a caller that streams batches gets (s2k_ecdsa_verify_batch_submit / s2k_wait); the verdict
+                # arrays are page-locked too
+                def pipelined(submit, nb, depth=4, lead=4):
+                    # steady state: `lead` batches fill the pipeline (the first transfer has nothing to hide behind), the clock
+                    # runs from the completion of batch `lead` to the completion of batch `lead + nb`
+                    tickets, done, t_0 = [], 0, None
+                    for k in range(nb + lead):
+                        tickets.append(submit(k))
+                        if len(tickets) >= depth:
+                            assert int(tickets.pop(0).wait().sum()) == n
+                            done += 1
+                            if done == lead:
+                                t_0 = time.perf_counter()
+                    for tk in tickets:
+                        assert int(tk.wait().sum()) == n
                         done += 1
                         if done == lead:
                             t_0 = time.perf_counter()
-                for tk in tickets:
-                    assert int(tk.wait().sum()) == n
-                    done += 1
-                    if done == lead:
-                        t_0 = time.perf_counter()
-                return (time.perf_counter() - t_0) * 1e3 / (done - lead)
-            pin3 = [pinned] + [[pinned_array(a.shape) for a in pinned] for _ in range(3)]
-            for q in pin3[1:]:
-                for dst, src in zip(q, pinned):
-                    dst[...] = src
-            outs3 = [pinned_array((n,)) for _ in range(4)]
-            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 4], out=outs3[k % 4]), 8)
-            pl_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 4], out=outs3[k % 4]), 12) for _ in range(3)]
-            line["pcie_inclusive"]["pipelined"] = {"value": n / (median(pl_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl_ms),
-                                                   "ms_per_batch_each": pl_ms, "batches": 12, "in_flight": 4,
-                                                   "fraction_of_resident_value": (n / (median(pl_ms) * 1e-3)) / value,
-                                                   "note": "s2k_ecdsa_verify_batch_submit / s2k_wait from page-locked buffers, batches of 2^%d, "
-                                                           "four in flight (two lanes of two), host bytes to host verdicts; steady state: 4 batches "
-                                                           "fill the pipeline, then 12 are timed completion to completion" % batch_log2}
-            # the same through a key set (s2k_ecdsa_verify_batch_keyset_submit): the keys named by index, tables built once
-            if n_keys < n and not args.no_extras:
-                from secp256k1_voi_amd import KEYSET_JOINT5
-                ks_keys, ks_inv = np.unique(pub, axis=0, return_inverse=True)
-                ks = eng.keyset_create(ks_keys, KEYSET_JOINT5)
-                kx3 = []
-                for q in pin3:
-                    kx = pinned_array((n,), np.uint32)
-                    kx[...] = ks_inv.reshape(-1).astype(np.uint32)
-                    kx3.append(kx)
-                sub_ks = lambda k: eng.ecdsa_verify_batch_keyset_submit(ks, kx3[k % 4], pin3[k % 4][1], pin3[k % 4][2], pin3[k % 4][3], out=outs3[k % 4])
-                pipelined(sub_ks, 8)
-                pk_ms = [pipelined(sub_ks, 12) for _ in range(3)]
-                line["pcie_inclusive"]["pipelined_keyset"] = {
-                    "value": n / (median(pk_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pk_ms), "ms_per_batch_each": pk_ms,
-                    "keys": int(len(ks)), "keyset_device_bytes": ks.device_bytes(), "batches": 12, "in_flight": 4,
-                    "note": "s2k_ecdsa_verify_batch_keyset_submit / s2k_wait: key indices, digests and signatures (100 bytes per "
-                            "signature) from page-locked buffers to host verdicts, 5-bit joint tables of the keys built once (not timed); "
-                            "never `value`"}
-                ks.close()
-                del kx3
-            pg3 = [(pub, digest, r, s)] + [tuple(a.copy() for a in (pub, digest, r, s)) for _ in range(3)]
-            pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 4]), 4)
-            pg_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 4]), 12) for _ in range(3)]
-            line["pcie_inclusive"]["pipelined_pageable"] = {"value": n / (median(pg_ms) * 1e-3), "unit": "verifications/s",
-                                                            "ms_per_batch": median(pg_ms), "ms_per_batch_each": pg_ms,
-                                                            "note": "the same from pageable memory: the runtime stages the copies and submit "
-                                                                    "blocks while it does - 3.1 ms in a bare process (5.2 ms per batch, "
-                                                                    "tools/boundary_probe.py), but this process has torch in it, where the "
-                                                                    "staging copy waits for the kernels in flight (8.6 ms per submit: "
-                                                                    "profiles/r04_pageable_submit_with_and_without_torch.txt)"}
-            del pinned, pin3, outs3, pg3
-            # the encoded boundary (SEC1 keys + DER signatures, what secec.PublicKey.Verify takes): bytes parsed on the device
-            if not args.no_extras:
-                line["encoded_2p%d" % batch_log2] = encoded_measurement(eng, pub, digest, r, s)
-            eng.wait_all()
+                    return (time.perf_counter() - t_0) * 1e3 / (done - lead)
+                pin3 = [pinned] + [[pinned_array(a.shape) for a in pinned] for _ in range(3)]
+                for q in pin3[1:]:
+                    for dst, src in zip(q, pinned):
+                        dst[...] = src
+                outs3 = [pinned_array((n,)) for _ in range(4)]
+                pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 4], out=outs3[k % 4]), 8)
+                pl_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pin3[k % 4], out=outs3[k % 4]), 12) for _ in range(3)]
+                line["pcie_inclusive"]["pipelined"] = {"value": n / (median(pl_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pl_ms),
+                                                       "ms_per_batch_each": pl_ms, "batches": 12, "in_flight": 4,
+                                                       "fraction_of_resident_value": (n / (median(pl_ms) * 1e-3)) / value,
+                                                       "note": "s2k_ecdsa_verify_batch_submit / s2k_wait from page-locked buffers, batches of 2^%d, "
+                                                               "four in flight (two lanes of two), host bytes to host verdicts; steady state: 4 batches "
+                                                               "fill the pipeline, then 12 are timed completion to completion" % batch_log2}
+                # the same through a key set (s2k_ecdsa_verify_batch_keyset_submit): the keys named by index, tables built once
+                if n_keys < n and not args.no_extras:
+                    from secp256k1_voi_amd import KEYSET_AUTO
+                    ks_keys, ks_inv = np.unique(pub, axis=0, return_inverse=True)
+                    ks = eng.keyset_create(ks_keys, KEYSET_AUTO)       # (5-bit joint tables where the device has the room)
+                    kx3 = []
+                    for q in pin3:
+                        kx = pinned_array((n,), np.uint32)
+                        kx[...] = ks_inv.reshape(-1).astype(np.uint32)
+                        kx3.append(kx)
+                    sub_ks = lambda k: eng.ecdsa_verify_batch_keyset_submit(ks, kx3[k % 4], pin3[k % 4][1], pin3[k % 4][2], pin3[k % 4][3], out=outs3[k % 4])
+                    pipelined(sub_ks, 8)
+                    pk_ms = [pipelined(sub_ks, 12) for _ in range(3)]
+                    line["pcie_inclusive"]["pipelined_keyset"] = {
+                        "value": n / (median(pk_ms) * 1e-3), "unit": "verifications/s", "ms_per_batch": median(pk_ms), "ms_per_batch_each": pk_ms,
+                        "keys": int(len(ks)), "keyset_device_bytes": ks.device_bytes(), "keyset_layout": ks.layout(), "batches": 12, "in_flight": 4,
+                        "note": "s2k_ecdsa_verify_batch_keyset_submit / s2k_wait: key indices, digests and signatures (100 bytes per "
+                                "signature) from page-locked buffers to host verdicts, joint tables of the keys (s2k_keyset_create's choice: keyset_layout 3 = 5-bit digits) built once (not timed); "
+                                "never `value`"}
+                    ks.close()
+                    del kx3
+                pg3 = [(pub, digest, r, s)] + [tuple(a.copy() for a in (pub, digest, r, s)) for _ in range(3)]
+                pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 4]), 4)
+                pg_ms = [pipelined(lambda k: eng.ecdsa_verify_batch_submit(*pg3[k % 4]), 12) for _ in range(3)]
+                line["pcie_inclusive"]["pipelined_pageable"] = {"value": n / (median(pg_ms) * 1e-3), "unit": "verifications/s",
+                                                                "ms_per_batch": median(pg_ms), "ms_per_batch_each": pg_ms,
+                                                                "note": "the same from pageable memory: the runtime stages the copies and submit "
+                                                                        "blocks while it does - 3.1 ms in a bare process (5.2 ms per batch, "
+                                                                        "tools/boundary_probe.py), but this process has torch in it, where the "
+                                                                        "staging copy waits for the kernels in flight (8.6 ms per submit: "
+                                                                        "profiles/r04_pageable_submit_with_and_without_torch.txt)"}
+                del pinned, pin3, outs3, pg3
+                # the encoded boundary (SEC1 keys + DER signatures, what secec.PublicKey.Verify takes): bytes parsed on the device
+                if not args.no_extras:
+                    line["encoded_2p%d" % batch_log2] = encoded_measurement(eng, pub, digest, r, s)
+                eng.wait_all()
+            except AssertionError as e:     # a failed guard of a host-path measurement: visible, and fails the run
+                line["pcie_inclusive_error"] = str(e) or "assertion failed"
+                rc = 1
+            except Exception as e:          # an infrastructure error there: the line is printed all the same
+                line["pcie_inclusive_error"] = "%s: %s" % (type(e).__name__, e)
+                rc = 1
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(pub, digest, r, s)
+            try:
+                line["cpu_baseline"] = cpu_baseline(pub, digest, r, s)
+            except Exception as e:          # (the checker could not be built or run on this box: the line is printed all the same)
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                rc = 1
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -789,7 +803,11 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
                    "keyset-chunks": "chunk tables (S2K_KEYSET_CHUNKS): 64 table additions per signature"}
         for option, key in (("keyset5", "keyset_resident"), ("keyset", "keyset_resident_joint_tables_4bit"), ("keyset-chunks", "keyset_resident_chunk_tables")):
             t_b = _time.perf_counter()
-            ks = eng.keyset_create(keys, KEYSET_OPTIONS[option][0])
+            try:
+                ks = eng.keyset_create(keys, KEYSET_OPTIONS[option][0])
+            except Exception as e:               # (no memory for this layout's tables: the others are measured all the same)
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e), "layout": layouts[option]}
+                continue
             build_s = _time.perf_counter() - t_b
 
             def with_keyset():
