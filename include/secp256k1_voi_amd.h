@@ -212,7 +212,7 @@ int s2k_keyset_create(s2k_ctx *ctx, size_t n_keys, const uint8_t *pub_xy /* n_ke
  *                      1.04 MiB per key on top of the chunk tables (68 GB for 2^16 keys);
  *   S2K_KEYSET_JOINT6  on 6-bit digits: 22 positions, 2048 sums each - 22 additions, 3.6 MiB per key (for sets of up to
  *                      2^15 keys or so on a 288 GB device);
- *   S2K_KEYSET_AUTO    (s2k_keyset_create) the widest of JOINT5 and JOINT that takes no more than a quarter of the device memory
+ *   S2K_KEYSET_AUTO    (s2k_keyset_create) the widest of JOINT5 and JOINT that takes no more than half of the device memory
  *                      free at the time, else chunks.
  * Verdicts are identical in every layout.  s2k_keyset_layout tells which one a set has. */
 #define S2K_KEYSET_AUTO 0

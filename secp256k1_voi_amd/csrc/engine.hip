@@ -1986,7 +1986,8 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
   if (rc == S2K_OK) rc = s2k_internal_keyset_build(ctx, ks->base, n_keys, st);
   // joint tables (one table addition per digit position instead of two; 320 KiB per key on top, 1.04 MiB at 5-bit digits: 26
   // positions, 3.6 MiB at 6-bit digits: 22): the layout asked for, or - S2K_KEYSET_AUTO - the widest of 5 and 4 bits that takes no
-  // more than a quarter of the device memory that is free now
+  // more than half of the device memory that is free now (2^16 keys at 5 bits are 70 GB: a quarter would ask for a device with
+  // 280 GB free, which the 288 GB one never has once a context lives on it)
   ks->joint = nullptr;
   ks->joint_bytes = 0;
   ks->jw = 0;
@@ -1996,8 +1997,8 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
     if (w == 0) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        if (s2k_internal_keyset_joint_bytes(n_keys, 5) + s2k_internal_keyset_joint_scratch_bytes(n_keys, 5) <= free_b / 4) w = 5;
-        else if (s2k_internal_keyset_joint_bytes(n_keys, 4) <= free_b / 4) w = 4;
+        if (s2k_internal_keyset_joint_bytes(n_keys, 5) + s2k_internal_keyset_joint_scratch_bytes(n_keys, 5) <= free_b / 2) w = 5;
+        else if (s2k_internal_keyset_joint_bytes(n_keys, 4) <= free_b / 2) w = 4;
       }
     }
     if (w) {

@@ -509,6 +509,47 @@ def test_table_buffer_allocation_failure_degrades(oracle):
     assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref) and eng4.key_grouping_stats()["tables"] == n // 32
 
 
+# ---- the reference's golden vectors through the key-set ladders ---------------------------------------------------------------
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])
+@pytest.mark.parametrize("fn", ["wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"])
+def test_wycheproof_through_key_sets(eng, oracle, fn, layout):
+    """The Wycheproof ECDSA cases (secec/wycheproof_test.go:317-334: edge public keys, Shamir and modular-inverse edge cases, point
+    duplication, x(R) >= n, ...) with their public keys as a KEY SET and every case naming its key by index: the verdicts of the
+    chunk ladder and of the 4-, 5- and 6-bit joint ladders must be the expected ones, case by case.  Then the RFC 6979 signatures
+    and the reused-nonce pair of the reference's tests the same way."""
+    d = load_golden(fn)
+    items, exp = [], []
+    for c in d["cases"]:
+        rs = oracle.parse_asn1_signature(H(c["sig"]))
+        if rs is None:
+            continue
+        items.append((H(c["pub"])[1:], H(c["digest"])[:32], rs[0], rs[1]))
+        exp.append(int(c["valid"]))
+    keys, inv = np.unique(np.frombuffer(b"".join(i[0] for i in items), np.uint8).reshape(-1, 64), axis=0, return_inverse=True)
+    ks = eng.keyset_create(keys, layout)
+    assert ks.layout() == layout
+    got = eng.ecdsa_verify_batch_keyset(ks, inv.reshape(-1).astype(np.uint32), [i[1] for i in items], [i[2] for i in items], [i[3] for i in items])
+    assert got.tolist() == exp
+    assert sum(exp) == {"wycheproof_ecdsa_sha256.json": 164, "wycheproof_ecdsa_sha512.json": 233}[fn]
+    ks.close()
+    if fn.endswith("sha256.json"):
+        k = load_golden("kats.json")["reused_k_pairs"]
+        cases = load_golden("rfc6979.json")["cases"]
+        pubs = [oracle.scalar_base_mult_vartime(H(c["private"]))[1:] for c in cases] + [oracle.scalar_base_mult_vartime(H(k["private"]))[1:]] * 2
+        digs = [H(c["digest"]) for c in cases] + [H(s_["digest"]) for s_ in k["sigs"]]
+        rs_ = [oracle.parse_asn1_signature(H(c["sig"])) for c in cases]
+        rr = [x[0] for x in rs_] + [H(s_["r"]) for s_ in k["sigs"]]
+        ss = [x[1] for x in rs_] + [H(s_["s"]) for s_ in k["sigs"]]
+        keys2, inv2 = np.unique(np.frombuffer(b"".join(pubs), np.uint8).reshape(-1, 64), axis=0, return_inverse=True)
+        ks2 = eng.keyset_create(keys2, layout)
+        kidx = inv2.reshape(-1).astype(np.uint32)
+        assert eng.ecdsa_verify_batch_keyset(ks2, kidx, digs, rr, ss).all()
+        m = len(cases)                                   # (RFC 6979 signatures are low-s; the reused-nonce pair need not be)
+        assert eng.ecdsa_verify_batch_keyset(ks2, kidx[:m], digs[:m], rr[:m], ss[:m], reject_malleable=True).all()
+        assert not eng.ecdsa_verify_batch_keyset(ks2, kidx[:m], digs[1:m] + digs[:1], rr[:m], ss[:m]).any()
+        ks2.close()
+
+
 # ---- key sets through submit / wait ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", [1, 2, 3, 4])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT, S2K_KEYSET_JOINT5, S2K_KEYSET_JOINT6
 def test_keyset_submit_wait(eng, oracle, layout):
