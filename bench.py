@@ -1105,8 +1105,30 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     ms_locate = timed(locate, 3)
     assert int(dval.sum().item()) == m - 1 and int(dval[bad].item()) == 0, "bisection did not single out the bad signature"
     dsig[bad, 63] ^= 1
+    # per-signature verification over a key set: the batch's x-only keys lifted once and kept as joint tables
+    ks_entry = None
+    try:
+        xs, inv = np.unique(pk, axis=0, return_inverse=True)
+        pts65, okd = eng.point_decode_batch(np.concatenate([np.full((len(xs), 1), 2, np.uint8), xs], axis=1), 33)
+        assert bool(okd.all())
+        ks = eng.keyset_create(np.ascontiguousarray(pts65[:, 1:]))
+        dkidx = torch.from_numpy(inv.reshape(-1).astype(np.uint32).view(np.int32)).to(dev)
+        dval.zero_()
+        ms_ks = timed(lambda: eng.schnorr_verify_batch_keyset_device(ks, m, dkidx.data_ptr(), dmsg.data_ptr(), 32, dsig.data_ptr(),
+                                                                     dval.data_ptr(), st), 5)
+        assert int(dval.sum().item()) == m, "BIP-340 verification over the key set did not accept the synthetic batch"
+        ks_entry = {"ms": ms_ks, "sigs_per_s": m / (ms_ks * 1e-3), "keys": int(len(ks)), "keyset_layout": ks.layout(),
+                    "keyset_device_bytes": ks.device_bytes(),
+                    "note": "s2k_schnorr_verify_batch_keyset_device: per-signature verdicts, the keys' tables built once (not timed)"}
+        ks.close()
+        del dkidx
+    except AssertionError:
+        raise
+    except Exception as e:
+        ks_entry = {"error": "%s: %s" % (type(e).__name__, e)}
     out["schnorr_rlc_2p20"] = {"sigs": m, "ms": ms, "sigs_per_s": m / (ms * 1e-3),
                                "per_signature_verify_ms": ms_single,
+                               "per_signature_verify_over_key_set": ks_entry,
                                "locate_one_bad_signature_ms": ms_locate,
                                "locate_stats": {"sub_combinations": int(stats[0]), "verified_one_by_one": int(stats[1]),
                                                 "levels": int(stats[2])},

@@ -397,6 +397,18 @@ int s2k_schnorr_verify_batch(s2k_ctx *ctx, size_t n, const uint8_t *pk /* n*32 *
 int s2k_schnorr_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pk, const void *d_msgs,
                                     const void *d_msg_offsets, size_t msg_len, const void *d_sig, uint32_t flags,
                                     void *d_valid, void *hip_stream);
+/* The same for signatures that name their key by its index in a key set of this context (s2k_keyset_create[_ex]: X || Y keys).
+ * BIP-340's public key is the x coordinate and its point lift_x(x), the one with even y (NewSchnorrPublicKeyFromPoint,
+ * schnorr.go:276-300, does that to a point): key k of the set stands for the x-only key X_k whatever the parity of its Y.
+ * valid[i] = SchnorrPublicKey(X of keys[key_index[i]]).Verify(msg_i, sig_i); an index outside the set, or a key that is no
+ * point of the curve: 0.  Same verdicts as s2k_schnorr_verify_batch on the expanded x-only keys, bit for bit, in every
+ * layout of the set; no grouping, key lift or table build per call.  flags: 0. */
+int s2k_schnorr_verify_batch_keyset(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const uint32_t *key_index /* n */,
+                                    const uint8_t *msgs, const uint64_t *msg_offsets, size_t msg_len,
+                                    const uint8_t *sig /* n*64 */, uint32_t flags, uint8_t *valid);
+int s2k_schnorr_verify_batch_keyset_device(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const void *d_key_index,
+                                           const void *d_msgs, const void *d_msg_offsets, size_t msg_len, const void *d_sig,
+                                           uint32_t flags, void *d_valid, void *hip_stream);
 
 /* Whole-batch BIP-340 verification as ONE multi-scalar multiplication of n + K + 1 points
  * ((sum a_i s_i) G - sum a_i R_i - sum over the K distinct keys P of (sum of a_i e_i over P's signatures) P

@@ -284,6 +284,8 @@ def load_library() -> C.CDLL:
     lib.s2k_group_member_stats.argtypes = [vp, vp]
     lib.s2k_schnorr_verify_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp]
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
+    lib.s2k_schnorr_verify_batch_keyset.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, u32, vp]
+    lib.s2k_schnorr_verify_batch_keyset_device.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci)]
     lib.s2k_schnorr_batch_verify_rlc_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci), vp]
     lib.s2k_schnorr_verify_batch_bisect.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp]
@@ -330,6 +332,7 @@ EXPORTED_SYMBOLS = [
     "s2k_group_keyset_create", "s2k_group_keyset_destroy", "s2k_group_keyset_size", "s2k_group_keyset_layout", "s2k_group_keyset_device_bytes",
     "s2k_group_ecdsa_verify_batch_keyset", "s2k_group_ecdsa_verify_batch_keyset_submit",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
+    "s2k_schnorr_verify_batch_keyset", "s2k_schnorr_verify_batch_keyset_device",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_schnorr_verify_batch_bisect", "s2k_schnorr_verify_batch_bisect_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
@@ -608,6 +611,31 @@ class Engine:
             self._check(self._lib.s2k_schnorr_verify_batch(self._h, n, pk32.ctypes.data, m.ctypes.data if m.size else None,
                                                            None, m.shape[1], sig64.ctypes.data, flags, out.ctypes.data))
         return out
+
+    def schnorr_verify_batch_keyset(self, keyset, key_index, msgs, sig64) -> np.ndarray:
+        """BIP-340 over a key set (s2k_schnorr_verify_batch_keyset): signature i is verified under the x coordinate of key
+        key_index[i] of `keyset` (a set of X || Y keys; the parity of Y does not matter)."""
+        ki = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
+        n = ki.shape[0]
+        sig64 = _arr(sig64, 64, n)
+        out = np.zeros(n, dtype=np.uint8)
+        if isinstance(msgs, (list, tuple)):
+            if len(msgs) != n:
+                raise ValueError(f"length mismatch: expected {n} messages, got {len(msgs)}")
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+            self._check(self._lib.s2k_schnorr_verify_batch_keyset(self._h, keyset._k, n, ki.ctypes.data, blob.ctypes.data, offs.ctypes.data, 0,
+                                                                  sig64.ctypes.data, 0, out.ctypes.data))
+        else:
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+            self._check(self._lib.s2k_schnorr_verify_batch_keyset(self._h, keyset._k, n, ki.ctypes.data, m.ctypes.data if m.size else None, None,
+                                                                  m.shape[1], sig64.ctypes.data, 0, out.ctypes.data))
+        return out
+
+    def schnorr_verify_batch_keyset_device(self, keyset, n, d_key_index, d_msgs, msg_len, d_sig, d_valid, stream=0):
+        self._check(self._lib.s2k_schnorr_verify_batch_keyset_device(self._h, keyset._k, int(n), d_key_index, d_msgs, None, int(msg_len), d_sig, 0,
+                                                                     d_valid, stream))
 
     def schnorr_batch_verify_rlc(self, pk32, msgs, sig64, seed32: bytes | None = None) -> bool:
         """True iff every (key, message, signature) triple verifies — one MSM of n + 2K + 2 terms

@@ -481,7 +481,9 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
 #endif
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2, MODE_POINT = 3, MODE_ECDSA_KEYED = 4, MODE_ECDSA_LEFT = 5,
        MODE_SCHNORR_KEYED = 6, MODE_SCHNORR_LEFT = 7, MODE_ECDSA_KEYSET = 8, MODE_ECDSA_KEYSET_JOINT = 9,
-       MODE_ECDSA_KEYSET_JOINT5 = 10, MODE_ECDSA_KEYSET_JOINT6 = 11 };
+       MODE_ECDSA_KEYSET_JOINT5 = 10, MODE_ECDSA_KEYSET_JOINT6 = 11,
+       // BIP-340 over a key set's tables, same four layouts: the ECDSA mode + 4
+       MODE_SCHNORR_KEYSET = 12, MODE_SCHNORR_KEYSET_JOINT = 13, MODE_SCHNORR_KEYSET_JOINT5 = 14, MODE_SCHNORR_KEYSET_JOINT6 = 15 };
 constexpr uint8_t VERDICT_PENDING = 2;   // k_verify_fast -> k_affine_finish
 constexpr uint32_t KVF_FORCE_WORKLIST = 0x80000000u;   // top bit of k_verify_fast's first argument (batches are below 2^31)
 
@@ -578,20 +580,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S2K_FA
 // final addition took 152, and asking for four waves outright spills - 26 VGPRs for <ECDSA_KEYED>, 28 for the key-set
 // ladder, which stays at 142 VGPRs and three waves.  tests/test_counts_cpu.py watches the instruction counts; the
 // resource usage is printed by tools/kernel_regs.sh.)
-__global__ void __launch_bounds__(256, (MODE == MODE_ECDSA_KEYSET_JOINT || MODE == MODE_ECDSA_KEYSET_JOINT5 || MODE == MODE_ECDSA_KEYSET_JOINT6) ? S2K_JOINT_WAVES : S2K_FAST_WAVES)
+__global__ void __launch_bounds__(256, (MODE == MODE_ECDSA_KEYSET_JOINT || MODE == MODE_ECDSA_KEYSET_JOINT5 || MODE == MODE_ECDSA_KEYSET_JOINT6 ||
+                                        MODE == MODE_SCHNORR_KEYSET_JOINT || MODE == MODE_SCHNORR_KEYSET_JOINT5 || MODE == MODE_SCHNORR_KEYSET_JOINT6)
+                                           ? S2K_JOINT_WAVES : S2K_FAST_WAVES)
 #endif
 k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
               const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
               key_groups kg) {
-  constexpr bool JOINT = MODE == MODE_ECDSA_KEYSET_JOINT;   // ... over its joint tables: one addition per digit position
-  constexpr int JW = MODE == MODE_ECDSA_KEYSET_JOINT5 ? 5 : MODE == MODE_ECDSA_KEYSET_JOINT6 ? 6 : 4;
+  constexpr bool SKS = MODE >= MODE_SCHNORR_KEYSET && MODE <= MODE_SCHNORR_KEYSET_JOINT6;   // BIP-340 over a key set
+  constexpr int KM = SKS ? MODE - 4 : MODE;                  // the key-set layout, as its ECDSA mode
+  constexpr bool JOINT = KM == MODE_ECDSA_KEYSET_JOINT;      // ... over its joint tables: one addition per digit position
+  constexpr int JW = KM == MODE_ECDSA_KEYSET_JOINT5 ? 5 : KM == MODE_ECDSA_KEYSET_JOINT6 ? 6 : 4;
   constexpr bool JOINTW = JW > 4;                            // ... over joint tables of 5- or 6-bit digits (kjw_geom: 26 / 22 positions)
-  constexpr bool KEYSET = MODE == MODE_ECDSA_KEYSET || JOINT || JOINTW;   // KEYED over a key set's 32-chunk tables: no doublings at all
+  constexpr bool KEYSET = KM == MODE_ECDSA_KEYSET || JOINT || JOINTW;   // KEYED over a key set's 32-chunk tables: no doublings at all
   constexpr bool KEYED = MODE == MODE_ECDSA_KEYED || MODE == MODE_SCHNORR_KEYED || KEYSET;
   constexpr bool GROUPED = KEYED || MODE == MODE_ECDSA_LEFT || MODE == MODE_SCHNORR_LEFT;
-  constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT || KEYSET;
+  constexpr bool ECDSA = MODE == MODE_ECDSA || MODE == MODE_ECDSA_KEYED || MODE == MODE_ECDSA_LEFT || (KEYSET && !SKS);
   const bool force_wl = (n_and_flags & KVF_FORCE_WORKLIST) != 0;
   const uint32_t n = n_and_flags & ~KVF_FORCE_WORKLIST;
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;         // lane: workspace column
@@ -687,7 +693,14 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
     qy = fe29_normalize(qy);
     qy = fe29_select((qy.n[0] & 1u) != 0, qy, fe29_normalize_weak(fe29_negate(qy, 1)));   // even y
   }
-  const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
+  bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
+  if constexpr (SKS) {
+    // BIP-340 multiplies P = lift_x(x), the point with EVEN y; the set holds the key as its caller gave it (X || Y): an odd Y
+    // means P = -Q, i.e. both half scalars change sign (`pub`: the set's key array)
+    const bool y_odd = (pub[(size_t)kg.ptab[idx] * 64 + 63] & 1u) != 0;
+    neg1 = neg1 != y_odd;
+    neg2 = neg2 != y_odd;
+  }
 
   // ---- table ----
   if constexpr (!KEYED) {
@@ -1723,6 +1736,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->s_aux2) (void)hipStreamDestroy(ctx->s_aux2);
   if (ctx->kg) (void)hipFree(ctx->kg);
   if (ctx->ktab) (void)hipFree(ctx->ktab);
+  if (ctx->xkeys) (void)hipFree(ctx->xkeys);
   for (size_t i = 0; i < ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
   for (size_t i = 0; i < ctx->msm_prof_cap; ++i) (void)hipEventDestroy(ctx->msm_prof_ev[i]);
   delete[] ctx->msm_prof_ev;
@@ -2369,6 +2383,142 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
                                                               (uint8_t*)d_valid, ctx->gtable, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return ctx_leave(ctx, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// BIP-340 over a key set: SchnorrPublicKey.Verify (secec/bitcoin/schnorr.go:221-253) for signatures that name their key by its
+// index in a key set.  The set holds X || Y keys; BIP-340's key is the x coordinate and its point lift_x(x), the one with
+// even y (NewSchnorrPublicKeyFromPoint, schnorr.go:276-300, does the same to a point): the challenge hashes X, and the
+// ladder takes the set's tables with both half scalars' signs flipped where the stored Y is odd.  Same verdicts as
+// s2k_schnorr_verify_batch on the expanded x-only key array; what is saved is grouping, key lifts and table build of every
+// call, and with joint tables half (or more) of the ladder.
+// ---------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+// pk32[i] = X of key kidx[i] (zeros for an index outside the set: that signature is on no ladder lane and stays invalid)
+__global__ void __launch_bounds__(256)
+k_ks_expand_x(uint32_t n, uint32_t nkeys, const uint32_t* __restrict__ kidx, const uint8_t* __restrict__ keys, uint8_t* __restrict__ pk32) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;          // one 16-byte half of a key per thread
+  const uint32_t i = t >> 1, h = t & 1u;
+  if (i >= n) return;
+  const uint32_t k = kidx[i];
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (k < nkeys) v = reinterpret_cast<const uint4*>(keys + (size_t)k * 64)[h];
+  reinterpret_cast<uint4*>(pk32 + (size_t)i * 32)[h] = v;
+}
+}  // namespace
+extern "C" {
+int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const void* d_key_index, const void* d_msgs,
+                                           const void* d_msg_offsets, size_t msg_len, const void* d_sig, uint32_t flags, void* d_valid,
+                                           void* hip_stream) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  const s2k_ctx* owner = ctx->parent ? ctx->parent : ctx;
+  if (!ks || ks->ctx != owner || ks->generation != owner->generation || ks->device != ctx->device)
+    return fail(ctx, S2K_ERR_ARG, "key set of another context");
+  if (n == 0) return S2K_OK;
+  if (!d_key_index || !d_sig || !d_valid || (!d_msgs && (d_msg_offsets || msg_len))) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (flags) return fail(ctx, S2K_ERR_ARG, "s2k_schnorr_verify_batch_keyset takes no flags");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  rc = s2k_internal_ensure_ws(ctx, n);
+  if (rc) return rc;
+  rc = ctx_aux_streams(ctx);
+  if (rc) return rc;
+  rc = s2k_internal_keyset_reserve(ctx, ks->n, n);      // before the fork: growing a buffer synchronises the device
+  if (rc) return rc;
+  // the expanded x-only keys (what the preparation hashes and the worklist kernel lifts): the context's key-expansion buffer
+  rc = ctx_reserve(ctx, &ctx->xkeys, &ctx->xkeys_bytes, n * 32 + 256);
+  if (rc) return rc;
+  const size_t stride = lane_stride(n);
+  uint32_t* ws = (uint32_t*)ctx->ws;
+  uint32_t* qt = ws + WS_QT * stride;
+  uint32_t* fin = ws + WS_FIN * stride;
+  uint32_t* prep = ws + WS_PREP * stride;
+  uint32_t* gp = ws + WS_GP * stride;
+  uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
+  uint32_t* wl = wl_count + 64;
+  uint8_t* pk = (uint8_t*)ctx->xkeys;
+  const uint8_t* sig = (const uint8_t*)d_sig;
+  const uint8_t* msgs = (const uint8_t*)d_msgs;
+  const uint64_t* offs = (const uint64_t*)d_msg_offsets;
+  size_t off[5];
+  (void)s2k_internal_keyset_bytes(ks->n, off);
+  const uint8_t* set_keys = ks->base + off[0];
+  ctx->kg_counters = nullptr;
+  ctx->last_wl_count = wl_count;
+  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(d_valid, 0, n, st));       // signatures naming no key of the set stay invalid
+  k_ks_expand_x<<<blocks_for(2 * n), 256, 0, st>>>((uint32_t)n, (uint32_t)ks->n, (const uint32_t*)d_key_index, set_keys, pk);
+  HIP_TRY(ctx, hipGetLastError());
+  // second stream: challenge hashes, scalars and the generator part s*G; caller's: the sort by key index
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
+  k_schnorr_prep<<<blocks_for(n), 256, 0, ctx->s_aux>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, ctx->gtable, gp, stride);
+  rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "launch failed");
+  key_groups kg{};
+  if (rc == S2K_OK) rc = s2k_internal_keyset_sort(ctx, ks->base, ks->n, n, (const uint32_t*)d_key_index, st, &kg);
+  ctx_aux_join(ctx, st);
+  if (rc) {
+    (void)ctx_leave(ctx, st);
+    return rc;
+  }
+  kg.gp = gp;
+  kg.jtab = ks->joint;
+#define S2K_SKS_LAUNCH(M) \
+  k_verify_fast<M><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, set_keys, sig, prep, qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, \
+                                                  nullptr, nullptr, kg)
+  if (ks->joint && ks->jw == 6) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT6);
+  else if (ks->joint && ks->jw == 5) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT5);
+  else if (ks->joint) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT);
+  else S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET);
+#undef S2K_SKS_LAUNCH
+  HIP_TRY(ctx, hipGetLastError());
+  {
+    const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
+    k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, fin, (uint8_t*)d_valid, stride, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  // (the worklist kernel re-does its lanes from the x-only key: lift_x gives the even-y point whatever the set's Y says)
+  k_schnorr_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
+                                                              ctx->gtable, qt, stride);
+  HIP_TRY(ctx, hipGetLastError());
+  return ctx_leave(ctx, st);
+}
+
+// Host-buffer form: key indices, messages and signatures staged on the context's compute stream
+int s2k_schnorr_verify_batch_keyset(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const uint32_t* key_index, const uint8_t* msgs,
+                                    const uint64_t* msg_offsets, size_t msg_len, const uint8_t* sig, uint32_t flags, uint8_t* valid) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (n == 0) return S2K_OK;
+  if (!key_index || !sig || !valid || (!msgs && (msg_offsets || msg_len))) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ctx_streams(ctx);
+  if (rc) return rc;
+  const size_t msg_bytes = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
+  const size_t sizes[5] = {n * 4, msg_bytes + 16, msg_offsets ? (n + 1) * 8 : 8, n * 64, n};
+  uint8_t* d[5];
+  rc = ctx_stage(ctx, sizes, 5, d);
+  if (rc) return rc;
+  hipStream_t st = ctx->s_comp;
+  rc = ctx_enter(ctx, st);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d[0], key_index, n * 4, hipMemcpyHostToDevice, st));
+  if (msg_bytes) HIP_TRY(ctx, hipMemcpyAsync(d[1], msgs, msg_bytes, hipMemcpyHostToDevice, st));
+  if (msg_offsets) HIP_TRY(ctx, hipMemcpyAsync(d[2], msg_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d[3], sig, n * 64, hipMemcpyHostToDevice, st));
+  rc = s2k_schnorr_verify_batch_keyset_device(ctx, ks, n, d[0], msgs ? d[1] : nullptr, msg_offsets ? d[2] : nullptr, msg_len, d[3], flags, d[4], st);
+  if (rc) {
+    s2k_internal_drain(ctx);
+    return rc;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->have_last = false;
+  return S2K_OK;
 }
 
 // Host-buffer entry point.  The batch is cut into chunks that are whole rounds of k_verify_fast

@@ -123,6 +123,8 @@ struct s2k_ctx {
   size_t kg_bytes = 0;
   void* ktab = nullptr;
   size_t ktab_bytes = 0;
+  void* xkeys = nullptr;             // BIP-340 over a key set: the x-only keys of a call's signatures, expanded from the set
+  size_t xkeys_bytes = 0;
   uint32_t* kg_counters = nullptr;   // device, KG_COUNTERS words (of the last call; null: it did not group)
   uint32_t kg_last_max_tables = 0;   // table cap of that call (the device counter of tables is not clamped)
   uint32_t* last_wl_count = nullptr; // device: the last verification call's complete-formula worklist length

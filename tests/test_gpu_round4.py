@@ -550,6 +550,81 @@ def test_wycheproof_through_key_sets(eng, oracle, fn, layout):
         ks2.close()
 
 
+# ---- BIP-340 over key sets ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])
+def test_schnorr_over_key_sets(eng, oracle, layout):
+    """s2k_schnorr_verify_batch_keyset: signatures name their key by index in a set of X || Y keys; BIP-340 verifies under the x
+    coordinate, i.e. under lift_x(X) - the set holds HALF of its keys with odd Y on purpose.  Verdicts must equal
+    s2k_schnorr_verify_batch on the expanded x-only keys and the oracle's: random valid and damaged signatures with messages of
+    many lengths, keys that are no curve points, indices outside the set; then the official BIP-340 vectors with their keys as
+    the set; then 2^17 signatures of 2^11 keys."""
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    rnd = random.Random(77)
+    nk, n = 40, 1500
+    ds = [rnd.randrange(1, R.N) for _ in range(nk)]
+    pts = [R.mul(dd, R.G) for dd in ds]
+    keys = np.zeros((nk + 2, 64), np.uint8)
+    for k, P in enumerate(pts):
+        y = P[1] if k % 2 == 0 else R.P - P[1]           # every other key: the point with the OTHER y (same x-only key)
+        keys[k] = np.frombuffer(b32(P[0]) + b32(y), np.uint8)
+    keys[nk] = np.frombuffer(b32(pts[0][0]) + b32((pts[0][1] + 1) % R.P), np.uint8)     # not on the curve
+    keys[nk + 1] = 0xFF                                                                   # coordinates >= p
+    pk, msg, sig, kidx = [], [], [], []
+    for i in range(n):
+        k = i % nk
+        m = rnd.randbytes(rnd.choice([0, 1, 31, 32, 33, 55, 56, 63, 64, 65, 119, 120, 200]))
+        s_ = R.schnorr_sign(ds[k], m, rnd.randbytes(32))
+        kind = i % 7
+        if kind == 1:
+            s_ = s_[:32] + b32((int.from_bytes(s_[32:], "big") + 1) % R.N)
+        elif kind == 2:
+            m = m + b"x"
+        elif kind == 3 and i % 21 == 3:
+            s_ = b32(R.P + 5) + s_[32:]                   # r >= p
+        elif kind == 4 and i % 28 == 4:
+            k = nk + (i % 2)                              # a key of the set that is no public key
+        elif kind == 5 and i % 35 == 5:
+            k = nk + 2 + (i % 3)                          # an index outside the set
+        kidx.append(k); msg.append(m); sig.append(s_)
+        pk.append(bytes(keys[k][:32]) if k < nk + 2 else bytes(32))
+    ks = eng.keyset_create(keys, layout)
+    got = eng.schnorr_verify_batch_keyset(ks, np.array(kidx, np.uint32), msg, sig)
+    ref = eng.schnorr_verify_batch(pk, msg, sig)
+    out_of_set = np.array([k >= nk for k in kidx])
+    assert not got[out_of_set].any()
+    assert np.array_equal(got[~out_of_set], ref[~out_of_set])
+    exp = np.array([int(oracle.schnorr_verify(p_, m_, s_) == 1) for p_, m_, s_ in zip(pk[:400], msg[:400], sig[:400])], np.uint8)
+    assert np.array_equal(got[:400][~out_of_set[:400]], exp[~out_of_set[:400]])
+    assert 0.5 * n < int(got.sum()) < n
+    ks.close()
+    # the official vectors: their x-only keys lifted (odd y for every other one); keys that do not lift stand in as off-curve points
+    d = load_golden("bip340.json")
+    vk = sorted({c["public_key"] for c in d["cases"]})
+    vkeys = np.zeros((len(vk), 64), np.uint8)
+    for j, hx in enumerate(vk):
+        x = int(hx, 16)
+        pt = R.lift_x(x, j % 2)                          # (None: x >= p or no point has this x)
+        vkeys[j] = np.frombuffer(H(hx) + (b32(pt[1]) if pt else bytes(32)), np.uint8)
+    ks = eng.keyset_create(vkeys, layout)
+    vidx = np.array([vk.index(c["public_key"]) for c in d["cases"]], np.uint32)
+    assert eng.schnorr_verify_batch_keyset(ks, vidx, [H(c["message"]) for c in d["cases"]], [H(c["signature"]) for c in d["cases"]]).tolist() == \
+        [int(c["valid"]) for c in d["cases"]]
+    ks.close()
+    # size: 2^17 signatures of 2^11 keys, every ninth damaged
+    big, nkb = 1 << 17, 1 << 11
+    pkb, msgb, sigb = (np.array(a) for a in synth_schnorr_batch(eng, big, nkb, seed=31))
+    sigb[::9, 40] ^= 2
+    xs, inv = np.unique(pkb, axis=0, return_inverse=True)
+    pts65, okd = eng.point_decode_batch(np.concatenate([np.full((len(xs), 1), 2, np.uint8), xs], axis=1), 33)
+    assert okd.all()
+    kb = np.ascontiguousarray(pts65[:, 1:])
+    kb[1::2, 32:] = np.frombuffer(b"".join(b32(R.P - int.from_bytes(bytes(y_), "big")) for y_ in kb[1::2, 32:]), np.uint8).reshape(-1, 32)
+    ks = eng.keyset_create(kb, layout)
+    gotb = eng.schnorr_verify_batch_keyset(ks, inv.reshape(-1).astype(np.uint32), msgb, sigb)
+    assert np.array_equal(gotb, eng.schnorr_verify_batch(pkb, msgb, sigb)) and int(gotb.sum()) == big - len(range(0, big, 9))
+    ks.close()
+
+
 # ---- key sets through submit / wait ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", [1, 2, 3, 4])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT, S2K_KEYSET_JOINT5, S2K_KEYSET_JOINT6
 def test_keyset_submit_wait(eng, oracle, layout):
