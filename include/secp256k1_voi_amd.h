@@ -320,6 +320,16 @@ int s2k_group_ecdsa_verify_encoded_batch_submit(s2k_group *g, size_t n, const ui
 /* stats[m * 4 + 0..3] for member m, of its last finished shard: signatures, first index, milliseconds from the member's
  * submit to its verdicts (host clock), device index. */
 int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
+/* BASELINE configs 3 and 4 across a group (synchronous; the multi-process forms are sharding.py's).  The BIP-340 whole-batch
+ * check: every member checks its contiguous shard as one random linear combination (s2k_schnorr_batch_verify_rlc; the
+ * members' coefficients are independent: every call mixes fresh operating-system randomness into the seed), *all_valid = 1
+ * iff every shard is accepted.  The multiscalar multiplication: every member sums its shard of the terms, the first member
+ * adds the partial sums.  Same results as the single-context calls (Point.MultiScalarMult, point_mul_multi.go:25-117). */
+int s2k_group_schnorr_batch_verify_rlc(s2k_group *g, size_t n, const uint8_t *pk /* n*32 */, const uint8_t *msgs,
+                                       const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig /* n*64 */,
+                                       const uint8_t *seed32, int *all_valid);
+int s2k_group_multi_scalar_mult(s2k_group *g, size_t n, const uint8_t *k /* n*32 */, const uint8_t *points /* n*65 */,
+                                uint8_t *out65);
 /* Key sets across a group: every member builds the tables of all n_keys keys on its own device (side by side; the
  * tables are replicated per device like the generator tables: s2k_group_keyset_device_bytes per member), and
  * s2k_group_ecdsa_verify_batch_keyset[_submit] shards a batch of (key index, digest, r, s) items like any other group

@@ -266,6 +266,8 @@ def load_library() -> C.CDLL:
     lib.s2k_group_last_error.argtypes = [vp]
     lib.s2k_group_last_error.restype = C.c_char_p
     lib.s2k_group_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
+    lib.s2k_group_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
+    lib.s2k_group_multi_scalar_mult.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_group_keyset_create.argtypes = [vp, sz, vp, ci, vp]
     lib.s2k_group_keyset_destroy.argtypes = [vp]
     lib.s2k_group_keyset_destroy.restype = None
@@ -328,7 +330,7 @@ EXPORTED_SYMBOLS = [
     "s2k_device_count", "s2k_group_create", "s2k_group_destroy", "s2k_group_size", "s2k_group_last_error",
     "s2k_group_set_key_grouping", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
     "s2k_group_ecdsa_verify_encoded_batch", "s2k_group_ecdsa_verify_encoded_batch_submit",
-    "s2k_group_member_stats",
+    "s2k_group_member_stats", "s2k_group_schnorr_batch_verify_rlc", "s2k_group_multi_scalar_mult",
     "s2k_group_keyset_create", "s2k_group_keyset_destroy", "s2k_group_keyset_size", "s2k_group_keyset_layout", "s2k_group_keyset_device_bytes",
     "s2k_group_ecdsa_verify_batch_keyset", "s2k_group_ecdsa_verify_batch_keyset_submit",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
@@ -1014,6 +1016,34 @@ class Group:
                                                                           do.ctypes.data, sb.ctypes.data, so.ctypes.data, encoding,
                                                                           digest_len, flags, out.ctypes.data, C.byref(t)))
         return Ticket(self, int(t.value), out, [pb, po, db, do, sb, so])
+
+    def schnorr_batch_verify_rlc(self, pk32, msgs, sig64, seed32: bytes | None = None) -> bool:
+        """BIP-340 whole-batch check with the signatures sharded over the members (s2k_group_schnorr_batch_verify_rlc)."""
+        pk32 = _arr(pk32, 32)
+        n = pk32.shape[0]
+        sig64 = _arr(sig64, 64, n)
+        seed = np.frombuffer(seed32 if seed32 is not None else os.urandom(32), dtype=np.uint8)
+        res = C.c_int(0)
+        if isinstance(msgs, (list, tuple)):
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+            self._check(self._lib.s2k_group_schnorr_batch_verify_rlc(self._h, n, pk32.ctypes.data, blob.ctypes.data, offs.ctypes.data, 0,
+                                                                     sig64.ctypes.data, seed.ctypes.data, C.byref(res)))
+        else:
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+            self._check(self._lib.s2k_group_schnorr_batch_verify_rlc(self._h, n, pk32.ctypes.data, m.ctypes.data if m.size else None, None,
+                                                                     m.shape[1], sig64.ctypes.data, seed.ctypes.data, C.byref(res)))
+        return bool(res.value)
+
+    def multi_scalar_mult(self, scalars, points) -> bytes:
+        """sum of scalars[i] * points[i] with the terms sharded over the members (s2k_group_multi_scalar_mult) -> 65-byte record"""
+        k = _arr(scalars, 32)
+        n = k.shape[0]
+        p = _arr(points, 65, n)
+        out = np.zeros(65, dtype=np.uint8)
+        self._check(self._lib.s2k_group_multi_scalar_mult(self._h, n, k.ctypes.data, p.ctypes.data, out.ctypes.data))
+        return out.tobytes()
 
     def keyset_create(self, pub_xy, layout: int = 0) -> "GroupKeySet":
         """The tables of a fixed list of public keys on every member's device (s2k_group_keyset_create)."""

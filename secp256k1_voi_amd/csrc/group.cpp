@@ -31,6 +31,11 @@ struct shard_job {
   const uint8_t *pub = nullptr, *dig = nullptr, *r = nullptr, *s = nullptr;   // packed arrays; encoded: pub / dig / s = the three blobs
   const s2k_group_keyset* gks = nullptr;       // key-set form: the keys named by index (kidx) into the group's key set
   const uint32_t* kidx = nullptr;
+  // whole-batch forms (synchronous on the member: one verdict / one partial sum per shard, written to `result`)
+  int kind = 0;                                // 0: per-signature verification (above); 1: BIP-340 whole-batch check; 2: multiscalar multiplication
+  const uint8_t* seed32 = nullptr;             // kind 1
+  size_t msg_len = 0;                          // kind 1: fixed message length (dig_off == nullptr), messages in `dig`
+  uint8_t* result = nullptr;                   // kind 1: one byte per member (1 accept, 0 reject); kind 2: 65 bytes per member
   const uint64_t *pub_off = nullptr, *dig_off = nullptr, *sig_off = nullptr;    // encoded form only (pub_off != nullptr)
   int encoding = 0;
   size_t digest_len = 0;
@@ -177,6 +182,31 @@ void member_main(member* me) {
       while (inflight.size() >= MAX_IN_FLIGHT) (void)finish_oldest(true);
       s2k_ticket t = 0;
       int rc = S2K_OK;
+      if (job.kind) {
+        // whole-batch forms run to their end on this thread (after the tickets in flight: completions are reported in order)
+        while (!inflight.empty()) (void)finish_oldest(true);
+        if (job.kind == 1) {
+          int ok = 1;
+          if (job.n) {
+            if (job.dig_off) {       // variable-length messages: the shard's offsets, rebased to its first message
+              std::vector<uint64_t> off(job.n + 1);
+              for (size_t i = 0; i <= job.n; ++i) off[i] = job.dig_off[job.lo + i] - job.dig_off[job.lo];
+              rc = s2k_schnorr_batch_verify_rlc(me->ctx, job.n, job.pub + job.lo * 32, job.dig + job.dig_off[job.lo], off.data(), 0,
+                                                job.s + job.lo * 64, job.seed32, &ok);
+            } else {
+              rc = s2k_schnorr_batch_verify_rlc(me->ctx, job.n, job.pub + job.lo * 32, job.dig ? job.dig + job.lo * job.msg_len : nullptr, nullptr,
+                                                job.msg_len, job.s + job.lo * 64, job.seed32, &ok);
+            }
+          }
+          job.result[me->index] = (uint8_t)(rc == S2K_OK && ok ? 1 : 0);
+        } else {
+          uint8_t* out = job.result + me->index * 65;
+          memset(out, 0, 65);                    // (an empty shard sums to the identity: the all-zero record)
+          if (job.n) rc = s2k_multi_scalar_mult(me->ctx, job.n, job.r + job.lo * 32, job.pub + job.lo * 65, out);
+        }
+        complete(me, job, rc);
+        continue;
+      }
       if (job.n && job.pub_off)   // encoded items: the offsets are absolute, so a shard is the same blobs with shifted offset arrays
         rc = s2k_ecdsa_verify_encoded_batch_submit(me->ctx, job.n, job.pub, job.pub_off + job.lo, job.dig, job.dig_off + job.lo, job.s,
                                                    job.sig_off + job.lo, job.encoding, job.digest_len, job.flags, job.valid + job.lo, &t);
@@ -432,6 +462,64 @@ int s2k_group_ecdsa_verify_batch_keyset(s2k_group* g, const s2k_group_keyset* gk
   const int rc = s2k_group_ecdsa_verify_batch_keyset_submit(g, gks, n, key_index, dig, r, s, flags, valid, &t);
   if (rc) return rc;
   return s2k_group_wait(g, t);
+}
+
+// BASELINE configs 3 and 4 across the group (the multi-process forms are sharding.py's
+// schnorr_batch_verify_sharded / msm_sharded).  Synchronous: a shard's answer is one verdict / one point.
+// BIP-340 whole-batch check: every member checks its contiguous shard as one random linear combination
+// (s2k_schnorr_batch_verify_rlc: the coefficients of a call are keyed by the seed AND 32 bytes of the operating system's
+// randomness, so the members' combinations are independent); the batch is accepted iff every shard is.
+int s2k_group_schnorr_batch_verify_rlc(s2k_group* g, size_t n, const uint8_t* pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                       size_t msg_len, const uint8_t* sig, const uint8_t* seed32, int* all_valid) {
+  if (!g || !all_valid) return S2K_ERR_ARG;
+  *all_valid = 0;
+  if (!seed32 || (n && (!pk || !sig))) return gfail(g, S2K_ERR_ARG, "null buffer");
+  if (n && !msgs && (msg_offsets ? msg_offsets[n] != 0 : msg_len != 0)) return gfail(g, S2K_ERR_ARG, "null message buffer");
+  std::vector<uint8_t> res(g->members.size(), 0);
+  shard_job proto;
+  proto.kind = 1;
+  proto.pub = pk;
+  proto.dig = msgs;
+  proto.dig_off = msg_offsets;
+  proto.msg_len = msg_len;
+  proto.s = sig;
+  proto.seed32 = seed32;
+  proto.result = res.data();
+  s2k_ticket t = 0;
+  int rc = group_submit(g, n, proto, &t);
+  if (rc) return rc;
+  rc = s2k_group_wait(g, t);
+  if (rc) return rc;
+  int ok = 1;
+  for (uint8_t v : res) ok &= v;
+  *all_valid = ok;
+  return S2K_OK;
+}
+
+// Multiscalar multiplication: every member sums its contiguous shard of the terms (s2k_multi_scalar_mult), the first member
+// adds up the partial sums (one more multiscalar multiplication with unit scalars: point addition with every special case)
+int s2k_group_multi_scalar_mult(s2k_group* g, size_t n, const uint8_t* k, const uint8_t* points, uint8_t* out65) {
+  if (!g || !out65) return S2K_ERR_ARG;
+  if (n && (!k || !points)) return gfail(g, S2K_ERR_ARG, "null buffer");
+  const size_t D = g->members.size();
+  std::vector<uint8_t> parts(D * 65, 0);
+  shard_job proto;
+  proto.kind = 2;
+  proto.r = k;
+  proto.pub = points;
+  proto.result = parts.data();
+  s2k_ticket t = 0;
+  int rc = group_submit(g, n, proto, &t);
+  if (rc) return rc;
+  rc = s2k_group_wait(g, t);
+  if (rc) return rc;
+  // the partial sums as points: the all-zero record of an identity becomes the one-byte identity's 65-byte form the entry point takes
+  std::vector<uint8_t> ones(D * 32, 0);
+  for (size_t i = 0; i < D; ++i) ones[i * 32 + 31] = 1;
+  group_wait_idle(g);                              // the members' threads are parked: member 0's context may be used from here
+  rc = s2k_multi_scalar_mult(g->members[0]->ctx, D, ones.data(), parts.data(), out65);
+  if (rc) return gfail(g, rc, "%s", s2k_last_error(g->members[0]->ctx));
+  return S2K_OK;
 }
 
 int s2k_group_wait(s2k_group* g, s2k_ticket ticket) {

@@ -233,6 +233,52 @@ def test_group_two_members_one_device(eng, oracle):
         S.Group([S.device_count()])            # no such device
 
 
+def test_group_whole_batch_forms_two_members_one_device(eng, oracle):
+    """BASELINE configs 3 and 4 across a group (two members on device 0): the multiscalar multiplication of sharded terms equals
+    the single-context call's and the known answer (sum k_i d_i) G, for sizes around the shard rounding, with identity and repeated
+    points; the BIP-340 whole-batch check accepts valid batches (fixed-length and ragged messages) and rejects them with one bad
+    signature in the first member's shard, in the last member's, or at the shard border."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    rnd = random.Random(12)
+    g = S.Group([0, 0])
+    try:
+        for n in (0, 1, 255, 256, 257, 700, 5000):
+            ds = [rnd.randrange(1, R.N) for _ in range(n)]
+            ks_ = [rnd.randrange(0, R.N) for _ in range(n)]
+            pts = eng.scalar_base_mult_batch(np.frombuffer(b"".join(b32(d) for d in ds), np.uint8).reshape(-1, 32)) if n else np.zeros((0, 65), np.uint8)
+            pts = np.array(pts)
+            if n > 10:
+                pts[3] = 0                                   # the identity among the points
+                pts[7] = pts[8]                              # a repeated point
+                ds[3], ds[7] = 0, ds[8]
+            scal = np.frombuffer(b"".join(b32(k) for k in ks_), np.uint8).reshape(-1, 32) if n else np.zeros((0, 32), np.uint8)
+            got = g.multi_scalar_mult(scal, pts)
+            assert got == eng.multi_scalar_mult(scal, pts), n
+            tot = sum(k * d for k, d in zip(ks_, ds)) % R.N
+            assert got == (oracle.scalar_base_mult_vartime(b32(tot)) if tot else bytes(65)), n
+        for n, ml in ((600, 32), (513, None), (2, 32), (0, 32)):
+            if n == 0:
+                assert g.schnorr_batch_verify_rlc(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8))
+                continue
+            if ml is None:                                   # ragged messages
+                dd = [rnd.randrange(1, R.N) for _ in range(n)]
+                msgs = [rnd.randbytes(rnd.choice([0, 1, 31, 33, 64, 100])) for _ in range(n)]
+                sigs = [R.schnorr_sign(d, m, rnd.randbytes(32)) for d, m in zip(dd, msgs)]
+                pk = np.frombuffer(b"".join(b32(R.mul(d, R.G)[0]) for d in dd), np.uint8).reshape(-1, 32)
+                sig = np.frombuffer(b"".join(sigs), np.uint8).reshape(-1, 64).copy()
+            else:
+                pk, msgs, sig = (np.array(a) for a in synth_schnorr_batch(eng, n, max(n // 7, 1), seed=n))
+            assert g.schnorr_batch_verify_rlc(pk, msgs, sig) and eng.schnorr_batch_verify_rlc(pk, msgs, sig)
+            per = (((n + 1) // 2) + 255) // 256 * 256        # the members' shards: [0, per) and [per, n)
+            for bad in sorted({0, min(per, n) - 1, min(per, n - 1), n - 1}):
+                sig[bad, 50] ^= 1
+                assert not g.schnorr_batch_verify_rlc(pk, msgs, sig), (n, bad)
+                sig[bad, 50] ^= 1
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("layout", [1, 2, 3])
 def test_group_keyset_two_members_one_device(eng, oracle, layout):
     """s2k_group_keyset_*: the key set on both members, batches of (key index, digest, r, s) sharded across them; verdicts
@@ -819,6 +865,11 @@ def test_group_bench_tool_one_device():
         d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["member_stats_last_shard"][0]["n"] == 1 << 16
         assert (d["keyset"] is not None and d["keyset"]["keys"] == 1 << 10) if extra else d["keyset"] is None
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "group_bench.py"), "--devices", "0,0", "--batch-log2", "14", "--whole-batch"],
+                       capture_output=True, text=True, timeout=900)          # configs 3 and 4, two members on the one device
+    assert p.returncode == 0, p.stderr[-1500:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["msm"]["terms"] == 2 << 14 and d["schnorr_rlc"]["sigs_per_s"] > 0
 
 
 # ---- key sets with joint tables -------------------------------------------------------------------------------------------

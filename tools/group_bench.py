@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """All GPUs of a node from ONE process through the C-ABI's device group (s2k_group_*): what a cgo host gets.
 
-    python tools/group_bench.py [--devices 0,1,...] [--batch-log2 20] [--keys-log2 16] [--batches 16] [--keyset]
+    python tools/group_bench.py [--devices 0,1,...] [--batch-log2 20] [--keys-log2 16] [--batches 16] [--keyset] [--whole-batch]
 
 Every listed device gets 2^batch_log2 signatures per group batch (weak scaling, like bench.py --gpus N: 2^21 per GPU is BASELINE
 config 5's shape); the packed arrays live in page-locked host memory, four group batches are kept in flight, and the clock runs
@@ -9,7 +9,10 @@ from the completion of the fourth batch to the completion of the last (steady st
 verifications/s host to host, per-member times of the last shards, and the verdict check (every batch carries a seeded
 pattern of damaged signatures that must come back as exactly that pattern).  --keyset: the keys' tables are built once on
 every device (s2k_group_keyset_create, joint tables; not timed) and the batches name their keys by index
-(s2k_group_ecdsa_verify_batch_keyset_submit).  No torch, no RCCL.  On this pool only one device
+(s2k_group_ecdsa_verify_batch_keyset_submit).  --whole-batch: BASELINE configs 3 and 4 instead - 2^batch_log2 terms / BIP-340
+signatures per device and call through s2k_group_multi_scalar_mult (result checked against the known answer) and
+s2k_group_schnorr_batch_verify_rlc (accepts; rejects with one bad signature), synchronous calls from pageable memory.  No torch,
+no RCCL.  On this pool only one device
 per box exists; `--devices 0` is what has been run."""
 import argparse
 import json
@@ -33,6 +36,7 @@ def main():
     ap.add_argument("--keys-log2", type=int, default=16)
     ap.add_argument("--batches", type=int, default=16)
     ap.add_argument("--keyset", action="store_true")
+    ap.add_argument("--whole-batch", action="store_true")
     a = ap.parse_args()
     ndev = S.device_count()
     devices = [int(x) for x in a.devices.split(",")] if a.devices else list(range(ndev))
@@ -41,6 +45,8 @@ def main():
         return 2
     per = 1 << a.batch_log2
     n = per * len(devices)
+    if a.whole_batch:
+        return whole_batch(devices, per, n, a)
     # one shard's worth of signatures is synthesised (on device 0, by a temporary engine) and tiled: every member gets the same
     # keys, which is what per-shard key grouping sees anyway
     eng = S.Engine(devices[0])
@@ -102,6 +108,53 @@ def main():
         gks.close()
     g.close()
     print(json.dumps(line), flush=True)
+    return 0
+
+
+def whole_batch(devices, per, n, a):
+    """configs 3 and 4 through the group: one shard's worth of inputs synthesised on device 0 and tiled over the members"""
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    eng = S.Engine(devices[0])
+    rng = np.random.default_rng(7)
+    d = rng.integers(0, 256, size=(per, 32), dtype=np.uint8)
+    d[:, 0] &= 0x7F
+    k = rng.integers(0, 256, size=(per, 32), dtype=np.uint8)
+    k[:, 0] &= 0x7F
+    pts = np.array(eng.scalar_base_mult_batch(d))
+    kd, _ = eng.fn_op_batch(S.OP_MUL, k, d)                  # k_i d_i mod n
+    acc = np.zeros((1, 32), np.uint8)
+    tot = 0
+    N_ = int("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141", 16)
+    for row in kd:
+        tot = (tot + int.from_bytes(bytes(row), "big")) % N_
+    tot = tot * len(devices) % N_
+    expect = bytes(np.array(eng.scalar_base_mult_batch(np.frombuffer(tot.to_bytes(32, "big"), np.uint8).reshape(1, 32)))[0])
+    pk, msgs, sig = (np.array(x) for x in synth_schnorr_batch(eng, per, min(per, 1 << a.keys_log2), seed=340))
+    eng.close()
+    del eng
+    K, P = np.tile(k, (len(devices), 1)), np.tile(pts, (len(devices), 1))
+    PK, M, SG = np.tile(pk, (len(devices), 1)), np.tile(msgs, (len(devices), 1)), np.tile(sig, (len(devices), 1))
+    g = S.Group(devices)
+    assert g.multi_scalar_mult(K, P) == expect, "group multiscalar multiplication: wrong sum"
+    reps = max(a.batches // 4, 3)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.multi_scalar_mult(K, P)
+    msm_ms = (time.perf_counter() - t0) * 1e3 / reps
+    assert g.schnorr_batch_verify_rlc(PK, M, SG), "group BIP-340 batch check rejected a valid batch"
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.schnorr_batch_verify_rlc(PK, M, SG)
+    rlc_ms = (time.perf_counter() - t0) * 1e3 / reps
+    SG[n - 1, 40] ^= 1
+    assert not g.schnorr_batch_verify_rlc(PK, M, SG), "group BIP-340 batch check accepted a bad signature"
+    g.close()
+    print(json.dumps({"metric": "BASELINE configs 3 and 4 through s2k_group over %d device(s), host (pageable) buffers, synchronous calls" % len(devices),
+                      "n_gpus": len(devices), "devices": devices, "per_gpu": per,
+                      "msm": {"terms": n, "ms": msm_ms, "terms_per_s": n / (msm_ms * 1e-3), "check": "sum equals (sum k_i d_i) G"},
+                      "schnorr_rlc": {"sigs": n, "ms": rlc_ms, "sigs_per_s": n / (rlc_ms * 1e-3),
+                                      "check": "accepts the valid batch, rejects it with the last signature damaged"},
+                      "data": "synthetic"}), flush=True)
     return 0
 
 
