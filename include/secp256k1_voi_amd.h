@@ -419,6 +419,10 @@ int s2k_schnorr_verify_batch_keyset(s2k_ctx *ctx, const s2k_keyset *ks, size_t n
 int s2k_schnorr_verify_batch_keyset_device(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const void *d_key_index,
                                            const void *d_msgs, const void *d_msg_offsets, size_t msg_len, const void *d_sig,
                                            uint32_t flags, void *d_valid, void *hip_stream);
+/* ... and as a ticket of the context's submit / wait slots (s2k_wait / s2k_poll / s2k_wait_all, above) */
+int s2k_schnorr_verify_batch_keyset_submit(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const uint32_t *key_index,
+                                           const uint8_t *msgs, const uint64_t *msg_offsets, size_t msg_len,
+                                           const uint8_t *sig, uint32_t flags, uint8_t *valid, uint64_t *ticket);
 
 /* Whole-batch BIP-340 verification as ONE multi-scalar multiplication of n + K + 1 points
  * ((sum a_i s_i) G - sum a_i R_i - sum over the K distinct keys P of (sum of a_i e_i over P's signatures) P

@@ -288,6 +288,7 @@ def load_library() -> C.CDLL:
     lib.s2k_schnorr_verify_batch_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_schnorr_verify_batch_keyset.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, u32, vp]
     lib.s2k_schnorr_verify_batch_keyset_device.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
+    lib.s2k_schnorr_verify_batch_keyset_submit.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, u32, vp, vp]
     lib.s2k_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci)]
     lib.s2k_schnorr_batch_verify_rlc_device.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.POINTER(ci), vp]
     lib.s2k_schnorr_verify_batch_bisect.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp]
@@ -334,7 +335,7 @@ EXPORTED_SYMBOLS = [
     "s2k_group_keyset_create", "s2k_group_keyset_destroy", "s2k_group_keyset_size", "s2k_group_keyset_layout", "s2k_group_keyset_device_bytes",
     "s2k_group_ecdsa_verify_batch_keyset", "s2k_group_ecdsa_verify_batch_keyset_submit",
     "s2k_schnorr_verify_batch", "s2k_schnorr_verify_batch_device",
-    "s2k_schnorr_verify_batch_keyset", "s2k_schnorr_verify_batch_keyset_device",
+    "s2k_schnorr_verify_batch_keyset", "s2k_schnorr_verify_batch_keyset_device", "s2k_schnorr_verify_batch_keyset_submit",
     "s2k_schnorr_batch_verify_rlc", "s2k_schnorr_batch_verify_rlc_device",
     "s2k_schnorr_verify_batch_bisect", "s2k_schnorr_verify_batch_bisect_device",
     "s2k_scalar_base_mult_batch", "s2k_scalar_mult_batch", "s2k_double_scalar_mult_basepoint_batch",
@@ -634,6 +635,29 @@ class Engine:
             self._check(self._lib.s2k_schnorr_verify_batch_keyset(self._h, keyset._k, n, ki.ctypes.data, m.ctypes.data if m.size else None, None,
                                                                   m.shape[1], sig64.ctypes.data, 0, out.ctypes.data))
         return out
+
+    def schnorr_verify_batch_keyset_submit(self, keyset, key_index, msgs, sig64, out=None) -> "Ticket":
+        """s2k_schnorr_verify_batch_keyset_submit; `msgs` an (n, L) uint8 array (fixed-length messages) or a list of byte strings."""
+        ki = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
+        n = ki.shape[0]
+        sig64 = sig64 if (isinstance(sig64, np.ndarray) and sig64.dtype == np.uint8 and sig64.flags["C_CONTIGUOUS"]) else _arr(sig64, 64, n)
+        if out is None:
+            out = np.zeros(n, dtype=np.uint8)
+        t = C.c_uint64(0)
+        if isinstance(msgs, (list, tuple)):
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+            blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+            keep = [ki, blob, offs, sig64, keyset]
+            self._check(self._lib.s2k_schnorr_verify_batch_keyset_submit(self._h, keyset._k, n, ki.ctypes.data, blob.ctypes.data, offs.ctypes.data, 0,
+                                                                         sig64.ctypes.data, 0, out.ctypes.data, C.byref(t)))
+        else:
+            m = msgs if (isinstance(msgs, np.ndarray) and msgs.dtype == np.uint8 and msgs.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(msgs, dtype=np.uint8)
+            m = m.reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+            keep = [ki, m, sig64, keyset]
+            self._check(self._lib.s2k_schnorr_verify_batch_keyset_submit(self._h, keyset._k, n, ki.ctypes.data, m.ctypes.data if m.size else None, None,
+                                                                         m.shape[1], sig64.ctypes.data, 0, out.ctypes.data, C.byref(t)))
+        return Ticket(self, int(t.value), out, keep)
 
     def schnorr_verify_batch_keyset_device(self, keyset, n, d_key_index, d_msgs, msg_len, d_sig, d_valid, stream=0):
         self._check(self._lib.s2k_schnorr_verify_batch_keyset_device(self._h, keyset._k, int(n), d_key_index, d_msgs, None, int(msg_len), d_sig, 0,

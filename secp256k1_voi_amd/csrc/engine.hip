@@ -2839,6 +2839,50 @@ int s2k_ecdsa_verify_batch_keyset_submit(s2k_ctx* ctx, const s2k_keyset* ks, siz
   return S2K_OK;
 }
 
+// s2k_schnorr_verify_batch_keyset in the ticket form (fixed-length or offset-delimited messages)
+int s2k_schnorr_verify_batch_keyset_submit(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, const uint32_t* key_index, const uint8_t* msgs,
+                                           const uint64_t* msg_offsets, size_t msg_len, const uint8_t* sig, uint32_t flags, uint8_t* valid,
+                                           s2k_ticket* ticket) {
+  if (!ctx || !ticket) return fail(ctx, S2K_ERR_ARG, "null argument");
+  *ticket = 0;
+  if (!ks || ks->ctx != ctx || ks->generation != ctx->generation || ks->device != ctx->device)
+    return fail(ctx, S2K_ERR_ARG, "key set of another context");
+  if (n && (!key_index || !sig || !valid || (!msgs && (msg_offsets || msg_len)))) return fail(ctx, S2K_ERR_ARG, "null buffer");
+  if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (flags) return fail(ctx, S2K_ERR_ARG, "s2k_schnorr_verify_batch_keyset takes no flags");
+  s2k_ctx::pipe_slot* sl = nullptr;
+  int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
+  if (rc) return rc;
+  if (n) {
+    s2k_ctx* c = sl->ctx;
+    uint8_t* h_out = sl->direct ? valid : sl->h_valid;
+    auto enqueue = [&]() -> int {
+      const size_t msg_bytes = msg_offsets ? (size_t)msg_offsets[n] : n * msg_len;
+      const size_t sizes[5] = {n * 4, msg_bytes + 16, msg_offsets ? (n + 1) * 8 : 8, n * 64, n};
+      uint8_t* d[5];
+      int rc2 = ctx_stage(c, sizes, 5, d);
+      if (rc2) return rc2;
+      HIP_TRY(c, hipMemcpyAsync(d[0], key_index, n * 4, hipMemcpyHostToDevice, c->s_copy));
+      if (msg_bytes) HIP_TRY(c, hipMemcpyAsync(d[1], msgs, msg_bytes, hipMemcpyHostToDevice, c->s_copy));
+      if (msg_offsets) HIP_TRY(c, hipMemcpyAsync(d[2], msg_offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->s_copy));
+      HIP_TRY(c, hipMemcpyAsync(d[3], sig, n * 64, hipMemcpyHostToDevice, c->s_copy));
+      HIP_TRY(c, hipEventRecord(c->ev_copied[0], c->s_copy));
+      HIP_TRY(c, hipStreamWaitEvent(c->s_comp, c->ev_copied[0], 0));
+      rc2 = s2k_schnorr_verify_batch_keyset_device(c, ks, n, d[0], msgs ? d[1] : nullptr, msg_offsets ? d[2] : nullptr, msg_len, d[3], 0, d[4], c->s_comp);
+      if (rc2) return rc2;
+      HIP_TRY(c, hipMemcpyAsync(h_out, d[4], n, hipMemcpyDeviceToHost, c->s_comp));
+      return S2K_OK;
+    };
+    rc = enqueue();
+    if (rc) {
+      s2k_internal_drain(c);
+      return fail(ctx, rc, "%s", c->err);
+    }
+  }
+  s2k_internal_pipe_issue(ctx, sl, ticket);
+  return S2K_OK;
+}
+
 int s2k_wait(s2k_ctx* ctx, s2k_ticket ticket) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (ticket == 0 || ticket >= ctx->pipe_next) return fail(ctx, S2K_ERR_ARG, "s2k_wait: ticket %llu was never issued", (unsigned long long)ticket);

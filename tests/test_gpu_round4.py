@@ -668,6 +668,15 @@ def test_schnorr_over_key_sets(eng, oracle, layout):
     ks = eng.keyset_create(kb, layout)
     gotb = eng.schnorr_verify_batch_keyset(ks, inv.reshape(-1).astype(np.uint32), msgb, sigb)
     assert np.array_equal(gotb, eng.schnorr_verify_batch(pkb, msgb, sigb)) and int(gotb.sum()) == big - len(range(0, big, 9))
+    # the ticket form: three batches in flight (fixed-length messages; ragged ones as a list), mixed with an ECDSA ticket
+    kx = inv.reshape(-1).astype(np.uint32)
+    cuts = [(0, 50000), (50000, 40001), (90001, big - 90001)]
+    tk = [eng.schnorr_verify_batch_keyset_submit(ks, kx[a:a + c], np.ascontiguousarray(msgb[a:a + c]), np.ascontiguousarray(sigb[a:a + c])) for a, c in cuts]
+    tl = eng.schnorr_verify_batch_keyset_submit(ks, kx[:300], [bytes(m_) for m_ in msgb[:300]], sigb[:300])
+    for t_, (a, c) in zip(tk, cuts):
+        assert np.array_equal(t_.wait(), gotb[a:a + c])
+    assert np.array_equal(tl.wait(), gotb[:300])
+    eng.wait_all()
     ks.close()
 
 
