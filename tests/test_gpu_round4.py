@@ -680,6 +680,36 @@ def test_schnorr_over_key_sets(eng, oracle, layout):
     ks.close()
 
 
+# ---- small and odd key sets ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [0, 1, 2, 3, 4])
+def test_keyset_small_and_duplicate_keys(eng, oracle, layout):
+    """A set of ONE key; a set that lists the same key several times (every copy is a key of its own: same verdicts under any of its
+    indices); a set whose only key is no curve point; batches of one signature and of a few thousand under one key (every lane of
+    every wave on the same table).  All layouts, AUTO included."""
+    from secp256k1_voi_amd.synth import synth_batch
+    n = 5000
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, 1, seed=61))
+    s[::5, 9] ^= 0x20
+    ref = eng.ecdsa_verify_batch(pub, dig, r, s)
+    assert np.array_equal(ref[:512], oracle.ecdsa_verify_batch(pub[:512], dig[:512], r[:512], s[:512], nthreads=os.cpu_count() or 1))
+    one = eng.keyset_create(pub[:1], layout)
+    zeros = np.zeros(n, np.uint32)
+    assert np.array_equal(eng.ecdsa_verify_batch_keyset(one, zeros, dig, r, s), ref)
+    assert np.array_equal(eng.ecdsa_verify_batch_keyset(one, zeros[:1], dig[:1], r[:1], s[:1]), ref[:1])
+    one.close()
+    other = np.array(synth_batch(eng, 1, 1, seed=62)[0])
+    dup = eng.keyset_create(np.concatenate([pub[:1], other, pub[:1], pub[:1]]), layout)       # copies of the key at 0, 2, 3
+    kidx = np.array([(0, 2, 3, 1)[i % 4] for i in range(n)], np.uint32)
+    got = eng.ecdsa_verify_batch_keyset(dup, kidx, dig, r, s)
+    assert np.array_equal(got[kidx != 1], ref[kidx != 1]) and not got[kidx == 1].any()
+    dup.close()
+    bad = pub[:1].copy()
+    bad[0, 63] ^= 1
+    nokey = eng.keyset_create(bad, layout)
+    assert not nokey.valid_keys().any() and not eng.ecdsa_verify_batch_keyset(nokey, zeros, dig, r, s).any()
+    nokey.close()
+
+
 # ---- key sets through submit / wait ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", [1, 2, 3, 4])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT, S2K_KEYSET_JOINT5, S2K_KEYSET_JOINT6
 def test_keyset_submit_wait(eng, oracle, layout):
