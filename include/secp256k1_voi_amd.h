@@ -209,8 +209,8 @@ int s2k_keyset_create(s2k_ctx *ctx, size_t n_keys, const uint8_t *pub_xy /* n_ke
  *                      under the endomorphism (320 KiB per key more): the two half scalars' digits at a position are ONE table
  *                      addition, 32 per signature;
  *   S2K_KEYSET_JOINT5  the same on 5-bit digits: 26 digit positions, 512 sums per position - 26 table additions per signature,
- *                      1.04 MiB per key on top of the chunk tables (68 GB for 2^16 keys);
- *   S2K_KEYSET_JOINT6  on 6-bit digits: 22 positions, 2048 sums each - 22 additions, 3.6 MiB per key (for sets of up to
+ *                      0.81 MiB per key on top of the chunk tables (56 GB for 2^16 keys);
+ *   S2K_KEYSET_JOINT6  on 6-bit digits: 22 positions, 2048 sums each - 22 additions, 2.75 MiB per key (for sets of up to
  *                      2^15 keys or so on a 288 GB device);
  *   S2K_KEYSET_AUTO    (s2k_keyset_create) the widest of JOINT5 and JOINT that takes no more than half of the device memory
  *                      free at the time, else chunks.

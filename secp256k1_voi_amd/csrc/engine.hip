@@ -772,7 +772,7 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
       // (wide joint tables: L = 2^(W POS) Q, the pair behind the positions of the key's joint table)
       fe29 lx, ly;
       if constexpr (JOINTW)
-        je_load(kg.jtab + (size_t)kg.ptab[idx] * kjw_geom<JW>::KEY_QUADS + (kjw_geom<JW>::LEAD + (neg1 == neg2 ? 0 : 1)) * KJ_ENTRY_QUADS, lx, ly);
+        jw_load(kg.jtab + (size_t)kg.ptab[idx] * kjw_geom<JW>::KEY_QUADS + (kjw_geom<JW>::LEAD + (neg1 == neg2 ? 0 : 1)) * kjw_geom<JW>::EQ, lx, ly);
       else
         ke_load_xy(kt + (size_t)(neg1 == neg2 ? G::LEAD : G::LEAD + 1) * 8, false, lx, ly);
       xa = xyzz29_from_affine(lx, fe29_cond_negate1(ly, neg1));
@@ -809,7 +809,7 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           const uint32_t ea = (w1 < NE) ? (NE - 1u - w1) : (w1 - NE), eb = (w2 < NE) ? (NE - 1u - w2) : (w2 - NE);
           const uint32_t j = (((uint32_t)c * NE + ea) * NE + eb) * 2u + (n1 != n2 ? 1u : 0u);
           fe29 x, y;
-          je_load(jt + (size_t)j * KJ_ENTRY_QUADS, x, y);
+          jw_load(jt + (size_t)j * J::EQ, x, y);
           xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
         }
       } else {
@@ -1961,7 +1961,7 @@ struct s2k_keyset {
   size_t n;
   uint8_t* base;      // device: keys | tables | validity | identity | counters (s2k_internal_keyset_bytes)
   size_t bytes;
-  uint4* joint;       // device: the joint tables (320 KiB per key; 1.04 / 3.6 MiB at 5- / 6-bit digits), or null: the ladder over the 32-chunk tables
+  uint4* joint;       // device: the joint tables (320 KiB per key; 0.81 / 2.75 MiB at 5- / 6-bit digits), or null: the ladder over the 32-chunk tables
   size_t joint_bytes;
   int jw;             // digit width of the joint tables: 4, 5 or 6 (0: none)
 };
@@ -1998,10 +1998,10 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
   if (rc == S2K_OK && hipMemcpyAsync(ks->base + off[0], pub_xy, n_keys * 64, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = fail(ctx, S2K_ERR_HIP, "copy of the keys failed");
   if (rc == S2K_OK) rc = s2k_internal_keyset_build(ctx, ks->base, n_keys, st);
-  // joint tables (one table addition per digit position instead of two; 320 KiB per key on top, 1.04 MiB at 5-bit digits: 26
-  // positions, 3.6 MiB at 6-bit digits: 22): the layout asked for, or - S2K_KEYSET_AUTO - the widest of 5 and 4 bits that takes no
-  // more than half of the device memory that is free now (2^16 keys at 5 bits are 70 GB: a quarter would ask for a device with
-  // 280 GB free, which the 288 GB one never has once a context lives on it)
+  // joint tables (one table addition per digit position instead of two; 320 KiB per key on top, 0.81 MiB at 5-bit digits: 26
+  // positions, 2.75 MiB at 6-bit digits: 22): the layout asked for, or - S2K_KEYSET_AUTO - the widest of 5 and 4 bits that takes no
+  // more than half of the device memory that is free now (2^16 keys at 5 bits are 56 GB: a quarter would ask for a device with
+  // 224 GB free, which the 288 GB one never has once a context lives on it)
   ks->joint = nullptr;
   ks->joint_bytes = 0;
   ks->jw = 0;

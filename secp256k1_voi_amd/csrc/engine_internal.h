@@ -334,7 +334,7 @@ constexpr size_t KJ_KEY_QUADS = (size_t)KS_CHUNKS * KJ_PER_CHUNK * KJ_ENTRY_QUAD
 // Wider joint tables (S2K_KEYSET_JOINT5 / S2K_KEYSET_JOINT6): the same idea on W-bit digits.  A half scalar k (odd, < 2^129) is
 // k = 2^(W POS) + sum_i d_i 2^(W i), d_i = 2 w_i - (2^W - 1), w_i the W-bit windows of (k - 1) / 2, POS = ceil(128 / W) of them;
 // per position the sums (2a + 1) B_i + s phi((2b + 1) B_i), a, b < 2^(W-1), s = +-, B_i = 2^(W i) Q: POS additions per signature
-// instead of 32 (26 at W = 5, 22 at W = 6) for 2^(2W - 1) entries per position (1.04 MiB / 3.6 MiB per key).  The points are
+// instead of 32 (26 at W = 5, 22 at W = 6) for 2^(2W - 1) entries per position (0.81 MiB / 2.75 MiB per key).  The points are
 // derived from the key's 32-chunk table by affine doublings and additions, so they live on the same isomorphic curve (same W
 // factor at the end of the ladder).  The ladder's two starting points, 2^(W POS) Q +- phi(2^(W POS) Q), follow the positions.
 template <int W>
@@ -343,7 +343,10 @@ struct kjw_geom {
   static constexpr int POS = (128 + W - 1) / W;                  // digit positions
   static constexpr int PER_POS = NE * NE * 2;                    // joint entries per position
   static constexpr size_t LEAD = (size_t)POS * PER_POS;          // entries LEAD, LEAD + 1: the lead pair
-  static constexpr size_t KEY_QUADS = (LEAD + 2) * KJ_ENTRY_QUADS;
+  // entries of 64 bytes: x and y as eight 32-bit words each (canonical values; converted to limbs on load: 34 instructions
+  // per lookup), so that a lookup is ONE aligned 64-byte fetch where an 80-byte entry of limbs straddles two or three
+  static constexpr int EQ = 4;
+  static constexpr size_t KEY_QUADS = (LEAD + 2) * EQ;
   static constexpr int LEAD_SHIFT = W * POS - 128;               // doublings from the chunk table's L = 2^128 Q to 2^(W POS) Q
 };
 static_assert(KT_SLOTS == 72 && KT_W_SLOT == 9 && kt_geom<32>::SLOTS == 288, "table geometry");

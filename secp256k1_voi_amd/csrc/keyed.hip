@@ -907,7 +907,7 @@ k_ksw_joint(uint32_t nkeys, const uint4* __restrict__ odd, uint4* __restrict__ j
   const uint32_t t = id / G::POS, c = id % G::POS;
   if (t >= nkeys) return;
   const uint4* e0 = odd + ((size_t)t * G::POS + c) * G::NE * KJ_ENTRY_QUADS;
-  uint4* j0 = jtab + (size_t)t * G::KEY_QUADS + (size_t)c * G::PER_POS * KJ_ENTRY_QUADS;
+  uint4* j0 = jtab + (size_t)t * G::KEY_QUADS + (size_t)c * G::PER_POS * G::EQ;
   const fe29 beta = fe29_from_words(FE_BETA);
   constexpr int PAIRS = G::NE * G::NE;
   fe29 pre = fe29_one();
@@ -919,7 +919,7 @@ k_ksw_joint(uint32_t nkeys, const uint4* __restrict__ odd, uint4* __restrict__ j
     je_load(e0 + (size_t)b * KJ_ENTRY_QUADS, xb, yb);
     const fe29 d = fe29_add(fe29_mul(xb, beta), fe29_negate(xa, 1));              // x2 - x1 [3]
     pre = fe29_mul(pre, d);
-    je_store1(j0 + (size_t)(2 * k) * KJ_ENTRY_QUADS, pre);
+    je_store1(j0 + (size_t)(2 * k) * G::EQ, pre);
   }
   fe29 inv = fe29_inv_gcd(pre);
 #pragma unroll 1
@@ -930,7 +930,7 @@ k_ksw_joint(uint32_t nkeys, const uint4* __restrict__ odd, uint4* __restrict__ j
     je_load(e0 + (size_t)b * KJ_ENTRY_QUADS, xb, yb);
     const fe29 bxb = fe29_mul(xb, beta);
     const fe29 d = fe29_add(bxb, fe29_negate(xa, 1));
-    const fe29 prev = k ? je_load1(j0 + (size_t)(2 * (k - 1)) * KJ_ENTRY_QUADS) : fe29_one();
+    const fe29 prev = k ? je_load1(j0 + (size_t)(2 * (k - 1)) * G::EQ) : fe29_one();
     const fe29 di = fe29_mul(inv, prev);                                         // 1 / (x2 - x1)
     inv = fe29_mul(inv, d);
     const fe29 nxs = fe29_negate(fe29_add(xa, bxb), 2);                          // -(x1 + x2) [3]
@@ -941,7 +941,7 @@ k_ksw_joint(uint32_t nkeys, const uint4* __restrict__ odd, uint4* __restrict__ j
       const fe29 lam = fe29_mul(dy, di);
       const fe29 x3 = fe29_sqr_plus(lam, nxs);
       const fe29 y3 = fe29_mul_plus(lam, fe29_add(xa, fe29_negate(x3, 1)), nya);
-      je_store(j0 + (size_t)(2 * k + s_) * KJ_ENTRY_QUADS, x3, y3);
+      jw_store(j0 + (size_t)(2 * k + s_) * G::EQ, x3, y3);
     }
   }
 }
@@ -959,7 +959,7 @@ k_ksw_lead(uint32_t nkeys, const uint4* __restrict__ ktab, uint4* __restrict__ j
     ke_load_xy(ktab + (size_t)t * (KS_SLOTS * 8) + (size_t)(kt_geom<KS_CHUNKS>::LEAD + k) * 8, false, x, y);
 #pragma unroll 1
     for (int d = 0; d < G::LEAD_SHIFT; ++d) aff_double(x, y);
-    je_store(jtab + (size_t)t * G::KEY_QUADS + (G::LEAD + k) * KJ_ENTRY_QUADS, x, y);
+    jw_store(jtab + (size_t)t * G::KEY_QUADS + (G::LEAD + k) * G::EQ, x, y);
   }
 }
 }  // namespace

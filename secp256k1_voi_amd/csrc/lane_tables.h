@@ -134,6 +134,22 @@ S2K_DEV void je_load(const uint4* __restrict__ e, fe29& x, fe29& y) {
   x.n[8] = t.x;
   y.n[8] = t.y;
 }
+// wide joint entries (kjw_geom): x and y as canonical 8 x 32-bit words, four quads
+S2K_DEV void jw_store(uint4* __restrict__ e, const fe29& x, const fe29& y) {
+  uint32_t xw[8], yw[8];
+  fe29_to_words(xw, fe29_normalize(x));
+  fe29_to_words(yw, fe29_normalize(y));
+  e[0] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+  e[1] = make_uint4(xw[4], xw[5], xw[6], xw[7]);
+  e[2] = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+  e[3] = make_uint4(yw[4], yw[5], yw[6], yw[7]);
+}
+S2K_DEV void jw_load(const uint4* __restrict__ e, fe29& x, fe29& y) {
+  const uint4 a = e[0], b = e[1], c = e[2], d = e[3];
+  const uint32_t xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, yw[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  x = fe29_from_words(xw);
+  y = fe29_from_words(yw);
+}
 // one field element parked in the first three quads of a joint entry's slot (the build's prefix products)
 S2K_DEV void je_store1(uint4* __restrict__ e, const fe29& v) {
   e[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);

@@ -268,7 +268,7 @@ def test_keyset_matches_batch_verifier(eng, oracle, layout):
     kidx[12] = 0xFFFFFFFF
     ks = eng.keyset_create(keys, layout)
     assert ks.layout() == layout
-    joint_bytes = {1: 0, 2: 32 * 128 * 80, 3: (26 * 512 + 2) * 80, 4: (22 * 2048 + 2) * 80}[layout]
+    joint_bytes = {1: 0, 2: 32 * 128 * 80, 3: (26 * 512 + 2) * 64, 4: (22 * 2048 + 2) * 64}[layout]
     assert len(ks) == len(keys) and len(keys) * (36864 + joint_bytes) <= ks.device_bytes() <= len(keys) * (36864 + joint_bytes) + (1 << 20)
     vk = ks.valid_keys()
     assert [k for k in range(len(keys)) if not vk[k]] == sorted(bad_keys)
