@@ -1066,8 +1066,43 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     out["msm_2p20"]["two_calls_in_flight_ms"] = ms2
     out["msm_2p20"]["two_calls_in_flight_note"] = ("two contexts on two host threads and streams, %d calls each, wall time per call; "
                                                    "no gain over one call after the other: kept as the measurement" % reps2)
-    eng_b.close()
     del dk, dp
+
+    # (c) from HOST memory: the synchronous host-pointer call pays transfer and kernels in series; two verifiers (two contexts,
+    # two host threads) taking whole batches alternately hide one's transfer behind the other's kernels - the library lets the
+    # phases of such calls take turns per device (msm.hip: phase_locks), so the two do not fall into lock step
+    from secp256k1_voi_amd import pinned_array
+
+    def host_two_verifiers(call_a, call_b, reps=6):
+        def loop(fn):
+            for _ in range(reps):
+                fn()
+        call_a(); call_b()
+        t_0 = time.perf_counter()
+        loop(call_a)
+        one = (time.perf_counter() - t_0) * 1e3 / reps
+        th = [threading.Thread(target=loop, args=(f,)) for f in (call_a, call_b)]
+        t_0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        return one, (time.perf_counter() - t_0) * 1e3 / (2 * reps)
+    hk, hp = [], []
+    for _ in range(2):
+        a_, b_ = pinned_array(k.shape), pinned_array(pts.shape)
+        a_[...] = k
+        b_[...] = pts
+        hk.append(a_)
+        hp.append(b_)
+
+    def host_msm(e_, j):
+        assert e_.multi_scalar_mult(hk[j], hp[j]) == want, "MSM from host memory differs"
+    one_ms, two_ms = host_two_verifiers(lambda: host_msm(eng, 0), lambda: host_msm(eng_b, 1))
+    out["msm_2p20"]["host_buffers"] = {"one_verifier_ms": one_ms, "two_verifiers_ms_per_call": two_ms, "terms_per_s_two_verifiers": m / (two_ms * 1e-3),
+                                       "note": "s2k_multi_scalar_mult from page-locked host memory (97 bytes per term over PCIe): one verifier, "
+                                               "and two (two contexts, two host threads) taking whole batches alternately; never `value`"}
+    del hk, hp
 
     # ---- config 4: 2^20 BIP-340 signatures as one random-linear-combination MSM ----
     pk, msgs, sig = synth_schnorr_batch(eng, m, min(m, 1 << 16), seed=340)
@@ -1126,7 +1161,26 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
         raise
     except Exception as e:
         ks_entry = {"error": "%s: %s" % (type(e).__name__, e)}
+    # from host memory, one verifier and two (as for config 3)
+    hb = []
+    for _ in range(2):
+        q = [pinned_array(a_.shape) for a_ in (pk, msgs, sig)]
+        for dst_, src_ in zip(q, (pk, msgs, sig)):
+            dst_[...] = src_
+        hb.append(q)
+
+    def host_rlc(e_, j):
+        assert e_.schnorr_batch_verify_rlc(*hb[j]), "BIP-340 batch from host memory rejected"
+    try:
+        one_ms, two_ms = host_two_verifiers(lambda: host_rlc(eng, 0), lambda: host_rlc(eng_b, 1))
+        host_entry = {"one_verifier_ms": one_ms, "two_verifiers_ms_per_call": two_ms, "sigs_per_s_two_verifiers": m / (two_ms * 1e-3),
+                      "note": "s2k_schnorr_batch_verify_rlc from page-locked host memory (128 bytes per signature over PCIe): one verifier, "
+                              "and two (two contexts, two host threads) taking whole batches alternately; never `value`"}
+    finally:
+        eng_b.close()
+    del hb
     out["schnorr_rlc_2p20"] = {"sigs": m, "ms": ms, "sigs_per_s": m / (ms * 1e-3),
+                               "host_buffers": host_entry,
                                "per_signature_verify_ms": ms_single,
                                "per_signature_verify_over_key_set": ks_entry,
                                "locate_one_bad_signature_ms": ms_locate,

@@ -433,6 +433,10 @@ int s2k_schnorr_verify_batch_keyset_submit(s2k_ctx *ctx, const s2k_keyset *ks, s
  * predictable seed does not make the coefficients predictable.  It does not say which signature
  * fails — s2k_schnorr_verify_batch_bisect does.  The
  * reference has single verification only (schnorr.go:221); this is BASELINE config 4. */
+/* (Host-pointer forms of the whole-batch calls - this one, s2k_schnorr_verify_batch_bisect, s2k_multi_scalar_mult - are
+ * synchronous: transfer, kernels, answer.  Two contexts on two host threads that take whole batches alternately overlap one's
+ * transfer with the other's kernels; the library makes the phases of such calls take turns per device, so the two settle at
+ * about the resident rate instead of falling into lock step.) */
 int s2k_schnorr_batch_verify_rlc(s2k_ctx *ctx, size_t n, const uint8_t *pk, const uint8_t *msgs,
                                  const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig,
                                  const uint8_t *seed32, int *all_valid);

@@ -5,5 +5,5 @@ python3 - <<'PY'
 import json
 d=json.loads(open("gpurun_out/r4aa/bench.json").read().strip().splitlines()[-1])
 print("value", d["value"], "ms", d["ms_per_step"], d.get("extras_error"))
-s=d["schnorr_rlc_2p20"]; print("rlc", s["ms"], "per-sig", s["per_signature_verify_ms"], "keyset", s["per_signature_verify_over_key_set"])
+s=d["schnorr_rlc_2p20"]; print("rlc", s["ms"], s.get("host_buffers")); print("msm", d["msm_2p20"]["ms"], d["msm_2p20"].get("host_buffers"))
 PY

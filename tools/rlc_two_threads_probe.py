@@ -48,6 +48,13 @@ def run(kind, nthreads, stagger_ms=0.0):
     return (time.perf_counter() - t0) * 1e3 / (reps * nthreads)
 
 
+if os.environ.get("PROBE_TRACE"):                  # for tools/gpu_rlc_overlap_trace.sh: only the staggered phase of one kind
+    kind = os.environ["PROBE_TRACE"]
+    run(kind, 2)
+    one = run(kind, 1)
+    print("TRACE_PHASE_START", flush=True)
+    print(kind, "staggered", run(kind, 2, stagger_ms=one / 2), "ms per batch; one verifier", one)
+    sys.exit(0)
 for kind in ("rlc", "msm"):
     run(kind, 2)                                   # buffers, streams
     one, two = run(kind, 1), run(kind, 2)
