@@ -1551,6 +1551,11 @@ static int grouped_front(s2k_ctx* ctx, hipStream_t st, size_t n, const uint8_t* 
   return rc;
 }
 
+s2k_phase_locks& s2k_internal_phase(int device) {
+  static s2k_phase_locks locks[64];
+  return locks[device & 63];
+}
+
 extern "C" {
 
 const char* s2k_version(void) { return "secp256k1_voi_amd 0.4 (gfx950)"; }
@@ -2166,10 +2171,12 @@ int s2k_ecdsa_verify_batch_keyset(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, 
   hipStream_t st = ctx->s_comp;
   rc = ctx_enter(ctx, st);
   if (rc) return rc;
+  s2k_phase_guard phase(ctx->device, n * 100);           // (two verifiers on two threads: engine_internal.h)
   HIP_TRY(ctx, hipMemcpyAsync(d[0], key_index, n * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[1], dig, n * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[2], r, n * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[3], s, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, phase.landed(st));
   rc = s2k_ecdsa_verify_batch_keyset_device(ctx, ks, n, d[0], d[1], d[2], d[3], flags, d[4], st);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));
@@ -2290,10 +2297,12 @@ int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const ui
   hipStream_t st = ctx->s_comp;
   rc = ctx_enter(ctx, st);
   if (rc) return rc;
+  s2k_phase_guard phase(ctx->device, n * 97);            // (two verifiers on two threads: engine_internal.h)
   HIP_TRY(ctx, hipMemcpyAsync(d[0], dig, n * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[1], r, n * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[2], s, n * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[3], recid, n, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, phase.landed(st));
   rc = s2k_ecdsa_recover_batch_device(ctx, n, d[0], d[1], d[2], d[3], flags, d[4], d[5], st);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(pub65, d[4], n * 65, hipMemcpyDeviceToHost, st));
@@ -2506,10 +2515,12 @@ int s2k_schnorr_verify_batch_keyset(s2k_ctx* ctx, const s2k_keyset* ks, size_t n
   hipStream_t st = ctx->s_comp;
   rc = ctx_enter(ctx, st);
   if (rc) return rc;
+  s2k_phase_guard phase(ctx->device, n * 68 + msg_bytes);   // (two verifiers on two threads: engine_internal.h)
   HIP_TRY(ctx, hipMemcpyAsync(d[0], key_index, n * 4, hipMemcpyHostToDevice, st));
   if (msg_bytes) HIP_TRY(ctx, hipMemcpyAsync(d[1], msgs, msg_bytes, hipMemcpyHostToDevice, st));
   if (msg_offsets) HIP_TRY(ctx, hipMemcpyAsync(d[2], msg_offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[3], sig, n * 64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, phase.landed(st));
   rc = s2k_schnorr_verify_batch_keyset_device(ctx, ks, n, d[0], msgs ? d[1] : nullptr, msg_offsets ? d[2] : nullptr, msg_len, d[3], flags, d[4], st);
   if (rc) {
     s2k_internal_drain(ctx);
@@ -2942,10 +2953,12 @@ int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const ui
   hipStream_t st = ctx->s_comp;
   rc = ctx_enter(ctx, st);
   if (rc) return rc;
+  s2k_phase_guard phase(ctx->device, n * 96 + total);    // (two verifiers on two threads: engine_internal.h)
   HIP_TRY(ctx, hipMemcpyAsync(d[0], pk, n * 32, hipMemcpyHostToDevice, st));
   if (total) HIP_TRY(ctx, hipMemcpyAsync(d[1], msgs, total, hipMemcpyHostToDevice, st));
   if (msg_offsets) HIP_TRY(ctx, hipMemcpyAsync(d[2], msg_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d[3], sig, n * 64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, phase.landed(st));
   rc = s2k_schnorr_verify_batch_device(ctx, n, d[0], d[1], msg_offsets ? d[2] : nullptr, msg_len, d[3], flags, d[4], st);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));

@@ -266,6 +266,35 @@ void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, uint64_t* tic
 void s2k_internal_drain(s2k_ctx* ctx);                                                          // after an error: nothing left in flight
 bool s2k_internal_host_pinned(const void* p, size_t bytes);
 
+// Synchronous host-pointer entry points are transfer, kernels, answer in series.  Two verifiers (two contexts on two host
+// threads) that take whole batches alternately could hide one's transfer behind the other's kernels, but left alone they fall
+// into lock step - both copy, then both compute.  So the PHASES of such calls take turns per device: one call's transfer in,
+// one call's kernels (and answer out) at a time.  s2k_phase_transfer locks the transfer phase of a call that moves at least
+// PHASE_MIN_BYTES (smaller calls: no-op guards); `landed()` waits for the copies on the stream and hands over to the kernel
+// phase.  A lone verifier meets no contention; what it pays is that its kernels are enqueued once its copies have landed
+// instead of behind them on the stream (tens of microseconds).  Measured: DESIGN.md section 5.
+struct s2k_phase_locks {
+  std::mutex xfer, comp;
+};
+s2k_phase_locks& s2k_internal_phase(int device);          // engine.hip
+constexpr size_t S2K_PHASE_MIN_BYTES = (size_t)4 << 20;
+struct s2k_phase_guard {
+  s2k_phase_locks& ph;
+  bool on;
+  std::unique_lock<std::mutex> x, c;
+  s2k_phase_guard(int device, size_t bytes) : ph(s2k_internal_phase(device)), on(bytes >= S2K_PHASE_MIN_BYTES), x(ph.xfer, std::defer_lock), c(ph.comp, std::defer_lock) {
+    if (on) x.lock();
+  }
+  // the copies are enqueued on `st`: wait for them, let the next call transfer, take the kernel phase
+  hipError_t landed(hipStream_t st) {
+    if (!on) return hipSuccess;
+    const hipError_t e = hipStreamSynchronize(st);
+    x.unlock();
+    c.lock();
+    return e;
+  }
+};
+
 // copy / compute streams and the events chaining them, for the host-buffer entry points
 inline int ctx_streams(s2k_ctx* ctx) {
   if (!ctx->s_copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));   // (a child context is given its parent's streams)

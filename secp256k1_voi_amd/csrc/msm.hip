@@ -1333,22 +1333,6 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
   return S2K_OK;
 }
 
-}  // extern "C"
-// The host-pointer forms of the whole-batch calls are synchronous: transfer, then kernels, then the answer.  Two verifiers
-// (two contexts on two host threads) that take whole batches alternately could hide one's transfer behind the other's
-// kernels - but started together they fall into lock step (both copy, then both compute: 4.66 against 5.01 ms per 2^20
-// BIP-340 signatures), and started half a period apart they drift back into it.  So the phases take turns per DEVICE: one
-// call's transfer at a time, one call's kernels at a time; a lone verifier meets no contention (its kernels are enqueued
-// once its copies have landed instead of behind them on the stream: tens of microseconds).  Batches too small for the
-// transfer to matter skip this.
-namespace {
-struct phase_locks {
-  std::mutex xfer, comp;
-};
-phase_locks g_phase[64];
-constexpr size_t PHASE_MIN_BYTES = (size_t)4 << 20;
-}  // namespace
-extern "C" {
 int s2k_multi_scalar_mult(s2k_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out65) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (!out65) return fail(ctx, S2K_ERR_ARG, "null output buffer");
@@ -1361,17 +1345,12 @@ int s2k_multi_scalar_mult(s2k_ctx* ctx, size_t n, const uint8_t* scalars, const 
   rc = ctx_stage(ctx, sizes, 3, d);
   if (rc) return rc;
   hipStream_t st = ctx->s_comp;
-  phase_locks& ph = g_phase[ctx->device & 63];
-  const bool phased = n * 97 >= PHASE_MIN_BYTES;
+  s2k_phase_guard phase(ctx->device, n * 97);            // (two verifiers on two threads: engine_internal.h)
   if (n) {
-    std::unique_lock<std::mutex> lk(ph.xfer, std::defer_lock);
-    if (phased) lk.lock();
     HIP_TRY(ctx, hipMemcpyAsync(d[0], scalars, n * 32, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d[1], points, n * 65, hipMemcpyHostToDevice, st));
-    if (phased) HIP_TRY(ctx, hipStreamSynchronize(st));
   }
-  std::unique_lock<std::mutex> lk(ph.comp, std::defer_lock);
-  if (phased) lk.lock();
+  HIP_TRY(ctx, phase.landed(st));
   rc = s2k_multi_scalar_mult_device(ctx, n, d[0], d[1], d[2], st);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(out65, d[2], 65, hipMemcpyDeviceToHost, st));
@@ -1681,18 +1660,10 @@ int s2k_schnorr_verify_batch_bisect(s2k_ctx* ctx, size_t n, const uint8_t* pk, c
   if (!pk || !sig || !valid || !seed32) return fail(ctx, S2K_ERR_ARG, "null buffer");
   uint8_t* d[5];
   hipStream_t st;
-  phase_locks& ph = g_phase[ctx->device & 63];
-  const bool phased = n * 128 >= PHASE_MIN_BYTES;
-  int rc;
-  {
-    std::unique_lock<std::mutex> lk(ph.xfer, std::defer_lock);
-    if (phased) lk.lock();
-    rc = stage_schnorr(ctx, n, pk, msgs, msg_offsets, msg_len, sig, d, &st);
-    if (rc) return rc;
-    if (phased) HIP_TRY(ctx, hipStreamSynchronize(st));
-  }
-  std::unique_lock<std::mutex> lk(ph.comp, std::defer_lock);
-  if (phased) lk.lock();
+  s2k_phase_guard phase(ctx->device, n * 128);           // (two verifiers on two threads: engine_internal.h)
+  int rc = stage_schnorr(ctx, n, pk, msgs, msg_offsets, msg_len, sig, d, &st);
+  if (rc) return rc;
+  HIP_TRY(ctx, phase.landed(st));
   rc = s2k_schnorr_verify_batch_bisect_device(ctx, n, d[0], d[1], msg_offsets ? d[2] : nullptr, msg_len, d[3], seed32, d[4], stats, st);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(valid, d[4], n, hipMemcpyDeviceToHost, st));
@@ -1733,18 +1704,10 @@ int s2k_schnorr_batch_verify_rlc(s2k_ctx* ctx, size_t n, const uint8_t* pk, cons
   if (!pk || !sig) return fail(ctx, S2K_ERR_ARG, "null buffer");
   uint8_t* d[5];
   hipStream_t st;
-  phase_locks& ph = g_phase[ctx->device & 63];
-  const bool phased = n * 128 >= PHASE_MIN_BYTES;
-  int rc;
-  {
-    std::unique_lock<std::mutex> lk(ph.xfer, std::defer_lock);
-    if (phased) lk.lock();
-    rc = stage_schnorr(ctx, n, pk, msgs, msg_offsets, msg_len, sig, d, &st);
-    if (rc) return rc;
-    if (phased) HIP_TRY(ctx, hipStreamSynchronize(st));
-  }
-  std::unique_lock<std::mutex> lk(ph.comp, std::defer_lock);
-  if (phased) lk.lock();
+  s2k_phase_guard phase(ctx->device, n * 128);           // (two verifiers on two threads: engine_internal.h)
+  int rc = stage_schnorr(ctx, n, pk, msgs, msg_offsets, msg_len, sig, d, &st);
+  if (rc) return rc;
+  HIP_TRY(ctx, phase.landed(st));
   return s2k_schnorr_batch_verify_rlc_device(ctx, n, d[0], d[1], msg_offsets ? d[2] : nullptr, msg_len, d[3], seed32, all_valid, st);
 }
 

@@ -25,17 +25,24 @@ def pinned(a):
     return p
 
 
-sets = [[pinned(x) for x in (pk, msgs, sig, k, pts)] for _ in range(2)]
+from secp256k1_voi_amd.synth import synth_batch
+epub, edig, er, es = (np.array(a) for a in synth_batch(engs[0], n, min(n, 1 << 16), seed=5))
+erid = np.zeros(n, np.uint8)
+sets = [[pinned(x) for x in (pk, msgs, sig, k, pts, edig, er, es, erid)] for _ in range(2)]
 
 
 def run(kind, nthreads, stagger_ms=0.0):
     def work(j):
-        e, (ppk, pm, ps, pkk, pp) = engs[j], sets[j]
+        e, (ppk, pm, ps, pkk, pp, pdig, pr, pss, prid) = engs[j], sets[j]
         if j and stagger_ms:
             time.sleep(stagger_ms * 1e-3)       # the second verifier starts half a period later: its transfer beside the first one's kernels
         for _ in range(reps):
             if kind == "rlc":
                 assert e.schnorr_batch_verify_rlc(ppk, pm, ps)
+            elif kind == "schnorr":
+                e.schnorr_verify_batch(ppk, pm, ps)
+            elif kind == "recover":
+                e.ecdsa_recover_batch(pdig, pr, pss, prid)
             else:
                 e.multi_scalar_mult(pkk, pp)
     for j in range(nthreads):
@@ -55,7 +62,7 @@ if os.environ.get("PROBE_TRACE"):                  # for tools/gpu_rlc_overlap_t
     print("TRACE_PHASE_START", flush=True)
     print(kind, "staggered", run(kind, 2, stagger_ms=one / 2), "ms per batch; one verifier", one)
     sys.exit(0)
-for kind in ("rlc", "msm"):
+for kind in ("rlc", "msm", "schnorr", "recover"):
     run(kind, 2)                                   # buffers, streams
     one, two = run(kind, 1), run(kind, 2)
     stag = run(kind, 2, stagger_ms=one / 2)
