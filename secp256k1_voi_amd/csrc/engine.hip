@@ -2013,16 +2013,21 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
   uint4* scratch = nullptr;
   if (rc == S2K_OK && layout != S2K_KEYSET_CHUNKS) {
     int w = layout == S2K_KEYSET_JOINT6 ? 6 : layout == S2K_KEYSET_JOINT5 ? 5 : layout == S2K_KEYSET_JOINT ? 4 : 0;
+    // test hook: pretend the device has no more than this many bytes free for joint tables (the choice of S2K_KEYSET_AUTO and
+    // the failure of an explicit layout can be exercised without filling a 288 GB device)
+    size_t pretend_free = ~(size_t)0;
+    if (const char* v = getenv("S2K_TEST_KEYSET_FREE_BYTES")) pretend_free = (size_t)strtoull(v, nullptr, 10);
     if (w == 0) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        if (free_b > pretend_free) free_b = pretend_free;
         if (s2k_internal_keyset_joint_bytes(n_keys, 5) + s2k_internal_keyset_joint_scratch_bytes(n_keys, 5) <= free_b / 2) w = 5;
         else if (s2k_internal_keyset_joint_bytes(n_keys, 4) <= free_b / 2) w = 4;
       }
     }
     if (w) {
       const size_t want = s2k_internal_keyset_joint_bytes(n_keys, w), want_scr = s2k_internal_keyset_joint_scratch_bytes(n_keys, w);
-      hipError_t e2 = hipMalloc((void**)&ks->joint, want);
+      hipError_t e2 = want + want_scr > pretend_free ? hipErrorOutOfMemory : hipMalloc((void**)&ks->joint, want);
       if (e2 == hipSuccess && want_scr) e2 = hipMalloc((void**)&scratch, want_scr);
       if (e2 == hipSuccess) {
         ks->joint_bytes = want;

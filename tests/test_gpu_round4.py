@@ -710,6 +710,42 @@ def test_keyset_small_and_duplicate_keys(eng, oracle, layout):
     nokey.close()
 
 
+# ---- the layout a key set gets when memory is short -------------------------------------------------------------------------
+def test_keyset_layout_choice_under_memory_limits(eng):
+    """S2K_TEST_KEYSET_FREE_BYTES makes s2k_keyset_create_ex believe the device has only that much room for joint tables:
+    S2K_KEYSET_AUTO takes 5-bit joint tables when they fit in half of it, else 4-bit ones, else chunk tables, and the set verifies
+    the same in each; an explicit joint layout that does not fit is an error (and leaves nothing behind: the next set is built)."""
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    nk, n = 400, 6000
+    pub, dig, r, s = (np.array(a) for a in synth_batch(eng, n, nk, seed=88))
+    keys, inv = np.unique(pub, axis=0, return_inverse=True)
+    kidx = inv.reshape(-1).astype(np.uint32)
+    s[::7, 4] ^= 1
+    ref = eng.ecdsa_verify_batch(pub, dig, r, s)
+    j5 = nk * (26 * 512 + 2) * 64 + nk * 26 * 16 * 80        # joint tables + build scratch at 5 bits
+    j4 = nk * 32 * 128 * 80
+    try:
+        for free, want in ((None, S.KEYSET_JOINT5), (2 * j5 + 4096, S.KEYSET_JOINT5), (2 * j5 - 4096, S.KEYSET_JOINT), (2 * j4 - 4096, S.KEYSET_CHUNKS), (0, S.KEYSET_CHUNKS)):
+            if free is None:
+                os.environ.pop("S2K_TEST_KEYSET_FREE_BYTES", None)
+            else:
+                os.environ["S2K_TEST_KEYSET_FREE_BYTES"] = str(free)
+            ks = eng.keyset_create(keys)
+            assert ks.layout() == want, (free, ks.layout())
+            assert np.array_equal(eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s), ref)
+            ks.close()
+        os.environ["S2K_TEST_KEYSET_FREE_BYTES"] = str(j4 - 1)
+        for layout in (S.KEYSET_JOINT, S.KEYSET_JOINT5, S.KEYSET_JOINT6):
+            with pytest.raises(S.EngineError):
+                eng.keyset_create(keys, layout)
+        ks = eng.keyset_create(keys, S.KEYSET_CHUNKS)
+        assert np.array_equal(eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s), ref)
+        ks.close()
+    finally:
+        os.environ.pop("S2K_TEST_KEYSET_FREE_BYTES", None)
+
+
 # ---- key sets through submit / wait ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", [1, 2, 3, 4])      # S2K_KEYSET_CHUNKS, S2K_KEYSET_JOINT, S2K_KEYSET_JOINT5, S2K_KEYSET_JOINT6
 def test_keyset_submit_wait(eng, oracle, layout):
