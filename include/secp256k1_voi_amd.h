@@ -274,7 +274,8 @@ int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
 /* s2k_ecdsa_verify_batch_keyset in the same form: signatures that name their key by its index in a key set of this context
  * (100 bytes per signature cross PCIe instead of 160, and no table is built).  Tickets of all submit entry points share
- * the context's four slots and may be mixed. */
+ * the context's four slots and may be mixed.  The key set has to live until the ticket has been waited for (s2k_keyset_destroy
+ * waits for the device first, so destroying it early blocks rather than breaks). */
 int s2k_ecdsa_verify_batch_keyset_submit(s2k_ctx *ctx, const s2k_keyset *ks, size_t n, const uint32_t *key_index,
                                          const uint8_t *digest32, const uint8_t *r, const uint8_t *s, uint32_t flags,
                                          uint8_t *valid, s2k_ticket *ticket);
