@@ -86,7 +86,7 @@ int s2k_ctx_create(int device_index, s2k_ctx **out);
 void s2k_ctx_destroy(s2k_ctx *ctx);
 const char *s2k_last_error(const s2k_ctx *ctx);
 const char *s2k_version(void);
-/* Compile-time configuration of this library ("GT_BITS=22 PREP_M=6 ... flags=<S2K_EXTRA_FLAGS>"),
+/* Compile-time configuration of this library ("GT_BITS=26 PREP_M=6 ... flags=<S2K_EXTRA_FLAGS>"),
  * so that a measurement can name the variant it ran (bench.py prints it). */
 const char *s2k_build_config(void);
 /* Measurement hooks (no reference counterpart; bench.py's live roofline).  While enabled, every
@@ -360,7 +360,7 @@ int s2k_pack_valid_device(s2k_ctx *ctx, size_t n, const void *d_valid, void *d_b
  * ONE of the context's buffers: see s2k_ctx_device_bytes for everything a verification call of n signatures holds. */
 size_t s2k_ecdsa_workspace_bytes(size_t n);
 /* Device memory the context holds once it has verified a batch of n signatures with its current key-grouping
- * settings (s2k_ctx_set_key_grouping): the resident generator tables (3 GiB), the per-signature workspace above, and -
+ * settings (s2k_ctx_set_key_grouping): the resident generator tables (40 GiB), the per-signature workspace above, and -
  * with the grouping on, the default, for n >= 256 - the grouping arrays and the per-key table buffer (n / min_group
  * tables of 9 KiB, at most max_tables: 2.4 GB at n = 2^20, 38 GB at 2^24, whether or not keys repeat).  The multi-scalar and BIP-340
  * batch entry points keep a workspace of their own on top (about 1.4 KB per term).  Size HBM by this, not by

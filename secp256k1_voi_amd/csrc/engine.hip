@@ -34,7 +34,7 @@ using namespace s2k;
 
 // ---------------------------------------------------------------------------------------
 // Generator tables, resident in HBM:  GT_WINDOWS = ceil(256 / GT_BITS) tables of 2^GT_BITS affine
-// points (64 MiB at 16 bits, 3 GiB at 22, 11 GiB at 24),
+// points (64 MiB at 16 bits, 3 GiB at 22, 11 GiB at 24, 40 GiB at 26: the default),
 //   T_0[d] = d * G - sum_{i>=1} B_i,   T_i[d] = (d + 1) * B_i,   B_i = 2^(GT_BITS i) * G,
 // so that  u*G = sum_i T_i[(u >> GT_BITS i) & mask]  with GT_WINDOWS mixed additions, no
 // doublings, no zero-digit special case (no entry is the identity) and no final correction.
@@ -1616,7 +1616,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_ensure_ws(s2k_ctx* ctx, s
   return S2K_OK;
 }
 
-// The resident generator tables (3 GiB, read-only once built) are shared by the contexts of a device: a second context
+// The resident generator tables (40 GiB, read-only once built) are shared by the contexts of a device: a second context
 // - one per goroutine / thread is the intended use, INTEGRATION.md - neither rebuilds nor holds another copy.  Reference
 // counted per device under a mutex; the last context to go frees them.
 namespace {
@@ -2703,7 +2703,7 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
 // submit / wait: the host-pointer entry points without the wait at their end.  The reference's caller holds its data in
 // host memory (secec/ecdsa.go:171-228) and a synchronous call pays transfer and compute in series: 7.1 ms from pinned
 // memory, 8.2 from pageable against 4.9 ms resident per 2^20 signatures (round 3).  Here the context owns child contexts
-// ("slots": own workspaces and staging buffers; the 3 GiB generator tables are shared per device) that take the submitted
+// ("slots": own workspaces and staging buffers; the 40 GiB generator tables are shared per device) that take the submitted
 // batches in turn.  The children run on the PARENT's streams, in two lanes: even tickets on the parent's own two compute
 // streams, odd tickets on a second pair, one copy stream for all.  Within a lane the kernels of consecutive tickets follow
 // each other in stream order, each ticket with the two-stream overlap of a resident call (grouping and tables beside

@@ -25,13 +25,17 @@ constexpr uint32_t KG_MAX_TABLES_DEFAULT = 1u << 22;
 // 2^20 verifications / table size / context creation): 16 bits 9.21 / 64 MiB / 0.05 s, 20 bits 9.10 /
 // 0.8 GiB, 22 bits 9.04 / 3 GiB / 0.3 s, 24 bits 9.03 / 11 GiB / 0.9 s.  Grouped flow, end of round 3 (generator part
 // on the second stream, tools/gpu_variant_ab.sh): 22 bits 5.05 ms, 24 bits 5.05 ms - one addition fewer hides nowhere.
-#define S2K_GT_BITS 22
+// End of round 4 (tools/gpu_gtbits_keyset.sh, two runs each on one box): 22 / 24 / 26 bits - grouped step 4.95-4.97 /
+// 4.97 / 4.85-4.87 ms, key set with 5-bit joint tables 2.46-2.47 / 2.42 / 2.41-2.42 ms.  26 bits are TEN windows (the next
+// step down, nine, would take 29 bits and 309 GB): two additions fewer than 22 bits, 40 GiB of tables per device (shared by
+// the contexts of a process), 2.8 s to build at context creation.  HBM capacity is what this engine spends: 26 it is.
+#define S2K_GT_BITS 26
 #endif
 constexpr int GT_BITS = S2K_GT_BITS;
 constexpr int GT_WINDOWS = (256 + GT_BITS - 1) / GT_BITS;
 constexpr uint32_t GT_MASK = (1u << GT_BITS) - 1u;
 constexpr size_t GT_ENTRIES = (size_t)GT_WINDOWS << GT_BITS;
-static_assert(GT_BITS >= 8 && GT_BITS <= 24, "generator window width out of range");
+static_assert(GT_BITS >= 8 && GT_BITS <= 26, "generator window width out of range");   // (26 bits: 10 windows, 43 GB)
 
 S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit) {
   const uint4* p = reinterpret_cast<const uint4*>(gt + ((((size_t)window << GT_BITS) | digit) << 4));

@@ -202,7 +202,9 @@ class Cfg:
         return sum(1 for b in body for i in range(*self.blocks[b]) if self.ins[i][1].startswith("v_"))
 
 
-def general(lib, gt_windows=12):
+def general(lib, gt_windows=None):
+    if gt_windows is None:
+        gt_windows = generator_windows(lib)
     g = Cfg(disassemble(lib, "_Z13k_verify_fastILi0EE"))
     top = g.top_level()
     assert len(top) == 4, ("unexpected loop structure of k_verify_fast<ECDSA>", [g.loops[k]["entries"] for k in top])
@@ -276,7 +278,16 @@ def keyset_joint_wide(lib, w):
             "instructions": len(g.ins)}
 
 
-def static_counts(lib=DEFAULT_LIB, gt_windows=12):
+def generator_windows(lib):
+    """ceil(256 / window bits) of THIS library (s2k_generator_window_bits: a host function, no GPU needed)"""
+    import ctypes
+    bits = int(ctypes.CDLL(os.path.abspath(lib)).s2k_generator_window_bits())
+    return (256 + bits - 1) // bits
+
+
+def static_counts(lib=DEFAULT_LIB, gt_windows=None):
+    if gt_windows is None:
+        gt_windows = generator_windows(lib)
     return {"k_verify_fast": general(lib, gt_windows), "k_verify_fast_keyed": keyed(lib), "k_verify_fast_keyset": keyset(lib),
             "k_verify_fast_keyset_joint": keyset_joint(lib), "k_verify_fast_keyset_joint5": keyset_joint_wide(lib, 5),
             "k_verify_fast_keyset_joint6": keyset_joint_wide(lib, 6)}
