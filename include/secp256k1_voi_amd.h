@@ -325,7 +325,7 @@ int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
  * check: every member checks its contiguous shard as one random linear combination (s2k_schnorr_batch_verify_rlc; the
  * members' coefficients are independent: every call mixes fresh operating-system randomness into the seed), *all_valid = 1
  * iff every shard is accepted.  The multiscalar multiplication: every member sums its shard of the terms, the first member
- * adds the partial sums.  Same results as the single-context calls (Point.MultiScalarMult, point_mul_multi.go:25-117). */
+ * adds the partial sums.  Same results as the single-context calls (Point.MultiScalarMultVartime, point_mul_multi.go:73-117: variable time). */
 int s2k_group_schnorr_batch_verify_rlc(s2k_group *g, size_t n, const uint8_t *pk /* n*32 */, const uint8_t *msgs,
                                        const uint64_t *msg_offsets, size_t msg_len, const uint8_t *sig /* n*64 */,
                                        const uint8_t *seed32, int *all_valid);
@@ -492,8 +492,9 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx *ctx, uint32_t impl, size_
 /* out[i] = a[i] + b[i] — Point.Add (point.go:62); out[i] = 2*a[i] — Point.Double (point.go:71) */
 int s2k_point_add_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
 int s2k_point_double_batch(s2k_ctx *ctx, size_t n, const uint8_t *a, uint8_t *out);
-/* out = sum_i k[i] * P[i] — Point.MultiScalarMult / MultiScalarMultVartime
- * (point_mul_multi.go:25,73).  n == 0 gives the identity.  Pippenger bucket method with
+/* out = sum_i k[i] * P[i] — Point.MultiScalarMultVartime (point_mul_multi.go:73-117) ONLY: variable time
+ * (data-dependent bucket sorts).  The constant-time Point.MultiScalarMult (:25-67) binds to
+ * s2k_ct_multi_scalar_mult below, never to this.  n == 0 gives the identity.  Pippenger bucket method with
  * complete additions (the reference uses Straus; same group element).  A malformed point
  * record is S2K_ERR_ARG.  The device form takes device pointers and synchronises the stream
  * before returning (it has to read back the status word). */
@@ -514,6 +515,14 @@ int s2k_point_decode_batch(s2k_ctx *ctx, size_t n, size_t enc_len, const uint8_t
  * SetUncompressedBytes (point_s11n.go:178); a malformed record is S2K_ERR_ARG. */
 /* out = k*P — Point.ScalarMult (point_mul_glv.go:257-303); k is reduced mod n (SetBytes) */
 int s2k_ct_scalar_mult(const uint8_t k[32], const uint8_t point65[65], uint8_t out65[65]);
+/* out = sum_i k[i]*P[i] — Point.MultiScalarMult (point_mul_multi.go:25-67), the CONSTANT-TIME form: Straus with one
+ * 15-entry table per point, masked full-table scans (projectivePointMultTable.SelectAndAdd, point_mul_table.go:34-41),
+ * doublings shared by all terms; n == 1 is Point.ScalarMult (:31-33), n == 0 the identity.  The scalars (reduced mod n,
+ * SetBytes) are secret; the points and n are public.  This — not s2k_multi_scalar_mult — is what Point.MultiScalarMult
+ * binds to; only MultiScalarMultVartime (:73-117) may go to the GPU.  Cost: 15 n complete additions for the tables,
+ * 252 doublings, 64 n additions; 1440 n bytes of scratch (S2K_ERR_NOMEM if it cannot be had, S2K_ERR_ARG for a
+ * malformed record or n > 2^24). */
+int s2k_ct_multi_scalar_mult(size_t n, const uint8_t *k /* n*32 */, const uint8_t *points65 /* n*65 */, uint8_t out65[65]);
 /* out = k*G — Point.ScalarBaseMult (point_mul_table.go:168-194) */
 int s2k_ct_scalar_base_mult(const uint8_t k[32], uint8_t out65[65]);
 /* shared_x = x(d*Q) — PrivateKey.ECDH (secec/secec.go:53-56); d in [1,n), Q a valid public key */

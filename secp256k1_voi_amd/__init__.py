@@ -312,6 +312,7 @@ def load_library() -> C.CDLL:
     lib.s2k_ct_scalar_base_mult.argtypes = [C.c_char_p, C.c_char_p]
     lib.s2k_ct_ecdh.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     lib.s2k_ct_debug_fe_mul_count.restype = C.c_uint64
+    lib.s2k_ct_multi_scalar_mult.argtypes = [sz, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.s2k_ct_ecdsa_sign_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
     _lib = lib
     return lib
@@ -344,6 +345,7 @@ EXPORTED_SYMBOLS = [
     "s2k_fp_op_batch", "s2k_fn_op_batch", "s2k_fn_split_glv_batch", "s2k_debug_gtable_entry", "s2k_generator_window_bits",
     "s2k_double_scalar_mult_basepoint_batch_ex", "s2k_fp_op_batch_ex", "s2k_fn_split_glv_batch_ex",
     "s2k_ct_scalar_mult", "s2k_ct_scalar_base_mult", "s2k_ct_ecdh", "s2k_ct_ecdsa_sign_raw", "s2k_ct_debug_fe_mul_count",
+    "s2k_ct_multi_scalar_mult",
 ]
 
 
@@ -388,6 +390,23 @@ def ct_scalar_mult(k: bytes, point65: bytes):
     for a malformed point."""
     out = C.create_string_buffer(65)
     return out.raw if load_library().s2k_ct_scalar_mult(bytes(k), bytes(point65), out) == 0 else None
+
+
+def ct_multi_scalar_mult(scalars, points):
+    """Point.MultiScalarMult (point_mul_multi.go:25-67), constant time in the scalars, CPU: Straus with masked table
+    scans; one term is Point.ScalarMult, none is the identity.  `scalars`: 32-byte strings, `points`: 65-byte records.
+    Returns the 65-byte record of the sum, or None for a malformed point.  A length mismatch raises (the reference
+    panics, :27-29)."""
+    scalars, points = [bytes(x) for x in scalars], [bytes(x) for x in points]
+    if len(scalars) != len(points):
+        raise ValueError("secp256k1: len(scalars) != len(points)")
+    if any(len(x) != 32 for x in scalars) or any(len(x) != 65 for x in points):
+        raise ValueError("scalars are 32 bytes, point records 65")
+    out = C.create_string_buffer(65)
+    rc = load_library().s2k_ct_multi_scalar_mult(len(scalars), b"".join(scalars) or None, b"".join(points) or None, out)
+    if rc == -4:
+        raise MemoryError("s2k_ct_multi_scalar_mult: out of memory")
+    return out.raw if rc == 0 else None
 
 
 def ct_scalar_base_mult(k: bytes) -> bytes:

@@ -515,6 +515,33 @@ void ct_scalar_mult(pt& v, const sc& s, const pt& p) {
   }
 }
 
+// Point.MultiScalarMult for l != 1 (point_mul_multi.go:35-66): Straus with one 15-entry table per point,
+// the doublings shared by all terms, the high nibble of each scalar byte before the low one, every
+// table access a masked scan (projectivePointMultTable.SelectAndAdd, point_mul_table.go:34-41).
+// `tbl` is caller-provided scratch of 15 * l points.  The sequence of field operations depends on l
+// alone (l is public: it is the length of the caller's slices).
+void ct_multi_scalar_mult(pt& v, size_t l, const sc* s, const pt* p, pt* tbl) {
+  for (size_t j = 0; j < l; ++j) make_table(tbl + 15 * j, p[j]);
+  pt_identity(v);
+  pt add;
+  for (int i = 0; i < 32; ++i) {   // scalar bytes, most significant first (Scalar.getBytes is big-endian)
+    int limb = (31 - i) >> 3, sh = ((31 - i) & 7) * 8;
+    for (int half = 0; half < 2; ++half) {
+      if (i != 0 || half != 0) {
+        pt_double(v, v);
+        pt_double(v, v);
+        pt_double(v, v);
+        pt_double(v, v);
+      }
+      for (size_t j = 0; j < l; ++j) {
+        u64 b = (s[j].v[limb] >> sh) & 0xff;
+        lookup_projective(add, tbl + 15 * j, half ? (b & 15) : (b >> 4));
+        pt_add(v, v, add);
+      }
+    }
+  }
+}
+
 // generator tables for ScalarBaseMult: 64 tables of [1..15] * 16^i * G, affine (the reference's
 // generatorHugeAffineTable / generatorOddAffineTable pair, point_mul_table.go:78-160), built once
 // from public data
@@ -600,6 +627,44 @@ int s2k_ct_scalar_base_mult(const uint8_t k[32], uint8_t out65[65]) {
   ct_scalar_base_mult(v, s);
   pt_to_record(out65, v);
   return S2K_OK;
+}
+
+// Point.MultiScalarMult (point_mul_multi.go:25-67), the constant-time form: n == 1 is Point.ScalarMult
+// (:31-33), n == 0 leaves the identity (the loops of :35-66 add nothing to v.Identity()), otherwise Straus
+// over per-point tables with masked scans.  The scalars are secret, the points and n are public.
+int s2k_ct_multi_scalar_mult(size_t n, const uint8_t* k, const uint8_t* points65, uint8_t out65[65]) {
+  if (!out65 || (n && (!k || !points65))) return S2K_ERR_ARG;
+  if (n > ((size_t)1 << 24)) return S2K_ERR_ARG;   // 15 tables entries of 96 bytes per term: keep the scratch below 24 GiB
+  pt v;
+  if (n == 0) {
+    pt_identity(v);
+    pt_to_record(out65, v);
+    return S2K_OK;
+  }
+  if (n == 1) return s2k_ct_scalar_mult(k, points65, out65);
+  pt* p = (pt*)malloc(n * sizeof(pt));
+  sc* s = (sc*)malloc(n * sizeof(sc));
+  pt* tbl = (pt*)malloc(n * 15 * sizeof(pt));
+  int rc = (p && s && tbl) ? S2K_OK : S2K_ERR_NOMEM;
+  if (rc == S2K_OK)
+    for (size_t j = 0; j < n; ++j)   // public data: may stop at the first malformed record
+      if (!pt_from_record(p[j], points65 + 65 * j)) {
+        rc = S2K_ERR_ARG;
+        break;
+      }
+  if (rc == S2K_OK) {
+    for (size_t j = 0; j < n; ++j) sc_from_be_reduce(s[j], k + 32 * j);
+    ct_multi_scalar_mult(v, n, s, p, tbl);
+    pt_to_record(out65, v);
+  }
+  if (s) {   // the only secret-derived scratch that outlives the call frame
+    volatile u64* w = (volatile u64*)s;
+    for (size_t i = 0; i < n * 4; ++i) w[i] = 0;
+  }
+  free(tbl);
+  free(s);
+  free(p);
+  return rc;
 }
 
 // PrivateKey.ECDH (secec/secec.go:53-56): x(d * Q).  The public point must be a valid non-identity

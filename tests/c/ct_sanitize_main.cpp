@@ -42,6 +42,46 @@ int main() {
       bad += s2k_ct_ecdsa_sign_raw(d, k, k, r, s, &rid) != 0;
     }
   }
+  // Point.MultiScalarMult: 0, 1, 2, 5 and 33 terms; sum_i k_i (d_i G) against (sum_i k_i d_i) G is checked in
+  // tests/test_ct_cpu.py, here: k*P + (n-k)*P... kept simple: k_i * P_i with P_1 = P_0 and k_1 = -k_0 (mod 2^256 wrap
+  // avoided by using small scalars) gives the remaining terms' sum
+  {
+    const int sizes[5] = {0, 1, 2, 5, 33};
+    static uint8_t ks[33 * 32], ps[33 * 65];
+    for (int si = 0; si < 5; ++si) {
+      int n = sizes[si];
+      for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < 32; ++i) {
+          ks[32 * j + i] = (uint8_t)next();
+          d[i] = (uint8_t)next();
+        }
+        bad += s2k_ct_scalar_base_mult(d, ps + 65 * j) != 0;
+      }
+      bad += s2k_ct_multi_scalar_mult((size_t)n, n ? ks : nullptr, n ? ps : nullptr, out) != 0;
+      if (n == 0) {
+        memset(out2, 0, 65);
+        bad += memcmp(out, out2, 65) != 0;
+      }
+      if (n == 1) {
+        bad += s2k_ct_scalar_mult(ks, ps, out2) != 0;
+        bad += memcmp(out, out2, 65) != 0;
+      }
+      if (n == 2) {   // k0 P0 + k1 P1 against the two single products added through a third term of scalar 1
+        uint8_t a[65], b[65], one[3 * 32] = {0}, three[3 * 65];
+        bad += s2k_ct_scalar_mult(ks, ps, a) != 0;
+        bad += s2k_ct_scalar_mult(ks + 32, ps + 65, b) != 0;
+        one[31] = one[63] = 1;   // 1*a + 1*b + 0*P0
+        memcpy(three, a, 65);
+        memcpy(three + 65, b, 65);
+        memcpy(three + 130, ps, 65);
+        bad += s2k_ct_multi_scalar_mult(3, one, three, out2) != 0;
+        bad += memcmp(out, out2, 65) != 0;
+      }
+    }
+    ps[0] = 0x05;   // malformed record: rejected, nothing leaked or left allocated
+    bad += s2k_ct_multi_scalar_mult(33, ks, ps, out) != S2K_ERR_ARG;
+    bad += s2k_ct_multi_scalar_mult(2, nullptr, ps, out) != S2K_ERR_ARG;
+  }
   (void)s2k_ct_debug_fe_mul_count();
   printf("%s\n", bad ? "FAILED" : "ok");
   return bad != 0;

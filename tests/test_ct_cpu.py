@@ -98,6 +98,65 @@ def test_ct_sign_raw(S, oracle):
     assert S.ct_ecdsa_sign_raw(b32(1), bytes(32), b32(R.N)) is None
 
 
+def test_ct_multi_scalar_mult_vs_oracle(S, oracle):
+    """Point.MultiScalarMult (point_mul_multi.go:25-67), constant-time form: equal to the oracle's Straus
+    (its restatement of MultiScalarMultVartime :73-117 — same group element) for 0, 1, 2, 32, 64 terms, with the
+    edge scalars and the identity / repeated / opposite points the reference's tests mix in
+    (point_mul_multi_test.go:14-72)."""
+    rnd = random.Random(515)
+    assert S.ct_multi_scalar_mult([], []) == bytes(65)
+    for n in (1, 2, 3, 32, 64):
+        pts = [R.enc65(R.mul(rnd.randrange(1, R.N), R.G)) for _ in range(n)]
+        ks = [b32(rnd.randrange(R.N)) for _ in range(n)]
+        if n >= 3:
+            ks[0], ks[1] = b32(0), b32(R.N - 1)
+            pts[2] = bytes(65)                              # the identity as a term
+        if n >= 32:
+            pts[5] = pts[4]                                 # the same point twice
+            pts[7] = oracle.point_neg(pts[6])               # and a pair of opposites with equal scalars: they cancel
+            ks[7] = ks[6]
+            ks[8] = b32((1 << 256) - 1)                     # SetBytes semantics: reduced mod n
+            ks[9] = b32(0x0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f)
+        exp = oracle.multi_scalar_mult_vartime([oracle.fn_reduce(k)[0] for k in ks], pts)
+        assert S.ct_multi_scalar_mult(ks, pts) == exp, n
+    # one term: exactly Point.ScalarMult (:31-33)
+    p, k = R.enc65(R.mul(77, R.G)), b32(rnd.randrange(R.N))
+    assert S.ct_multi_scalar_mult([k], [p]) == S.ct_scalar_mult(k, p)
+    # known discrete logs: sum k_i (d_i G) == (sum k_i d_i) G
+    ds = [rnd.randrange(1, R.N) for _ in range(17)]
+    kk = [rnd.randrange(R.N) for _ in range(17)]
+    pts = [S.ct_scalar_base_mult(b32(d)) for d in ds]
+    assert S.ct_multi_scalar_mult([b32(k) for k in kk], pts) == S.ct_scalar_base_mult(b32(sum(a * b for a, b in zip(ds, kk)) % R.N))
+    # malformed record -> None; length mismatch -> the reference's panic
+    assert S.ct_multi_scalar_mult([k, k], [p, b"\x05" + p[1:]]) is None
+    with pytest.raises(ValueError):
+        S.ct_multi_scalar_mult([k], [p, p])
+
+
+def test_ct_multi_scalar_mult_operation_count(S):
+    """The sequence of field operations of the constant-time MultiScalarMult depends on the number of terms only:
+    same multiplication count for zero, sparse, dense and random scalars, and the count is what Straus with full
+    table scans costs — 15 l table entries (7 doublings + 7 additions + the copy), 252 shared doublings, 64 l
+    additions (point_mul_multi.go:35-66); the variable-time form would skip the zero digits."""
+    lib = S.load_library()
+    rnd = random.Random(516)
+    S.ct_scalar_base_mult(b32(1))
+    for n in (2, 5, 32):
+        pts = [S.ct_scalar_base_mult(b32(rnd.randrange(1, R.N))) for _ in range(n)]
+        lib.s2k_ct_debug_fe_mul_count()
+        counts = set()
+        for fill in (lambda: 0, lambda: 1, lambda: R.N - 1, lambda: (1 << 256) - 1, lambda: 1 << 255, lambda: 0x10001,
+                     lambda: rnd.randrange(R.N), lambda: rnd.randrange(R.N), lambda: rnd.randrange(1 << 64)):
+            assert S.ct_multi_scalar_mult([b32(fill()) for _ in range(n)], pts) is not None
+            counts.add(lib.s2k_ct_debug_fe_mul_count())
+        assert len(counts) == 1, (n, counts)
+        # per operation in ct_cpu.cpp: addition 14 products (12 + two by the constant 21), doubling 9 (8 + one by 21);
+        # output: one inversion (255 squarings + 15 products) + 2; input validation: 3 per record
+        add, dbl = 14, 9
+        expect = n * (7 * dbl + 7 * add) + 252 * dbl + 64 * n * add + (255 + 15 + 2) + 3 * n
+        assert counts == {expect}, (n, counts, expect)
+
+
 def test_ct_operation_count_is_scalar_independent(S):
     """The variable-time paths skip zero digits and pick formulas by value; the constant-time twins must
     execute the same sequence whatever the scalar: same number of field multiplications for 0, 1, sparse,
@@ -153,9 +212,12 @@ def test_ct_machine_code_has_no_data_dependent_branches(S):
     # bits of the PUBLIC exponent n - 2 in the scalar inversion
     limits = {"ct_scalar_mult": 2, "ct_scalar_base_mult": 4, "lookup_projective": 1, "make_table": 1, "pt_add": 0, "pt_add_mixed": 0,
               "pt_double": 0, "pt_to_record": 0, "sc_split_glv": 0, "fe_inv": 2, "fe_sqr_n": 1, "sc_inv": 3, "sc_reduce_wide": 0,
-              "s2k_ct_scalar_mult": 3, "s2k_ct_scalar_base_mult": 2, "s2k_ct_ecdh": 6, "s2k_ct_ecdsa_sign_raw": 6}
+              "s2k_ct_scalar_mult": 3, "s2k_ct_scalar_base_mult": 2, "s2k_ct_ecdh": 6, "s2k_ct_ecdsa_sign_raw": 6,
+              # loops over the (public) number of terms and over the 32 scalar bytes; allocation / argument checks
+              "ct_multi_scalar_mult": 8, "s2k_ct_multi_scalar_mult": 24}
     for name, lim in limits.items():
         assert counts.get(name, 0) <= lim, (name, counts.get(name))
     # nothing that looks like a switch over a 4-bit window value
     for name in ("ct_scalar_mult", "ct_scalar_base_mult", "lookup_projective"):
         assert counts.get(name, 0) < 8
+    assert "ct_multi_scalar_mult" in counts or "s2k_ct_multi_scalar_mult" in counts, sorted(counts)
