@@ -272,6 +272,12 @@ int s2k_ecdsa_verify_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy,
 int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
+/* Times of a ticket on the device's clock, for placement diagnostics (s2k_group_member_stats_ex): after
+ * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records when its host-to-device copies start and end and when its
+ * verdicts are ready; s2k_ticket_times gives ms[0] = the copies, ms[1] = first copy to verdicts for one of the last eight
+ * retired tickets (S2K_PENDING and zeros otherwise). */
+int s2k_ctx_ticket_timing(s2k_ctx *ctx, int enable);
+int s2k_ticket_times(s2k_ctx *ctx, s2k_ticket ticket, double ms[2]);
 /* s2k_ecdsa_verify_batch_keyset in the same form: signatures that name their key by its index in a key set of this context
  * (100 bytes per signature cross PCIe instead of 160, and no table is built).  Tickets of all submit entry points share
  * the context's four slots and may be mixed.  The key set has to live until the ticket has been waited for (s2k_keyset_destroy
@@ -299,6 +305,18 @@ int s2k_ecdsa_verify_encoded_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t 
  * s2k_device_count: devices visible to the runtime (0 when there is none). */
 typedef struct s2k_group s2k_group;
 int s2k_device_count(void);
+/* Host topology of a device (topology.cpp; sysfs, S2K_SYSFS_ROOT replaces "/sys"): its PCI bus id ("0000:05:00.0"), the NUMA
+ * node it hangs off (-1: unknown, single-node machines included), and the two actions built on it: restrict the CALLING
+ * thread to the CPUs of a node that it may run on (returns how many, 0 = nothing changed; never widens the mask), prefer
+ * a node for a range of pages (0 = done or nothing to do, -1 = refused).  s2k_topology_*: the parsers, with the sysfs
+ * root as an argument (NULL: the default). */
+int s2k_device_pci_bus_id(int device, char *out, size_t len /* >= 13 */);
+int s2k_device_numa_node(int device);
+int s2k_bind_thread_to_node(int node);
+int s2k_topology_prefer_node(void *p, size_t bytes, int node);
+int s2k_topology_node_count(const char *sysfs_root);
+int s2k_topology_numa_node_of_pci(const char *sysfs_root, const char *bus_id);
+int s2k_topology_node_cpus(const char *sysfs_root, int node, int *cpus, size_t cap);
 int s2k_group_create(const int *devices, size_t n_devices, s2k_group **out);
 void s2k_group_destroy(s2k_group *g);
 size_t s2k_group_size(const s2k_group *g);
@@ -321,6 +339,21 @@ int s2k_group_ecdsa_verify_encoded_batch_submit(s2k_group *g, size_t n, const ui
 /* stats[m * 4 + 0..3] for member m, of its last finished shard: signatures, first index, milliseconds from the member's
  * submit to its verdicts (host clock), device index. */
 int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
+/* The same and more, stats[m * 8 + 0..7]: signatures, first index, host milliseconds, device index, NUMA node of the device
+ * (-1 unknown), CPUs the member's thread is bound to (0: not bound), and of the last finished shard the milliseconds of its
+ * host-to-device copies and the milliseconds from its first copy to its verdicts, on the device's clock (the first call
+ * switches that timing on: zero until a shard has been submitted after it).  Placement: every member's thread binds itself
+ * to the CPUs of its device's NUMA node (sysfs; no-op on one node, when the node is unknown or the cpuset forbids it). */
+int s2k_group_member_stats_ex(s2k_group *g, double *stats /* 8 * members */);
+/* Items per member of a batch of n: member i takes [i * size, min(n, (i + 1) * size)). */
+size_t s2k_group_shard_size(const s2k_group *g, size_t n);
+/* A page-locked array of n items of bytes_per_item bytes laid out for the group: the pages of every member's shard are
+ * placed on the NUMA node of that member's device (first touched there; mbind where the kernel allows), so that on a
+ * two-socket node no device pulls its shard across the socket link.  One node / unknown nodes: an ordinary pinned block.
+ * NULL on failure (s2k_group_last_error).  Freed by s2k_group_host_free or with the group.  The reference keeps its data on
+ * the Go heap (secec/ecdsa.go:171-228), which cannot be pinned (s2k_host_register above): a cgo shim fills these instead. */
+void *s2k_group_host_alloc(s2k_group *g, size_t bytes_per_item, size_t n);
+void s2k_group_host_free(s2k_group *g, void *p);
 /* BASELINE configs 3 and 4 across a group (synchronous; the multi-process forms are sharding.py's).  The BIP-340 whole-batch
  * check: every member checks its contiguous shard as one random linear combination (s2k_schnorr_batch_verify_rlc; the
  * members' coefficients are independent: every call mixes fresh operating-system randomness into the seed), *all_valid = 1
@@ -587,7 +620,14 @@ enum {
   /* one round border of the keyed ladder as k_verify_fast<ECDSA_KEYED> runs it: P lifted as for XYZZ_ADD, + Q in XYZZ,
    * XYZZ -> Jacobian, two Jacobian doublings, Jacobian -> XYZZ, + Q in XYZZ, XYZZ -> Jacobian: out = 4 P + 5 Q;
    * flag = 0 when Z ends as 0 (P = +-Q: ZZ = 0 must survive the changes of form and the doublings) */
-  S2K_HP_XYZZ_ROUND
+  S2K_HP_XYZZ_ROUND,
+  /* fe29r.h: the field with one limb per lane of a 16-lane DPP row, the complete formulas with one product per row (the
+   * serial tail of the multi-scalar multiplication since round 5; ONE WAVE per item).  FER_MUL a*b, FER_MUL_PLUS a*b+c,
+   * FER_MUL_ADD_MUL a*b+c*d, FER_SMALL 21a: the item's four rows multiply four different lazy forms of the operands, flag =
+   * the rows agree.  PT29R_DBL / PT29R_ADD: inputs, outputs and chaining (bits 20.. of `lazy`) as PT29Q_*; bit 0 of `lazy`:
+   * P's y with two units; flag 2 = the rows disagree.  FER_SWAPS (n >= 8): out[0..255] = the lane numbers after
+   * v_permlane16_swap (even | odd rows) and v_permlane32_swap (low | high half). */
+  S2K_HP_FER_MUL, S2K_HP_FER_MUL_PLUS, S2K_HP_FER_MUL_ADD_MUL, S2K_HP_FER_SMALL, S2K_HP_PT29R_DBL, S2K_HP_PT29R_ADD, S2K_HP_FER_SWAPS
 };
 int s2k_fp_op_batch_ex(s2k_ctx *ctx, uint32_t impl, int op, uint32_t lazy, size_t n, const uint8_t *const in[5],
                        uint8_t *out, uint8_t *out2, uint8_t *flag);

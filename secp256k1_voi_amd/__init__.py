@@ -49,7 +49,8 @@ KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS, KEYS_ADAPTIVE = 0, 1, 2, 3     # s2k_ctx_set_k
 KEYSET_AUTO, KEYSET_CHUNKS, KEYSET_JOINT, KEYSET_JOINT5, KEYSET_JOINT6 = 0, 1, 2, 3, 4   # s2k_keyset_create_ex
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
  HP_COND_NEGATE1, HP_INV, HP_SQRT, HP_EQ, HP_MUL_SMALL21, HP_NORMALIZE_WEAK, HP_JDBL, HP_JADD, HP_PT29_DBL, HP_PT29_ADD,
- HP_PT29_ADD_MIXED, HP_INV_GCD, HP_JADD_FULL, HP_PT29Q_DBL, HP_PT29Q_ADD, HP_XYZZ_ADD, HP_XYZZ_ROUND) = range(27)
+ HP_PT29_ADD_MIXED, HP_INV_GCD, HP_JADD_FULL, HP_PT29Q_DBL, HP_PT29Q_ADD, HP_XYZZ_ADD, HP_XYZZ_ROUND,
+ HP_FER_MUL, HP_FER_MUL_PLUS, HP_FER_MUL_ADD_MUL, HP_FER_SMALL, HP_PT29R_DBL, HP_PT29R_ADD, HP_FER_SWAPS) = range(34)
 
 IDENTITY = bytes(65)
 
@@ -313,6 +314,22 @@ def load_library() -> C.CDLL:
     lib.s2k_ct_ecdh.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     lib.s2k_ct_debug_fe_mul_count.restype = C.c_uint64
     lib.s2k_ct_multi_scalar_mult.argtypes = [sz, C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.s2k_device_pci_bus_id.argtypes = [ci, C.c_char_p, sz]
+    lib.s2k_device_numa_node.argtypes = [ci]
+    lib.s2k_bind_thread_to_node.argtypes = [ci]
+    lib.s2k_topology_prefer_node.argtypes = [vp, sz, ci]
+    lib.s2k_topology_node_count.argtypes = [C.c_char_p]
+    lib.s2k_topology_numa_node_of_pci.argtypes = [C.c_char_p, C.c_char_p]
+    lib.s2k_topology_node_cpus.argtypes = [C.c_char_p, ci, C.POINTER(ci), sz]
+    lib.s2k_ctx_ticket_timing.argtypes = [vp, ci]
+    lib.s2k_ticket_times.argtypes = [vp, C.c_uint64, C.POINTER(C.c_double)]
+    lib.s2k_group_member_stats_ex.argtypes = [vp, vp]
+    lib.s2k_group_shard_size.argtypes = [vp, sz]
+    lib.s2k_group_shard_size.restype = sz
+    lib.s2k_group_host_alloc.argtypes = [vp, sz, sz]
+    lib.s2k_group_host_alloc.restype = vp
+    lib.s2k_group_host_free.argtypes = [vp, vp]
+    lib.s2k_group_host_free.restype = None
     lib.s2k_ct_ecdsa_sign_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
     _lib = lib
     return lib
@@ -346,6 +363,9 @@ EXPORTED_SYMBOLS = [
     "s2k_double_scalar_mult_basepoint_batch_ex", "s2k_fp_op_batch_ex", "s2k_fn_split_glv_batch_ex",
     "s2k_ct_scalar_mult", "s2k_ct_scalar_base_mult", "s2k_ct_ecdh", "s2k_ct_ecdsa_sign_raw", "s2k_ct_debug_fe_mul_count",
     "s2k_ct_multi_scalar_mult",
+    "s2k_device_pci_bus_id", "s2k_device_numa_node", "s2k_bind_thread_to_node", "s2k_topology_prefer_node", "s2k_topology_node_count",
+    "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
+    "s2k_group_member_stats_ex", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
 ]
 
 
@@ -440,7 +460,37 @@ def _concat(items):
     return blob, offs
 
 
-class Engine:
+def _out_array(out, n):
+    """The verdict array of a submit call: a fresh one, or the caller's - which the library writes n bytes into, later, from
+    another thread: it has to be exactly a writable C-contiguous uint8 array of n items."""
+    if out is None:
+        return np.zeros(n, dtype=np.uint8)
+    if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == (n,) and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]):
+        raise ValueError(f"out must be a writable C-contiguous uint8 array of shape ({n},)")
+    return out
+
+
+class _TicketOwner:
+    """Keeps the buffers of the batches in flight alive.  The library reads the inputs and writes the verdicts of a ticket
+    asynchronously (DMA from pinned arrays; s2k_internal_pipe_retire copies verdicts on the fifth submit, in s2k_wait_all and
+    in s2k_ctx_destroy): a Ticket that is dropped without wait() must not take its arrays with it.  A ticket
+    leaves the table when it is waited for, or when the library has retired it: at most four are in flight, the submit of
+    ticket t + 4 retires ticket t before it returns."""
+    _IN_FLIGHT = 4
+
+    def _hold(self, ticket: int, out, keep):
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[ticket] = (out, keep)
+        for t in [t for t in self._inflight if t + self._IN_FLIGHT <= ticket]:
+            del self._inflight[t]
+        return Ticket(self, ticket, out)
+
+    def _release(self, ticket: int):
+        getattr(self, "_inflight", {}).pop(ticket, None)
+
+
+class Engine(_TicketOwner):
     """One context bound to one GPU (s2k_ctx)."""
 
     def __init__(self, device: int = 0):
@@ -454,8 +504,9 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.s2k_ctx_destroy(self._h)
+            self._lib.s2k_ctx_destroy(self._h)      # (retires the batches in flight: their buffers are needed until it returns)
             self._h = None
+            self._inflight = {}
 
     def __del__(self):
         try:
@@ -508,15 +559,12 @@ class Engine:
             elif a.shape[0] != n:
                 raise ValueError(f"length mismatch: expected {n} items, got {a.shape[0]}")
             arrs.append(a)
-        if out is None:
-            out = np.zeros(n, dtype=np.uint8)
-        elif out.shape != (n,) or out.dtype != np.uint8:
-            raise ValueError("out must be a uint8 array of n items")
+        out = _out_array(out, n)
         t = C.c_uint64(0)
         self._check(self._lib.s2k_ecdsa_verify_batch_submit(self._h, n, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
                                                             arrs[3].ctypes.data, REJECT_MALLEABLE if reject_malleable else 0,
                                                             out.ctypes.data, C.byref(t)))
-        return Ticket(self, int(t.value), out, arrs)
+        return self._hold(int(t.value), out, arrs)
 
     def ecdsa_verify_encoded_batch_submit(self, pubs, digests, sigs, encoding=ENCODING_ASN1, digest_len=0,
                                           reject_malleable=False, bip0066=False) -> "Ticket":
@@ -533,10 +581,11 @@ class Engine:
         self._check(self._lib.s2k_ecdsa_verify_encoded_batch_submit(self._h, n, pb.ctypes.data, po.ctypes.data, db.ctypes.data,
                                                                     do.ctypes.data, sb.ctypes.data, so.ctypes.data, encoding,
                                                                     digest_len, flags, out.ctypes.data, C.byref(t)))
-        return Ticket(self, int(t.value), out, [pb, po, db, do, sb, so])
+        return self._hold(int(t.value), out, [pb, po, db, do, sb, so])
 
     def wait_all(self):
         self._check(self._lib.s2k_wait_all(self._h))
+        self._inflight = {}
 
     # ---- key sets ----------------------------------------------------------------------
     def keyset_create(self, pub_xy, layout: int = 0) -> "KeySet":
@@ -575,16 +624,13 @@ class Engine:
             if a.shape[0] != n:
                 raise ValueError(f"length mismatch: expected {n} items, got {a.shape[0]}")
             arrs.append(a)
-        if out is None:
-            out = np.zeros(n, dtype=np.uint8)
-        elif out.shape != (n,) or out.dtype != np.uint8:
-            raise ValueError("out must be a uint8 array of n items")
+        out = _out_array(out, n)
         t = C.c_uint64(0)
         self._check(self._lib.s2k_ecdsa_verify_batch_keyset_submit(self._h, keyset._k, n, arrs[0].ctypes.data, arrs[1].ctypes.data,
                                                                    arrs[2].ctypes.data, arrs[3].ctypes.data,
                                                                    REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data,
                                                                    C.byref(t)))
-        return Ticket(self, int(t.value), out, arrs + [keyset])
+        return self._hold(int(t.value), out, arrs + [keyset])
 
     def ecdsa_verify_batch_keyset_device(self, keyset, n, d_key_index, d_digest32, d_r, d_s, d_valid, flags=0, stream=0):
         self._check(self._lib.s2k_ecdsa_verify_batch_keyset_device(self._h, keyset._k, int(n), d_key_index, d_digest32, d_r, d_s,
@@ -660,8 +706,7 @@ class Engine:
         ki = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
         n = ki.shape[0]
         sig64 = sig64 if (isinstance(sig64, np.ndarray) and sig64.dtype == np.uint8 and sig64.flags["C_CONTIGUOUS"]) else _arr(sig64, 64, n)
-        if out is None:
-            out = np.zeros(n, dtype=np.uint8)
+        out = _out_array(out, n)
         t = C.c_uint64(0)
         if isinstance(msgs, (list, tuple)):
             offs = np.zeros(n + 1, dtype=np.uint64)
@@ -676,7 +721,7 @@ class Engine:
             keep = [ki, m, sig64, keyset]
             self._check(self._lib.s2k_schnorr_verify_batch_keyset_submit(self._h, keyset._k, n, ki.ctypes.data, m.ctypes.data if m.size else None, None,
                                                                          m.shape[1], sig64.ctypes.data, 0, out.ctypes.data, C.byref(t)))
-        return Ticket(self, int(t.value), out, keep)
+        return self._hold(int(t.value), out, keep)
 
     def schnorr_verify_batch_keyset_device(self, keyset, n, d_key_index, d_msgs, msg_len, d_sig, d_valid, stream=0):
         self._check(self._lib.s2k_schnorr_verify_batch_keyset_device(self._h, keyset._k, int(n), d_key_index, d_msgs, None, int(msg_len), d_sig, 0,
@@ -957,24 +1002,25 @@ class Engine:
 
 
 class Ticket:
-    """A batch in flight (s2k_ticket): wait() blocks until its verdicts are there and returns them."""
+    """A batch in flight (s2k_ticket): wait() blocks until its verdicts are there and returns them.  The arrays of the batch
+    belong to the owner (Engine / Group) until then: dropping a Ticket is safe."""
 
-    def __init__(self, owner, ticket, out, keep):
-        self._owner, self.ticket, self._out, self._keep = owner, ticket, out, keep
+    def __init__(self, owner, ticket, out):
+        self._owner, self.ticket, self._out = owner, ticket, out
         self._done = False
 
     def wait(self) -> np.ndarray:
         if not self._done:
             self._owner._wait(self.ticket)
             self._done = True
-            self._keep = None
+            self._owner._release(self.ticket)
         return self._out
 
     def done(self) -> bool:
         """s2k_poll: True once the verdicts are delivered (never blocks)."""
         if not self._done and hasattr(self._owner, "_poll") and self._owner._poll(self.ticket):
             self._done = True
-            self._keep = None
+            self._owner._release(self.ticket)
         return self._done
 
 
@@ -983,7 +1029,7 @@ def device_count() -> int:
     return int(load_library().s2k_device_count())
 
 
-class Group:
+class Group(_TicketOwner):
     """Several devices behind one process (s2k_group): one context and one host thread per listed device, contiguous
     index shards, verdicts written straight into the result array."""
 
@@ -1003,8 +1049,9 @@ class Group:
         if getattr(self, "_h", None):
             for ks in list(self._keysets):
                 ks.close()
-            self._lib.s2k_group_destroy(self._h)
+            self._lib.s2k_group_destroy(self._h)    # (finishes the batches in flight first; frees the group's host blocks)
             self._h = None
+            self._inflight = {}
 
     def __del__(self):
         try:
@@ -1025,20 +1072,45 @@ class Group:
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         self._check(self._lib.s2k_group_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
 
+    def shard_size(self, n: int) -> int:
+        """items per member of a batch of n (s2k_group_shard_size)"""
+        return int(self._lib.s2k_group_shard_size(self._h, int(n)))
+
+    def host_alloc(self, n: int, width: int) -> np.ndarray:
+        """An (n, width) uint8 array in page-locked memory whose shard ranges lie on the NUMA node of the member that will read
+        them (s2k_group_host_alloc).  The memory belongs to the group: it is freed by host_free() or with the group, and the
+        array must not be used after that."""
+        p = self._lib.s2k_group_host_alloc(self._h, int(width), int(n))
+        if not p:
+            raise EngineError(f"s2k_group_host_alloc failed: {self._lib.s2k_group_last_error(self._h).decode()}")
+        a = np.ctypeslib.as_array((C.c_uint8 * (n * width)).from_address(p)).reshape(n, width)
+        return a
+
+    def host_free(self, a: np.ndarray):
+        self._lib.s2k_group_host_free(self._h, a.ctypes.data)
+
+    def member_stats_ex(self):
+        """Per member: dict(n, lo, ms, device, numa_node, bound_cpus, h2d_ms, device_ms) of its last finished shard
+        (s2k_group_member_stats_ex; the device-clock times are zero until a shard has run after the first call)."""
+        m = len(self)
+        st = np.zeros(8 * m, dtype=np.float64)
+        self._check(self._lib.s2k_group_member_stats_ex(self._h, st.ctypes.data))
+        keys = ("n", "lo", "ms", "device", "numa_node", "bound_cpus", "h2d_ms", "device_ms")
+        return [dict(zip(keys, st[8 * i:8 * i + 8].tolist())) for i in range(m)]
+
     def ecdsa_verify_batch_submit(self, pub_xy, digest32, r, s, out=None, reject_malleable: bool = False) -> Ticket:
         arrs = [(_arr(a, w) if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]) else a.reshape(-1, w))
                 for a, w in ((pub_xy, 64), (digest32, 32), (r, 32), (s, 32))]
         n = arrs[2].shape[0]
         if any(a.shape[0] != n for a in arrs):
             raise ValueError("length mismatch")
-        if out is None:
-            out = np.zeros(n, dtype=np.uint8)
+        out = _out_array(out, n)
         t = C.c_uint64(0)
         self._check(self._lib.s2k_group_ecdsa_verify_batch_submit(self._h, n, arrs[0].ctypes.data, arrs[1].ctypes.data,
                                                                   arrs[2].ctypes.data, arrs[3].ctypes.data,
                                                                   REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data,
                                                                   C.byref(t)))
-        return Ticket(self, int(t.value), out, arrs)
+        return self._hold(int(t.value), out, arrs)
 
     def ecdsa_verify_batch(self, pub_xy, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
         return self.ecdsa_verify_batch_submit(pub_xy, digest32, r, s, reject_malleable=reject_malleable).wait()
@@ -1058,7 +1130,7 @@ class Group:
         self._check(self._lib.s2k_group_ecdsa_verify_encoded_batch_submit(self._h, n, pb.ctypes.data, po.ctypes.data, db.ctypes.data,
                                                                           do.ctypes.data, sb.ctypes.data, so.ctypes.data, encoding,
                                                                           digest_len, flags, out.ctypes.data, C.byref(t)))
-        return Ticket(self, int(t.value), out, [pb, po, db, do, sb, so])
+        return self._hold(int(t.value), out, [pb, po, db, do, sb, so])
 
     def schnorr_batch_verify_rlc(self, pk32, msgs, sig64, seed32: bytes | None = None) -> bool:
         """BIP-340 whole-batch check with the signatures sharded over the members (s2k_group_schnorr_batch_verify_rlc)."""
@@ -1099,14 +1171,13 @@ class Group:
                        for a in (digest32, r, s)]
         if any(a.shape[0] != n for a in arrs):
             raise ValueError("length mismatch")
-        if out is None:
-            out = np.zeros(n, dtype=np.uint8)
+        out = _out_array(out, n)
         t = C.c_uint64(0)
         self._check(self._lib.s2k_group_ecdsa_verify_batch_keyset_submit(self._h, keyset._k, n, arrs[0].ctypes.data, arrs[1].ctypes.data,
                                                                          arrs[2].ctypes.data, arrs[3].ctypes.data,
                                                                          REJECT_MALLEABLE if reject_malleable else 0, out.ctypes.data,
                                                                          C.byref(t)))
-        return Ticket(self, int(t.value), out, arrs + [keyset])
+        return self._hold(int(t.value), out, arrs + [keyset])
 
     def ecdsa_verify_batch_keyset(self, keyset, key_index, digest32, r, s, reject_malleable: bool = False) -> np.ndarray:
         return self.ecdsa_verify_batch_keyset_submit(keyset, key_index, digest32, r, s, reject_malleable=reject_malleable).wait()

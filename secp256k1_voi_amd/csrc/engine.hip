@@ -1578,6 +1578,17 @@ int s2k_device_count(void) {
   }
   return count;
 }
+// "0000:05:00.0" of a device (hipDeviceGetPCIBusId): what topology.cpp looks up in sysfs
+int s2k_device_pci_bus_id(int device, char* out, size_t len) {
+  if (!out || len < 13) return S2K_ERR_ARG;
+  out[0] = 0;
+  if (hipDeviceGetPCIBusId(out, (int)len, device) != hipSuccess) {
+    (void)hipGetLastError();
+    out[0] = 0;
+    return S2K_ERR_NO_DEVICE;
+  }
+  return S2K_OK;
+}
 
 // workspace (32-bit words per lane, lane stride = n rounded up to 64):
 //   [0,256)    per-lane point table of the fast path: 8 entries x 8 quads (tb_*); the complete path
@@ -1718,6 +1729,10 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
     sl.h_valid = nullptr;
     if (sl.done) (void)hipEventDestroy(sl.done);
     sl.done = nullptr;
+    for (hipEvent_t* e : {&sl.t_begin, &sl.t_copied, &sl.t_end}) {
+      if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
   }
   if (ctx->kga_note) {                                // (a kernel still in flight may hold the address)
     (void)hipDeviceSynchronize();
@@ -1841,7 +1856,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (n == 0) return S2K_OK;
   if (!d_pub || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   int rc = ctx_enter(ctx, st);
@@ -2088,7 +2103,7 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
     return fail(ctx, S2K_ERR_ARG, "key set of another context");
   if (n == 0) return S2K_OK;
   if (!d_key_index || !d_dig || !d_r || !d_s || !d_valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   if (flags & S2K_ECDSA_FORCE_COMPLETE) return fail(ctx, S2K_ERR_ARG, "S2K_ECDSA_FORCE_COMPLETE does not apply to key sets");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
@@ -2241,7 +2256,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (n == 0) return S2K_OK;
   if (!d_dig || !d_r || !d_s || !d_recid || !d_pub65 || !d_ok) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   int rc = ctx_enter(ctx, st);
@@ -2324,7 +2339,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   if (n == 0) return S2K_OK;
   if (!d_pk || !d_sig || !d_valid || (!d_msgs && (d_msg_offsets || msg_len)))
     return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   int rc = ctx_enter(ctx, st);
@@ -2431,7 +2446,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
     return fail(ctx, S2K_ERR_ARG, "key set of another context");
   if (n == 0) return S2K_OK;
   if (!d_key_index || !d_sig || !d_valid || (!d_msgs && (d_msg_offsets || msg_len))) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   if (flags) return fail(ctx, S2K_ERR_ARG, "s2k_schnorr_verify_batch_keyset takes no flags");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;
@@ -2733,6 +2748,19 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_retire(s2k_ctx* ctx,
   } else if (!sl.direct) {
     memcpy(sl.dst, sl.h_valid, sl.n);
   }
+  if (rc == S2K_OK && sl.timed) {                    // s2k_ctx_ticket_timing: transfer and whole-ticket time on the device's clock
+    float h2d = 0, all = 0;
+    if (hipEventSynchronize(sl.t_end) == hipSuccess && hipEventElapsedTime(&h2d, sl.t_begin, sl.t_copied) == hipSuccess &&
+        hipEventElapsedTime(&all, sl.t_begin, sl.t_end) == hipSuccess) {
+      const unsigned i = ctx->pipe_times_n++ % 8u;
+      ctx->pipe_times_ticket[i] = sl.ticket;
+      ctx->pipe_times_ms[i][0] = h2d;
+      ctx->pipe_times_ms[i][1] = all;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  sl.timed = false;
   sl.ticket = 0;
   return rc;
 }
@@ -2746,26 +2774,61 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
     if (rc) pipe_note_failure(ctx, t, rc);           // (reported by s2k_wait on that ticket)
   }
   if (!sl.ctx) {
+    // first use of the slot.  All or nothing: a failure anywhere leaves the slot as it was found (no child context, no
+    // event), so that the next submit tries again from the start instead of running on a half-built slot.
     int rc = ctx_streams(ctx);                        // the parent's three streams carry every ticket
     if (rc == S2K_OK) rc = ctx_aux_streams(ctx);
     if (rc) return rc;
-    rc = s2k_ctx_create(ctx->device, &sl.ctx);
-    if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
     const bool odd_lane = (ctx->pipe_next & 1u) != 0;   // (PIPE_SLOTS is even: a slot always serves the same lane)
     static const bool one_lane = [] { const char* v = getenv("S2K_SUBMIT_ONE_LANE"); return v && atoi(v) != 0; }();   // measurement knob
-    if (odd_lane && !one_lane && !ctx->lane1_comp) {
-      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane1_comp, hipStreamNonBlocking));
-      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lane1_aux, hipStreamNonBlocking));
+    if (odd_lane && !one_lane && !(ctx->lane1_comp && ctx->lane1_aux)) {   // the second lane's two streams: both or neither
+      hipStream_t a = nullptr, b = nullptr;
+      if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
+        const hipError_t e = hipGetLastError();
+        if (a) (void)hipStreamDestroy(a);
+        if (b) (void)hipStreamDestroy(b);
+        return fail(ctx, S2K_ERR_HIP, "submit: streams of the second lane: %s", hipGetErrorString(e));
+      }
+      ctx->lane1_comp = a;
+      ctx->lane1_aux = b;
     }
-    sl.ctx->s_copy = ctx->s_copy;
-    sl.ctx->s_comp = (odd_lane && !one_lane) ? ctx->lane1_comp : ctx->s_comp;
-    sl.ctx->s_aux = (odd_lane && !one_lane) ? ctx->lane1_aux : ctx->s_aux;
-    sl.ctx->streams_shared = true;
-    rc = ctx_streams(sl.ctx);                         // (its events)
-    if (rc == S2K_OK) rc = ctx_aux_streams(sl.ctx);
-    if (rc) return fail(ctx, rc, "%s", sl.ctx->err);
-    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    s2k_ctx* child = nullptr;
+    rc = s2k_ctx_create(ctx->device, &child);
+    if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
+    child->s_copy = ctx->s_copy;
+    child->s_comp = (odd_lane && !one_lane) ? ctx->lane1_comp : ctx->s_comp;
+    child->s_aux = (odd_lane && !one_lane) ? ctx->lane1_aux : ctx->s_aux;
+    child->streams_shared = true;
+    rc = ctx_streams(child);                          // (its events)
+    if (rc == S2K_OK) rc = ctx_aux_streams(child);
+    hipEvent_t done = nullptr;
+    if (rc == S2K_OK && hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
+      snprintf(child->err, sizeof child->err, "hipEventCreate: %s", hipGetErrorString(hipGetLastError()));
+      rc = S2K_ERR_HIP;
+    }
+    if (rc) {
+      rc = fail(ctx, rc, "submit: child context: %s", child->err);
+      s2k_ctx_destroy(child);                         // (streams_shared: the parent's streams stay)
+      return rc;
+    }
+    sl.ctx = child;
+    sl.done = done;
   }
+  if (ctx->pipe_timing && !sl.t_begin) {              // timing events on demand; a failure only means no times for this slot
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    bool ok = true;
+    for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreate(&e[i]) == hipSuccess;
+    if (ok) {
+      sl.t_begin = e[0];
+      sl.t_copied = e[1];
+      sl.t_end = e[2];
+    } else {
+      (void)hipGetLastError();
+      for (int i = 0; i < 3; ++i)
+        if (e[i]) (void)hipEventDestroy(e[i]);
+    }
+  }
+  sl.timed = ctx->pipe_timing && sl.t_begin && hipEventRecord(sl.t_begin, ctx->s_copy) == hipSuccess;
   // the child verifies with the parent's settings of the moment
   sl.ctx->kg_mode = ctx->kg_mode;
   sl.ctx->parent = ctx;
@@ -2787,7 +2850,13 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   return S2K_OK;
 }
 __attribute__((visibility("hidden"))) void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, s2k_ticket* ticket) {
-  (void)hipEventRecord(sl->done, sl->ctx->s_comp);    // behind the ticket's last operation (on its lane's stream)
+  if (sl->timed) sl->timed = hipEventRecord(sl->t_copied, ctx->s_copy) == hipSuccess && hipEventRecord(sl->t_end, sl->ctx->s_comp) == hipSuccess;
+  if (hipEventRecord(sl->done, sl->ctx->s_comp) != hipSuccess) {    // behind the ticket's last operation (on its lane's stream)
+    // no event to wait on: the ticket is made to finish here, so that s2k_wait finds it done (or reports this failure)
+    const hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(sl->ctx->s_comp);
+    (void)fail(ctx, S2K_ERR_HIP, "submit: hipEventRecord: %s", hipGetErrorString(e));
+  }
   sl->ticket = ctx->pipe_next++;
   *ticket = sl->ticket;
 }
@@ -2799,7 +2868,7 @@ int s2k_ecdsa_verify_batch_submit(s2k_ctx* ctx, size_t n, const uint8_t* pub, co
   if (!ctx || !ticket) return fail(ctx, S2K_ERR_ARG, "null argument");
   *ticket = 0;
   if (n && (!pub || !dig || !r || !s || !valid)) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   s2k_ctx::pipe_slot* sl = nullptr;
   int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
   if (rc) return rc;
@@ -2821,7 +2890,7 @@ int s2k_ecdsa_verify_batch_keyset_submit(s2k_ctx* ctx, const s2k_keyset* ks, siz
   if (!ks || ks->ctx != ctx || ks->generation != ctx->generation || ks->device != ctx->device)
     return fail(ctx, S2K_ERR_ARG, "key set of another context");
   if (n && (!key_index || !dig || !r || !s || !valid)) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   if (flags & S2K_ECDSA_FORCE_COMPLETE) return fail(ctx, S2K_ERR_ARG, "S2K_ECDSA_FORCE_COMPLETE does not apply to key sets");
   s2k_ctx::pipe_slot* sl = nullptr;
   int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
@@ -2864,7 +2933,7 @@ int s2k_schnorr_verify_batch_keyset_submit(s2k_ctx* ctx, const s2k_keyset* ks, s
   if (!ks || ks->ctx != ctx || ks->generation != ctx->generation || ks->device != ctx->device)
     return fail(ctx, S2K_ERR_ARG, "key set of another context");
   if (n && (!key_index || !sig || !valid || (!msgs && (msg_offsets || msg_len)))) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH || msg_len > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   if (flags) return fail(ctx, S2K_ERR_ARG, "s2k_schnorr_verify_batch_keyset takes no flags");
   s2k_ctx::pipe_slot* sl = nullptr;
   int rc = s2k_internal_pipe_slot(ctx, n, valid, &sl);
@@ -2940,6 +3009,24 @@ int s2k_wait_all(s2k_ctx* ctx) {
   return rc;
 }
 
+// Per-ticket times on the device's clock (for placement diagnostics, s2k_group_member_stats_ex): enable, submit, wait, ask.
+int s2k_ctx_ticket_timing(s2k_ctx* ctx, int enable) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  ctx->pipe_timing = enable != 0;
+  return S2K_OK;
+}
+int s2k_ticket_times(s2k_ctx* ctx, s2k_ticket ticket, double ms[2]) {
+  if (!ctx || !ms) return fail(ctx, S2K_ERR_ARG, "null argument");
+  for (unsigned i = 0; i < 8; ++i)
+    if (ticket && ctx->pipe_times_ticket[i] == ticket) {
+      ms[0] = ctx->pipe_times_ms[i][0];
+      ms[1] = ctx->pipe_times_ms[i][1];
+      return S2K_OK;
+    }
+  ms[0] = ms[1] = 0;
+  return S2K_PENDING;      // not retired yet, timing was off, or more than eight tickets ago
+}
+
 int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msgs,
                              const uint64_t* msg_offsets, size_t msg_len, const uint8_t* sig, uint32_t flags,
                              uint8_t* valid) {
@@ -2980,7 +3067,7 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
   if (impl != S2K_IMPL_COMPLETE && impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "unknown implementation selector");
   if (n == 0) return S2K_OK;
   if (!u2 || !points || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ctx_streams(ctx);
   if (rc) return rc;

@@ -159,6 +159,8 @@ struct s2k_ctx {
     uint8_t* h_valid = nullptr;    // page-locked landing buffer of the verdicts (when dst is pageable)
     size_t h_valid_bytes = 0;
     bool direct = false;           // dst is page-locked itself: the device-to-host copy lands there
+    hipEvent_t t_begin = nullptr, t_copied = nullptr, t_end = nullptr;   // s2k_ctx_ticket_timing: before / behind the ticket's host-to-device copies, behind its verdicts
+    bool timed = false;            // the three events were recorded for the ticket in flight
   };
   static constexpr unsigned PIPE_SLOTS = 4;   // batches in flight: two LANES (even and odd tickets), each with one batch
                                               // computing and one arriving
@@ -168,9 +170,17 @@ struct s2k_ctx {
   uint64_t pipe_failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tickets retired with an error (by a later submit), and their codes
   int pipe_failed_rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned pipe_failed_n = 0;
+  bool pipe_timing = false;        // s2k_ctx_ticket_timing
+  uint64_t pipe_times_ticket[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last retired tickets and their times (s2k_ticket_times)
+  float pipe_times_ms[8][2] = {};
+  unsigned pipe_times_n = 0;
   uint64_t generation = 0;         // distinguishes contexts that reuse an address (key sets compare it)
   char err[512] = {0};
 };
+
+// Most items one call takes: the worklist entries of the ladder kernels carry a 2-bit tag above a 30-bit index (WL_TAG_LIMIT,
+// engine.hip), so an index with bit 30 set must never reach them.
+constexpr size_t S2K_MAX_BATCH = (size_t)1 << 30;
 
 inline thread_local char g_err[512];
 

@@ -8,6 +8,9 @@
 // (SURVEY.md section 8e), every member pushes its shard through its own context's submit / wait pair, and the verdicts
 // land in the caller's array at the shard's offset.  No RCCL, no device-to-device traffic; the only shared state is the
 // job queue.  Host code only: everything that touches a GPU goes through the C-ABI of the context.
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -58,12 +61,19 @@ struct member {
   std::deque<shard_job> q;
   bool stop = false;
   // statistics of the last finished shard
-  double st_n = 0, st_lo = 0, st_ms = 0;
+  double st_n = 0, st_lo = 0, st_ms = 0, st_h2d_ms = 0, st_dev_ms = 0;
+  // placement (topology.cpp): the NUMA node the device hangs off (-1 unknown) and the CPUs the member's thread was bound to (0: left alone)
+  int numa_node = -1, bound_cpus = 0;
 };
 
 struct pending {
   int remaining = 0;
   int rc = S2K_OK;
+};
+
+struct host_block {     // s2k_group_host_alloc
+  void* p = nullptr;
+  size_t bytes = 0;
 };
 
 }  // namespace
@@ -81,10 +91,29 @@ struct s2k_group {
   std::condition_variable cv;
   std::map<uint64_t, pending> pend;
   uint64_t next_ticket = 1;
+  // tickets whose result was dropped from `pend` after they FAILED: s2k_group_wait still reports them (as s2k_ctx does
+  // with pipe_failed)
+  uint64_t failed_ticket[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int failed_rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned failed_n = 0;
+  std::vector<host_block> blocks;
+  bool timing = false;             // s2k_group_member_stats_ex was asked for: the members' contexts time their tickets
   char err[512] = {0};
 };
 
 namespace {
+
+// the 100 microsecond nap between two polls of the oldest shard.  On the steady clock - except under ThreadSanitizer: gcc 11's
+// runtime does not intercept pthread_cond_clockwait (what wait_for on the steady clock compiles to), loses track of the mutex
+// across the wait and reports races that are not there; the system clock takes the intercepted pthread_cond_timedwait.
+template <class Pred>
+void poll_wait(std::condition_variable& cv, std::unique_lock<std::mutex>& lock, Pred pred) {
+#if defined(__SANITIZE_THREAD__)
+  cv.wait_until(lock, std::chrono::system_clock::now() + std::chrono::microseconds(100), pred);
+#else
+  cv.wait_for(lock, std::chrono::microseconds(100), pred);
+#endif
+}
 
 int gfail(s2k_group* g, int code, const char* fmt, ...) {
   char buf[512];
@@ -99,13 +128,17 @@ int gfail(s2k_group* g, int code, const char* fmt, ...) {
   return code;
 }
 
-void complete(member* me, const shard_job& job, int rc) {
+void complete(member* me, const shard_job& job, int rc, s2k_ticket ctx_ticket = 0) {
   s2k_group* g = me->group;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t0).count();
+  double dev_ms[2] = {0, 0};
+  if (ctx_ticket) (void)s2k_ticket_times(me->ctx, ctx_ticket, dev_ms);   // zeros unless s2k_ctx_ticket_timing is on
   std::lock_guard<std::mutex> lock(g->m);
   me->st_n = (double)job.n;
   me->st_lo = (double)job.lo;
   me->st_ms = ms;
+  me->st_h2d_ms = dev_ms[0];
+  me->st_dev_ms = dev_ms[1];
   auto it = g->pend.find(job.ticket);
   if (it == g->pend.end()) return;
   if (rc && !it->second.rc) {
@@ -122,6 +155,9 @@ void complete(member* me, const shard_job& job, int rc) {
 // member's device exactly as consecutive s2k_ecdsa_verify_batch_submit calls do.
 void member_main(member* me) {
   {
+    // the thread that feeds a device runs on the CPUs next to it (no-op on one node, in a cpuset without them, ...)
+    me->numa_node = s2k_device_numa_node(me->device);
+    me->bound_cpus = s2k_bind_thread_to_node(me->numa_node);
     s2k_ctx* ctx = nullptr;
     const int rc = s2k_ctx_create(me->device, &ctx);
     std::lock_guard<std::mutex> lock(me->m);
@@ -146,7 +182,7 @@ void member_main(member* me) {
     flying& f = inflight.front();
     const int rc = block ? s2k_wait(me->ctx, f.ticket) : s2k_poll(me->ctx, f.ticket);
     if (rc == S2K_PENDING) return false;
-    complete(me, f.job, rc);
+    complete(me, f.job, rc, f.ticket);
     inflight.pop_front();
     return true;
   };
@@ -164,7 +200,7 @@ void member_main(member* me) {
         // with one or two in flight a new one must not wait for it: poll (polling at 10 kHz all the time cost 2-7 % of the
         // rate: every query goes through the runtime)
         if (inflight.size() >= 3) block_on_oldest = true;
-        else me->cv.wait_for(lock, std::chrono::microseconds(100), [&] { return !me->q.empty(); });
+        else poll_wait(me->cv, lock, [&] { return !me->q.empty(); });
       }
       if (!block_on_oldest && !me->q.empty()) {
         job = me->q.front();
@@ -284,6 +320,10 @@ void s2k_group_destroy(s2k_group* g) {
     if (me->ctx) s2k_ctx_destroy(me->ctx);
     delete me;
   }
+  for (host_block& b : g->blocks) {                // buffers the caller did not return
+    (void)s2k_host_unregister(b.p);
+    (void)munmap(b.p, b.bytes);
+  }
   delete g;
 }
 
@@ -325,7 +365,14 @@ static int group_submit(s2k_group* g, size_t n, const shard_job& proto, s2k_tick
       return busy < 4;
     });
     t = g->next_ticket++;
-    while (g->pend.size() > 16 && g->pend.begin()->second.remaining == 0) g->pend.erase(g->pend.begin());   // old results
+    while (g->pend.size() > 16 && g->pend.begin()->second.remaining == 0) {   // old results: only failures are remembered
+      if (g->pend.begin()->second.rc) {
+        const unsigned i = g->failed_n++ % 8u;
+        g->failed_ticket[i] = g->pend.begin()->first;
+        g->failed_rc[i] = g->pend.begin()->second.rc;
+      }
+      g->pend.erase(g->pend.begin());
+    }
     pending p;
     p.remaining = (int)D;
     g->pend[t] = p;
@@ -529,10 +576,28 @@ int s2k_group_wait(s2k_group* g, s2k_ticket ticket) {
     snprintf(g->err, sizeof g->err, "s2k_group_wait: ticket %llu was never issued", (unsigned long long)ticket);
     return S2K_ERR_ARG;
   }
-  auto it = g->pend.find(ticket);
-  if (it == g->pend.end()) return S2K_OK;          // long done, its result dropped from the table
-  g->cv.wait(lock, [&] { return it->second.remaining == 0; });
-  return it->second.rc;
+  // the entry is looked up again after every wake-up: a submit on another thread may erase finished entries (and with
+  // them any iterator) while this thread waits without the lock
+  int rc = S2K_OK;
+  bool dropped = false;
+  g->cv.wait(lock, [&] {
+    auto it = g->pend.find(ticket);
+    if (it == g->pend.end()) {
+      dropped = true;
+      return true;
+    }
+    rc = it->second.rc;
+    return it->second.remaining == 0;
+  });
+  if (dropped) {                                   // long done, its result dropped from the table: a failure is still known
+    for (unsigned i = 0; i < 8; ++i)
+      if (g->failed_ticket[i] == ticket) {
+        snprintf(g->err, sizeof g->err, "ticket %llu failed (code %d)", (unsigned long long)ticket, g->failed_rc[i]);
+        return g->failed_rc[i];
+      }
+    return S2K_OK;
+  }
+  return rc;
 }
 
 int s2k_group_ecdsa_verify_batch(s2k_group* g, size_t n, const uint8_t* pub, const uint8_t* dig, const uint8_t* r, const uint8_t* s,
@@ -554,6 +619,106 @@ int s2k_group_member_stats(s2k_group* g, double* stats) {
     stats[4 * i + 3] = (double)me->device;
   }
   return S2K_OK;
+}
+
+// stats[m * 8 + 0..7] for member m: the four values of s2k_group_member_stats, then the NUMA node of its device (-1 unknown),
+// the CPUs its thread is bound to (0: not bound), and of its last finished shard the milliseconds its host-to-device copies took and
+// the milliseconds from the first copy to the verdicts (both on the device's clock; the first call switches the timing on,
+// so they are zero until a shard has been submitted after it).
+int s2k_group_member_stats_ex(s2k_group* g, double* stats) {
+  if (!g || !stats) return S2K_ERR_ARG;
+  bool enable = false;
+  {
+    std::lock_guard<std::mutex> lock(g->m);
+    enable = !g->timing;
+    g->timing = true;
+  }
+  if (enable) {
+    group_wait_idle(g);                              // the members' threads are parked: their contexts may be touched from here
+    for (member* me : g->members) (void)s2k_ctx_ticket_timing(me->ctx, 1);
+  }
+  std::lock_guard<std::mutex> lock(g->m);
+  for (size_t i = 0; i < g->members.size(); ++i) {
+    const member* me = g->members[i];
+    double* o = stats + 8 * i;
+    o[0] = me->st_n;
+    o[1] = me->st_lo;
+    o[2] = me->st_ms;
+    o[3] = (double)me->device;
+    o[4] = (double)me->numa_node;
+    o[5] = (double)me->bound_cpus;
+    o[6] = me->st_h2d_ms;
+    o[7] = me->st_dev_ms;
+  }
+  return S2K_OK;
+}
+
+// The partition group_submit uses, for callers that lay out their own buffers: member i takes the items
+// [i * per, min(n, (i + 1) * per)), per = ceil(n / members) rounded up to 256.
+size_t s2k_group_shard_size(const s2k_group* g, size_t n) {
+  if (!g || g->members.empty()) return 0;
+  const size_t D = g->members.size();
+  return ((n + D - 1) / D + 255) & ~(size_t)255;
+}
+
+// A page-locked array of n items of bytes_per_item bytes whose pages lie next to the device that will read them: the range of
+// every member's shard (s2k_group_shard_size) is placed on the NUMA node of that member's device (mbind where the kernel allows,
+// and first touched by a thread bound to the node's CPUs either way), then the whole block is pinned (s2k_host_register).  One
+// node, unknown nodes: an ordinary pinned block.  Pages that two shards share go to the lower shard's node.  NULL on failure.
+void* s2k_group_host_alloc(s2k_group* g, size_t bytes_per_item, size_t n) {
+  if (!g || bytes_per_item == 0 || n == 0 || n > ((size_t)1 << 40) / bytes_per_item) return nullptr;
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  const size_t bytes = (n * bytes_per_item + page - 1) / page * page;
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) {
+    (void)gfail(g, S2K_ERR_NOMEM, "s2k_group_host_alloc: mmap of %zu bytes failed", bytes);
+    return nullptr;
+  }
+  const size_t D = g->members.size(), per = s2k_group_shard_size(g, n);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < D; ++i) {
+    const size_t lo = i * per < n ? i * per : n, hi = lo + per < n ? lo + per : n;
+    if (hi <= lo) continue;
+    // whole pages of the shard's byte range: from the first page that STARTS in it (the page a shard shares with the one below
+    // belongs to that one) to the page that holds its last byte
+    const size_t b0 = (lo * bytes_per_item + page - 1) / page * page, b1 = i + 1 == D || hi == n ? bytes : (hi * bytes_per_item + page - 1) / page * page;
+    const size_t first = i == 0 ? 0 : b0;
+    if (b1 <= first) continue;
+    const int node = g->members[i]->numa_node;
+    uint8_t* base = (uint8_t*)p + first;
+    const size_t len = b1 - first;
+    th.emplace_back([base, len, node, page] {
+      (void)s2k_topology_prefer_node(base, len, node);
+      (void)s2k_bind_thread_to_node(node);             // first touch from the node's own CPUs
+      for (size_t o = 0; o < len; o += page) base[o] = 0;
+    });
+  }
+  for (std::thread& t : th) t.join();
+  if (s2k_host_register(p, bytes) != S2K_OK) {       // (no GPU, or the runtime refused: the caller gets nothing rather than pageable memory)
+    (void)gfail(g, S2K_ERR_HIP, "s2k_group_host_alloc: pinning %zu bytes failed", bytes);
+    (void)munmap(p, bytes);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g->m);
+  g->blocks.push_back(host_block{p, bytes});
+  return p;
+}
+
+void s2k_group_host_free(s2k_group* g, void* p) {
+  if (!g || !p) return;
+  host_block b;
+  {
+    std::lock_guard<std::mutex> lock(g->m);
+    for (size_t i = 0; i < g->blocks.size(); ++i)
+      if (g->blocks[i].p == p) {
+        b = g->blocks[i];
+        g->blocks.erase(g->blocks.begin() + (long)i);
+        break;
+      }
+  }
+  if (!b.p) return;                                  // not one of this group's blocks
+  (void)s2k_host_unregister(b.p);
+  (void)munmap(b.p, b.bytes);
 }
 
 }  // extern "C"

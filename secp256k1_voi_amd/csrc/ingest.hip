@@ -299,7 +299,7 @@ static int encoded_check_args(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const
   if (!pubs || !pub_off || !digests || !dig_off || !sigs || !sig_off || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (encoding != S2K_ENCODING_ASN1 && encoding != S2K_ENCODING_COMPACT && encoding != S2K_ENCODING_COMPACT_RECOVERABLE)
     return fail(ctx, S2K_ERR_ARG, "unknown encoding");
-  if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
+  if (n >= S2K_MAX_BATCH) return fail(ctx, S2K_ERR_ARG, "batch too large (at most 2^30 - 1 items per call)");
   if (*flags & S2K_ECDSA_BIP0066) {
     if (encoding != S2K_ENCODING_ASN1) return fail(ctx, S2K_ERR_ARG, "BIP-0066 needs the ASN.1 encoding");
     *digest_len = 32;                                 // optsShitcoin: SHA-256

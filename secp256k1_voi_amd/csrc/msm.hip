@@ -34,6 +34,7 @@
 #include "fe29_inv.h"
 #include "pt29.h"
 #include "pt29q.h"
+#include "fe29r.h"
 #include "xyzz29.h"
 #include "sc.h"
 #include "sha256.h"
@@ -781,6 +782,161 @@ __global__ void __launch_bounds__(64) k_msm_final(msm_geom g, uint32_t* __restri
   store_be32_unaligned(out65 + 33, yw);
 }
 
+// ---------------------------------------------------------------------------------------
+// The bucket reduction for 16-bit windows since round 5: no running sums, no offset multiplications.
+// The 9 x 32768 keys are 1152 ROWS of 256 consecutive keys; the 128 rows of a window form a grid, magnitude of key (h, l)
+// = 256 h + l + 1 (the top window's second slot: rows 128..255 of its grid), so
+//     S_w = sum_key m B = 256 * sum_h h Row_h  +  sum_l (l + 1) Col_l ,   Row_h = sum_l B[h][l],  Col_l = sum_h B[h][l]:
+// every bucket goes into ONE row sum and ONE column sum (2 additions per bucket, all of them leaves of trees: no addition
+// waits for a running sum), and what is left are weighted sums of 128 or 256 points, taken bit plane by bit plane
+// (sum_i w_i E_i = sum_b 2^b sum_{i : bit b of w_i} E_i: plain sums again, then eight doublings).
+//   k_msm_fold         level 1, one lane per addition (pt29_add), trees through LDS: 1152 row sums and 9 x 256 column sums
+//                      (per block of 128 rows) -> lvl[0 .. 3456)
+//   k_msm_planes       level 2, ONE WAVE per addition (fe29r.h: the operations are few and wait for each other): a workgroup
+//                      of 16 waves per (weighted sum, bit): 8 members per wave, then a tree through LDS -> lvl[PL ..)
+//   k_msm_plane_horner one wave per weighted sum: sum_b 2^b plane_b -> lvl[WS ..)
+//   k_msm_final16      Horner over the 16 half-windows (120 doublings, 16 additions) on one wave, row arithmetic
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t FOLD_NROWS = 1152, FOLD_NBLK = 9, FOLD_COL0 = FOLD_NROWS, FOLD_PL0 = FOLD_COL0 + FOLD_NBLK * 256;   // 3456
+constexpr uint32_t FOLD_NWS = 17, FOLD_BITS = 9, FOLD_WS0 = FOLD_PL0 + FOLD_NWS * FOLD_BITS, FOLD_END = FOLD_WS0 + FOLD_NWS;
+constexpr uint32_t FOLD_ROW_BLOCKS = FOLD_NROWS / 2, FOLD_COL_BLOCKS = FOLD_NBLK * 32;
+
+// The narrow levels of a workgroup's trees: `groups` independent sums whose partials lie in LDS, partial i of group g in slot
+// g * GS + i * IS.  From 64 additions per level down a lane per addition would leave three quarters of the workgroup idle
+// and pay a lone lane's 1800 instructions per level: here a QUAD does each addition (pt29q.h: 820).
+S2K_DEV void fold_quad_tree(uint32_t* sh, uint32_t groups, uint32_t GS, uint32_t IS, uint32_t half0, uint32_t t) {
+  const uint32_t q = t & 3u, cc = q < 2 ? q : 2u, qd = t >> 2;
+  for (uint32_t half = half0; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (qd < groups * half) {                           // (whole quads)
+      const uint32_t g = qd / half, i = qd % half, sa = g * GS + i * IS, sb = g * GS + (i + half) * IS;
+      const fe29 r = pt29q_add(ptq_load(sh, 128, sa, cc), ptq_load(sh, 128, sb, cc), q);
+      if (q < 3) ptq_store(sh, 128, sa, cc, r);
+    }
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(256, 4)      // all 864 workgroups resident at once (4 waves per SIMD: 128 registers)
+k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ lvl, size_t lstride) {
+  __shared__ uint32_t sh[PT_WORDS * 128];
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x < FOLD_ROW_BLOCKS) {
+    // two rows per workgroup, 128 threads each: two keys per thread and one level of the tree a lane per addition (128
+    // additions per level), then 128 partials in LDS (row r: slots 64 r ..) and six levels by quads
+    const uint32_t half_id = t >> 7, u = t & 127u, row = 2 * blockIdx.x + half_id;
+    const size_t k0 = (size_t)row * 256 + u;
+    pt29 acc = pt29_add(pt_load(sums, stride, k0), pt_load(sums, stride, k0 + 128));
+    if (u >= 64) pt_store(sh, 128, half_id * 64 + (u - 64), acc);
+    __syncthreads();
+    if (u < 64) acc = pt29_add(acc, pt_load(sh, 128, half_id * 64 + u));
+    __syncthreads();
+    if (u < 64) pt_store(sh, 128, half_id * 64 + u, acc);
+    fold_quad_tree(sh, 2, 64, 1, 32, t);
+    if (t < 2) pt_store(lvl, lstride, 2 * blockIdx.x + t, pt_load(sh, 128, t * 64));
+  } else {
+    // block of 128 rows x 8 columns: thread (hg, lc) sums rows 4 hg .. 4 hg + 3 of column 8 lb + lc; the tree over hg: one
+    // level a lane per addition (128 additions), then 128 partials in LDS (slot 8 hg + lc) and four levels by quads
+    const uint32_t cb = blockIdx.x - FOLD_ROW_BLOCKS, blk = cb >> 5, lb = cb & 31u, hg = t >> 3, lc = t & 7u;
+    const size_t k0 = ((size_t)blk * 128 + 4 * hg) * 256 + 8 * lb + lc;
+    pt29 acc = pt29_add(pt_load(sums, stride, k0), pt_load(sums, stride, k0 + 256));
+#pragma unroll 1
+    for (uint32_t i = 2; i < 4; ++i) acc = pt29_add(acc, pt_load(sums, stride, k0 + 256 * i));
+    if (hg >= 16) pt_store(sh, 128, (hg - 16) * 8 + lc, acc);
+    __syncthreads();
+    if (hg < 16) acc = pt29_add(acc, pt_load(sh, 128, hg * 8 + lc));
+    __syncthreads();
+    if (hg < 16) pt_store(sh, 128, hg * 8 + lc, acc);
+    fold_quad_tree(sh, 8, 1, 8, 8, t);
+    if (t < 8) pt_store(lvl, lstride, FOLD_COL0 + blk * 256 + 8 * lb + t, pt_load(sh, 128, t));
+  }
+}
+
+// weighted sum ws: 0..7 = the row sums of window ws (weights h; window 7 has 256 rows), 8..16 = the column sums of the block
+// of rows ws - 8 (weights l + 1).  Member m of bit b: the m-th weight with bit b set.
+S2K_DEV uint32_t fold_members(uint32_t ws, uint32_t b) {
+  if (ws < 8) {
+    const uint32_t H = ws == 7 ? 256u : 128u;
+    return (1u << b) < H ? H / 2 : 0u;
+  }
+  return b < 8 ? 128u : 1u;      // weights 1 .. 256: bit 8 is the weight 256 alone
+}
+S2K_DEV uint32_t fold_member_slot(uint32_t ws, uint32_t b, uint32_t m) {
+  const uint32_t w = b < 8 ? (((m >> b) << (b + 1)) | (1u << b) | (m & ((1u << b) - 1u))) : 256u;
+  return ws < 8 ? ws * 128 + w : FOLD_COL0 + (ws - 8) * 256 + (w - 1);
+}
+__global__ void __launch_bounds__(1024)
+k_msm_planes(uint32_t* __restrict__ lvl, size_t lstride) {
+  __shared__ uint32_t sh[PT_WORDS * 8];
+  const uint32_t ws = blockIdx.x / FOLD_BITS, b = blockIdx.x % FOLD_BITS, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const fer_consts k = fer_setup(lane);
+  const uint32_t M = fold_members(ws, b);
+  pt29r acc = pt29r_identity(k);
+  if (wave < M) {
+    acc = pt29r_load(lvl, lstride, fold_member_slot(ws, b, wave), k);
+#pragma unroll 1
+    for (uint32_t m = wave + 16; m < M; m += 16) acc = pt29r_add(acc, pt29r_load(lvl, lstride, fold_member_slot(ws, b, m), k), k);
+  }
+  for (uint32_t half = 8; half >= 1; half >>= 1) {      // (wave-uniform branches: whole waves store, load and add)
+    __syncthreads();
+    if (wave >= half && wave < 2 * half) pt29r_store(sh, 8, wave - half, acc, k);
+    __syncthreads();
+    if (wave < half) acc = pt29r_add(acc, pt29r_load(sh, 8, wave, k), k);
+  }
+  if (wave == 0) pt29r_store(lvl, lstride, FOLD_PL0 + ws * FOLD_BITS + b, acc, k);
+}
+// one wave per weighted sum: sum_b 2^b plane_b
+__global__ void __launch_bounds__(64)
+k_msm_plane_horner(uint32_t* __restrict__ lvl, size_t lstride) {
+  const uint32_t ws = blockIdx.x;
+  const fer_consts k = fer_setup(threadIdx.x);
+  int b = (int)FOLD_BITS - 1;
+  while (b > 0 && fold_members(ws, (uint32_t)b) == 0) --b;
+  pt29r acc = pt29r_load(lvl, lstride, FOLD_PL0 + ws * FOLD_BITS + b, k);
+#pragma unroll 1
+  for (--b; b >= 0; --b) {
+    acc = pt29r_double(acc, k);
+    acc = pt29r_add(acc, pt29r_load(lvl, lstride, FOLD_PL0 + ws * FOLD_BITS + b, k), k);
+  }
+  pt29r_store(lvl, lstride, FOLD_WS0 + ws, acc, k);
+}
+// result = sum_w 2^(16 w) (256 RW_w + CW_w), CW_7 = the column sums of both blocks of the top window
+__global__ void __launch_bounds__(64)
+k_msm_final16(const uint32_t* __restrict__ lvl, size_t lstride, uint8_t* __restrict__ out65, int affine) {
+  const fer_consts k = fer_setup(threadIdx.x);
+  pt29r accr = pt29r_load(lvl, lstride, FOLD_WS0 + 7, k);
+#pragma unroll 1
+  for (int w = 7; w >= 0; --w) {
+    if (w < 7) {
+#pragma unroll 1
+      for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
+      accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + w, k), k);
+    }
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
+    accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 8 + w, k), k);
+    if (w == 7) accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 16, k), k);
+  }
+  const pt29 acc = pt29r_gather(accr, k);
+  if (threadIdx.x != 0) return;
+  if (fe29_is_zero(acc.z)) {
+    for (int i = 0; i < 65; ++i) out65[i] = 0;
+    return;
+  }
+  if (!affine) {
+    out65[0] = 0x04;
+    for (int i = 1; i < 65; ++i) out65[i] = 0;
+    return;
+  }
+  fe29 zi = fe29_inv_gcd(fe29_normalize_weak(acc.z));
+  fe29 x = fe29_normalize(fe29_mul(acc.x, zi)), y = fe29_normalize(fe29_mul(acc.y, zi));
+  uint32_t xw[8], yw[8];
+  fe29_to_words(xw, x);
+  fe29_to_words(yw, y);
+  out65[0] = 0x04;
+  store_be32_unaligned(out65 + 1, xw);
+  store_be32_unaligned(out65 + 33, yw);
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct msm_ws {
@@ -920,11 +1076,20 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   }();
   const uint32_t ws = (g.c == 16 && n >= ((size_t)1 << 17) && split_env > 0 && split_env < (int)g.nw) ? (uint32_t)split_env : 0u;
   uint32_t* big2 = m.big + (STITCH_BIG_CAP + 1);
+  static const bool fold_off = getenv("S2K_MSM_OLD_REDUCE") != nullptr;      // A/B hook: the round-3 reduction (chunks of 8 buckets, quads)
+  const bool fold16 = g.c == 16 && ws == 0 && !fold_off && m.nslots + 1 >= FOLD_END;
   auto tail = [&](hipStream_t s_, uint32_t slot_lo, uint32_t slot_hi, uint32_t* big) -> int {   // stitch, reduce, tree of the slots [slot_lo, slot_hi)
     const uint32_t key_lo = slot_lo * g.nb, key_hi = slot_hi == g.nslot ? (uint32_t)m.nkeys : slot_hi * g.nb;
     k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
     k_msm_stitch_big<<<64, 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big);
     HIP_TRY(ctx, hipGetLastError());
+    if (fold16 && slot_lo == 0 && slot_hi == g.nslot) {   // 16-bit windows, whole key range: row / column sums, bit planes (above)
+      k_msm_fold<<<FOLD_ROW_BLOCKS + FOLD_COL_BLOCKS, 256, 0, s_>>>(m.sums, m.sum_stride, m.partial, m.nslots + 1);
+      k_msm_planes<<<FOLD_NWS * FOLD_BITS, 1024, 0, s_>>>(m.partial, m.nslots + 1);
+      k_msm_plane_horner<<<FOLD_NWS, 64, 0, s_>>>(m.partial, m.nslots + 1);
+      HIP_TRY(ctx, hipGetLastError());
+      return S2K_OK;
+    }
     k_msm_reduce<<<blocks_for(4 * (size_t)(slot_hi - slot_lo) * g.nchunk), 256, 0, s_>>>(g, m.sums, m.sum_stride, m.partial, slot_lo, slot_hi);
     HIP_TRY(ctx, hipGetLastError());
     // level 1: groups of up to 512 chunk results; level 2: the group sums of each slot
@@ -941,7 +1106,10 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     int rc = tail(st, 0, g.nslot, m.big);
     if (rc) return rc;
     msm_prof_mark(ctx, st, 4);
-    k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, g.nw, 0u);
+    if (fold16)
+      k_msm_final16<<<1, 64, 0, st>>>(m.partial, m.nslots + 1, d_out65, affine ? 1 : 0);
+    else
+      k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, g.nw, 0u);
     HIP_TRY(ctx, hipGetLastError());
   } else {
     int rc = ctx_aux_streams(ctx);

@@ -13,6 +13,7 @@
 #include "jacobian29.h"
 #include "pt29.h"
 #include "pt29q.h"
+#include "fe29r.h"
 #include "xyzz29.h"
 #include "sc26.h"
 
@@ -445,6 +446,127 @@ k_pt29q_op(int op, uint32_t lazy, uint32_t n, uint32_t reps, hp_args args, uint8
   if (flag) flag[idx] = f;
 }
 
+// The row-spread field and group law of fe29r.h, ONE WAVE PER ITEM (the item's four rows all hold it; for the field products
+// the four rows multiply the operands in four different lazy forms and must agree).  Inputs as for k_pt29q_op.
+//   FER_MUL a*b | FER_MUL_PLUS a*b+c | FER_MUL_ADD_MUL a*b+c*d | FER_SMALL 21 a  (out = row 0's result, flag = the rows agree)
+//   PT29R_DBL / PT29R_ADD: chained `reps` times like the quad forms
+//   FER_SWAPS: out[0..255] = what v_permlane16_swap / v_permlane32_swap make of the lane numbers (n >= 8)
+__global__ void __launch_bounds__(256)
+k_pt29r_op(int op, uint32_t lazy, uint32_t n, uint32_t reps, hp_args args, uint8_t* __restrict__ out, uint8_t* __restrict__ out2,
+           uint8_t* __restrict__ flag) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t idx = t >> 6;
+  const uint32_t lane = (uint32_t)t & 63u;
+  if (idx >= n) return;                       // (whole waves leave together)
+  const fer_consts k = fer_setup(lane);
+  if (op == S2K_HP_FER_SWAPS) {
+    if (idx != 0) return;
+    fer e, o, lo, hi;
+    fer_pairs(lane, e, o);
+    fer_halves(lane, lo, hi);
+    out[lane] = (uint8_t)e;
+    out[64 + lane] = (uint8_t)o;
+    out[128 + lane] = (uint8_t)lo;
+    out[192 + lane] = (uint8_t)hi;
+    return;
+  }
+  fe29 v[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    v[j] = fe29_zero();
+    if (args.in[j]) {
+      uint32_t w[8];
+      load_be32(w, args.in[j] + idx * 32);
+      v[j] = fe29_from_words(w);
+    }
+  }
+  if (op == S2K_HP_FER_MUL || op == S2K_HP_FER_MUL_PLUS || op == S2K_HP_FER_MUL_ADD_MUL || op == S2K_HP_FER_SMALL) {
+    // Row r multiplies the operands in its own lazy forms (codes of fe29_lazy_form: bits 1:0 multiples of p added, bit 2
+    // borrow-spread; units = 1 + both), chosen so that every row stays inside the budget of a reduction - units multiplied
+    // and summed over the terms at most 7: a, b | a, b, addend c | a, b, c, d.  `lazy` & 1 swaps the roles of the factors.
+    constexpr uint32_t PAT[4][4] = {{0, 0, 0, 0}, {1, 0, 0, 1}, {4, 1, 0, 0}, {2, 0, 4, 0}};   // [row][operand]: 2 | 2+2 | 4+1 | 3+2
+    constexpr uint32_t PAT_PLUS[4] = {0, 2, 1, 0};                                             // addend c with a, b as above: 1+1 | 2+3 | 4+2 | 3+1
+    fer f[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      uint32_t code = j < 4 ? PAT[k.row][(lazy & 1u) ? (j ^ 1) : j] : 0u;
+      if (op == S2K_HP_FER_MUL_PLUS && j == 2) code = PAT_PLUS[k.row];
+      if (op == S2K_HP_FER_SMALL) code = j == 0 ? (k.row == 3 ? 6u : PAT[k.row][0]) : 0u;       // a small multiple takes up to 4 units
+      f[j] = fer_from_fe29(fe29_lazy_form(fe29_normalize_weak(v[j]), code), k);
+    }
+    fer r;
+    if (op == S2K_HP_FER_MUL) r = fer_mul(f[0], f[1], k);
+    else if (op == S2K_HP_FER_MUL_PLUS) r = fer_mul_plus(f[0], f[1], f[2], k);
+    else if (op == S2K_HP_FER_MUL_ADD_MUL) r = fer_mul_add_mul(f[0], f[1], f[2], f[3], k);
+    else r = fer_small_norm(f[0], 21u, k);
+    const fe29 rr = fe29_normalize(fer_to_fe29(r));        // this row's result, canonical, in every lane of the row
+    uint32_t agree = 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) agree &= (uint32_t)(__builtin_amdgcn_readlane((int)rr.n[i], 0) == __builtin_amdgcn_readlane((int)rr.n[i], 16) &&
+                                                    __builtin_amdgcn_readlane((int)rr.n[i], 0) == __builtin_amdgcn_readlane((int)rr.n[i], 32) &&
+                                                    __builtin_amdgcn_readlane((int)rr.n[i], 0) == __builtin_amdgcn_readlane((int)rr.n[i], 48));
+    if (lane != 0) return;
+    uint32_t w[8];
+    fe29_to_words(w, rr);
+    store_be32(out + idx * 32, w);
+    if (flag) flag[idx] = (uint8_t)agree;
+    return;
+  }
+  const fe29 &a = v[0], &b = v[1], &c = v[2], &d = v[3], &e = v[4];
+  pt29 p, s;
+  const bool p_inf = fe29_is_zero(c);
+  const fe29 cn = fe29_normalize_weak(c);
+  p.x = fe29_mul(a, cn);
+  p.y = fe29_mul(b, cn);
+  p.z = cn;
+  s.x = fe29_mul(d, cn);
+  s.y = fe29_mul(e, cn);
+  s.z = cn;
+  if (p_inf) {
+    p = pt29_identity();
+    s.x = fe29_normalize_weak(d);
+    s.y = fe29_normalize_weak(e);
+    s.z = fe29_one();
+  }
+  p.y = fe29_lazy_form(p.y, lazy & 1u);        // y may come with two units
+  pt29r rc = pt29r_from(p, k);
+  const pt29r sc_ = pt29r_from(s, k);
+#pragma unroll 1
+  for (uint32_t i = 0; i < reps; ++i) rc = op == S2K_HP_PT29R_DBL ? pt29r_double(rc, k) : pt29r_add(rc, sc_, k);
+  const pt29 r = pt29r_gather(rc, k);
+  // the four rows must hold the same point
+  uint32_t agree = 1;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const fe29* cs[3] = {&r.x, &r.y, &r.z};
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const int v0 = __builtin_amdgcn_readlane((int)cs[cc]->n[i], 0);
+      agree &= (uint32_t)(v0 == __builtin_amdgcn_readlane((int)cs[cc]->n[i], 16) && v0 == __builtin_amdgcn_readlane((int)cs[cc]->n[i], 32) &&
+                          v0 == __builtin_amdgcn_readlane((int)cs[cc]->n[i], 48));
+    }
+  }
+  if (lane != 0) return;
+  fe29 x = fe29_zero(), y = fe29_zero();
+  uint8_t f = 1;
+  if (fe29_is_zero(r.z)) {
+    f = 0;
+  } else {
+    fe29 zi = fe29_inv(r.z);
+    x = fe29_mul(r.x, zi);
+    y = fe29_mul(r.y, zi);
+  }
+  if (!agree) f = 2;
+  uint32_t w[8];
+  fe29_to_words(w, fe29_normalize(x));
+  store_be32(out + idx * 32, w);
+  if (out2) {
+    fe29_to_words(w, fe29_normalize(y));
+    store_be32(out2 + idx * 32, w);
+  }
+  if (flag) flag[idx] = f;
+}
+
 // odd GLV split of the hot path (sc_split_glv_odd): magnitudes (129 bits) and sign bits
 __global__ void __launch_bounds__(256)
 k_split_glv_odd(uint32_t n, const uint8_t* __restrict__ k, uint8_t* __restrict__ k1o, uint8_t* __restrict__ k2o,
@@ -616,7 +738,8 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
   if (impl != S2K_IMPL_FAST) return fail(ctx, S2K_ERR_ARG, "s2k_fp_op_batch_ex serves S2K_IMPL_FAST only (8x32: s2k_fp_op_batch)");
   const uint32_t reps = lazy >> 20;           // quad operations: bits 20.. of `lazy` = how often the operation is chained (0: once)
   lazy &= 0xfffffu;
-  if (op < 0 || op > S2K_HP_XYZZ_ROUND) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (op < 0 || op > S2K_HP_FER_SWAPS) return fail(ctx, S2K_ERR_ARG, "bad op");
+  if (op == S2K_HP_FER_SWAPS && n < 8) return fail(ctx, S2K_ERR_ARG, "S2K_HP_FER_SWAPS writes 256 bytes: n >= 8");
   if (n == 0) return S2K_OK;
   if (!in || !in[0] || !out) return fail(ctx, S2K_ERR_ARG, "null buffer");
   if (n > 0x7fffffffu) return fail(ctx, S2K_ERR_ARG, "batch too large");
@@ -634,7 +757,9 @@ int s2k_fp_op_batch_ex(s2k_ctx* ctx, uint32_t impl, int op, uint32_t lazy, size_
   HIP_TRY(ctx, dout.alloc(n * 32));
   if (out2) HIP_TRY(ctx, dout2.alloc(n * 32));
   if (flag) HIP_TRY(ctx, dflag.alloc(n));
-  if (op == S2K_HP_PT29Q_DBL || op == S2K_HP_PT29Q_ADD)
+  if (op >= S2K_HP_FER_MUL && op <= S2K_HP_FER_SWAPS)
+    k_pt29r_op<<<blocks_for(64 * n), 256>>>(op, lazy, (uint32_t)n, reps ? reps : 1u, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);
+  else if (op == S2K_HP_PT29Q_DBL || op == S2K_HP_PT29Q_ADD)
     k_pt29q_op<<<blocks_for(4 * n), 256>>>(op, lazy, (uint32_t)n, reps ? reps : 1u, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);
   else
     k_fp29_op<<<blocks_for(n), 256>>>(op, lazy, (uint32_t)n, args, (uint8_t*)dout.p, (uint8_t*)dout2.p, (uint8_t*)dflag.p);

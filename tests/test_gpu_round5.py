@@ -1,0 +1,178 @@
+"""Round 5 on the GPU.  The row-spread field and group law (csrc/fe29r.h: one limb per lane of a 16-lane DPP row, one product
+per row — the serial tail of the multi-scalar multiplication) through the C-ABI against big integers; the lane-level model
+of the same code is tests/fer_model.py (CPU).  Reference symbols served: fiat Mul / Add / Opp
+(secp256k1montgomery.go:87,750,844), addComplete / doubleComplete (point_projective.go:24,208)."""
+import random
+
+import numpy as np
+import pytest
+
+import pyref as R
+from test_gpu_hotpath import FP_EDGE, b32, curve_points, eng, ints, lazy, shuffled, structured_29, wycheproof_points  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+P = R.P
+
+
+def test_fer_lane_exchanges(eng):
+    """v_permlane16_swap / v_permlane32_swap do what fe29r.h assumes (fer_pairs, fer_halves), on the lane numbers."""
+    import secp256k1_voi_amd as S
+    out, _, _ = eng.fp_op_batch_ex(S.HP_FER_SWAPS, [[b32(0)] * 8])
+    v = np.asarray(out).reshape(-1)
+    lane = np.arange(64)
+    row, j = lane >> 4, lane & 15
+    assert np.array_equal(v[0:64], (row & 2) * 16 + j), v[0:64]                # even = (v0, v0, v2, v2)
+    assert np.array_equal(v[64:128], ((row & 2) + 1) * 16 + j), v[64:128]      # odd  = (v1, v1, v3, v3)
+    assert np.array_equal(v[128:192], (row & 1) * 16 + j), v[128:192]          # low half everywhere: rows (0, 1, 0, 1)
+    assert np.array_equal(v[192:256], ((row & 1) + 2) * 16 + j), v[192:256]    # high half everywhere: rows (2, 3, 2, 3)
+
+
+@pytest.mark.parametrize("swap", [0, 1])
+def test_fer_products(eng, swap):
+    """fer_mul / fer_mul_plus / fer_mul_add_mul / fer_small_norm: the four rows of a wave multiply four different lazy forms
+    of the same operands (k_pt29r_op: up to 3 x 2 + 1 x 1 units, the budget of a reduction) and must agree (flag), value
+    against big integers."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(500 + swap)
+    vals = FP_EDGE + structured_29(rnd, 300) + [rnd.randrange(2**256) for _ in range(500)]
+    a = vals
+    b, c, d = shuffled(vals, 1), shuffled(vals, 2), shuffled(vals, 3)
+    cols = [[b32(x) for x in col] for col in (a, b, c, d)]
+    lz = swap
+    out, _, flag = eng.fp_op_batch_ex(S.HP_FER_MUL, cols[:2], lz)
+    assert all(flag) and ints(out) == [x * y % P for x, y in zip(a, b)]
+    out, _, flag = eng.fp_op_batch_ex(S.HP_FER_MUL_PLUS, cols[:3], lz)
+    assert all(flag) and ints(out) == [(x * y + z) % P for x, y, z in zip(a, b, c)]
+    out, _, flag = eng.fp_op_batch_ex(S.HP_FER_MUL_ADD_MUL, cols, lz)
+    assert all(flag) and ints(out) == [(x * y + z * w) % P for x, y, z, w in zip(a, b, c, d)]
+    out, _, flag = eng.fp_op_batch_ex(S.HP_FER_SMALL, cols[:1], lz)
+    assert all(flag) and ints(out) == [21 * x % P for x in a]
+
+
+@pytest.mark.parametrize("ylazy", [0, 1])
+def test_pt29r_row_formulas(eng, oracle, ylazy):
+    """pt29r_add / pt29r_double: same cases as the single-lane and quad forms - P + P, P - P, identity + Q, random Z - and
+    chained on their own outputs (P + 5 Q, 2^17 P: the Horner recurrence is 16 doublings and an addition), against the
+    affine group law on big integers; flag 2 would mean the four rows of a wave disagree."""
+    import secp256k1_voi_amd as S
+    rnd = random.Random(530)
+    pts = wycheproof_points(oracle)[:150] + curve_points(rnd, 450)
+    qs = shuffled(pts, 531)
+    for i in range(0, len(pts), 5):
+        qs[i] = pts[i] if (i // 5) % 2 == 0 else R.neg(pts[i])
+    z = [rnd.randrange(1, P) for _ in pts]
+    for i in range(3, len(pts), 11):
+        z[i] = 0                       # P = identity
+    cols = [[b32(p[0]) for p in pts], [b32(p[1]) for p in pts], [b32(v) for v in z],
+            [b32(q[0]) for q in qs], [b32(q[1]) for q in qs]]
+
+    def expect(op, reps):
+        out = []
+        for p, q, zz in zip(pts, qs, z):
+            r = None if zz == 0 else p
+            for _ in range(reps):
+                r = R.add(r, r) if op == "dbl" else R.add(r, q)
+            out.append(r)
+        return out
+
+    def check(x, y, flag, exp):
+        for xi, yi, f, e in zip(ints(x), ints(y), flag, exp):
+            if e is None:
+                assert f == 0
+            else:
+                assert f == 1 and (xi, yi) == e
+    for reps in (1, 5):
+        check(*eng.fp_op_batch_ex(S.HP_PT29R_ADD, cols, ylazy | reps << 20), expect("add", reps))
+    for reps in (1, 17):
+        check(*eng.fp_op_batch_ex(S.HP_PT29R_DBL, cols, ylazy | reps << 20), expect("dbl", reps))
+
+
+def test_group_config5_shape_eight_members_one_device(oracle):
+    """BASELINE config 5's exact shape through the single-process group on this pool's one device: 2^24
+    signatures, EIGHT members (all on device 0: eight contexts, eight host threads, shards of 2^21), the caller's arrays in
+    the group's own page-locked blocks (s2k_group_host_alloc: shard ranges placed per member), verdicts against the seeded
+    damage pattern - a shard that was cut at the wrong index, verified twice or not at all cannot pass - and the head and
+    tail of the batch against the oracle.  The partition arithmetic, the eight-way queueing and the placement code have then
+    run at full size; what one device cannot show is the rate."""
+    import os
+    import torch
+    assert torch.cuda.is_available()
+    import secp256k1_voi_amd as S
+    from secp256k1_voi_amd.synth import synth_batch
+    eng = S.Engine(0)
+    n, base_n = 1 << 24, 1 << 20
+    base = [np.array(x) for x in synth_batch(eng, base_n, 1 << 16, seed=0xC0F5)]
+    eng.close()
+    grp = S.Group([0] * 8)
+    try:
+        assert len(grp) == 8 and grp.shard_size(n) == 1 << 21 and grp.shard_size(n - 1) == 1 << 21 and grp.shard_size(1000) == 256
+        bufs = [grp.host_alloc(n, w) for w in (64, 32, 32, 32)]
+        for d, x in zip(bufs, base):
+            for rep in range(n // base_n):                 # sixteen copies of the 2^20 signatures ...
+                d[rep * base_n:(rep + 1) * base_n] = x
+        i = np.arange(n, dtype=np.uint64)
+        bad = ((i * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(61)) == 0      # ... each damaged at its own places
+        bufs[3][bad, 31] ^= 1
+        out = grp.host_alloc(n, 1)
+        out[...] = 9
+        grp.member_stats_ex()                              # switches the per-ticket timing on
+        t = grp.ecdsa_verify_batch_submit(*bufs, out=out.reshape(-1))
+        got = t.wait()
+        assert np.array_equal(got, (~bad).astype(np.uint8))
+        st = grp.member_stats_ex()
+        assert [int(s["n"]) for s in st] == [1 << 21] * 8 and [int(s["lo"]) for s in st] == [k << 21 for k in range(8)], st
+        assert all(s["h2d_ms"] > 0 and s["device_ms"] >= s["h2d_ms"] and s["device"] == 0 for s in st), st
+        m = 2048
+        for lo in (0, n - m, (3 << 21) - m // 2):          # the head, the tail and a shard border against the oracle
+            sl = slice(lo, lo + m)
+            assert np.array_equal(got[sl], oracle.ecdsa_verify_batch(*(np.ascontiguousarray(b[sl]) for b in bufs), nthreads=os.cpu_count() or 1))
+        # a ragged size: the last member's shard is short, one is empty
+        n2 = (7 << 21) - 12345
+        got2 = grp.ecdsa_verify_batch_submit(*(b[:n2] for b in bufs), out=out.reshape(-1)[:n2]).wait()
+        assert np.array_equal(got2, (~bad[:n2]).astype(np.uint8))
+        for b in bufs + [out]:
+            grp.host_free(b)
+    finally:
+        grp.close()
+
+
+def test_ticket_times_and_dropped_tickets(eng):
+    """s2k_ctx_ticket_timing / s2k_ticket_times, and the buffers of a ticket that is dropped without wait(): the engine keeps
+    them until the library has retired the ticket (the arrays used to die with the Ticket object while the copy
+    engine was still reading them)."""
+    import ctypes as C
+    import gc
+    import secp256k1_voi_amd as S
+    from test_gpu_round4 import damaged_batch
+    lib = eng._lib
+    n = 1 << 16
+    arrs = damaged_batch(eng, n, 500, 5150)
+    exp = eng.ecdsa_verify_batch(*arrs)
+    lib.s2k_ctx_ticket_timing(eng._h, 1)
+    try:
+        t = eng.ecdsa_verify_batch_submit(*arrs)
+        assert np.array_equal(t.wait(), exp)
+        ms = (C.c_double * 2)()
+        assert lib.s2k_ticket_times(eng._h, t.ticket, ms) == 0 and 0 < ms[0] <= ms[1] < 1000, list(ms)
+        assert lib.s2k_ticket_times(eng._h, t.ticket + 100, ms) == 1          # S2K_PENDING: unknown ticket
+    finally:
+        lib.s2k_ctx_ticket_timing(eng._h, 0)
+    # six tickets, none kept: the fifth and sixth submit retire the first two, the rest is retired by wait_all
+    outs = []
+    for k in range(6):
+        a = [np.array(x) for x in arrs]
+        out = S.pinned_array((n,))
+        out[...] = 9
+        outs.append(out)
+        eng.ecdsa_verify_batch_submit(*a, out=out)                            # Ticket dropped at once
+        del a
+        gc.collect()
+    assert len(eng._inflight) == 4
+    eng.wait_all()
+    assert not eng._inflight
+    for out in outs:
+        assert np.array_equal(np.asarray(out), exp)
+    with pytest.raises(ValueError):
+        eng.ecdsa_verify_batch_submit(*arrs, out=np.zeros(n - 1, np.uint8))   # a short verdict array is refused
+    with pytest.raises(ValueError):
+        eng.ecdsa_verify_batch_submit(*arrs, out=np.zeros(2 * n, np.uint8)[::2])

@@ -29,6 +29,18 @@ import secp256k1_voi_amd as S
 from secp256k1_voi_amd.synth import synth_batch
 
 
+def member_lines(g, bytes_per_signature):
+    """per member: its last shard, where its device hangs (NUMA node, CPUs its thread is bound to), and the transfer / compute
+    split of the shard on the device's clock with the host-to-device rate that follows"""
+    out = []
+    for s in g.member_stats_ex():
+        s = dict(s)
+        s["h2d_GBps"] = (s["n"] * bytes_per_signature / (s["h2d_ms"] * 1e-3) / 1e9) if s["h2d_ms"] > 0 else None
+        s["after_copies_ms"] = s["device_ms"] - s["h2d_ms"] if s["device_ms"] else None
+        out.append(s)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--devices", default=None)
@@ -54,9 +66,12 @@ def main():
     eng.close()
     del eng
     lead, depth = 4, 4
+    g = S.Group(devices)
+    g.member_stats_ex()            # placement and per-ticket timing on from the first shard
     bufs, outs, masks = [], [], []
     for k in range(depth):
-        pb = [S.pinned_array((n, x.shape[1])) for x in base]
+        # the group's own page-locked blocks: every member's shard range lies on the NUMA node of its device (s2k_group_host_alloc)
+        pb = [g.host_alloc(n, x.shape[1]) for x in base]
         for d, x in zip(pb, base):
             for m in range(len(devices)):
                 d[m * per:(m + 1) * per] = x
@@ -65,8 +80,7 @@ def main():
         pb[3][bad, 31] ^= 1
         bufs.append(pb)
         masks.append((~bad).astype(np.uint8))
-        outs.append(S.pinned_array((n,)))
-    g = S.Group(devices)
+        outs.append(g.host_alloc(n, 1).reshape(-1))
     gks = None
     if a.keyset:
         keys, inv = np.unique(base[0], axis=0, return_inverse=True)
@@ -101,7 +115,7 @@ def main():
             "value": n / (ms * 1e-3), "unit": "verifications/s", "n_gpus": len(devices), "devices": devices,
             "ms_per_group_batch": ms, "signatures_per_group_batch": n, "per_gpu_value": per / (ms * 1e-3),
             "batches_timed": done - lead, "in_flight": depth, "scaling": "weak", "data": "synthetic, page-locked host memory",
-            "member_stats_last_shard": g.member_stats(),
+            "member_stats_last_shard": member_lines(g, 100 if gks is not None else 160),
             "keyset": None if gks is None else {"keys": len(gks), "device_bytes_per_member": gks.device_bytes(), "layout": "joint tables"},
             "check": "every batch's verdicts equal its seeded damage pattern (one bit of s flipped in every 61st signature)"}
     if gks is not None:
