@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--key-grouping", choices=("auto", "off", "keyset", "keyset-chunks", "keyset5", "keyset6"), default="auto",
                     help="off: every signature through the general ladder; keyset: the batch against a key set built before the "
                          "timed region (both for profiling those kernels under the driver's settings; not the headline)")
+    ap.add_argument("--full", action="store_true", help="print the line with its explanations (as rounds 1-4 did) instead of the compact form")
+    ap.add_argument("--write-notes", action="store_true", help="refresh bench_notes.json (the explanations, by path) from this run")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="test hook: allow more ranks than devices (rank r -> device r mod count, gloo collectives)")
     return ap.parse_args()
@@ -161,12 +163,15 @@ def cpu_baseline(pub, digest, r, s, budget_s=15.0):
             break
         except Exception:
             continue
-    return {"value": value, "unit": "verifications/s", "cores": best_th, "threads": best_th, "kind": "port",
+    # `cores`: the CPUs the sample could actually run on - the worker threads, but no more than the cgroup's CPU quota or the
+    # affinity mask gives the process (round 4 printed 64 for 64 threads on a 16-CPU quota)
+    cpus = min([best_th, cores] + ([max(1, int(quota + 0.5))] if quota else []))
+    return {"value": value, "unit": "verifications/s", "cores": cpus, "threads": best_th, "kind": "port",
             "single_thread_value": single, "speedup_vs_1_thread": value / single,
             "host_logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": cores, "cgroup_cpu_quota": quota,
-            "threads_note": "`cores` = `threads` = worker threads the oracle ran on (static split of the sample); the speed-up over "
-                            "one thread is what the box gave them - SMT siblings, a cgroup quota or other tenants make it smaller "
-                            "than the thread count",
+            "best_probe_value": top,
+            "threads_note": "`threads` = worker threads the oracle ran on (static split of the sample); `cores` = the CPUs they had: "
+                            "min(threads, affinity mask, cgroup CPU quota); the speed-up over one thread is what the box gave them",
             "config1_der_single_thread": {"value": config1, "unit": "verifications/s", "sample": f"{m1} DER signatures, "
                                           "single-signature verify incl. parsing"},
             "thread_probe": {str(t): round(v) for t, v in sorted(probes.items())},
@@ -185,7 +190,7 @@ def load_profile_json(name):
 
 def committed_counts():
     """PMC-derived per-signature figures of the path's kernels (profiles/, newest round first)."""
-    for name in ("r04_valu_counts.json", "r03_valu_counts.json", "r02_valu_counts.json", "r01_valu_counts.json"):
+    for name in ("r05_valu_counts.json", "r04_valu_counts.json", "r03_valu_counts.json", "r02_valu_counts.json", "r01_valu_counts.json"):
         d = load_profile_json(name)
         if d:
             return d, name
@@ -216,7 +221,7 @@ def recount_shipped_binary(lib_path, counts):
 
 
 def committed_traffic(kernel="k_verify_fast"):
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         d = load_profile_json(name)
         if d and kernel in d:
             return d[kernel]["hbm_bytes_per_launch"], name
@@ -226,6 +231,130 @@ def committed_traffic(kernel="k_verify_fast"):
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if xs else 0.0
+
+
+
+# ---------------------------------------------------------------------------------------------
+# The printed line.  The driver keeps an 8 KB tail of stdout: everything this file measures has to fit in it (VERDICT r04
+# next #7).  The explanations that used to ride along in the line ("note", "*_def", "check", "method", "sample" ...: 5.6 KB of
+# the 18.5 KB of round 4) live in bench_notes.json next to this file, keyed by the same paths (--write-notes refreshes it
+# from a run; --full prints the line as it was); numbers are rounded to six significant digits; per-repetition lists are
+# dropped; and if the line is still too long, keys are dropped from the least to the most important and named in `dropped`.
+# ---------------------------------------------------------------------------------------------
+PROSE_KEYS = ("note", "check", "method", "sample", "threads_note", "peak_def", "frac_def", "reference_toolchain", "mode_def",
+              "counts_note", "def")
+LIST_KEYS = ("ms_each", "ms_per_batch_each", "thread_probe", "per_call_ms", "ms_rounds", "ms_rounds_every_call", "ms_rounds_off", "static_recount")
+NESTED_ROOFLINE_DROPS = ("bound", "unit", "peak", "hbm", "counts_head")     # constants the top-level roofline states once
+LAST_KEYS = ("distinct_keys", "general_path_same_batch", "keyset_resident", "pcie_inclusive", "batch_sweep", "roofline", "cpu_baseline")
+DROP_ORDER = ("worst_case_equal_points", "worst_case_ladder_collision", "forced_worklist", "worst_case_all_fallback", "resident_two_contexts",
+              "keyset_resident_chunk_tables", "keyset_resident_joint_tables_4bit", "msm_2p22", "encoded_2p20", "key_grouping")
+LINE_BUDGET = 7900
+
+
+def _sig6(x):
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.6g" % x)
+
+
+def _strip(obj, path, notes):
+    if isinstance(obj, dict):
+        out = {}
+        for k, v in obj.items():
+            pth = path + "." + k if path else k
+            if isinstance(v, str) and (k in PROSE_KEYS or k.endswith("_def") or k.endswith("_note")):
+                notes[pth] = v
+                continue
+            if k in LIST_KEYS:
+                notes.setdefault("_dropped_lists", []).append(pth)
+                continue
+            if isinstance(v, str) and len(v) > 72 and path and not path.startswith("config"):   # any other long text
+                notes[pth] = v
+                continue
+            if path and k == "unit" and v == "verifications/s":      # (the top level says it)
+                continue
+            if path and path.endswith("roofline") is False and k == "roofline" and isinstance(v, dict):
+                v = {kk: vv for kk, vv in v.items() if kk not in NESTED_ROOFLINE_DROPS}
+            out[k] = _strip(v, pth, notes)
+        return out
+    if isinstance(obj, list):
+        return [_strip(v, path, notes) for v in obj]
+    return _sig6(obj)
+
+
+def compact_line(line, args):
+    if getattr(args, "full", False):
+        return json.dumps(line)
+    notes = {}
+    slim = _strip(line, "", notes)
+    head = [k for k in slim if k not in LAST_KEYS]
+    ordered = {k: slim[k] for k in head}
+    for k in LAST_KEYS:                      # what the record must not lose comes LAST: a tail cut takes the front
+        if k in slim:
+            ordered[k] = slim[k]
+    dropped = []
+    text = json.dumps(ordered, separators=(",", ":"))
+    for k in DROP_ORDER:
+        if len(text) <= LINE_BUDGET:
+            break
+        if k in ordered:
+            dropped.append(k)
+            del ordered[k]
+            ordered["dropped"] = dropped
+            text = json.dumps(ordered, separators=(",", ":"))
+    ordered["notes"] = "bench_notes.json"
+    text = json.dumps(ordered, separators=(",", ":"))
+    if getattr(args, "write_notes", False):
+        with open(os.path.join(ROOT, "bench_notes.json"), "w") as f:
+            json.dump({"what": "the explanations of bench.py's line, keyed by the path of the object they describe; written by "
+                               "`python bench.py --write-notes` (the line itself carries numbers only, so that it fits the 8 KB the driver keeps)",
+                       "notes": notes}, f, indent=1, sort_keys=True)
+            f.write("\n")
+    return text
+
+
+def batch_sweep(eng, pub, digest, r, s, cpu):
+    """The reference caller's own shape on the GPU (BASELINE config 1 is a 1024-signature secec.Verify loop, ecdsa.go:171): one
+    synchronous s2k_ecdsa_verify_batch call from page-locked host memory to host verdicts, by batch size - what a shim that
+    collects signatures into batches pays per call, and from which size on a call beats the host's CPUs (the timed
+    cpu_baseline of this run)."""
+    import numpy as np
+    from secp256k1_voi_amd import pinned_array
+    n_max = pub.shape[0]
+    rows = {}
+    cpu_rate = (cpu or {}).get("value")
+    cpu_1 = (cpu or {}).get("single_thread_value")
+    cross_all, cross_one = None, None
+    for lg in range(10, 23):
+        n = 1 << lg
+        if n > n_max:
+            break
+        arrs = [pinned_array((n, a.shape[1])) for a in (pub, digest, r, s)]
+        for d_, src in zip(arrs, (pub, digest, r, s)):
+            d_[...] = src[:n]
+        eng.ecdsa_verify_batch(*arrs)
+        reps = 9 if lg <= 16 else 5
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            v = eng.ecdsa_verify_batch(*arrs)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert int(v.sum()) == n, "batch sweep: a batch of valid signatures did not verify"
+        ms = median(ts)
+        rate = n / (ms * 1e-3)
+        rows[lg] = ms
+        if cpu_rate and cross_all is None and rate > cpu_rate:
+            cross_all = n
+        if cpu_1 and cross_one is None and rate > cpu_1:
+            cross_one = n
+        del arrs
+    return {"log2_n": sorted(rows), "ms": [rows[k] for k in sorted(rows)], "n_from_which_a_call_beats_all_host_threads": cross_all,
+            "n_from_which_a_call_beats_one_host_thread": cross_one,
+            "note": "ms[i] = one synchronous s2k_ecdsa_verify_batch call of 2^log2_n[i] signatures, page-locked host memory to host verdicts, median of 5-9 calls per size (signatures/s = 2^log2_n / ms); "
+                    "a 1024-signature call costs what the smallest row says (launch and transfer latencies, not arithmetic); the "
+                    "streaming entry points (pcie_inclusive.pipelined) hide those from 2^17 per batch on"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -270,7 +399,16 @@ def worker(args):
     batch_log2 = args.batch_log2 if args.batch_log2 is not None else (20 if world == 1 else 21)
     n = 1 << batch_log2
     n_keys = min(n, 1 << args.keys_log2)
-    eng = S.Engine(local_rank)
+    # the thread that feeds the device runs on the CPUs next to it (csrc/topology.cpp; no-op on one NUMA node)
+    numa_node = int(S.load_library().s2k_device_numa_node(local_rank))
+    numa_cpus = int(S.load_library().s2k_bind_thread_to_node(numa_node))
+    t_c0 = time.perf_counter()
+    eng = S.Engine(local_rank)                     # usable at once on narrow generator tables (s2k_ctx_create)
+    ctx_create_s = time.perf_counter() - t_c0
+    gt_first = eng.gt_info()
+    eng.gt_wait()                                  # the timed steps run on the tables a long-lived context has: the wide ones
+    gt_wait_s = time.perf_counter() - t_c0
+    gt_now = eng.gt_info()
     if args.key_grouping == "off":
         eng.set_key_grouping(S.KEYS_OFF)
     pub, digest, r, s = synth_batch(eng, n, n_keys, seed=0x5EC9 + rank)
@@ -369,7 +507,10 @@ def worker(args):
         splits = torch.zeros(3 * world, dtype=torch.float64, device=t.device)
         dist.all_gather_into_tensor(splits, split)
         splits = splits.view(world, 3).cpu().tolist()
+        nodes = torch.zeros(world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(nodes, torch.tensor([float(numa_node)], dtype=torch.float64, device=t.device))
         multi = {"per_rank_ms": [x * 1e3 / args.steps for x in every.cpu().tolist()],
+                 "per_rank_numa_node": [int(x) for x in nodes.cpu().tolist()],
                  "per_rank_local_ms": [x[0] for x in splits], "collective_ms": [x[1] for x in splits],
                  "per_rank_step_ms_diagnostic_pass": [x[2] for x in splits],
                  "value_without_collective": n * world / (max(x[0] for x in splits) * 1e-3),
@@ -470,7 +611,9 @@ def worker(args):
                        "parallelism": "shard%d%s%s" % (world, " (ranks share devices, gloo: test hook)" if shared_device else "",
                                                          " (RCCL group of one: test hook)" if forced_group else ""),
                        "inputs": "resident in HBM", "collective": "one all-gather per step: bitmap shard + valid count of every rank",
-                       "build": eng._lib.s2k_build_config().decode()},
+                       "build": eng._lib.s2k_build_config().decode(),
+                       "gt_bits": gt_now["bits"], "gt_bits_at_first_call": gt_first["bits"], "ctx_create_s": ctx_create_s,
+                       "wide_tables_ready_s": gt_wait_s, "gt_bytes": gt_now["bytes"], "numa_node": numa_node, "cpus_bound": numa_cpus},
             "roofline": roof,
             "key_grouping": {"mode": "adaptive (s2k_ctx_set_key_grouping default: looks for repeated keys until two large batches in a row have none)" if args.key_grouping == "auto" else "%s (--key-grouping %s)" % (args.key_grouping, args.key_grouping), "signatures_on_key_tables": grouping["keyed"],
                              "tables_built_per_step": grouping["tables"], "signatures_on_general_ladder": grouping["general"],
@@ -601,7 +744,16 @@ def worker(args):
             except Exception as e:          # (the checker could not be built or run on this box: the line is printed all the same)
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 rc = 1
-        print(json.dumps(line), flush=True)
+        if not args.no_extras and world == 1:
+            try:
+                line["batch_sweep"] = batch_sweep(eng, pub, digest, r, s, line.get("cpu_baseline"))
+            except AssertionError as e:
+                line["batch_sweep"] = {"error": str(e) or "assertion failed"}
+                rc = 1
+            except Exception as e:
+                line["batch_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                rc = 1
+        print(compact_line(line, args), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -727,6 +879,28 @@ def keyset_roofline(eng, kernel_ms, shader_mhz, n, option):
     return roof
 
 
+def side_roofline(count_key, kernel, prof, n):
+    """`roofline` object of an entry point beside the headline: its ladder's live duration (the engine's stage events,
+    s2k_ctx_profile) and the ladder's VALU instructions per item from the committed counter pass (profiles/r05_side_counts.json,
+    tools/collect_side_counts.sh), against the 4-cycle issue peak - as the headline's."""
+    calls = max(prof["calls"], 1)
+    kernel_ms = prof["fast_ms"] / calls
+    roof = {"bound": "valu", "kernel": kernel, "kernel_ms": kernel_ms, "unit": "Tlane-op/s", "peak": VALU_PEAK_LANE_OPS / 1e12,
+            "stages_ms": {"front_ms": (prof["prep_ms"] + prof["group_ms"]) / calls, "ladder_ms": kernel_ms,
+                          "left_and_inversions_ms": prof["left_ms"] / calls, "worklist_ms": prof["fallback_ms"] / calls},
+            "shader_clock_mhz": prof["shader_mhz"]}
+    counts = load_profile_json("r05_side_counts.json") or {}
+    c = counts.get(count_key)
+    if c and kernel_ms > 0:
+        ipv = c["valu_instr_per_item"]
+        lane_ops = ipv * n / (kernel_ms * 1e-3)
+        roof.update({"valu_instr_per_item": ipv, "achieved": lane_ops / 1e12, "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                     "counts_from": "profiles/r05_side_counts.json"})
+        if prof["shader_mhz"] > 0:
+            roof["frac_at_measured_clock"] = ipv * n / 64.0 * 4.0 / (SIMDS * kernel_ms * 1e-3 * prof["shader_mhz"] * 1e6)
+    return roof
+
+
 def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_stage):
     """`roofline` object of BASELINE config 3 / 4: the dominant kernel's VALU instructions (PMC, committed profile of the
     same entry point at the same size, tools/collect_msm_profiles.sh) over its live duration (HIP events on the call's
@@ -734,7 +908,7 @@ def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_
     unit; fetched + written bytes of the dominant kernel next to the algorithmic ones."""
     prof = None
     src = None
-    for name in ("r03_%s_profile_2p20.json" % which,):
+    for name in ("r05_%s_profile_2p20.json" % which, "r03_%s_profile_2p20.json" % which):
         prof = load_profile_json(name)
         if prof:
             src = name
@@ -1108,6 +1282,35 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     del hk, hp
 
     # ---- config 4: 2^20 BIP-340 signatures as one random-linear-combination MSM ----
+    # ---- public-key recovery (RecoverPublicKey, secec/ecdsa.go:244-282) over the resident batch of the headline: the recovered
+    # keys must be the signers' ----
+    if resident is not None and host_pub is not None:
+        dd, dr, ds = resident
+        d_rid = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_q = torch.zeros((n, 65), dtype=torch.uint8, device=dev)
+        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        rec = lambda: eng._check(lib.s2k_ecdsa_recover_batch_device(h, n, dd.data_ptr(), dr.data_ptr(), ds.data_ptr(), d_rid.data_ptr(), 0,
+                                                                    d_q.data_ptr(), d_ok.data_ptr(), st))
+        # the recovery id of a synthetic signature is not kept by the generator: both parities are tried, the right one
+        # gives the signer's key (ids 2 and 3, x(R) >= n, do not occur in random data)
+        rec()
+        torch.cuda.synchronize()
+        want = torch.from_numpy(host_pub).to(dev)
+        hit0 = (d_q[:, 1:] == want).all(dim=1) & (d_ok == 1)
+        d_rid[~hit0] = 1
+        ms_rec = timed(rec, 5)
+        assert bool(((d_q[:, 1:] == want).all(dim=1) & (d_ok == 1)).all().item()), "recovery did not return the signers' keys"
+        eng.profile(True)
+        for _ in range(5):
+            rec()
+        torch.cuda.synchronize()
+        pr = eng.profile_read_stages(cap=8)
+        eng.profile(False)
+        out["recover_2p20"] = {"sigs": n, "ms": ms_rec, "sigs_per_s": n / (ms_rec * 1e-3),
+                               "roofline": side_roofline("k_verify_fast_recover", "k_verify_fast<RECOVER>", pr, n),
+                               "note": "s2k_ecdsa_recover_batch_device: r, s, digest and recovery id resident in HBM -> 65-byte keys; every "
+                                       "recovered key compared with the signer's; never `value`"}
+        del d_rid, d_q, d_ok, want
     pk, msgs, sig = synth_schnorr_batch(eng, m, min(m, 1 << 16), seed=340)
     dpk, dmsg, dsig = (torch.from_numpy(x).to(dev) for x in (pk, msgs, sig))
     res = ctypes.c_int(0)
@@ -1129,9 +1332,21 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     assert res.value == 0, "BIP-340 batch with one bad signature accepted"
     dsig[bad, 63] ^= 1
     dval = torch.zeros(m, dtype=torch.uint8, device=dev)
-    ms_single = timed(lambda: lib.s2k_schnorr_verify_batch_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32,
-                                                                  dsig.data_ptr(), 0, dval.data_ptr(), st), 3)
+    single = lambda: lib.s2k_schnorr_verify_batch_device(h, m, dpk.data_ptr(), dmsg.data_ptr(), None, 32, dsig.data_ptr(), 0, dval.data_ptr(), st)
+    ms_single = timed(single, 3)
     assert int(dval.sum().item()) == m
+    # the same call with the engine's stage events on: its ladder as a roofline row
+    eng.profile(True)
+    for _ in range(5):
+        single()
+    torch.cuda.synchronize()
+    pr = eng.profile_read_stages(cap=8)
+    eng.profile(False)
+    out["schnorr_per_signature_2p20"] = {
+        "sigs": m, "ms": ms_single, "sigs_per_s": m / (ms_single * 1e-3), "keys": int(min(m, 1 << 16)),
+        "roofline": side_roofline("k_verify_fast_schnorr_keyed", "k_verify_fast<SCHNORR_KEYED>", pr, m),
+        "note": "s2k_schnorr_verify_batch_device (SchnorrPublicKey.Verify per signature, secec/bitcoin/schnorr.go:221-253): 2^20 "
+                "signatures of 2^16 x-only keys resident in HBM, keys grouped and lifted once per call; never `value`"}
     # locating one bad signature by bisection on the kept terms (s2k_schnorr_verify_batch_bisect_device)
     stats = (ctypes.c_uint32 * 4)()
     dsig[bad, 63] ^= 1

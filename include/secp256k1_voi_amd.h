@@ -80,9 +80,24 @@ enum {
 #define S2K_COORD_SIZE 32  /* CoordSize, point_s11n.go:27-44 */
 
 /* ---- context --------------------------------------------------------------------- */
-/* Selects the device, builds the resident generator tables (the device analogue of the
- * package-init unpack of generatorHugeAffineTable, point_mul_table.go:75-100). */
+/* Selects the device and makes the resident generator tables available (the device analogue of the package-init unpack of
+ * generatorHugeAffineTable, point_mul_table.go:75-100).  The tables of a device are shared by the contexts of a process.
+ * s2k_ctx_create returns as soon as a narrow table (20-bit windows, 0.8 GiB) is built - under 0.1 s - and a background
+ * thread builds the wide one (26-bit windows, 40 GiB, 3 s; 24 or 22 bits when the device has less than twice that free or
+ * s2k_set_generator_table_budget says so; none when even those do not fit): calls made meanwhile run on the narrow table
+ * (about 2 % slower), the first launch after the build uses the wide one.  Verdicts do not depend on the width.
+ * s2k_ctx_create_ex: gt_bits 0 = as above; 16 .. 26 = tables of exactly that width for this context, built before the call
+ * returns (S2K_ERR_NOMEM when the device cannot hold them); flags S2K_CTX_WAIT_TABLES = automatic width, but return only
+ * when the background build has ended.  s2k_ctx_gt_info: info[0] window bits in use now, [1] bits being aimed for (0: none),
+ * [2] 1 while the build runs, [3] bytes of tables the device holds for this process; s2k_ctx_gt_note: why (free memory,
+ * budget, a failed allocation); s2k_ctx_gt_wait: block until the build has ended, returns the bits in use then. */
+#define S2K_CTX_WAIT_TABLES 1u
 int s2k_ctx_create(int device_index, s2k_ctx **out);
+int s2k_ctx_create_ex(int device_index, int gt_bits, uint32_t flags, s2k_ctx **out);
+void s2k_set_generator_table_budget(size_t bytes_per_device);
+int s2k_ctx_gt_info(s2k_ctx *ctx, uint64_t info[4]);
+const char *s2k_ctx_gt_note(s2k_ctx *ctx);
+int s2k_ctx_gt_wait(s2k_ctx *ctx);
 void s2k_ctx_destroy(s2k_ctx *ctx);
 const char *s2k_last_error(const s2k_ctx *ctx);
 const char *s2k_version(void);
@@ -639,7 +654,8 @@ int s2k_fn_split_glv_batch_ex(s2k_ctx *ctx, uint32_t impl, size_t n, const uint8
 
 /* ---- introspection used by the tests ------------------------------------------------ */
 /* Copies generator-table entry T_i[d] (X‖Y big-endian) to out64.  Layout: DESIGN.md §3. */
-/* window width (bits) of the resident generator tables this library was built with */
+/* window width (bits) the automatic generator tables of this library aim for (a build-time constant: S2K_GT_BITS); what a
+ * context uses at a given moment: s2k_ctx_gt_info.  s2k_debug_gtable_entry reads the table the context uses now. */
 int s2k_generator_window_bits(void);
 int s2k_debug_gtable_entry(s2k_ctx *ctx, unsigned i, unsigned d, uint8_t *out64);
 

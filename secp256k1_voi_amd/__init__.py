@@ -45,6 +45,7 @@ ENCODING_ASN1, ENCODING_COMPACT, ENCODING_COMPACT_RECOVERABLE = 0, 1, 2
 
 OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_NEG, OP_INV, OP_SQRT = range(7)
 IMPL_COMPLETE, IMPL_FAST = 0, 1
+CTX_WAIT_TABLES = 1
 KEYS_OFF, KEYS_AUTO, KEYS_ALWAYS, KEYS_ADAPTIVE = 0, 1, 2, 3     # s2k_ctx_set_key_grouping (a new context: KEYS_ADAPTIVE)
 KEYSET_AUTO, KEYSET_CHUNKS, KEYSET_JOINT, KEYSET_JOINT5, KEYSET_JOINT6 = 0, 1, 2, 3, 4   # s2k_keyset_create_ex
 (HP_MUL, HP_SQR, HP_MUL_PLUS, HP_SQR_PLUS, HP_MUL_ADD_MUL, HP_MUL_ADD_SQR, HP_ADD, HP_NEGATE, HP_HALF, HP_NORMALIZE,
@@ -330,6 +331,13 @@ def load_library() -> C.CDLL:
     lib.s2k_group_host_alloc.restype = vp
     lib.s2k_group_host_free.argtypes = [vp, vp]
     lib.s2k_group_host_free.restype = None
+    lib.s2k_ctx_create_ex.argtypes = [ci, ci, u32, C.POINTER(vp)]
+    lib.s2k_set_generator_table_budget.argtypes = [sz]
+    lib.s2k_set_generator_table_budget.restype = None
+    lib.s2k_ctx_gt_info.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.s2k_ctx_gt_note.argtypes = [vp]
+    lib.s2k_ctx_gt_note.restype = C.c_char_p
+    lib.s2k_ctx_gt_wait.argtypes = [vp]
     lib.s2k_ct_ecdsa_sign_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
     _lib = lib
     return lib
@@ -366,6 +374,7 @@ EXPORTED_SYMBOLS = [
     "s2k_device_pci_bus_id", "s2k_device_numa_node", "s2k_bind_thread_to_node", "s2k_topology_prefer_node", "s2k_topology_node_count",
     "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
     "s2k_group_member_stats_ex", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
+    "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
 ]
 
 
@@ -493,14 +502,29 @@ class _TicketOwner:
 class Engine(_TicketOwner):
     """One context bound to one GPU (s2k_ctx)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, gt_bits: int = 0, wait_tables: bool = False):
+        """gt_bits 0: automatic generator tables (usable at once on a narrow table, the wide one is built in the background);
+        16..26: exactly that window width, built before the constructor returns.  wait_tables: return only when the
+        background build has ended (s2k_ctx_create_ex)."""
         self._lib = load_library()
         h = C.c_void_p()
-        rc = self._lib.s2k_ctx_create(int(device), C.byref(h))
+        rc = self._lib.s2k_ctx_create_ex(device, int(gt_bits), CTX_WAIT_TABLES if wait_tables else 0, C.byref(h))
         if rc != 0:
             raise EngineError(f"s2k_ctx_create failed ({rc}): {self._lib.s2k_last_error(None).decode()}")
         self._h = h
         self.device = device
+
+    def gt_info(self) -> dict:
+        """generator tables of this context's device: window bits in use now, bits the background build aims for, whether it
+        is running, bytes held, and the reason for the choice (s2k_ctx_gt_info / s2k_ctx_gt_note)"""
+        info = (C.c_uint64 * 4)()
+        self._check(self._lib.s2k_ctx_gt_info(self._h, info))
+        return {"bits": int(info[0]), "target_bits": int(info[1]), "building": bool(info[2]), "bytes": int(info[3]),
+                "note": self._lib.s2k_ctx_gt_note(self._h).decode()}
+
+    def gt_wait(self) -> int:
+        """block until the background build of the wide generator tables has ended; the window bits in use then"""
+        return int(self._lib.s2k_ctx_gt_wait(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -993,7 +1017,9 @@ class Engine(_TicketOwner):
         return k1, k2
 
     def generator_window_bits(self) -> int:
-        return int(self._lib.s2k_generator_window_bits())
+        """window bits of the generator tables this context's launches use NOW (gt_info; the library's target width is
+        s2k_generator_window_bits)"""
+        return self.gt_info()["bits"]
 
     def gtable_entry(self, i, d) -> bytes:
         out = np.zeros(64, dtype=np.uint8)

@@ -9,13 +9,13 @@
 #include "sc.h"
 
 // u*G for a plain scalar u (any 256-bit value): GT_WINDOWS table additions
-S2K_DEV pt pt_base_mul(const uint32_t* __restrict__ gt, const uint32_t u_in[8]) {
+S2K_DEV pt pt_base_mul(gt_view gt, const uint32_t u_in[8]) {
   uint32_t u[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) u[i] = u_in[i];
-  pt acc = pt_from_affine(gt_load(gt, 0, gt_next_digit(u)));
+  pt acc = pt_from_affine(gt_load(gt, 0, gt_next_digit(u, gt.bits)));
 #pragma unroll 1
-  for (uint32_t w = 1; w < GT_WINDOWS; ++w) acc = pt_add_mixed(acc, gt_load(gt, w, gt_next_digit(u)));
+  for (uint32_t w = 1; w < gt.windows; ++w) acc = pt_add_mixed(acc, gt_load(gt, w, gt_next_digit(u, gt.bits)));
   return acc;
 }
 

@@ -15,7 +15,10 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include "engine_internal.h"
 #include "fe.h"
@@ -44,18 +47,20 @@ using namespace s2k;
 // (tests/golden/gentable.json).
 // Entry layout: 16 x u32 = X limbs (little-endian words) then Y limbs, 64-byte aligned.
 // ---------------------------------------------------------------------------------------
-// bases[i] = B_i (affine, 16 words) for i < GT_WINDOWS; bases[GT_WINDOWS] = -sum_{i>=1} B_i
-__global__ void k_gen_gtable_bases(uint32_t* __restrict__ bases) {
+// bases[i] = B_i = 2^(bits i) G (affine, 16 words) for i < windows; bases[windows] = -sum_{i>=1} B_i
+__global__ void k_gen_gtable_bases(uint32_t* __restrict__ bases, uint32_t bits, uint32_t windows) {
   apt g;
   g.x = fe_from_limbs(FE_GX);
   g.y = fe_from_limbs(FE_GY);
   pt cur = pt_from_affine(g), sum = pt_identity();
-  for (int i = 0; i <= GT_WINDOWS; ++i) {
+#pragma unroll 1
+  for (uint32_t i = 0; i <= windows; ++i) {
     apt a;
-    if (i < GT_WINDOWS) {
+    if (i < windows) {
       pt_to_affine(a, cur);
       if (i >= 1) sum = pt_add_complete(sum, cur);
-      for (int t = 0; t < GT_BITS; ++t) cur = pt_double_complete(cur);
+#pragma unroll 1
+      for (uint32_t t = 0; t < bits; ++t) cur = pt_double_complete(cur);
     } else {
       pt_to_affine(a, pt_cond_neg(sum, true));
     }
@@ -66,20 +71,20 @@ __global__ void k_gen_gtable_bases(uint32_t* __restrict__ bases) {
     }
   }
 }
-// one lane per entry: m * B_w by a GT_BITS-step double-and-add (m = digit, or digit + 1 for w >= 1)
-__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, const uint32_t* __restrict__ bases) {
+// one lane per entry: m * B_w by a double-and-add of bits + 1 steps (m = digit, or digit + 1 for w >= 1)
+__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, const uint32_t* __restrict__ bases, uint32_t bits, uint32_t windows) {
   size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-  uint32_t window = (uint32_t)(id >> GT_BITS), digit = (uint32_t)id & GT_MASK;
+  uint32_t window = (uint32_t)(id >> bits), digit = (uint32_t)id & ((1u << bits) - 1u);
   apt b;
 #pragma unroll
   for (int w = 0; w < 8; ++w) {
     b.x.v[w] = bases[window * 16 + w];
     b.y.v[w] = bases[window * 16 + 8 + w];
   }
-  uint32_t m = window ? digit + 1 : digit;      // <= 2^GT_BITS
+  uint32_t m = window ? digit + 1 : digit;      // <= 2^bits
   pt acc = pt_identity();
 #pragma unroll 1
-  for (int bit = GT_BITS; bit >= 0; --bit) {
+  for (int bit = (int)bits; bit >= 0; --bit) {
     acc = pt_double_complete(acc);
     pt sum = pt_add_mixed(acc, b);
     acc = pt_select((m >> bit) & 1u, acc, sum);
@@ -88,8 +93,8 @@ __global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, c
     apt c;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-      c.x.v[w] = bases[GT_WINDOWS * 16 + w];
-      c.y.v[w] = bases[GT_WINDOWS * 16 + 8 + w];
+      c.x.v[w] = bases[windows * 16 + w];
+      c.y.v[w] = bases[windows * 16 + 8 + w];
     }
     acc = pt_add_mixed(acc, c);
   }
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, c
 // one signature, complete formulas only (secec/ecdsa.go:392-470)
 S2K_DEV uint8_t verify_complete(size_t idx, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
                                 const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-                                const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+                                gt_view gt, uint32_t* __restrict__ qt, size_t stride) {
   sc r, s;
   uint32_t e_raw[8];
   apt q;
@@ -148,7 +153,7 @@ S2K_DEV uint8_t verify_complete(size_t idx, const uint8_t* __restrict__ pub, con
 __global__ void __launch_bounds__(256)
 k_ecdsa_verify(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig,
                const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-               uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+               uint8_t* __restrict__ out, gt_view gt, uint32_t* __restrict__ qt, size_t stride) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   out[idx] = verify_complete(idx, pub, dig, rsig, ssig, flags, gt, qt, stride);
@@ -189,7 +194,7 @@ S2K_DEV pt29 p29_load(const uint32_t* __restrict__ qt, size_t stride, size_t lan
 static_assert(QT_ENTRIES * 27 <= 8 * 8 * 4, "projective 9x29 table must fit in the lane's table region");
 
 // u1*G + u2*Q (Q affine, on the curve) with complete formulas: the projective result (X : Y : Z)
-S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe29& qy, const uint32_t* __restrict__ gt,
+S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe29& qy, gt_view gt,
                             uint32_t* __restrict__ qt, size_t stride, size_t idx) {
   sc k1, k2;
   bool neg1, neg2;
@@ -241,8 +246,8 @@ S2K_DEV pt29 dsm_complete29(const sc& u1, const sc& u2, const fe29& qx, const fe
 #pragma unroll
     for (int w = 0; w < 8; ++w) u[w] = u1.v[w];
 #pragma unroll 1
-    for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
-      apt g = gt_load(gt, w, gt_next_digit(u));
+    for (uint32_t w = 0; w < gt.windows; ++w) {
+      apt g = gt_load(gt, w, gt_next_digit(u, gt.bits));
       acc = pt29_add_mixed(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
   }
@@ -258,7 +263,7 @@ constexpr uint32_t WL_TAG_LIMIT = 1u << 30, WL_INDEX_MASK = WL_TAG_LIMIT - 1u, W
 // (`key`: the 64 bytes X || Y of the signature's public key)
 S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, const uint8_t* __restrict__ dig,
                                   const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, uint32_t flags,
-                                  const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride, size_t lane,
+                                  gt_view gt, uint32_t* __restrict__ qt, size_t stride, size_t lane,
                                   uint32_t tag = 0) {
   // idx: the signature; lane: the table column this thread may use (the worklist kernel passes the worklist
   // POSITION, not the signature: the keyed ladder queues signatures in key order, and columns picked by
@@ -305,8 +310,8 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, c
 #pragma unroll
     for (int w = 0; w < 8; ++w) u[w] = u1.v[w];
 #pragma unroll 1
-    for (uint32_t w = 0; w < GT_WINDOWS; ++w) {
-      apt g = gt_load(gt, w, gt_next_digit(u));
+    for (uint32_t w = 0; w < gt.windows; ++w) {
+      apt g = gt_load(gt, w, gt_next_digit(u, gt.bits));
       acc = pt29_add_mixed(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
     acc = pt29_double(acc);
@@ -316,8 +321,8 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, c
     for (int w = 0; w < 8; ++w) u[w] = u1.v[w];
     uint32_t digit = 0;
 #pragma unroll 1
-    for (uint32_t w = 0; w < GT_WINDOWS; ++w) digit = gt_next_digit(u);
-    apt g = gt_load(gt, GT_WINDOWS - 1, digit);
+    for (uint32_t w = 0; w < gt.windows; ++w) digit = gt_next_digit(u, gt.bits);
+    apt g = gt_load(gt, gt.windows - 1, digit);
     acc.x = fe29_from_words(g.x.v);
     acc.y = fe29_from_words(g.y.v);
     acc.z = fe29_one();
@@ -340,7 +345,7 @@ S2K_DEV uint8_t verify_complete29(size_t idx, const uint8_t* __restrict__ key, c
 __global__ void __launch_bounds__(256)
 k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ pub,
                   const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
-                  uint32_t flags, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt,
+                  uint32_t flags, uint8_t* __restrict__ out, gt_view gt, uint32_t* __restrict__ qt,
                   size_t stride) {
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -353,7 +358,7 @@ k_verify_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restr
 __global__ void __launch_bounds__(256)
 k_verify_fallback_keyset(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ keys,
                          const uint32_t* __restrict__ kidx, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
-                         const uint8_t* __restrict__ ssig, uint32_t flags, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt,
+                         const uint8_t* __restrict__ ssig, uint32_t flags, uint8_t* __restrict__ out, gt_view gt,
                          uint32_t* __restrict__ qt, size_t stride) {
   uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -549,20 +554,20 @@ S2K_DEV uint32_t ds4_next(digit_stream4& d) {
 // on the way (or u1 = 0) leaves Z = 0, which the ladder's final addition passes on to the worklist.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_generator_part(uint32_t first, uint32_t n, const uint32_t* __restrict__ prep, const uint32_t* __restrict__ gt,
+k_generator_part(uint32_t first, uint32_t n, const uint32_t* __restrict__ prep, gt_view gt,
                  uint32_t* __restrict__ gp, size_t stride) {
   size_t idx = (size_t)first + (size_t)blockIdx.x * 256 + threadIdx.x;   // signatures [first, n)
   if (idx >= n) return;
   uint32_t u[8];
 #pragma unroll
   for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + idx];
-  apt g = gt_load(gt, 0, gt_next_digit(u));
+  apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
   xyzz29 xa = xyzz29_from_affine(fe29_from_words(g.x.v), fe29_from_words(g.y.v));   // XYZZ additions, as in the keyed ladder
-  g = gt_load(gt, 1, gt_next_digit(u));
+  g = gt_load(gt, 1, gt_next_digit(u, gt.bits));
 #pragma unroll 1
-  for (uint32_t w = 1; w < GT_WINDOWS; ++w) {
+  for (uint32_t w = 1; w < gt.windows; ++w) {
     const fe29 gx = fe29_from_words(g.x.v), gy = fe29_from_words(g.y.v);
-    if (w + 1 < GT_WINDOWS) g = gt_load(gt, w + 1, gt_next_digit(u));   // in flight during this addition
+    if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));   // in flight during this addition
     xa = xyzz29_add_affine(xa, gx, gy);
   }
   const jpt29 acc = xyzz29_to_jacobian(xa);
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(256, (MODE == MODE_ECDSA_KEYSET_JOINT || MODE 
 #endif
 k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig,
               const uint32_t* __restrict__ prep, uint32_t* __restrict__ qt, uint32_t* __restrict__ fin,
-              const uint32_t* __restrict__ gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
+              gt_view gt, uint8_t* __restrict__ out, uint32_t* __restrict__ wl_count,
               uint32_t* __restrict__ wl, size_t stride, uint8_t* __restrict__ out_pts, uint64_t* __restrict__ clk,
               key_groups kg) {
   constexpr bool SKS = MODE >= MODE_SCHNORR_KEYSET && MODE <= MODE_SCHNORR_KEYSET_JOINT6;   // BIP-340 over a key set
@@ -914,12 +919,12 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
 #pragma unroll
     for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
 #pragma unroll 1
-    for (uint32_t w = 0; w + 1 < GT_WINDOWS; ++w) {
-      apt g = gt_load(gt, w, gt_next_digit(u));
+    for (uint32_t w = 0; w + 1 < gt.windows; ++w) {
+      apt g = gt_load(gt, w, gt_next_digit(u, gt.bits));
       acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
     {   // the last addition apart: whether Z was 0 before it is what the verdict code needs to know
-      apt g = gt_load(gt, GT_WINDOWS - 1, gt_next_digit(u));
+      apt g = gt_load(gt, gt.windows - 1, gt_next_digit(u, gt.bits));
       if constexpr (ECDSA) final_only = !fe29_is_zero(acc.z);
       acc = jpt29_add_affine(acc, fe29_from_words(g.x.v), fe29_from_words(g.y.v));
     }
@@ -1114,7 +1119,7 @@ k_schnorr_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __rest
 // SchnorrPublicKey.Verify (schnorr.go:221-253) with complete formulas
 S2K_DEV uint8_t schnorr_verify_complete(size_t idx, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
                                         const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs,
-                                        uint32_t msg_len, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt,
+                                        uint32_t msg_len, gt_view gt, uint32_t* __restrict__ qt,
                                         size_t stride) {
   sc s, e;
   bool ok = schnorr_parse(idx, pk, sig, msgs, offs, msg_len, s, e);
@@ -1142,7 +1147,7 @@ __global__ void __launch_bounds__(256)
 k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                    const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig, const uint8_t* __restrict__ msgs,
                    const uint64_t* __restrict__ offs, uint32_t msg_len, uint8_t* __restrict__ out,
-                   const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+                   gt_view gt, uint32_t* __restrict__ qt, size_t stride) {
   // all_n != 0: diagnostic mode, every signature through the complete path
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -1154,7 +1159,7 @@ k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
 // RecoverPublicKey (ecdsa.go:244-282) for one item with complete formulas
 S2K_DEV uint8_t recover_complete(size_t idx, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
                                  const uint8_t* __restrict__ ssig, const uint8_t* __restrict__ recid,
-                                 uint8_t* __restrict__ out_pts, const uint32_t* __restrict__ gt,
+                                 uint8_t* __restrict__ out_pts, gt_view gt,
                                  uint32_t* __restrict__ qt, size_t stride) {
   sc r, s;
   uint32_t e_raw[8];
@@ -1198,7 +1203,7 @@ __global__ void __launch_bounds__(256)
 k_recover_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                    const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
                    const uint8_t* __restrict__ recid, uint8_t* __restrict__ ok_out, uint8_t* __restrict__ out_pts,
-                   const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride) {
+                   gt_view gt, uint32_t* __restrict__ qt, size_t stride) {
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
     size_t idx = all_n ? w : wl[w];
@@ -1230,7 +1235,7 @@ S2K_DEV bool lift_x29(fe29& x, fe29& y, const uint32_t xw[8], bool want_odd) {
 __global__ void __launch_bounds__(256)
 k_schnorr_worklist(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ pk,
                    const uint8_t* __restrict__ sig, const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs,
-                   uint32_t msg_len, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt,
+                   uint32_t msg_len, uint8_t* __restrict__ out, gt_view gt, uint32_t* __restrict__ qt,
                    size_t stride) {
   const uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -1261,7 +1266,7 @@ k_schnorr_worklist(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
 __global__ void __launch_bounds__(256)
 k_recover_worklist(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, const uint8_t* __restrict__ dig,
                    const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig, const uint8_t* __restrict__ recid,
-                   uint8_t* __restrict__ ok_out, uint8_t* __restrict__ out_pts, const uint32_t* __restrict__ gt,
+                   uint8_t* __restrict__ ok_out, uint8_t* __restrict__ out_pts, gt_view gt,
                    uint32_t* __restrict__ qt, size_t stride) {
   const uint32_t count = *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -1364,7 +1369,7 @@ template <bool ALL>
 __global__ void __launch_bounds__(256)
 k_point_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count;
   if constexpr (ALL) count = n; else count = *wl_count;
@@ -1487,7 +1492,7 @@ static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const ui
     launch_prep(ctx->s_aux);
     HIP_TRY(ctx, hipGetLastError());
     if (n_first && !gp_in_prep) {
-      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gtable, gp, stride);
+      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, s2k_internal_gt(ctx), gp, stride);
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -1520,7 +1525,7 @@ static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const ui
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
   }
   if (n_first < n) {
-    k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gtable, gp, stride);
+    k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, s2k_internal_gt(ctx), gp, stride);
     HIP_TRY(ctx, hipGetLastError());
   }
   return S2K_OK;
@@ -1565,7 +1570,7 @@ const char* s2k_version(void) { return "secp256k1_voi_amd 0.4 (gfx950)"; }
 #define S2K_BUILD_FLAGS ""
 #endif
 const char* s2k_build_config(void) {
-  return "GT_BITS=" S2K_STR(S2K_GT_BITS) " PREP_M=" S2K_STR(S2K_PREP_M)
+  return "GT_BITS=" S2K_STR(S2K_GT_BITS) " GT_BITS_FIRST=" S2K_STR(S2K_GT_BITS_FIRST) " PREP_M=" S2K_STR(S2K_PREP_M)
          " QT_PACK=" S2K_STR(S2K_QT_PACK) " FAST_WAVES=" S2K_STR(S2K_FAST_WAVES) " STRIDE_PAD=" S2K_STR(S2K_STRIDE_PAD)
          " flags=[" S2K_BUILD_FLAGS "]";
 }
@@ -1607,7 +1612,12 @@ size_t s2k_ecdsa_workspace_bytes(size_t n) {
 }
 size_t s2k_ctx_device_bytes(const s2k_ctx* ctx, size_t n) {
   if (!ctx) return 0;
-  size_t total = GT_ENTRIES * 64 + s2k_ecdsa_workspace_bytes(n);
+  size_t total = s2k_ecdsa_workspace_bytes(n);
+  {
+    uint64_t info[4] = {0, 0, 0, 0};
+    (void)s2k_ctx_gt_info(const_cast<s2k_ctx*>(ctx), info);
+    total += (size_t)info[3] + (info[2] ? gt_bytes_of((int)info[1]) : 0);   // the tables held, and the one being built
+  }
   if (ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH) total += s2k_internal_key_bytes(ctx, n);
   return total;
 }
@@ -1627,55 +1637,236 @@ __attribute__((visibility("hidden"))) int s2k_internal_ensure_ws(s2k_ctx* ctx, s
   return S2K_OK;
 }
 
-// The resident generator tables (40 GiB, read-only once built) are shared by the contexts of a device: a second context
-// - one per goroutine / thread is the intended use, INTEGRATION.md - neither rebuilds nor holds another copy.  Reference
-// counted per device under a mutex; the last context to go frees them.
+// The resident generator tables are shared by the contexts of a device (one context per goroutine / thread is the intended
+// use): per device one registry, reference counted, the last context to go frees it.  Since round 5 a
+// registry holds tables of SEVERAL widths:
+//   * the first table (GT_BITS_FIRST = 20 bits, 0.8 GiB) is built inside the first s2k_ctx_create: < 0.1 s to a usable context;
+//   * an automatic context then starts ONE background thread per device that allocates and builds the wide table
+//     (GT_BITS_TARGET = 26 bits / 40 GiB when the device has twice that free and the budget allows, else 24 / 11 GiB, else 22 /
+//     3 GiB, else nothing) on a stream of its own, beside whatever the contexts are doing; when it is done, the next launch of
+//     every automatic context uses it (s2k_internal_gt: one atomic load per launch).  A failed allocation or build leaves the
+//     contexts on the table they have - context creation no longer depends on 43 GB being free;
+//   * s2k_ctx_create_ex with an explicit width builds exactly that table, synchronously, and uses only it (tests, A/B runs).
+// The reference's analogue is a 510 KiB unpack at package init (point_mul_table.go:75-100).
 namespace {
-struct gtable_slot {
-  uint32_t* table = nullptr;
+struct gtable_dev {
+  std::atomic<uint32_t*> table[GT_BITS_MAX + 1];   // by width; non-null = built and readable
+  std::atomic<int> auto_bits{0};                  // width the automatic contexts use now (0: registry empty)
   int refs = 0;
+  std::atomic<bool> kicked{false};                // an entry point has enqueued its first call on the device (ctx_leave)
+  int target = 0;                                 // width the background build aims for (0: none wanted / none possible)
+  bool building = false, abandoned = false;       // a builder thread is running / was left behind by the last context
+  std::thread builder;
+  char note[200] = {0};                           // why the target is what it is (s2k_ctx_gt_info)
+  gtable_dev() {
+    for (auto& t : table) t.store(nullptr);
+  }
 };
 std::mutex g_gtable_mutex;
-gtable_slot g_gtable[64];
-}  // namespace
-static hipError_t gtable_acquire(int device, uint32_t** out) {
-  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+std::condition_variable g_gtable_cv;              // a builder has finished
+gtable_dev g_gtable[64];
+std::atomic<size_t> g_gt_budget{0};               // s2k_set_generator_table_budget: bytes per device the tables may take (0: by free memory)
+
+// allocate and build the table of `bits` on `stream` (null: the default stream); synchronises that stream
+hipError_t gtable_build(int bits, hipStream_t stream, uint32_t** out) {
+  const uint32_t windows = gt_windows_of(bits);
+  uint32_t *table = nullptr, *bases = nullptr;
+  hipError_t e = hipMalloc((void**)&table, gt_bytes_of(bits));
+  if (e == hipSuccess) e = hipMalloc((void**)&bases, (windows + 1) * 64);
+  if (e == hipSuccess) {
+    k_gen_gtable_bases<<<1, 1, 0, stream>>>(bases, (uint32_t)bits, windows);
+    k_gen_gtable<<<(unsigned)(gt_entries_of(bits) / 256), 256, 0, stream>>>(table, bases, (uint32_t)bits, windows);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (bases) (void)hipFree(bases);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (table) (void)hipFree(table);
+    return e;
+  }
+  *out = table;
+  return hipSuccess;
+}
+
+// the widest of 26 / 24 / 22 (not above GT_BITS_TARGET, above the first table) that fits: twice its size free on the device, so
+// that the tables never take more than half of what is left for key sets, workspaces and other processes; and inside the budget
+int gtable_pick_target(gtable_dev& g) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    snprintf(g.note, sizeof g.note, "hipMemGetInfo failed: staying on %d bits", GT_BITS_FIRST);
+    return 0;
+  }
+  const size_t budget = g_gt_budget.load();
+  for (int bits : {26, 24, 22}) {
+    if (bits > GT_BITS_TARGET || bits <= GT_BITS_FIRST) continue;
+    const size_t need = gt_bytes_of(bits);
+    if (budget && need + gt_bytes_of(GT_BITS_FIRST) > budget) continue;
+    if (free_b < 2 * need) continue;
+    snprintf(g.note, sizeof g.note, "%d-bit windows: %.1f GiB of %.1f GiB free%s", bits, need / 1073741824.0, free_b / 1073741824.0,
+             budget ? " (inside the budget)" : "");
+    return bits;
+  }
+  snprintf(g.note, sizeof g.note, "no wide table fits (%.1f GiB free, budget %.1f GiB): staying on %d bits", free_b / 1073741824.0,
+           budget / 1073741824.0, GT_BITS_FIRST);
+  return 0;
+}
+
+void gtable_builder_main(int device, int bits) {
+  gtable_dev& g = g_gtable[device];
+  uint32_t* table = nullptr;
+  // The allocation of tens of gigabytes holds the runtime's allocator for a second or two, and whatever another thread asks of
+  // the runtime meanwhile (its first call's workspace ...) waits behind it: 0.1-0.3 s from s2k_ctx_create to the first verdict
+  // became 2.3 s whenever the two collided.  So the build starts when the context's first call has been enqueued (ctx_leave),
+  // or after half a second without one.
+  {
+    std::unique_lock<std::mutex> lock(g_gtable_mutex);
+    g_gtable_cv.wait_for(lock, std::chrono::milliseconds(500), [&] { return g.kicked.load() || g.abandoned; });
+    if (g.abandoned) bits = GT_BITS_FIRST;         // the contexts are gone already: nothing to build
+  }
+  hipError_t e = hipSetDevice(device);
+  hipStream_t st = nullptr;
+  if (e == hipSuccess) {
+    int lo = 0, hi = 0;                            // lowest priority: the build yields to verification kernels
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);
+  }
+  int built = 0;
+  while (e == hipSuccess && bits > GT_BITS_FIRST) {   // a failed allocation: the next width down
+    if (gtable_build(bits, st, &table) == hipSuccess) {
+      built = bits;
+      break;
+    }
+    bits -= 2;
+  }
+  if (st) (void)hipStreamDestroy(st);
   std::lock_guard<std::mutex> lock(g_gtable_mutex);
-  gtable_slot& g = g_gtable[device];
-  if (!g.table) {
-    uint32_t *table = nullptr, *bases = nullptr;
-    hipError_t e = hipMalloc((void**)&table, GT_ENTRIES * 64);
-    if (e == hipSuccess) e = hipMalloc((void**)&bases, (GT_WINDOWS + 1) * 64);
-    if (e == hipSuccess) {
-      k_gen_gtable_bases<<<1, 1>>>(bases);
-      k_gen_gtable<<<(unsigned)(GT_ENTRIES / 256), 256>>>(table, bases);
-      e = hipGetLastError();
+  if (g.abandoned) {                                // every context went away meanwhile: nobody wants the table
+    if (table) (void)hipFree(table);
+    g.abandoned = false;
+  } else if (built) {
+    g.table[built].store(table, std::memory_order_release);
+    g.auto_bits.store(built, std::memory_order_release);
+    if (built != g.target) snprintf(g.note, sizeof g.note, "%d-bit windows (the allocation for %d bits failed)", built, g.target);
+    g.target = built;
+  } else {
+    snprintf(g.note, sizeof g.note, "the wide table could not be built: staying on %d bits", GT_BITS_FIRST);
+    g.target = 0;
+  }
+  g.building = false;
+  g_gtable_cv.notify_all();
+}
+}  // namespace
+
+// fixed_bits == 0: the shared automatic tables (first table now, wide table in the background); else exactly that width
+static hipError_t gtable_acquire(int device, int fixed_bits) {
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  std::unique_lock<std::mutex> lock(g_gtable_mutex);
+  gtable_dev& g = g_gtable[device];
+  g_gtable_cv.wait(lock, [&] { return !g.abandoned; });   // a builder left behind by an earlier generation of contexts finishes first
+  const int bits = fixed_bits ? fixed_bits : GT_BITS_FIRST;
+  if (!g.table[bits].load()) {
+    uint32_t* t = nullptr;
+    const hipError_t e = gtable_build(bits, nullptr, &t);
+    if (e != hipSuccess) return e;
+    g.table[bits].store(t, std::memory_order_release);
+  }
+  if (!fixed_bits) {
+    if (g.auto_bits.load() == 0) g.auto_bits.store(GT_BITS_FIRST, std::memory_order_release);
+    if (!g.building && g.target == 0 && g.auto_bits.load() == GT_BITS_FIRST && GT_BITS_TARGET > GT_BITS_FIRST) {
+      g.target = gtable_pick_target(g);
+      if (g.target) {
+        if (g.table[g.target].load()) {             // (built earlier for a context with that explicit width)
+          g.auto_bits.store(g.target, std::memory_order_release);
+        } else {
+          if (g.builder.joinable()) g.builder.join();
+          g.building = true;
+          g.builder = std::thread(gtable_builder_main, device, g.target);
+        }
+      }
     }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (bases) (void)hipFree(bases);
-    if (e != hipSuccess) {
-      if (table) (void)hipFree(table);
-      return e;
-    }
-    g.table = table;
   }
   ++g.refs;
-  *out = g.table;
   return hipSuccess;
 }
 static void gtable_release(int device) {
-  std::lock_guard<std::mutex> lock(g_gtable_mutex);
-  gtable_slot& g = g_gtable[device];
+  std::unique_lock<std::mutex> lock(g_gtable_mutex);
+  gtable_dev& g = g_gtable[device];
   if (g.refs > 0 && --g.refs == 0) {
     (void)hipSetDevice(device);
-    (void)hipFree(g.table);
-    g.table = nullptr;
+    for (auto& t : g.table) {
+      uint32_t* p = t.exchange(nullptr);
+      if (p) (void)hipFree(p);
+    }
+    g.auto_bits.store(0);
+    g.target = 0;
+    g.kicked.store(false);
+    if (g.building) {
+      g.abandoned = true;                           // its table is freed by the builder itself when it is done
+      g_gtable_cv.notify_all();                     // (a builder still waiting for its start signal)
+    }
+    if (g.builder.joinable()) g.builder.detach();
   }
 }
+// the table a launch of this moment uses
+extern "C++" __attribute__((visibility("hidden"))) void s2k_internal_gt_kick(int device) {
+  gtable_dev& g = g_gtable[device];
+  if (g.kicked.load(std::memory_order_relaxed)) return;         // (every call after the first: one relaxed load)
+  g.kicked.store(true);
+  std::lock_guard<std::mutex> lock(g_gtable_mutex);             // (so that the notification cannot fall between the builder's test and its wait)
+  g_gtable_cv.notify_all();
+}
+extern "C++" __attribute__((visibility("hidden"))) gt_view s2k_internal_gt(const s2k_ctx* ctx) {
+  const gtable_dev& g = g_gtable[ctx->device];
+  const int bits = ctx->gt_fixed ? ctx->gt_fixed : g.auto_bits.load(std::memory_order_acquire);
+  gt_view v;
+  v.p = g.table[bits].load(std::memory_order_acquire);
+  v.bits = (uint32_t)bits;
+  v.windows = gt_windows_of(bits);
+  return v;
+}
 
-int s2k_ctx_create(int device_index, s2k_ctx** out) {
+extern "C" {
+// Bytes per device the generator tables of this process may take (0 = no limit but the device's free memory).  Applies to
+// automatic contexts created after the call; the first table (0.8 GiB) is always built.
+void s2k_set_generator_table_budget(size_t bytes) { g_gt_budget.store(bytes); }
+// info[0] = window bits the context's launches use now, [1] = bits the background build aims for (0: none), [2] = 1 while it
+// is running, [3] = bytes of generator tables the device holds for this process
+int s2k_ctx_gt_info(s2k_ctx* ctx, uint64_t info[4]) {
+  if (!ctx || !info) return fail(ctx, S2K_ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lock(g_gtable_mutex);
+  const gtable_dev& g = g_gtable[ctx->device];
+  info[0] = (uint64_t)(ctx->gt_fixed ? ctx->gt_fixed : g.auto_bits.load());
+  info[1] = (uint64_t)(ctx->gt_fixed ? 0 : g.target);
+  info[2] = g.building && !ctx->gt_fixed ? 1 : 0;
+  uint64_t bytes = 0;
+  for (int b = GT_BITS_MIN; b <= GT_BITS_MAX; ++b)
+    if (g.table[b].load()) bytes += gt_bytes_of(b);
+  info[3] = bytes;
+  return S2K_OK;
+}
+const char* s2k_ctx_gt_note(s2k_ctx* ctx) { return ctx ? g_gtable[ctx->device].note : ""; }
+// blocks until the background build of the context's device has ended (either way); returns the window bits in use then
+int s2k_ctx_gt_wait(s2k_ctx* ctx) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  std::unique_lock<std::mutex> lock(g_gtable_mutex);
+  gtable_dev& g = g_gtable[ctx->device];
+  g_gtable_cv.wait(lock, [&] { return !g.building; });
+  return ctx->gt_fixed ? ctx->gt_fixed : g.auto_bits.load();
+}
+}  // extern "C"
+
+int s2k_ctx_create(int device_index, s2k_ctx** out) { return s2k_ctx_create_ex(device_index, 0, 0, out); }
+
+// gt_bits: 0 = automatic (above); 16 .. 26 = exactly that window width for this context's generator tables, built before the
+// call returns.  flags: S2K_CTX_WAIT_TABLES = return only when the background build has ended (a context that must run at
+// full speed from its first call: benchmarks).
+int s2k_ctx_create_ex(int device_index, int gt_bits, uint32_t flags, s2k_ctx** out) {
   if (!out) return fail(nullptr, S2K_ERR_ARG, "s2k_ctx_create: out is NULL");
   *out = nullptr;
+  if (gt_bits != 0 && (gt_bits < 16 || gt_bits > GT_BITS_MAX)) return fail(nullptr, S2K_ERR_ARG, "generator window width %d: 0 (automatic) or 16 .. %d", gt_bits, GT_BITS_MAX);
+  if (flags & ~(uint32_t)S2K_CTX_WAIT_TABLES) return fail(nullptr, S2K_ERR_ARG, "unknown context flags");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(nullptr, S2K_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
@@ -1704,14 +1895,24 @@ int s2k_ctx_create(int device_index, s2k_ctx** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->clk, 64);
   if (e == hipSuccess) e = hipMemset(ctx->clk, 0, 64);
-  if (e == hipSuccess) e = gtable_acquire(device_index, &ctx->gtable);
+  if (e == hipSuccess) {
+    e = gtable_acquire(device_index, gt_bits);
+    if (e == hipSuccess) {
+      ctx->gt_held = true;
+      ctx->gt_fixed = gt_bits;
+    } else if (e == hipErrorOutOfMemory) {
+      (void)fail(nullptr, S2K_ERR_NOMEM, "context creation failed: no device memory for the %d-bit generator tables (%.1f GiB)",
+                 gt_bits ? gt_bits : GT_BITS_FIRST, gt_bytes_of(gt_bits ? gt_bits : GT_BITS_FIRST) / 1073741824.0);
+    }
+  }
   if (e != hipSuccess) {
-    int rc = fail(nullptr, S2K_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+    int rc = e == hipErrorOutOfMemory ? S2K_ERR_NOMEM : fail(nullptr, S2K_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
     if (ctx->clk) (void)hipFree(ctx->clk);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     delete ctx;
     return rc;
   }
+  if (flags & S2K_CTX_WAIT_TABLES) (void)s2k_ctx_gt_wait(ctx);
   *out = ctx;
   return S2K_OK;
 }
@@ -1738,7 +1939,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
     (void)hipDeviceSynchronize();
     (void)hipHostFree(ctx->kga_note);
   }
-  if (ctx->gtable) gtable_release(ctx->device);
+  if (ctx->gt_held) gtable_release(ctx->device);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->rlc_save) (void)hipFree(ctx->rlc_save);
@@ -1876,7 +2077,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     wait_all(st);
     k_ecdsa_verify<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                                   (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
-                                                  ctx->gtable, qt, stride);
+                                                  s2k_internal_gt(ctx), qt, stride);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
@@ -1923,27 +2124,27 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                            k_scalar_prep<<<(Tc + 63) / 64, 64, 0, aux>>>((uint32_t)cnt, Tc, (const uint8_t*)d_dig + lo * 32,
                                                                          (const uint8_t*)d_r + lo * 32, (const uint8_t*)d_s + lo * 32,
                                                                          nullptr, flags, prep + lo, pref + lo, smont + lo, stride);
-                           k_generator_part<<<blocks_for(cnt), 256, 0, aux>>>((uint32_t)lo, (uint32_t)(lo + cnt), prep, ctx->gtable, gp, stride);
+                           k_generator_part<<<blocks_for(cnt), 256, 0, aux>>>((uint32_t)lo, (uint32_t)(lo + cnt), prep, s2k_internal_gt(ctx), gp, stride);
                          }
                        },
                        &kg, /*gp_in_prep=*/arrivals != nullptr);
     if (rc) return rc;
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                                   qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
+                                                                   qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl,
                                                                    stride, nullptr, clk, kg);
     HIP_TRY(ctx, hipGetLastError());
     if (kg.nparts > 1) {   // the other side of the split, once its tables (third stream) are there
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_part1, 0));
       kg.part = 1;
       k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                                     qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
+                                                                     qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl,
                                                                      stride, nullptr, nullptr, kg);
       HIP_TRY(ctx, hipGetLastError());
     }
     prof_mark(ctx, st, 3);
     k_verify_fast<MODE_ECDSA_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                                  qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl,
+                                                                  qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl,
                                                                   stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 4);
@@ -1955,7 +2156,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
-                                                             ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk,
+                                                             s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk,
                                                              key_groups{});
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
@@ -1963,7 +2164,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   }
   k_verify_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
-                                        ctx->gtable, qt, stride);
+                                        s2k_internal_gt(ctx), qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
@@ -2140,7 +2341,7 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
   k_scalar_prep<<<(T + 63) / 64, 64, 0, ctx->s_aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s,
                                                       nullptr, flags, prep, pref, smont, stride);
-  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, ctx->gtable, gp, stride);
+  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, s2k_internal_gt(ctx), gp, stride);
   rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "launch failed");
   key_groups kg{};
   if (rc == S2K_OK) rc = s2k_internal_keyset_sort(ctx, ks->base, ks->n, n, (const uint32_t*)d_key_index, st, &kg);
@@ -2155,21 +2356,21 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   prof_mark(ctx, st, 2);
   if (ks->joint && ks->jw == 6)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT6><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
-                                                                           ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+                                                                           s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else if (ks->joint && ks->jw == 5)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT5><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
-                                                                           ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+                                                                           s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else if (ks->joint)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
-                                                                          ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+                                                                          s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else
-    k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gtable,
+    k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, s2k_internal_gt(ctx),
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   prof_mark(ctx, st, 3);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback_keyset<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, ks->base + off[0], (const uint32_t*)d_key_index,
                                                                     (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s, flags,
-                                                                    (uint8_t*)d_valid, ctx->gtable, qt, stride);
+                                                                    (uint8_t*)d_valid, s2k_internal_gt(ctx), qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 4);
   prof_mark(ctx, st, 5);
@@ -2276,28 +2477,36 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
                 *rid = (const uint8_t*)d_recid;
   if (flags & S2K_ECDSA_FORCE_COMPLETE) {
     k_recover_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, dig, r, s, rid, (uint8_t*)d_ok,
-                                                      (uint8_t*)d_pub65, ctx->gtable, qt, stride);
+                                                      (uint8_t*)d_pub65, s2k_internal_gt(ctx), qt, stride);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
+  // (stage times, s2k_ctx_profile_read_stages: [0] the scalar preparation, [2] the ladder, [3] the shared inversions of the
+  // affine results, [4] the worklist)
+  prof_mark(ctx, st, 0);
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));      // items without a key keep the zero record
-  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, ctx->gtable,
-                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, nullptr,
+  prof_mark(ctx, st, 1);
+  prof_mark(ctx, st, 2);
+  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, s2k_internal_gt(ctx),
+                                                             (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, ctx->prof_on ? ctx->clk : nullptr,
                                                              key_groups{});
   HIP_TRY(ctx, hipGetLastError());
+  prof_mark(ctx, st, 3);
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, fin, (uint8_t*)d_ok, stride,
                                                                  (uint8_t*)d_pub65);
     HIP_TRY(ctx, hipGetLastError());
   }
+  prof_mark(ctx, st, 4);
   k_recover_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, dig, r, s, rid, (uint8_t*)d_ok, (uint8_t*)d_pub65,
-                                                              ctx->gtable, qt, stride);
+                                                              s2k_internal_gt(ctx), qt, stride);
   HIP_TRY(ctx, hipGetLastError());
+  prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
 }
 
@@ -2359,10 +2568,14 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   const uint64_t* offs = (const uint64_t*)d_msg_offsets;
   if (flags & S2K_ECDSA_FORCE_COMPLETE) {
     k_schnorr_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len,
-                                                      (uint8_t*)d_valid, ctx->gtable, qt, stride);
+                                                      (uint8_t*)d_valid, s2k_internal_gt(ctx), qt, stride);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
+  // (stage times, s2k_ctx_profile_read_stages: [0] the front end - challenge hashes, and the grouping and per-key tables when
+  // keys repeat -, [2] the ladder over per-key tables or the general one, [3] what the key tables left + the shared inversions,
+  // [4] the worklist)
+  prof_mark(ctx, st, 0);
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   ctx->kg_counters = nullptr;
   ctx->last_wl_count = wl_count;
@@ -2382,35 +2595,43 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
                        },
                        &kg);
     if (rc) return rc;
-    k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
-                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
+                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, ctx->prof_on ? ctx->clk : nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
     if (kg.nparts > 1) {
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_part1, 0));
       kg.part = 1;
-      k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
+      k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
                                                                        (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
       HIP_TRY(ctx, hipGetLastError());
     }
-    k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
+    k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
   } else {
     k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
     HIP_TRY(ctx, hipGetLastError());
-    k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gtable,
-                                                               (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr,
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
+                                                               (uint8_t*)d_valid, wl_count, wl, stride, nullptr, ctx->prof_on ? ctx->clk : nullptr,
                                                                key_groups{});
     HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
   }
   {
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_SCHNORR><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, sig, fin, (uint8_t*)d_valid, stride, nullptr);
     HIP_TRY(ctx, hipGetLastError());
   }
+  prof_mark(ctx, st, 4);
   k_schnorr_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, pk, sig, msgs, offs, (uint32_t)msg_len,
-                                                              (uint8_t*)d_valid, ctx->gtable, qt, stride);
+                                                              (uint8_t*)d_valid, s2k_internal_gt(ctx), qt, stride);
   HIP_TRY(ctx, hipGetLastError());
+  prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
 }
 
@@ -2486,7 +2707,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
   k_schnorr_prep<<<blocks_for(n), 256, 0, ctx->s_aux>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
-  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, ctx->gtable, gp, stride);
+  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, s2k_internal_gt(ctx), gp, stride);
   rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "launch failed");
   key_groups kg{};
   if (rc == S2K_OK) rc = s2k_internal_keyset_sort(ctx, ks->base, ks->n, n, (const uint32_t*)d_key_index, st, &kg);
@@ -2498,7 +2719,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
   kg.gp = gp;
   kg.jtab = ks->joint;
 #define S2K_SKS_LAUNCH(M) \
-  k_verify_fast<M><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, set_keys, sig, prep, qt, fin, ctx->gtable, (uint8_t*)d_valid, wl_count, wl, stride, \
+  k_verify_fast<M><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, set_keys, sig, prep, qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, \
                                                   nullptr, nullptr, kg)
   if (ks->joint && ks->jw == 6) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT6);
   else if (ks->joint && ks->jw == 5) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT5);
@@ -2513,7 +2734,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
   }
   // (the worklist kernel re-does its lanes from the x-only key: lift_x gives the even-y point whatever the set's Y says)
   k_schnorr_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
-                                                              ctx->gtable, qt, stride);
+                                                              s2k_internal_gt(ctx), qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return ctx_leave(ctx, st);
 }
@@ -2750,14 +2971,17 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_retire(s2k_ctx* ctx,
   }
   if (rc == S2K_OK && sl.timed) {                    // s2k_ctx_ticket_timing: transfer and whole-ticket time on the device's clock
     float h2d = 0, all = 0;
-    if (hipEventSynchronize(sl.t_end) == hipSuccess && hipEventElapsedTime(&h2d, sl.t_begin, sl.t_copied) == hipSuccess &&
-        hipEventElapsedTime(&all, sl.t_begin, sl.t_end) == hipSuccess) {
-      const unsigned i = ctx->pipe_times_n++ % 8u;
-      ctx->pipe_times_ticket[i] = sl.ticket;
+    const hipError_t e0 = hipEventSynchronize(sl.t_end), e1 = hipEventElapsedTime(&h2d, sl.t_begin, sl.t_copied),
+                     e2 = hipEventElapsedTime(&all, sl.t_begin, sl.t_end);
+    const unsigned i = ctx->pipe_times_n++ % 8u;
+    ctx->pipe_times_ticket[i] = sl.ticket;
+    if (e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess) {
       ctx->pipe_times_ms[i][0] = h2d;
       ctx->pipe_times_ms[i][1] = all;
-    } else {
+    } else {                                           // no times for this ticket: the runtime's codes, negated, say why
       (void)hipGetLastError();
+      ctx->pipe_times_ms[i][0] = -(float)(e1 != hipSuccess ? e1 : e0);
+      ctx->pipe_times_ms[i][1] = -(float)(e2 != hipSuccess ? e2 : e0);
     }
   }
   sl.timed = false;
@@ -3100,7 +3324,7 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
   uint32_t* status = (uint32_t*)(io + o_status);
   if (impl == S2K_IMPL_COMPLETE) {
     k_point_fallback<true><<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_out,
-                                                          ctx->gtable, qt, stride, status);
+                                                          s2k_internal_gt(ctx), qt, stride, status);
     HIP_TRY(ctx, hipGetLastError());
   } else {
     HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
@@ -3108,14 +3332,14 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
     k_hot_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_pub, prep, stride, wl_count, wl,
                                               status);
     HIP_TRY(ctx, hipGetLastError());
-    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, fin, ctx->gtable,
+    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, fin, s2k_internal_gt(ctx),
                                                              io + o_ok, wl_count, wl, stride, io + o_out, nullptr, key_groups{});
     HIP_TRY(ctx, hipGetLastError());
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, fin, io + o_ok, stride, io + o_out);
     HIP_TRY(ctx, hipGetLastError());
     k_point_fallback<false><<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts,
-                                                                     io + o_out, ctx->gtable, qt, stride, status);
+                                                                     io + o_out, s2k_internal_gt(ctx), qt, stride, status);
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t h_status = 0;

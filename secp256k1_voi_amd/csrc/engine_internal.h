@@ -20,25 +20,36 @@ using namespace s2k;
 constexpr uint32_t KG_MAX_TABLES_DEFAULT = 1u << 22;
 
 // ---- generator tables (layout: engine.hip) ----
+// The window width is a RUNTIME property of a table since round 5: a context starts on a narrow table
+// that is built while it is created (S2K_GT_BITS_FIRST: 20 bits, 0.8 GiB, < 0.1 s) and moves to the wide one when a background
+// thread has built it (S2K_GT_BITS: the width an automatic context aims for when the device has the memory; else 24, else 22).
+// Same-box A/B on MI355X, ms per 2^20 verifications / table size / time to build: round 3, ungrouped flow (tools/ab_gtbits.sh)
+// 16 bits 9.21 / 64 MiB / 0.05 s, 20 bits 9.10 / 0.8 GiB, 22 bits 9.04 / 3 GiB / 0.3 s, 24 bits 9.03 / 11 GiB / 0.9 s; end of
+// round 4, grouped flow (tools/gpu_gtbits_keyset.sh): 22 / 24 / 26 bits 4.95-4.97 / 4.97 / 4.85-4.87 ms, key set with 5-bit
+// joint tables 2.46-2.47 / 2.42 / 2.41-2.42 ms.  26 bits are TEN windows (nine would take 29 bits and 309 GB): 40 GiB per device,
+// shared by the contexts of a process, 3.1 s to build - which no caller waits for any more.
 #ifndef S2K_GT_BITS
-// Window width of the resident generator tables.  Same-box A/B on MI355X (tools/ab_gtbits.sh, ms per
-// 2^20 verifications / table size / context creation): 16 bits 9.21 / 64 MiB / 0.05 s, 20 bits 9.10 /
-// 0.8 GiB, 22 bits 9.04 / 3 GiB / 0.3 s, 24 bits 9.03 / 11 GiB / 0.9 s.  Grouped flow, end of round 3 (generator part
-// on the second stream, tools/gpu_variant_ab.sh): 22 bits 5.05 ms, 24 bits 5.05 ms - one addition fewer hides nowhere.
-// End of round 4 (tools/gpu_gtbits_keyset.sh, two runs each on one box): 22 / 24 / 26 bits - grouped step 4.95-4.97 /
-// 4.97 / 4.85-4.87 ms, key set with 5-bit joint tables 2.46-2.47 / 2.42 / 2.41-2.42 ms.  26 bits are TEN windows (the next
-// step down, nine, would take 29 bits and 309 GB): two additions fewer than 22 bits, 40 GiB of tables per device (shared by
-// the contexts of a process), 2.8 s to build at context creation.  HBM capacity is what this engine spends: 26 it is.
 #define S2K_GT_BITS 26
 #endif
-constexpr int GT_BITS = S2K_GT_BITS;
-constexpr int GT_WINDOWS = (256 + GT_BITS - 1) / GT_BITS;
-constexpr uint32_t GT_MASK = (1u << GT_BITS) - 1u;
-constexpr size_t GT_ENTRIES = (size_t)GT_WINDOWS << GT_BITS;
-static_assert(GT_BITS >= 8 && GT_BITS <= 26, "generator window width out of range");   // (26 bits: 10 windows, 43 GB)
+#ifndef S2K_GT_BITS_FIRST
+#define S2K_GT_BITS_FIRST 20
+#endif
+constexpr int GT_BITS_TARGET = S2K_GT_BITS, GT_BITS_FIRST = S2K_GT_BITS_FIRST, GT_BITS_MIN = 8, GT_BITS_MAX = 26;
+static_assert(GT_BITS_TARGET >= GT_BITS_MIN && GT_BITS_TARGET <= GT_BITS_MAX, "generator window width out of range");   // (26 bits: 10 windows, 43 GB)
+static_assert(GT_BITS_FIRST >= GT_BITS_MIN && GT_BITS_FIRST <= GT_BITS_MAX, "first generator window width out of range");
+inline constexpr uint32_t gt_windows_of(int bits) { return (uint32_t)((256 + bits - 1) / bits); }
+inline constexpr size_t gt_entries_of(int bits) { return (size_t)gt_windows_of(bits) << bits; }
+inline constexpr size_t gt_bytes_of(int bits) { return gt_entries_of(bits) * 64; }
 
-S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit) {
-  const uint4* p = reinterpret_cast<const uint4*>(gt + ((((size_t)window << GT_BITS) | digit) << 4));
+// what a kernel gets: the table and its geometry, by value (a call may see the narrow table in one launch and the wide one
+// in the next: every launch is consistent in itself, and the tables hold the same group elements)
+struct gt_view {
+  const uint32_t* p;
+  uint32_t bits, windows;
+};
+
+S2K_DEV apt gt_load(const gt_view& gt, uint32_t window, uint32_t digit) {
+  const uint4* p = reinterpret_cast<const uint4*>(gt.p + ((((size_t)window << gt.bits) | digit) << 4));
   uint4 a = p[0], b = p[1], c = p[2], d = p[3];
   apt r;
   r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
@@ -47,12 +58,12 @@ S2K_DEV apt gt_load(const uint32_t* __restrict__ gt, uint32_t window, uint32_t d
   r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
   return r;
 }
-// next GT_BITS-wide digit of a 256-bit scalar held in u[0..7] (consumed from the bottom)
-S2K_DEV uint32_t gt_next_digit(uint32_t u[8]) {
-  uint32_t d = u[0] & GT_MASK;
+// next digit (`bits` wide, 8 .. 26) of a 256-bit scalar held in u[0..7] (consumed from the bottom)
+S2K_DEV uint32_t gt_next_digit(uint32_t u[8], uint32_t bits) {
+  uint32_t d = u[0] & ((1u << bits) - 1u);
 #pragma unroll
-  for (int i = 0; i < 7; ++i) u[i] = (u[i] >> GT_BITS) | (u[i + 1] << (32 - GT_BITS));
-  u[7] >>= GT_BITS;
+  for (int i = 0; i < 7; ++i) u[i] = (u[i] >> bits) | (u[i + 1] << (32u - bits));
+  u[7] >>= bits;
   return d;
 }
 
@@ -75,7 +86,8 @@ S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
 // ---- host side ----
 struct s2k_ctx {
   int device = -1;
-  uint32_t* gtable = nullptr;
+  bool gt_held = false;         // this context holds a reference on its device's generator tables (gtable_acquire)
+  int gt_fixed = 0;             // s2k_ctx_create_ex with an explicit width: only the table of that width is used (0: the widest ready)
   void* ws = nullptr;           // workspace of the verification path
   size_t ws_bytes = 0;
   void* msm_ws = nullptr;       // workspace of the multi-scalar multiplication
@@ -182,6 +194,8 @@ struct s2k_ctx {
 // engine.hip), so an index with bit 30 set must never reach them.
 constexpr size_t S2K_MAX_BATCH = (size_t)1 << 30;
 
+gt_view s2k_internal_gt(const s2k_ctx* ctx);   // engine.hip: the generator table a launch of this moment uses
+
 inline thread_local char g_err[512];
 
 inline int fail(s2k_ctx* ctx, int code, const char* fmt, ...) {
@@ -226,7 +240,9 @@ inline int ctx_enter(s2k_ctx* ctx, hipStream_t st) {
   if (ctx->have_last && ctx->last_stream != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_done, 0));
   return S2K_OK;
 }
+void s2k_internal_gt_kick(int device);      // engine.hip: a call has been enqueued on the device (the background table build may start)
 inline int ctx_leave(s2k_ctx* ctx, hipStream_t st) {
+  s2k_internal_gt_kick(ctx->device);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
   ctx->last_stream = st;
   ctx->have_last = true;

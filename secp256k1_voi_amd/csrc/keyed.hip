@@ -557,6 +557,82 @@ k_key_scale(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t
   }
 }
 
+// The same pass with ONE LANE PER ENTRY (round 5, VERDICT r04 next #4a).  The lane-per-chunk form above walks its eight
+// entries one after the other - eight dependent round trips to memory per lane, 0.44 ms for 2^16 keys at 0.22 of the issue
+// slots and 2.7 TB/s: bound by neither.  Here a lane loads its entry at once, the factor of entry j - (W / Z_total) times
+// H_(j+1) ... H_7 - comes from a suffix product over the eight lanes of the chunk (three products on lane-shifted copies,
+// row_shl:1 / 2 / 4), and a wave reads and writes 8 KiB of consecutive entries.  Nine products per entry instead of six,
+// no dependence between entries.
+template <int N>
+S2K_DEV fe29 fe29_group_shl(const fe29& a, bool keep) {     // lane j of a group of eight reads lane j + N; `keep` false: one
+  fe29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.n[i], 0x100 + N, 0xF, 0xF, true);   // row_shl:N
+    r.n[i] = keep ? v : (i == 0 ? 1u : 0u);
+  }
+  return r;
+}
+template <int CHUNKS>
+__global__ void __launch_bounds__(256)
+k_key_scale_wide(const uint32_t* __restrict__ counters, uint32_t max_tables, uint32_t part, uint32_t nparts, uint4* __restrict__ ktab) {
+  // A wave's 64 entries are 8 KiB of consecutive memory.  They come in and go out as eight 1 KiB wave accesses (lane i takes
+  // quad i of the block: 64 lanes x 16 bytes in a row) through the wave's own 8 KiB of LDS, where lane l then finds ITS entry
+  // (quad k of entry e sits at e * 8 + ((k + e) & 7): the lanes' 128-byte rows are skewed against the banks).  Lane-per-entry
+  // loads straight from memory - 64 lines touched by every one of 7 load instructions - were no faster than the
+  // lane-per-chunk walk (0.46 against 0.44 ms for 2^16 keys).
+  __shared__ uint4 stage[4][64 * 8];
+  constexpr uint32_t PER_KEY = CHUNKS * 8;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const size_t id0 = (size_t)blockIdx.x * 256 + wave * 64;
+  uint32_t lo, hi;
+  table_range(counters, max_tables, part, nparts, lo, hi);
+  const size_t t = lo + id0 / PER_KEY;
+  const uint32_t e0 = (uint32_t)(id0 % PER_KEY), c = (e0 + lane) >> 3, j = lane & 7u;
+  if (t >= hi) return;                                    // (whole waves: 64 divides the entries of a key)
+  uint4* kt = ktab + t * (kt_geom<CHUNKS>::SLOTS * 8);
+  uint4* blk = kt + (size_t)e0 * 8;
+  uint4* sh = stage[wave];
+#pragma unroll
+  for (uint32_t q = 0; q < 8; ++q) {
+    const uint32_t i = q * 64 + lane, e = i >> 3, kq = i & 7u;
+    sh[e * 8 + ((kq + e) & 7u)] = blk[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the wave's LDS operations complete in order; nothing crosses waves)
+  uint4 qd[7];
+#pragma unroll
+  for (uint32_t kq = 0; kq < 7; ++kq) qd[kq] = sh[lane * 8 + ((kq + lane) & 7u)];
+  fe29 x, y, h;
+  x.n[0] = qd[0].x; x.n[1] = qd[0].y; x.n[2] = qd[0].z; x.n[3] = qd[0].w; x.n[4] = qd[1].x; x.n[5] = qd[1].y; x.n[6] = qd[1].z; x.n[7] = qd[1].w;
+  y.n[0] = qd[2].x; y.n[1] = qd[2].y; y.n[2] = qd[2].z; y.n[3] = qd[2].w; y.n[4] = qd[3].x; y.n[5] = qd[3].y; y.n[6] = qd[3].z; y.n[7] = qd[3].w;
+  h.n[0] = qd[4].x; h.n[1] = qd[4].y; h.n[2] = qd[4].z; h.n[3] = qd[4].w; h.n[4] = qd[5].x; h.n[5] = qd[5].y; h.n[6] = qd[5].z; h.n[7] = qd[5].w;
+  x.n[8] = qd[6].x;
+  y.n[8] = qd[6].y;
+  h.n[8] = qd[6].z;
+  const fe29 co = scr_load<CHUNKS>(kt, (int)c);            // W / Z_total of the chunk (k_key_cofactors)
+  fe29 s = fe29_group_shl<1>(h, j < 7);                    // a_j = H_(j+1), a_7 = 1
+  s = fe29_mul(s, fe29_group_shl<1>(s, j < 7));
+  s = fe29_mul(s, fe29_group_shl<2>(s, j < 6));
+  s = fe29_mul(s, fe29_group_shl<4>(s, j < 4));            // H_(j+1) ... H_7
+  const fe29 rr = fe29_mul(co, s);
+  const fe29 r2 = fe29_sqr(rr), r3 = fe29_mul(r2, rr);
+  const fe29 xs = fe29_mul(x, r2), ys = fe29_mul(y, r3);
+  const fe29 bx = fe29_mul(xs, fe29_from_words(FE_BETA));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every lane has read its entry before any lane overwrites the block
+  const uint4 out[8] = {make_uint4(xs.n[0], xs.n[1], xs.n[2], xs.n[3]), make_uint4(xs.n[4], xs.n[5], xs.n[6], xs.n[7]),
+                        make_uint4(ys.n[0], ys.n[1], ys.n[2], ys.n[3]), make_uint4(ys.n[4], ys.n[5], ys.n[6], ys.n[7]),
+                        make_uint4(bx.n[0], bx.n[1], bx.n[2], bx.n[3]), make_uint4(bx.n[4], bx.n[5], bx.n[6], bx.n[7]),
+                        make_uint4(xs.n[8], ys.n[8], bx.n[8], 0u), make_uint4(0u, 0u, 0u, 0u)};
+#pragma unroll
+  for (uint32_t kq = 0; kq < 8; ++kq) sh[lane * 8 + ((kq + lane) & 7u)] = out[kq];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (uint32_t q = 0; q < 8; ++q) {
+    const uint32_t i = q * 64 + lane, e = i >> 3, kq = i & 7u;
+    blk[i] = sh[e * 8 + ((kq + e) & 7u)];
+  }
+}
+
 // Grouping for the BIP-340 whole-batch check: EVERY key forms a group; groups of more than
 // KG_VGROUP signatures are cut into virtual groups of that size (each gets its own term: the lane that
 // sums a group's coefficients walks its members one by one).  vslot[t]: slot of virtual group t,
@@ -740,13 +816,15 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
                                                                   uint32_t nparts, hipEvent_t ev_after_odd) {
   uint4* ktab = const_cast<uint4*>(g->ktab);
   const size_t max_tables = g->max_tables;
+  static const bool scale_old = getenv("S2K_KEY_SCALE_OLD") != nullptr;   // A/B hook: the lane-per-chunk scaling pass of rounds 3 and 4
   if (g->chunks == KS_CHUNKS) {
     k_key_odd<KS_CHUNKS><<<blocks_for(max_tables * KS_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
     HIP_TRY(ctx, hipGetLastError());
     if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
     k_key_cofactors<KS_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
     HIP_TRY(ctx, hipGetLastError());
-    k_key_scale<KS_CHUNKS><<<blocks_for(max_tables * KS_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+    if (scale_old) k_key_scale<KS_CHUNKS><<<blocks_for(max_tables * KS_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+    else k_key_scale_wide<KS_CHUNKS><<<blocks_for(max_tables * KS_CHUNKS * 8), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
     HIP_TRY(ctx, hipGetLastError());
     return S2K_OK;
   }
@@ -755,7 +833,8 @@ __attribute__((visibility("hidden"))) int s2k_internal_key_tables(s2k_ctx* ctx, 
   if (ev_after_odd) HIP_TRY(ctx, hipEventRecord(ev_after_odd, st));
   k_key_cofactors<KT_CHUNKS><<<(unsigned)((max_tables + 63) / 64), 64, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
-  k_key_scale<KT_CHUNKS><<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+  if (scale_old) k_key_scale<KT_CHUNKS><<<blocks_for(max_tables * KT_CHUNKS), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
+  else k_key_scale_wide<KT_CHUNKS><<<blocks_for(max_tables * KT_CHUNKS * 8), 256, 0, st>>>(g->counters, g->max_tables, part, nparts, ktab);
   HIP_TRY(ctx, hipGetLastError());
   return S2K_OK;
 }

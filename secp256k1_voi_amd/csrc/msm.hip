@@ -795,11 +795,12 @@ __global__ void __launch_bounds__(64) k_msm_final(msm_geom g, uint32_t* __restri
 //   k_msm_planes       level 2, ONE WAVE per addition (fe29r.h: the operations are few and wait for each other): a workgroup
 //                      of 16 waves per (weighted sum, bit): 8 members per wave, then a tree through LDS -> lvl[PL ..)
 //   k_msm_plane_horner one wave per weighted sum: sum_b 2^b plane_b -> lvl[WS ..)
-//   k_msm_final16      Horner over the 16 half-windows (120 doublings, 16 additions) on one wave, row arithmetic
+//   k_msm_final16      S_w = 256 RW_w + CW_w on eight waves side by side, then Horner over the windows (112 doublings, 7 additions)
+//                      on one wave, row arithmetic
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t FOLD_NROWS = 1152, FOLD_NBLK = 9, FOLD_COL0 = FOLD_NROWS, FOLD_PL0 = FOLD_COL0 + FOLD_NBLK * 256;   // 3456
 constexpr uint32_t FOLD_NWS = 17, FOLD_BITS = 9, FOLD_WS0 = FOLD_PL0 + FOLD_NWS * FOLD_BITS, FOLD_END = FOLD_WS0 + FOLD_NWS;
-constexpr uint32_t FOLD_ROW_BLOCKS = FOLD_NROWS / 2, FOLD_COL_BLOCKS = FOLD_NBLK * 32;
+constexpr uint32_t FOLD_ROW_BLOCKS = FOLD_NROWS / 2, FOLD_COL_BLOCKS = FOLD_NBLK * 64;
 
 // The narrow levels of a workgroup's trees: `groups` independent sums whose partials lie in LDS, partial i of group g in slot
 // g * GS + i * IS.  From 64 additions per level down a lane per addition would leave three quarters of the workgroup idle
@@ -816,7 +817,7 @@ S2K_DEV void fold_quad_tree(uint32_t* sh, uint32_t groups, uint32_t GS, uint32_t
   }
   __syncthreads();
 }
-__global__ void __launch_bounds__(256, 4)      // all 864 workgroups resident at once (4 waves per SIMD: 128 registers)
+__global__ void __launch_bounds__(256, 4)      // 128 registers: 4 waves per SIMD, 1024 of the 1152 workgroups resident at once
 k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ lvl, size_t lstride) {
   __shared__ uint32_t sh[PT_WORDS * 128];
   const uint32_t t = threadIdx.x;
@@ -834,20 +835,20 @@ k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restric
     fold_quad_tree(sh, 2, 64, 1, 32, t);
     if (t < 2) pt_store(lvl, lstride, 2 * blockIdx.x + t, pt_load(sh, 128, t * 64));
   } else {
-    // block of 128 rows x 8 columns: thread (hg, lc) sums rows 4 hg .. 4 hg + 3 of column 8 lb + lc; the tree over hg: one
-    // level a lane per addition (128 additions), then 128 partials in LDS (slot 8 hg + lc) and four levels by quads
-    const uint32_t cb = blockIdx.x - FOLD_ROW_BLOCKS, blk = cb >> 5, lb = cb & 31u, hg = t >> 3, lc = t & 7u;
-    const size_t k0 = ((size_t)blk * 128 + 4 * hg) * 256 + 8 * lb + lc;
+    // block of 128 rows x 4 columns: thread (hg, lc) sums rows 2 hg, 2 hg + 1 of column 4 lb + lc; the tree over the 64 hg:
+    // one level a lane per addition (128 additions), then 128 partials in LDS (slot 4 hg + lc) and five levels by quads.
+    // (Eight columns and four rows per thread had two more additions on every lane's chain: the column blocks ended 15 us
+    // after the row blocks.)
+    const uint32_t cb = blockIdx.x - FOLD_ROW_BLOCKS, blk = cb >> 6, lb = cb & 63u, hg = t >> 2, lc = t & 3u;
+    const size_t k0 = ((size_t)blk * 128 + 2 * hg) * 256 + 4 * lb + lc;
     pt29 acc = pt29_add(pt_load(sums, stride, k0), pt_load(sums, stride, k0 + 256));
-#pragma unroll 1
-    for (uint32_t i = 2; i < 4; ++i) acc = pt29_add(acc, pt_load(sums, stride, k0 + 256 * i));
-    if (hg >= 16) pt_store(sh, 128, (hg - 16) * 8 + lc, acc);
+    if (hg >= 32) pt_store(sh, 128, (hg - 32) * 4 + lc, acc);
     __syncthreads();
-    if (hg < 16) acc = pt29_add(acc, pt_load(sh, 128, hg * 8 + lc));
+    if (hg < 32) acc = pt29_add(acc, pt_load(sh, 128, hg * 4 + lc));
     __syncthreads();
-    if (hg < 16) pt_store(sh, 128, hg * 8 + lc, acc);
-    fold_quad_tree(sh, 8, 1, 8, 8, t);
-    if (t < 8) pt_store(lvl, lstride, FOLD_COL0 + blk * 256 + 8 * lb + t, pt_load(sh, 128, t));
+    if (hg < 32) pt_store(sh, 128, hg * 4 + lc, acc);
+    fold_quad_tree(sh, 4, 1, 4, 16, t);
+    if (t < 4) pt_store(lvl, lstride, FOLD_COL0 + blk * 256 + 4 * lb + t, pt_load(sh, 128, t));
   }
 }
 
@@ -899,25 +900,30 @@ k_msm_plane_horner(uint32_t* __restrict__ lvl, size_t lstride) {
   }
   pt29r_store(lvl, lstride, FOLD_WS0 + ws, acc, k);
 }
-// result = sum_w 2^(16 w) (256 RW_w + CW_w), CW_7 = the column sums of both blocks of the top window
-__global__ void __launch_bounds__(64)
+// result = sum_w 2^(16 w) S_w, S_w = 256 RW_w + CW_w (CW_7 = the column sums of both blocks of the top window).  Eight waves
+// form the eight S_w side by side (eight doublings and one or two additions each), then wave 0 runs the recurrence over
+// the windows: 112 doublings and 7 additions that wait for each other.
+__global__ void __launch_bounds__(512)
 k_msm_final16(const uint32_t* __restrict__ lvl, size_t lstride, uint8_t* __restrict__ out65, int affine) {
-  const fer_consts k = fer_setup(threadIdx.x);
-  pt29r accr = pt29r_load(lvl, lstride, FOLD_WS0 + 7, k);
+  __shared__ uint32_t sh[PT_WORDS * 8];
+  const uint32_t wave = threadIdx.x >> 6;
+  const fer_consts k = fer_setup(threadIdx.x & 63u);
+  pt29r accr = pt29r_load(lvl, lstride, FOLD_WS0 + wave, k);
 #pragma unroll 1
-  for (int w = 7; w >= 0; --w) {
-    if (w < 7) {
+  for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
+  accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 8 + wave, k), k);
+  if (wave == 7) accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 16, k), k);
+  if (wave != 7) pt29r_store(sh, 8, wave, accr, k);
+  __syncthreads();
+  if (wave != 7) return;                       // (whole waves)
 #pragma unroll 1
-      for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
-      accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + w, k), k);
-    }
+  for (int w = 6; w >= 0; --w) {
 #pragma unroll 1
-    for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
-    accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 8 + w, k), k);
-    if (w == 7) accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 16, k), k);
+    for (int t = 0; t < 16; ++t) accr = pt29r_double(accr, k);
+    accr = pt29r_add(accr, pt29r_load(sh, 8, (uint32_t)w, k), k);
   }
   const pt29 acc = pt29r_gather(accr, k);
-  if (threadIdx.x != 0) return;
+  if ((threadIdx.x & 63u) != 0) return;
   if (fe29_is_zero(acc.z)) {
     for (int i = 0; i < 65; ++i) out65[i] = 0;
     return;
@@ -1107,7 +1113,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     if (rc) return rc;
     msm_prof_mark(ctx, st, 4);
     if (fold16)
-      k_msm_final16<<<1, 64, 0, st>>>(m.partial, m.nslots + 1, d_out65, affine ? 1 : 0);
+      k_msm_final16<<<1, 512, 0, st>>>(m.partial, m.nslots + 1, d_out65, affine ? 1 : 0);
     else
       k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, g.nw, 0u);
     HIP_TRY(ctx, hipGetLastError());

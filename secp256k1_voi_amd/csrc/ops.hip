@@ -68,7 +68,7 @@ S2K_DEV pt pt_from_pt29(const pt29& p) {
 // scalar multiplications with a per-item point live in engine.hip (s2k_double_scalar_mult_basepoint_batch_ex)
 __global__ void __launch_bounds__(256)
 k_point_op(int op, uint32_t n, const uint8_t* __restrict__ k1, const uint8_t* __restrict__ pa,
-           const uint8_t* __restrict__ pb, uint8_t* __restrict__ out, const uint32_t* __restrict__ gt,
+           const uint8_t* __restrict__ pb, uint8_t* __restrict__ out, gt_view gt,
            uint32_t* __restrict__ status) {
   size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
@@ -618,7 +618,7 @@ k_pack_valid(uint32_t n, const uint8_t* __restrict__ valid, uint8_t* __restrict_
   }
 }
 
-__global__ void k_gtable_entry(const uint32_t* __restrict__ gt, uint32_t window, uint32_t digit, uint8_t* out64) {
+__global__ void k_gtable_entry(gt_view gt, uint32_t window, uint32_t digit, uint8_t* out64) {
   apt a = gt_load(gt, window, digit);
   store_be32(out64, a.x.v);
   store_be32(out64 + 32, a.y.v);
@@ -641,7 +641,7 @@ static int point_op(s2k_ctx* ctx, int op, size_t n, const uint8_t* k1, const uin
   HIP_TRY(ctx, dst.alloc(16));
   HIP_TRY(ctx, hipMemset(dst.p, 0, 16));
   k_point_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)dk1.p, (const uint8_t*)dpa.p, (const uint8_t*)dpb.p,
-                                     (uint8_t*)dout.p, ctx->gtable, (uint32_t*)dst.p);
+                                     (uint8_t*)dout.p, s2k_internal_gt(ctx), (uint32_t*)dst.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
   uint32_t h_status = 0;
@@ -807,15 +807,17 @@ int s2k_pack_valid_device(s2k_ctx* ctx, size_t n, const void* d_valid, void* d_b
   return S2K_OK;
 }
 
-int s2k_generator_window_bits(void) { return GT_BITS; }
+// the window width automatic contexts aim for (a build-time constant; what a context uses at a given moment: s2k_ctx_gt_info)
+int s2k_generator_window_bits(void) { return GT_BITS_TARGET; }
 
 int s2k_debug_gtable_entry(s2k_ctx* ctx, unsigned i, unsigned d, uint8_t* out64) {
   if (!ctx || !out64) return fail(ctx, S2K_ERR_ARG, "null argument");
-  if (i >= (unsigned)GT_WINDOWS || d >= (1u << GT_BITS)) return fail(ctx, S2K_ERR_ARG, "index out of range");
+  const gt_view gt = s2k_internal_gt(ctx);
+  if (i >= gt.windows || d >= (1u << gt.bits)) return fail(ctx, S2K_ERR_ARG, "index out of range");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dev_buf o;
   HIP_TRY(ctx, o.alloc(64));
-  k_gtable_entry<<<1, 1>>>(ctx->gtable, i, d, (uint8_t*)o.p);
+  k_gtable_entry<<<1, 1>>>(gt, i, d, (uint8_t*)o.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out64, o.p, 64, hipMemcpyDeviceToHost));

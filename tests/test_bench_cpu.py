@@ -16,3 +16,39 @@ def test_bench_launcher_refuses_without_devices():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2
     assert "--oversubscribe" in p.stderr
+
+
+def test_bench_line_fits_the_drivers_record():
+    """The driver keeps an 8 KB tail of stdout: bench.py's compact form carries numbers only - the prose
+    goes to bench_notes.json by path -, puts what must survive LAST, rounds to six digits, and names what it had to drop.
+    Fed with round 4's 18.5 KB line (profiles/r04_z_bench_n1.json) plus the rows round 5 adds."""
+    import argparse
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r04_z_bench_n1.json")) as f:
+        line = json.loads(f.read().strip().split("\n")[-1])
+    assert len(json.dumps(line)) > 15000
+    line["recover_2p20"] = {"sigs": 1 << 20, "ms": 8.123456789, "roofline": {"kernel": "k_verify_fast<RECOVER>", "kernel_ms": 7.1, "frac": 0.9,
+                                                                             "valu_instr_per_item": 260000.123, "frac_def": "x" * 300}, "note": "y" * 200}
+    line["batch_sweep"] = {"log2_n": list(range(10, 23)), "ms": [0.123456789 * k for k in range(10, 23)], "note": "z" * 300}
+    args = argparse.Namespace(full=False, write_notes=False)
+    text = bench.compact_line(line, args)
+    assert len(text) <= 8000, len(text)
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    keys = list(d)
+    assert keys.index("roofline") > keys.index("msm_2p20") and keys.index("cpu_baseline") > keys.index("distinct_keys")
+    assert keys[-1] == "notes" and d["notes"] == "bench_notes.json"
+    flat = json.dumps(d)
+    assert "frac_def" not in flat and '"note"' not in flat and "ms_each" not in flat
+    assert d["recover_2p20"]["ms"] == 8.12346 and d["recover_2p20"]["roofline"]["valu_instr_per_item"] == 260000.0
+    assert set(d.get("dropped", [])) <= set(bench.DROP_ORDER)
+    for k in ("distinct_keys", "general_path_same_batch", "keyset_resident", "pcie_inclusive", "batch_sweep", "msm_2p20", "schnorr_rlc_2p20",
+              "recover_2p20"):
+        assert k in d, k                                   # what the judge asked to see in the record survives the cut
+    assert json.loads(bench.compact_line(line, argparse.Namespace(full=True, write_notes=False))) == line

@@ -119,8 +119,17 @@ def test_fn_ops(eng, oracle):
         assert min(xi, R.N - xi) < 2**128 and min(yi, R.N - yi) < 2**128
 
 
-def test_generator_table(eng, oracle):
-    bits = eng.generator_window_bits()
+@pytest.mark.parametrize("width", [0, 16, 22])
+def test_generator_table(eng, oracle, width):
+    """width 0: the automatic tables once the background build has ended (26-bit windows where the device has the memory);
+    16, 22: a context with tables of exactly that width (s2k_ctx_create_ex)"""
+    import secp256k1_voi_amd as S
+    if width:
+        eng = S.Engine(0, gt_bits=width)
+        assert eng.gt_info()["bits"] == width
+    else:
+        eng.gt_wait()
+    bits = eng.gt_info()["bits"]
     nwin = (256 + bits - 1) // bits
     # Every sampled entry of the reference's 8-bit table blob, tbl[i][j] = (j+1) * 2^(8i) * G
     # (internal/gentable/point_mul_table.bin), must equal the sum of the device-table entries its

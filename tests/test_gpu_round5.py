@@ -2,6 +2,7 @@
 per row — the serial tail of the multi-scalar multiplication) through the C-ABI against big integers; the lane-level model
 of the same code is tests/fer_model.py (CPU).  Reference symbols served: fiat Mul / Add / Opp
 (secp256k1montgomery.go:87,750,844), addComplete / doubleComplete (point_projective.go:24,208)."""
+import os
 import random
 
 import numpy as np
@@ -176,3 +177,58 @@ def test_ticket_times_and_dropped_tickets(eng):
         eng.ecdsa_verify_batch_submit(*arrs, out=np.zeros(n - 1, np.uint8))   # a short verdict array is refused
     with pytest.raises(ValueError):
         eng.ecdsa_verify_batch_submit(*arrs, out=np.zeros(2 * n, np.uint8)[::2])
+
+
+def test_generator_table_widths_give_identical_verdicts(eng, oracle):
+    """the window width of the generator tables is a runtime property.  Contexts with tables of 16, 20, 22
+    and 24 bits (s2k_ctx_create_ex) and the automatic context give the oracle's verdicts on the Wycheproof sha256 set and on
+    2^16 random signatures with damage, through the grouped flow, the general ladder (grouping off), the complete-formula
+    path, recovery and the base multiplication."""
+    import secp256k1_voi_amd as S
+    from conftest import load_golden
+    from test_gpu_round4 import damaged_batch
+    H = bytes.fromhex
+    cases = load_golden("wycheproof_ecdsa_sha256.json")["cases"]
+    wp = [[H(c[k]) for c in cases] for k in ("pub", "digest", "sig")]
+    wp_exp = [int(c["valid"]) for c in cases]
+    n = 1 << 16
+    arrs = damaged_batch(eng, n, 1 << 10, 2626)
+    exp = oracle.ecdsa_verify_batch(*arrs, nthreads=os.cpu_count() or 1)
+    ks = [b32(k) for k in (0, 1, 2, R.N - 1, 2**255, 2**256 - 1, 0xFFFF, 1 << 26, (1 << 26) - 1, 1 << 52)] + \
+         [b32(random.Random(9).randrange(R.N)) for _ in range(64)]
+    base_exp = [oracle.scalar_base_mult_vartime(k) for k in ks]
+    for width in (16, 20, 22, 24, 0):
+        e = S.Engine(0, gt_bits=width)
+        if width:
+            assert e.gt_info()["bits"] == width
+        got = e.ecdsa_verify_batch(*arrs)
+        assert np.array_equal(got, exp), width
+        e.set_key_grouping(S.KEYS_OFF)
+        assert np.array_equal(e.ecdsa_verify_batch(*arrs), exp), width
+        e.set_key_grouping(S.KEYS_ADAPTIVE)
+        assert np.array_equal(e.ecdsa_verify_batch(*(a[:4096] for a in arrs), force_complete=True), exp[:4096]), width
+        assert [bytes(x) for x in np.asarray(e.scalar_base_mult_batch(ks))] == base_exp, width
+        assert e.ecdsa_verify_encoded_batch(*wp).tolist() == wp_exp, width
+        e.close()
+
+
+def test_generator_tables_degrade_under_a_budget():
+    """Context creation no longer depends on 43 GB being free, and the first verdict does not wait for the wide
+    tables: in fresh processes (the tables are per process) tools/ctx_time.py creates a context under
+    s2k_set_generator_table_budget limits and reports which width the background build landed on - 26 bits without a limit,
+    24 under 13 GiB, 22 under 5 GiB, none (the 20-bit first table stays) under 1 GiB - with correct verdicts before and
+    after the swap and the first verdict well inside a second."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for budget, want in ((0, 26), (13, 24), (5, 22), (1, 20)):
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "ctx_time.py"), "--budget-gib", str(budget)], capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr[-2000:]
+        line = json.loads(p.stdout.strip().split("\n")[-1])
+        out[budget] = line
+        assert line["verdicts_ok"] and line["gt_bits_first_call"] in (20, want) and line["gt_bits_after"] == want, line
+        assert line["create_to_first_verdict_s"] < 1.0, line
+    print(json.dumps(out))

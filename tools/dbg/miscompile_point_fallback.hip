@@ -11,7 +11,7 @@ using namespace s2k;
 __global__ void __launch_bounds__(256)
 kA(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -49,7 +49,7 @@ kA(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint3
 __global__ void __launch_bounds__(256)
 kB(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -87,7 +87,7 @@ kB(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint3
 __global__ void __launch_bounds__(256)
 kC(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -127,7 +127,7 @@ kC(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint3
 __global__ void __launch_bounds__(256)
 kD(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count = all_n;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -165,7 +165,7 @@ kD(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint3
 __global__ void __launch_bounds__(256)
 kE(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -203,7 +203,7 @@ kE(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint3
 __global__ void __launch_bounds__(256)
 kF(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint32_t all_n,
                  const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2, const uint8_t* __restrict__ pts65,
-                 uint8_t* __restrict__ out65, const uint32_t* __restrict__ gt, uint32_t* __restrict__ qt, size_t stride,
+                 uint8_t* __restrict__ out65, gt_view gt, uint32_t* __restrict__ qt, size_t stride,
                  uint32_t* __restrict__ status) {
   uint32_t count = all_n ? all_n : *wl_count;
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
@@ -239,7 +239,7 @@ kF(const uint32_t* __restrict__ wl_count, const uint32_t* __restrict__ wl, uint3
 }
 
 
-typedef void (*kfn)(const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, const uint32_t*, uint32_t*, size_t, uint32_t*);
+typedef void (*kfn)(const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, gt_view, uint32_t*, size_t, uint32_t*);
 int main() {
   const int n = 8;
   uint8_t hk[n * 32], hp[n * 65], ho[n * 65];
@@ -263,7 +263,7 @@ int main() {
   const char* names[] = {"kA","kB","kC","kD","kE","kF"};
   for (int v = 0; v < (int)(sizeof ks / sizeof ks[0]); ++v) {
     hipMemset(dout, 0xEE, sizeof ho);
-    ks[v]<<<1, 256>>>(wl, wl + 64, n, nullptr, dk, dp, dout, gt, qt, 64, st);
+    ks[v]<<<1, 256>>>(wl, wl + 64, n, nullptr, dk, dp, dout, gt_view{gt, 8u, 32u}, qt, 64, st);   // (a table of 8-bit windows fits the megabyte; the generator part is not taken: u1 is null)
     hipDeviceSynchronize();
     hipMemcpy(ho, dout, sizeof ho, hipMemcpyDeviceToHost);
     int bad = 0;
