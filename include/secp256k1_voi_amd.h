@@ -95,6 +95,10 @@ enum {
 int s2k_ctx_create(int device_index, s2k_ctx **out);
 int s2k_ctx_create_ex(int device_index, int gt_bits, uint32_t flags, s2k_ctx **out);
 void s2k_set_generator_table_budget(size_t bytes_per_device);
+/* Caps for the other two table kinds of this process (0 = none): the bytes s2k_keyset_create_ex may count as free when it chooses
+ * (S2K_KEYSET_AUTO) or checks a joint-table layout, and the largest per-key table buffer a verification call may allocate (a
+ * larger request is treated as a failed allocation: the call degrades as it does under real memory pressure). */
+void s2k_set_table_memory_budgets(size_t keyset_free_bytes, size_t key_table_bytes);
 int s2k_ctx_gt_info(s2k_ctx *ctx, uint64_t info[4]);
 const char *s2k_ctx_gt_note(s2k_ctx *ctx);
 int s2k_ctx_gt_wait(s2k_ctx *ctx);

@@ -334,6 +334,8 @@ def load_library() -> C.CDLL:
     lib.s2k_ctx_create_ex.argtypes = [ci, ci, u32, C.POINTER(vp)]
     lib.s2k_set_generator_table_budget.argtypes = [sz]
     lib.s2k_set_generator_table_budget.restype = None
+    lib.s2k_set_table_memory_budgets.argtypes = [sz, sz]
+    lib.s2k_set_table_memory_budgets.restype = None
     lib.s2k_ctx_gt_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.s2k_ctx_gt_note.argtypes = [vp]
     lib.s2k_ctx_gt_note.restype = C.c_char_p
@@ -374,7 +376,7 @@ EXPORTED_SYMBOLS = [
     "s2k_device_pci_bus_id", "s2k_device_numa_node", "s2k_bind_thread_to_node", "s2k_topology_prefer_node", "s2k_topology_node_count",
     "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
     "s2k_group_member_stats_ex", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
-    "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
+    "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
 ]
 
 

@@ -1666,6 +1666,7 @@ std::mutex g_gtable_mutex;
 std::condition_variable g_gtable_cv;              // a builder has finished
 gtable_dev g_gtable[64];
 std::atomic<size_t> g_gt_budget{0};               // s2k_set_generator_table_budget: bytes per device the tables may take (0: by free memory)
+std::atomic<size_t> g_keyset_budget{0};           // s2k_set_table_memory_budgets: what counts as free for a key set's joint tables (0: what is free)
 
 // allocate and build the table of `bits` on `stream` (null: the default stream); synchronises that stream
 hipError_t gtable_build(int bits, hipStream_t stream, uint32_t** out) {
@@ -1831,6 +1832,14 @@ extern "C" {
 // Bytes per device the generator tables of this process may take (0 = no limit but the device's free memory).  Applies to
 // automatic contexts created after the call; the first table (0.8 GiB) is always built.
 void s2k_set_generator_table_budget(size_t bytes) { g_gt_budget.store(bytes); }
+// Caps on the two other table kinds, per process (0 = none): what s2k_keyset_create_ex treats as free memory when it chooses or
+// checks a joint-table layout, and the largest per-key table buffer a verification call may allocate (larger requests are
+// treated as failed allocations: the table cap halves, below 1024 tables the batch is verified without tables).  These replace
+// the S2K_TEST_* environment variables of round 4 (no ambient test hooks in allocation paths).
+void s2k_set_table_memory_budgets(size_t keyset_free_bytes, size_t key_table_bytes) {
+  g_keyset_budget.store(keyset_free_bytes);
+  s2k_internal_key_table_limit().store(key_table_bytes);
+}
 // info[0] = window bits the context's launches use now, [1] = bits the background build aims for (0: none), [2] = 1 while it
 // is running, [3] = bytes of generator tables the device holds for this process
 int s2k_ctx_gt_info(s2k_ctx* ctx, uint64_t info[4]) {
@@ -2229,10 +2238,9 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
   uint4* scratch = nullptr;
   if (rc == S2K_OK && layout != S2K_KEYSET_CHUNKS) {
     int w = layout == S2K_KEYSET_JOINT6 ? 6 : layout == S2K_KEYSET_JOINT5 ? 5 : layout == S2K_KEYSET_JOINT ? 4 : 0;
-    // test hook: pretend the device has no more than this many bytes free for joint tables (the choice of S2K_KEYSET_AUTO and
-    // the failure of an explicit layout can be exercised without filling a 288 GB device)
-    size_t pretend_free = ~(size_t)0;
-    if (const char* v = getenv("S2K_TEST_KEYSET_FREE_BYTES")) pretend_free = (size_t)strtoull(v, nullptr, 10);
+    // s2k_set_table_memory_budgets: no more than this many bytes count as free for joint tables (an operator's cap - and how
+    // the choice of S2K_KEYSET_AUTO and the failure of an explicit layout are exercised without filling a 288 GB device)
+    const size_t pretend_free = g_keyset_budget.load() ? g_keyset_budget.load() : ~(size_t)0;
     if (w == 0) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {

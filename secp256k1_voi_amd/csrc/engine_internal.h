@@ -194,6 +194,11 @@ struct s2k_ctx {
 // engine.hip), so an index with bit 30 set must never reach them.
 constexpr size_t S2K_MAX_BATCH = (size_t)1 << 30;
 
+#include <atomic>
+inline std::atomic<size_t>& s2k_internal_key_table_limit() {   // s2k_set_table_memory_budgets (engine.hip), read by keyed.hip
+  static std::atomic<size_t> v{0};
+  return v;
+}
 gt_view s2k_internal_gt(const s2k_ctx* ctx);   // engine.hip: the generator table a launch of this moment uses
 
 inline thread_local char g_err[512];

@@ -36,7 +36,7 @@ def test_bench_line_fits_the_drivers_record():
     line["batch_sweep"] = {"log2_n": list(range(10, 23)), "ms": [0.123456789 * k for k in range(10, 23)], "note": "z" * 300}
     args = argparse.Namespace(full=False, write_notes=False)
     text = bench.compact_line(line, args)
-    assert len(text) <= 8000, len(text)
+    assert len(text) <= 7800, len(text)
     d = json.loads(text)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):

@@ -511,7 +511,7 @@ def test_encoded_parse_staging_paths(eng, oracle):
 
 # ---- the table buffer degrades instead of failing -------------------------------------------------------
 def test_table_buffer_allocation_failure_degrades(oracle):
-    """S2K_TEST_TABLE_BYTES_LIMIT makes s2k_internal_key_reserve treat larger table buffers as unobtainable: the cap is
+    """s2k_set_table_memory_budgets(0, limit) makes s2k_internal_key_reserve treat larger table buffers as unobtainable: the cap is
     halved until the buffer fits (fewer, longer groups get tables), below 1024 tables the batch is verified without tables
     - the verification call never fails, the verdicts never change."""
     import secp256k1_voi_amd as S
@@ -527,20 +527,20 @@ def test_table_buffer_allocation_failure_degrades(oracle):
         # default plan: n / 4 = 32768 tables of 9 KiB = 302 MB.  100 MB: the cap goes 32768 -> 16384 -> 8192 (75 MB),
         # threshold 16 signatures per key: all 4096 keys still get their tables
         eng2 = S.Engine(0)
-        os.environ["S2K_TEST_TABLE_BYTES_LIMIT"] = str(100 << 20)
+        S.load_library().s2k_set_table_memory_budgets(0, 100 << 20)
         assert np.array_equal(eng2.ecdsa_verify_batch(*arrs), ref)
         st = eng2.key_grouping_stats()
         assert st["tables"] == n // 32 and st["keyed"] + st["general"] == n
         assert eng2.device_bytes(n) < eng.device_bytes(n)                       # the memory query follows the cap
         # 20 MB: 2048 tables, threshold 64 per key: no key qualifies, everything on the general ladder
         eng3 = S.Engine(0)
-        os.environ["S2K_TEST_TABLE_BYTES_LIMIT"] = str(20 << 20)
+        S.load_library().s2k_set_table_memory_budgets(0, 20 << 20)
         assert np.array_equal(eng3.ecdsa_verify_batch(*arrs), ref)
         st = eng3.key_grouping_stats()
         assert st["tables"] == 0 and st["general"] == n
         # 1 MB: not even 1024 tables: verified without the grouping at all
         eng4 = S.Engine(0)
-        os.environ["S2K_TEST_TABLE_BYTES_LIMIT"] = str(1 << 20)
+        S.load_library().s2k_set_table_memory_budgets(0, 1 << 20)
         assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref)
         st = eng4.key_grouping_stats()
         assert st["tables"] == 0 and st["keyed"] == 0
@@ -549,7 +549,7 @@ def test_table_buffer_allocation_failure_degrades(oracle):
         pk, msgs, sig = synth_schnorr_batch(eng4, 4096, 64, seed=9)
         assert eng4.schnorr_verify_batch(pk, msgs, sig).all()
     finally:
-        os.environ.pop("S2K_TEST_TABLE_BYTES_LIMIT", None)
+        S.load_library().s2k_set_table_memory_budgets(0, 0)
     # the limit gone and the setting renewed: tables again
     eng4.set_key_grouping(S.KEYS_AUTO)
     assert np.array_equal(eng4.ecdsa_verify_batch(*arrs), ref) and eng4.key_grouping_stats()["tables"] == n // 32
@@ -712,7 +712,7 @@ def test_keyset_small_and_duplicate_keys(eng, oracle, layout):
 
 # ---- the layout a key set gets when memory is short -------------------------------------------------------------------------
 def test_keyset_layout_choice_under_memory_limits(eng):
-    """S2K_TEST_KEYSET_FREE_BYTES makes s2k_keyset_create_ex believe the device has only that much room for joint tables:
+    """s2k_set_table_memory_budgets(free, 0) makes s2k_keyset_create_ex count only that much room for joint tables:
     S2K_KEYSET_AUTO takes 5-bit joint tables when they fit in half of it, else 4-bit ones, else chunk tables, and the set verifies
     the same in each; an explicit joint layout that does not fit is an error (and leaves nothing behind: the next set is built)."""
     import secp256k1_voi_amd as S
@@ -726,16 +726,13 @@ def test_keyset_layout_choice_under_memory_limits(eng):
     j5 = nk * (26 * 512 + 2) * 64 + nk * 26 * 16 * 80        # joint tables + build scratch at 5 bits
     j4 = nk * 32 * 128 * 80
     try:
-        for free, want in ((None, S.KEYSET_JOINT5), (2 * j5 + 4096, S.KEYSET_JOINT5), (2 * j5 - 4096, S.KEYSET_JOINT), (2 * j4 - 4096, S.KEYSET_CHUNKS), (0, S.KEYSET_CHUNKS)):
-            if free is None:
-                os.environ.pop("S2K_TEST_KEYSET_FREE_BYTES", None)
-            else:
-                os.environ["S2K_TEST_KEYSET_FREE_BYTES"] = str(free)
+        for free, want in ((None, S.KEYSET_JOINT5), (2 * j5 + 4096, S.KEYSET_JOINT5), (2 * j5 - 4096, S.KEYSET_JOINT), (2 * j4 - 4096, S.KEYSET_CHUNKS), (1, S.KEYSET_CHUNKS)):
+            S.load_library().s2k_set_table_memory_budgets(free or 0, 0)
             ks = eng.keyset_create(keys)
             assert ks.layout() == want, (free, ks.layout())
             assert np.array_equal(eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s), ref)
             ks.close()
-        os.environ["S2K_TEST_KEYSET_FREE_BYTES"] = str(j4 - 1)
+        S.load_library().s2k_set_table_memory_budgets(j4 - 1, 0)
         for layout in (S.KEYSET_JOINT, S.KEYSET_JOINT5, S.KEYSET_JOINT6):
             with pytest.raises(S.EngineError):
                 eng.keyset_create(keys, layout)
@@ -743,7 +740,7 @@ def test_keyset_layout_choice_under_memory_limits(eng):
         assert np.array_equal(eng.ecdsa_verify_batch_keyset(ks, kidx, dig, r, s), ref)
         ks.close()
     finally:
-        os.environ.pop("S2K_TEST_KEYSET_FREE_BYTES", None)
+        S.load_library().s2k_set_table_memory_budgets(0, 0)
 
 
 # ---- key sets through submit / wait ------------------------------------------------------------------------------------

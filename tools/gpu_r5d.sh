@@ -1,4 +1,6 @@
 #!/bin/bash
+# (when this ran the lane-per-entry scaling pass was the default and S2K_KEY_SCALE_OLD=1 selected the lane-per-chunk one; the default is the
+# lane-per-chunk pass again since - profiles/r05_key_scale_ab.txt - and S2K_KEY_SCALE_WIDE=1 selects the other)
 # round 5, fourth GPU pass: whole GPU suite; k_key_scale lane-per-entry vs lane-per-chunk (same box); multiscalar tail after the
 # column-block and S_w changes
 REPO=$PWD; O=$REPO/gpurun_out/r5d; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (when this ran the lane-per-entry scaling pass was the default and S2K_KEY_SCALE_OLD=1 selected the lane-per-chunk one; the default is the
+# lane-per-chunk pass again since - profiles/r05_key_scale_ab.txt - and S2K_KEY_SCALE_WIDE=1 selects the other)
 # round 5, fifth GPU pass: first-verdict latency with the gated table build; k_key_scale through LDS vs the lane-per-chunk walk (same box);
 # the whole bench line in its compact form (new rows: recover_2p20, schnorr_per_signature_2p20, batch_sweep)
 REPO=$PWD; O=$REPO/gpurun_out/r5e; mkdir -p $O

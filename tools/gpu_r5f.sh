@@ -1,4 +1,6 @@
 #!/bin/bash
+# (when this ran the lane-per-entry scaling pass was the default and S2K_KEY_SCALE_OLD=1 selected the lane-per-chunk one; the default is the
+# lane-per-chunk pass again since - profiles/r05_key_scale_ab.txt - and S2K_KEY_SCALE_WIDE=1 selects the other)
 # round 5, sixth GPU pass: share of the generator part launched beside the key chain (S2K_GP_FIRST_PERCENT), now that the scaling pass is shorter
 REPO=$PWD; O=$REPO/gpurun_out/r5f; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $REPO
