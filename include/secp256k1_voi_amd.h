@@ -364,6 +364,9 @@ int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
  * switches that timing on: zero until a shard has been submitted after it).  Placement: every member's thread binds itself
  * to the CPUs of its device's NUMA node (sysfs; no-op on one node, when the node is unknown or the cpuset forbids it). */
 int s2k_group_member_stats_ex(s2k_group *g, double *stats /* 8 * members */);
+/* Blocks until the wide generator tables of every member's device are in (s2k_ctx_gt_wait per member); returns the smallest
+ * window width in use.  For benchmarks and services that want their full rate from the first batch. */
+int s2k_group_gt_wait(s2k_group *g);
 /* Items per member of a batch of n: member i takes [i * size, min(n, (i + 1) * size)). */
 size_t s2k_group_shard_size(const s2k_group *g, size_t n);
 /* A page-locked array of n items of bytes_per_item bytes laid out for the group: the pages of every member's shard are

@@ -325,6 +325,7 @@ def load_library() -> C.CDLL:
     lib.s2k_ctx_ticket_timing.argtypes = [vp, ci]
     lib.s2k_ticket_times.argtypes = [vp, C.c_uint64, C.POINTER(C.c_double)]
     lib.s2k_group_member_stats_ex.argtypes = [vp, vp]
+    lib.s2k_group_gt_wait.argtypes = [vp]
     lib.s2k_group_shard_size.argtypes = [vp, sz]
     lib.s2k_group_shard_size.restype = sz
     lib.s2k_group_host_alloc.argtypes = [vp, sz, sz]
@@ -375,7 +376,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ct_multi_scalar_mult",
     "s2k_device_pci_bus_id", "s2k_device_numa_node", "s2k_bind_thread_to_node", "s2k_topology_prefer_node", "s2k_topology_node_count",
     "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
-    "s2k_group_member_stats_ex", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
+    "s2k_group_member_stats_ex", "s2k_group_gt_wait", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
     "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
 ]
 
@@ -1099,6 +1100,10 @@ class Group(_TicketOwner):
 
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         self._check(self._lib.s2k_group_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
+
+    def gt_wait(self) -> int:
+        """block until every member's device has its wide generator tables (s2k_group_gt_wait); the smallest width in use"""
+        return int(self._lib.s2k_group_gt_wait(self._h))
 
     def shard_size(self, n: int) -> int:
         """items per member of a batch of n (s2k_group_shard_size)"""

@@ -653,6 +653,19 @@ int s2k_group_member_stats_ex(s2k_group* g, double* stats) {
   return S2K_OK;
 }
 
+// Blocks until the background build of the wide generator tables has ended on every member's device (s2k_ctx_gt_wait): a
+// benchmark, or a service that wants its full rate from the first batch, calls this once after s2k_group_create.  Returns the
+// smallest window width in use among the members.
+int s2k_group_gt_wait(s2k_group* g) {
+  if (!g) return S2K_ERR_ARG;
+  int bits = 0;
+  for (member* me : g->members) {                    // (touches the per-device table registry only, not the contexts' streams)
+    const int b = s2k_ctx_gt_wait(me->ctx);
+    if (b > 0 && (bits == 0 || b < bits)) bits = b;
+  }
+  return bits;
+}
+
 // The partition group_submit uses, for callers that lay out their own buffers: member i takes the items
 // [i * per, min(n, (i + 1) * per)), per = ceil(n / members) rounded up to 256.
 size_t s2k_group_shard_size(const s2k_group* g, size_t n) {

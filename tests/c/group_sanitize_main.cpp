@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> keys(64 * 5, 1);
     CHECK(s2k_group_keyset_create(g, 5, keys.data(), 0, &gks) == S2K_OK && s2k_group_keyset_size(gks) == 5);
     std::vector<double> stx(8 * D);
-    if (round & 1) CHECK(s2k_group_member_stats_ex(g, stx.data()) == S2K_OK);
+    if (round & 1) CHECK(s2k_group_member_stats_ex(g, stx.data()) == S2K_OK && s2k_group_gt_wait(g) == 26);
     std::vector<batch*> flying, all;
     const int ops = 20 + (int)(rnd() % 30);
     for (int op = 0; op < ops; ++op) {

@@ -67,6 +67,7 @@ def main():
     del eng
     lead, depth = 4, 4
     g = S.Group(devices)
+    gt_bits = g.gt_wait()          # the wide generator tables are built in the background: a benchmark waits for them
     g.member_stats_ex()            # placement and per-ticket timing on from the first shard
     bufs, outs, masks = [], [], []
     for k in range(depth):
@@ -115,7 +116,7 @@ def main():
             "value": n / (ms * 1e-3), "unit": "verifications/s", "n_gpus": len(devices), "devices": devices,
             "ms_per_group_batch": ms, "signatures_per_group_batch": n, "per_gpu_value": per / (ms * 1e-3),
             "batches_timed": done - lead, "in_flight": depth, "scaling": "weak", "data": "synthetic, page-locked host memory",
-            "member_stats_last_shard": member_lines(g, 100 if gks is not None else 160),
+            "gt_bits": gt_bits, "member_stats_last_shard": member_lines(g, 100 if gks is not None else 160),
             "keyset": None if gks is None else {"keys": len(gks), "device_bytes_per_member": gks.device_bytes(), "layout": "joint tables"},
             "check": "every batch's verdicts equal its seeded damage pattern (one bit of s flipped in every 61st signature)"}
     if gks is not None:

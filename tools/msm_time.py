@@ -8,7 +8,7 @@ import numpy as np, torch
 import secp256k1_voi_amd as S
 from secp256k1_voi_amd.synth import synth_msm_terms, synth_schnorr_batch
 
-eng = S.Engine(0)
+eng = S.Engine(0, wait_tables=True)      # (the wide generator tables are built in the background: a measurement waits for them)
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)

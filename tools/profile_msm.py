@@ -14,7 +14,7 @@ from secp256k1_voi_amd.synth import synth_msm_terms, synth_schnorr_batch
 what = sys.argv[1] if len(sys.argv) > 1 else "msm"
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 n = 1 << (int(sys.argv[3]) if len(sys.argv) > 3 else 20)
-eng = S.Engine(0)
+eng = S.Engine(0, wait_tables=True)      # (the wide generator tables are built in the background: a measurement waits for them)
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 if what == "msm":

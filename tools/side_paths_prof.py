@@ -7,7 +7,7 @@ import numpy as np
 import secp256k1_voi_amd as S
 from secp256k1_voi_amd.synth import synth_batch, synth_schnorr_batch
 
-eng = S.Engine(0)
+eng = S.Engine(0, wait_tables=True)      # (the wide generator tables are built in the background: a measurement waits for them)
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 pub, dig, r, s = synth_batch(eng, n, 1 << 16, seed=5)
 rid = np.zeros(n, np.uint8)

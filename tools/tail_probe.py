@@ -8,7 +8,7 @@ torch.cuda.init()
 import secp256k1_voi_amd as S
 from secp256k1_voi_amd.synth import synth_batch
 
-eng = S.Engine(0)
+eng = S.Engine(0, wait_tables=True)      # (the wide generator tables are built in the background: a measurement waits for them)
 dev = torch.device("cuda", 0)
 N = 6 * 196608
 pub, dig, r, s = synth_batch(eng, N, 1 << 16, seed=3)
