@@ -2979,8 +2979,17 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_retire(s2k_ctx* ctx,
   }
   if (rc == S2K_OK && sl.timed) {                    // s2k_ctx_ticket_timing: transfer and whole-ticket time on the device's clock
     float h2d = 0, all = 0;
-    const hipError_t e0 = hipEventSynchronize(sl.t_end), e1 = hipEventElapsedTime(&h2d, sl.t_begin, sl.t_copied),
-                     e2 = hipEventElapsedTime(&all, sl.t_begin, sl.t_end);
+    // (t_copied sits on the copy stream behind the ticket's transfers; with more streams in the process than hardware queues
+    // its marker can still be waiting in a shared queue when the ticket's verdicts are there - eight members on one device
+    // showed it: then it is waited for, the copies themselves are long done)
+    const hipError_t e0 = hipEventSynchronize(sl.t_end);
+    hipError_t e1 = hipEventElapsedTime(&h2d, sl.t_begin, sl.t_copied);
+    if (e1 == hipErrorNotReady) {
+      (void)hipGetLastError();
+      (void)hipEventSynchronize(sl.t_copied);
+      e1 = hipEventElapsedTime(&h2d, sl.t_begin, sl.t_copied);
+    }
+    const hipError_t e2 = hipEventElapsedTime(&all, sl.t_begin, sl.t_end);
     const unsigned i = ctx->pipe_times_n++ % 8u;
     ctx->pipe_times_ticket[i] = sl.ticket;
     if (e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess) {
