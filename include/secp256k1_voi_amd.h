@@ -291,6 +291,14 @@ int s2k_ecdsa_verify_batch_submit(s2k_ctx *ctx, size_t n, const uint8_t *pub_xy,
 int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
+/* Small batches.  A call of up to a few thousand signatures leaves the device empty whatever it runs, and costs the latency
+ * of ONE signature's ladder; for batches of up to max_n signatures (default 4096; 0 = never) s2k_ecdsa_verify_batch[_device /
+ * _submit] therefore run a ladder that spends a whole wavefront on each signature (k_verify_row: the row arithmetic of
+ * fe29r.h, complete formulas): 0.24 instead of 0.65 ms for 1024 signatures - the reference's own shape is a loop of single
+ * PublicKey.Verify calls (secec/ecdsa.go:171; BASELINE config 1 verifies 1024).  Same verdicts (tests/test_gpu_round5.py).
+ * A grouping mode set by name (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed at every size; the default (S2K_KEYS_ADAPTIVE)
+ * and S2K_KEYS_OFF take this ladder. */
+int s2k_ctx_set_small_batch_max(s2k_ctx *ctx, uint32_t max_n);
 /* Times of a ticket on the device's clock, for placement diagnostics (s2k_group_member_stats_ex): after
  * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records when its host-to-device copies start and end and when its
  * verdicts are ready; s2k_ticket_times gives ms[0] = the copies, ms[1] = first copy to verdicts for one of the last eight

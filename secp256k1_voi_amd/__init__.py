@@ -332,6 +332,7 @@ def load_library() -> C.CDLL:
     lib.s2k_group_host_alloc.restype = vp
     lib.s2k_group_host_free.argtypes = [vp, vp]
     lib.s2k_group_host_free.restype = None
+    lib.s2k_ctx_set_small_batch_max.argtypes = [vp, u32]
     lib.s2k_ctx_create_ex.argtypes = [ci, ci, u32, C.POINTER(vp)]
     lib.s2k_set_generator_table_budget.argtypes = [sz]
     lib.s2k_set_generator_table_budget.restype = None
@@ -377,7 +378,7 @@ EXPORTED_SYMBOLS = [
     "s2k_device_pci_bus_id", "s2k_device_numa_node", "s2k_bind_thread_to_node", "s2k_topology_prefer_node", "s2k_topology_node_count",
     "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
     "s2k_group_member_stats_ex", "s2k_group_gt_wait", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
-    "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
+    "s2k_ctx_set_small_batch_max", "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
 ]
 
 
@@ -524,6 +525,10 @@ class Engine(_TicketOwner):
         self._check(self._lib.s2k_ctx_gt_info(self._h, info))
         return {"bits": int(info[0]), "target_bits": int(info[1]), "building": bool(info[2]), "bytes": int(info[3]),
                 "note": self._lib.s2k_ctx_gt_note(self._h).decode()}
+
+    def set_small_batch_max(self, max_n: int):
+        """batches of up to max_n signatures take the wave-per-signature ladder (s2k_ctx_set_small_batch_max; 0: never)"""
+        self._check(self._lib.s2k_ctx_set_small_batch_max(self._h, int(max_n)))
 
     def gt_wait(self) -> int:
         """block until the background build of the wide generator tables has ended; the window bits in use then"""

@@ -27,6 +27,7 @@
 #include "xyzz29.h"
 #include "lane_tables.h"
 #include "pt29.h"
+#include "fe29r.h"
 #include "complete_path.h"
 #include "point.h"
 #include "sc.h"
@@ -997,6 +998,139 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
     c[2] = t0w;
     c[3] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Small batches: ONE WAVE PER SIGNATURE (round 5).  A call of up to a few thousand signatures - the reference's own
+// shape is a loop of single Verify calls, BASELINE config 1 verifies 1024 - leaves the chip empty whatever the kernel: what
+// it costs is the latency of one lane's ladder, 261 k dependent instructions, 0.7 ms for 64 signatures as for 8192
+// (bench.py batch_sweep).  Here the ladder runs in the row arithmetic of fe29r.h (a field element = one register, one limb
+// per lane of a 16-lane row, the four products of a formula layer in the four rows of the wave): the same signed-odd-digit
+// GLV ladder as k_verify_fast - table {1,3,..,15} Q, 32 windows of four doublings and two additions, the generator part from
+// the resident tables - on the COMPLETE projective formulas (pt29r_add / pt29r_double: no exceptional case, so no worklist
+// and no second kernel), ~70 k instructions of one wave per signature.  Digits, table indices and generator-table addresses
+// are wave-uniform.  Verdicts are those of the other paths (same preparation kernel, same accept rule ecdsa.go:392-470).
+// ---------------------------------------------------------------------------------------
+// limb j (lane j of every row) of a 256-bit value given as eight little-endian words every lane holds
+S2K_DEV fer fer_from_words(const uint32_t w[8], const fer_consts& k) {
+  const uint32_t bit = 29u * k.j, idx = bit >> 5, sh = bit & 31u;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lo = idx == (uint32_t)i ? w[i] : lo;
+    hi = idx + 1 == (uint32_t)i ? w[i] : hi;
+  }
+  const uint64_t v = ((uint64_t)hi << 32) | lo;
+  return k.j <= 8 ? ((uint32_t)(v >> sh) & F29_M) : 0u;       // (limb 8: bits 232..255, 24 of them)
+}
+// value == 0 (mod p), the same answer in every lane
+S2K_DEV bool fer_is_zero(fer a, const fer_consts& k) { return fe29_is_zero(fer_to_fe29(fer_norm(a, k))); }
+
+__global__ void __launch_bounds__(256)
+k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep,
+             gt_view gt, uint8_t* __restrict__ out, size_t stride) {
+  const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (sig >= n) return;                                         // (whole waves)
+  const fer_consts k = fer_setup(lane);
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  uint32_t xw[8], yw[8];
+  load_be32(xw, pub + (size_t)sig * 64);
+  load_be32(yw, pub + (size_t)sig * 64 + 32);
+  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
+  const fer one = k.j == 0 ? 1u : 0u;
+  pt29r T[8];
+  T[0].x = fer_from_words(xw, k);
+  T[0].y = fer_from_words(yw, k);
+  T[0].z = one;
+  {   // y^2 == x^3 + 7 (point_s11n.go:298-307)
+    const fer x2 = fer_mul(T[0].x, T[0].x, k);
+    const fer seven = k.j == 0 ? 7u : 0u;
+    const fer rhs = fer_mul_plus(x2, T[0].x, seven, k);
+    const fer lhs = fer_mul(T[0].y, T[0].y, k);
+    ok = ok && fer_is_zero(fer_add(lhs, fer_negate(rhs, 1, k)), k);
+  }
+  if (!ok) {                                                    // (wave-uniform)
+    if (lane == 0) out[sig] = 0;
+    return;
+  }
+  // ---- table: odd multiples, projective ----
+  {
+    const pt29r D = pt29r_double(T[0], k);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) T[j] = pt29r_add(T[j - 1], D, k);
+  }
+  const fer beta = fer_from_words(FE_BETA, k);
+  // ---- ladder over |k1|, |k2| (odd, < 2^129: sc_split_glv_odd in the preparation kernel) ----
+  sc k1 = sc_zero(), k2 = sc_zero();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    k1.v[w] = prep[(size_t)(8 + w) * stride + sig];
+    k2.v[w] = prep[(size_t)(12 + w) * stride + sig];
+  }
+  k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;
+  k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;
+  const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
+  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+  auto entry_of = [&](uint32_t e, bool lam, bool neg) -> pt29r {     // +-T[e] or its image under the endomorphism
+    pt29r a = T[0];
+    switch (__builtin_amdgcn_readfirstlane((int)e)) {               // (uniform: a scalar branch)
+      case 1: a = T[1]; break;
+      case 2: a = T[2]; break;
+      case 3: a = T[3]; break;
+      case 4: a = T[4]; break;
+      case 5: a = T[5]; break;
+      case 6: a = T[6]; break;
+      case 7: a = T[7]; break;
+      default: break;
+    }
+    if (lam) a.x = fer_mul(a.x, beta, k);
+    if (neg) a.y = fer_negate(a.y, 1, k);                             // [2]: the addition normalises y
+    return a;
+  };
+  pt29r acc = pt29r_add(entry_of(0, false, neg1), entry_of(0, true, neg2), k);   // the top digits are +1
+#pragma unroll 1
+  for (int i = 31; i >= 0; --i) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) acc = pt29r_double(acc, k);
+    const uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t w = t ? w2 : w1;
+      const bool neg = (t ? neg2 : neg1) != (w < 8u);
+      const uint32_t e = (w < 8u) ? (7u - w) : (w - 8u);
+      acc = pt29r_add(acc, entry_of(e, t != 0, neg), k);
+    }
+  }
+  // ---- generator part: u1 * G from the resident tables (no entry is the identity, no digit is special) ----
+  {
+    uint32_t u[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
+    apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
+#pragma unroll 1
+    for (uint32_t w = 0; w < gt.windows; ++w) {
+      pt29r q;
+      q.x = fer_from_words(g.x.v, k);
+      q.y = fer_from_words(g.y.v, k);
+      q.z = one;
+      if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));   // in flight during the addition
+      acc = pt29r_add(acc, q, k);
+    }
+  }
+  // ---- verdict: R != infinity and x(R) mod n == r (ecdsa.go:450-465), x(R) = X / Z ----
+  uint8_t verdict = 0;
+  if (!fer_is_zero(acc.z, k)) {
+    uint32_t rw[8];
+    load_be32(rw, rsig + (size_t)sig * 32);
+    bool match = fer_is_zero(fer_add(acc.x, fer_negate(fer_mul(fer_from_words(rw, k), acc.z, k), 1, k)), k);
+    if (u256_lt(rw, FE_P_MINUS_N)) {
+      uint32_t r2[8];
+      u256_add(r2, rw, SC_N);
+      match = match || fer_is_zero(fer_add(acc.x, fer_negate(fer_mul(fer_from_words(r2, k), acc.z, k), 1, k)), k);
+    }
+    verdict = match ? 1 : 0;
+  }
+  if (lane == 0) out[sig] = verdict;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2102,6 +2236,10 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
   bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  // small batches: a wave per signature beats any table (k_verify_row); a grouping mode somebody asked for by name
+  // (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed instead
+  const bool row = n <= ctx->row_max && !kvf && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
+  if (row) grouped = false;
   ctx->kg_note_dst = nullptr;
   if (grouped && ctx->kg_mode == S2K_KEYS_ADAPTIVE && n >= KG_ADAPT_MIN_BATCH) grouped = kg_adaptive_decide(ctx);
   if (grouped) {
@@ -2157,6 +2295,21 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                                                                   stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 4);
+  } else if (row) {
+    // small batches: a wave per signature on the complete formulas (k_verify_row); nothing is left for the worklist kernel
+    wait_all(st);
+    k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_verify_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+                                                          s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    prof_mark(ctx, st, 4);
+    prof_mark(ctx, st, 5);
+    return ctx_leave(ctx, st);
   } else {
     wait_all(st);
     k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
@@ -3076,6 +3229,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   sl.ctx->kg_min_group = ctx->kg_min_group;
   sl.ctx->kg_hash_bits = ctx->kg_hash_bits;
   sl.ctx->kg_max_tables = ctx->kg_max_tables;
+  sl.ctx->row_max = ctx->row_max;
   sl.direct = host_pinned(valid, n);
   if (!sl.direct && sl.h_valid_bytes < n) {
     if (sl.h_valid) (void)hipHostFree(sl.h_valid);
@@ -3250,6 +3404,12 @@ int s2k_wait_all(s2k_ctx* ctx) {
   return rc;
 }
 
+// Batches of up to max_n signatures take the wave-per-signature ladder (k_verify_row); 0 switches it off.
+int s2k_ctx_set_small_batch_max(s2k_ctx* ctx, uint32_t max_n) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  ctx->row_max = max_n;
+  return S2K_OK;
+}
 // Per-ticket times on the device's clock (for placement diagnostics, s2k_group_member_stats_ex): enable, submit, wait, ask.
 int s2k_ctx_ticket_timing(s2k_ctx* ctx, int enable) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");

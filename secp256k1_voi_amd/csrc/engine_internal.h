@@ -83,6 +83,14 @@ S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
   }
 }
 
+// Largest batch the wave-per-signature ladder (k_verify_row, engine.hip) takes: above it the lane-per-signature kernels win
+// (profiles/r05_small_batch_ab.txt: 0.24 against 0.65 ms up to 1024 signatures - one wave per SIMD -, 0.78 against 1.07 ms
+// at 8192, 1.39 against 1.09 at 16384 device-resident; from host memory 0.30 against 0.70 ms up to 1024, 0.56 against 0.70
+// at 4096, 0.89 against 0.75 at 8192).
+#ifndef S2K_ROW_MAX_DEFAULT
+#define S2K_ROW_MAX_DEFAULT 4096
+#endif
+
 // ---- host side ----
 struct s2k_ctx {
   int device = -1;
@@ -126,6 +134,7 @@ struct s2k_ctx {
   size_t msm_prof_cap = 0, msm_prof_used = 0;
   bool msm_prof_on = false;
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
+  uint32_t row_max = S2K_ROW_MAX_DEFAULT;   // batches of up to this many signatures take the wave-per-signature ladder (s2k_ctx_set_small_batch_max)
   int kg_mode = S2K_KEYS_ADAPTIVE;
   uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = KG_MAX_TABLES_DEFAULT;
   uint32_t kg_table_cap = 0;         // 0: none; else the table count the device had memory for (s2k_internal_key_reserve)

@@ -235,3 +235,67 @@ def test_generator_tables_degrade_under_a_budget():
         assert line["verdicts_ok"] and line["gt_bits_first_call"] in (20, want) and line["gt_bits_after"] == want, line
         assert line["create_to_first_verdict_s"] < 1.0, line
     print(json.dumps(out))
+
+
+def test_small_batch_ladder_agrees_with_the_lane_ladder(oracle):
+    """k_verify_row (a wave per signature on the complete formulas, the default for batches of up to 4096 signatures) and the
+    lane-per-signature kernels give the oracle's verdicts on the reference's vectors and on boundary-value inputs: Wycheproof
+    sha256 + sha512 (parsed by the oracle's ParseASN1Signature), the RFC 6979 signatures with shifted digests, random
+    batches of 1 .. 5000 signatures with damage and the low-s rule, and the structured fuzz of test_gpu_parity (every field of
+    a signature replaced by a value from the boundary pool).  Each input runs through BOTH ladders (s2k_ctx_set_small_batch_max
+    8192 / 0), so the lane ladder keeps its coverage of the small vector sets."""
+    import secp256k1_voi_amd as S
+    from conftest import load_golden
+    from workload import make_ecdsa_batch
+    H = bytes.fromhex
+    eng = S.Engine(0)
+    batches = []
+    for fn in ("wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"):
+        items = []
+        for c in load_golden(fn)["cases"]:
+            rs = oracle.parse_asn1_signature(H(c["sig"]))
+            if rs is not None:
+                items.append((H(c["pub"])[1:], H(c["digest"])[:32], rs[0], rs[1], int(c["valid"])))
+        arrs = [np.frombuffer(b"".join(i[k] for i in items), np.uint8).reshape(len(items), w) for k, w in ((0, 64), (1, 32), (2, 32), (3, 32))]
+        batches.append((arrs, np.array([i[4] for i in items], np.uint8), False))
+    d = load_golden("rfc6979.json")["cases"]
+    pubs = np.frombuffer(b"".join(oracle.scalar_base_mult_vartime(H(c["private"]))[1:] for c in d), np.uint8).reshape(-1, 64)
+    digs = np.frombuffer(b"".join(H(c["digest"]) for c in d), np.uint8).reshape(-1, 32)
+    rs_ = [oracle.parse_asn1_signature(H(c["sig"])) for c in d]
+    rr = np.frombuffer(b"".join(x[0] for x in rs_), np.uint8).reshape(-1, 32)
+    ss = np.frombuffer(b"".join(x[1] for x in rs_), np.uint8).reshape(-1, 32)
+    batches.append(([pubs, digs, rr, ss], np.ones(len(d), np.uint8), True))
+    batches.append(([pubs, np.roll(digs, 1, axis=0), rr, ss], np.zeros(len(d), np.uint8), False))
+    for n, seed in ((1, 3), (2, 9), (63, 4), (64, 5), (65, 6), (257, 7), (1000, 8), (2048, 10), (5000, 11)):
+        w = make_ecdsa_batch(oracle, n, seed=seed, corrupt_every=3, low_s=(seed % 2 == 0))
+        arrs = [np.ascontiguousarray(w[k]) for k in ("pub", "digest", "r", "s")]
+        for rm in (False, True):
+            batches.append((arrs, oracle.ecdsa_verify_batch(*arrs, reject_malleable=rm, nthreads=8), rm))
+    # boundary values in every field
+    rnd = random.Random(78)
+    w = make_ecdsa_batch(oracle, 2000, seed=77, n_keys=32, corrupt_every=0, low_s=False)
+    pool = [0, 1, 2, R.N - 1, R.N, R.N + 1, R.P - 1, R.P, R.P + 1, 2**256 - 1, (R.N - 1) // 2, (R.N + 1) // 2, R.GX, R.GY, R.P - R.N, R.P - R.N - 1]
+    arrs = [np.array(w[k]) for k in ("pub", "digest", "r", "s")]
+    for i in range(2000):
+        if rnd.random() < 0.5:
+            f = rnd.randrange(5)
+            v = np.frombuffer(b32(rnd.choice(pool)), np.uint8)
+            if f == 0:
+                arrs[0][i, :32] = v
+            elif f == 1:
+                arrs[0][i, 32:] = v
+            else:
+                arrs[f - 1][i] = v
+    for rm in (False, True):
+        batches.append((arrs, oracle.ecdsa_verify_batch(*arrs, reject_malleable=rm, nthreads=8), rm))
+    for row_max in (8192, 0):
+        eng.set_small_batch_max(row_max)
+        for arrs, exp, rm in batches:
+            got = eng.ecdsa_verify_batch(*arrs, reject_malleable=rm)
+            assert np.array_equal(got, exp), (row_max, len(exp), rm, np.nonzero(got != exp)[0][:8])
+    # the same through submit / wait (child contexts inherit the setting)
+    eng.set_small_batch_max(8192)
+    arrs, exp, rm = batches[0]
+    t = [eng.ecdsa_verify_batch_submit(*arrs), eng.ecdsa_verify_batch_submit(*arrs)]
+    assert np.array_equal(t[1].wait(), exp) and np.array_equal(t[0].wait(), exp)
+    eng.close()
