@@ -292,12 +292,14 @@ int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
 /* Small batches.  A call of up to a few thousand signatures leaves the device empty whatever it runs, and costs the latency
- * of ONE signature's ladder; for batches of up to max_n signatures (default 4096; 0 = never) s2k_ecdsa_verify_batch[_device /
- * _submit] therefore run a ladder that spends a whole wavefront on each signature (k_verify_row: the row arithmetic of
- * fe29r.h, complete formulas): 0.24 instead of 0.65 ms for 1024 signatures - the reference's own shape is a loop of single
- * PublicKey.Verify calls (secec/ecdsa.go:171; BASELINE config 1 verifies 1024).  Same verdicts (tests/test_gpu_round5.py).
- * A grouping mode set by name (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed at every size; the default (S2K_KEYS_ADAPTIVE)
- * and S2K_KEYS_OFF take this ladder. */
+ * of ONE signature's ladder; for batches of up to max_n items (default 4096; 0 = never) s2k_ecdsa_verify_batch,
+ * s2k_schnorr_verify_batch and s2k_ecdsa_recover_batch (and their _device / _submit forms) therefore run ladders that spend
+ * a whole wavefront on each item (k_verify_row / k_schnorr_row / k_recover_row: the row arithmetic of fe29r.h, complete
+ * formulas): 0.19 instead of 0.68 ms for 1024 ECDSA signatures, 0.24 instead of 0.83 for BIP-340, 0.35 instead of 0.87 for
+ * recovery - the reference's own shape is a loop of single PublicKey.Verify calls (secec/ecdsa.go:171; BASELINE config 1
+ * verifies 1024).  Same results (tests/test_gpu_round5.py::test_small_batch_*).  A grouping mode set by name
+ * (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed at every size; the default (S2K_KEYS_ADAPTIVE) and S2K_KEYS_OFF take these
+ * ladders. */
 int s2k_ctx_set_small_batch_max(s2k_ctx *ctx, uint32_t max_n);
 /* Times of a ticket on the device's clock, for placement diagnostics (s2k_group_member_stats_ex): after
  * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records when its host-to-device copies start and end and when its

@@ -1026,6 +1026,105 @@ S2K_DEV fer fer_from_words(const uint32_t w[8], const fer_consts& k) {
 // value == 0 (mod p), the same answer in every lane
 S2K_DEV bool fer_is_zero(fer a, const fer_consts& k) { return fe29_is_zero(fer_to_fe29(fer_norm(a, k))); }
 
+// canonical value odd?  (the same answer in every lane of a row)
+S2K_DEV bool fer_is_odd(fer a, const fer_consts& k) { return (fe29_normalize(fer_to_fe29(fer_norm(a, k))).n[0] & 1u) != 0; }
+S2K_DEV fer fer_sqr_n(fer a, int n, const fer_consts& k) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = fer_mul(a, a, k);
+  return a;
+}
+// a^((p+1)/4): the chain of fe29_sqrt (Sqrt, internal/field/field_sqrt_ratio.go:14), row by row - four roots per wave
+S2K_DEV fer fer_sqrt_chain(fer a, const fer_consts& k) {
+  const fer x2 = fer_mul(fer_mul(a, a, k), a, k);
+  const fer x3 = fer_mul(fer_mul(x2, x2, k), a, k);
+  const fer x6 = fer_mul(fer_sqr_n(x3, 3, k), x3, k);
+  const fer x9 = fer_mul(fer_sqr_n(x6, 3, k), x3, k);
+  const fer x11 = fer_mul(fer_sqr_n(x9, 2, k), x2, k);
+  const fer x22 = fer_mul(fer_sqr_n(x11, 11, k), x11, k);
+  const fer x44 = fer_mul(fer_sqr_n(x22, 22, k), x22, k);
+  const fer x88 = fer_mul(fer_sqr_n(x44, 44, k), x44, k);
+  const fer x176 = fer_mul(fer_sqr_n(x88, 88, k), x88, k);
+  const fer x220 = fer_mul(fer_sqr_n(x176, 44, k), x44, k);
+  const fer x223 = fer_mul(fer_sqr_n(x220, 3, k), x3, k);
+  fer t = fer_mul(fer_sqr_n(x223, 23, k), x22, k);
+  t = fer_mul(fer_sqr_n(t, 6, k), x2, k);
+  return fer_sqr_n(t, 2, k);
+}
+// x^3 + 7
+S2K_DEV fer fer_curve_rhs(fer x, const fer_consts& k) {
+  const fer seven = k.j == 0 ? 7u : 0u;
+  return fer_mul_plus(fer_mul(x, x, k), x, seven, k);
+}
+
+// u * G + k1 * Q + k2 * lambda(Q) for ONE signature on the whole wave (Q affine and on the curve; u, |k1|, |k2|, signs from
+// the planes of the preparation kernel): the table of the key lives in LDS, one 256-byte line per coordinate of an entry
+// (lane l of the wave at word l) - x, y, z and lambda's x (beta * x) of (2j + 1) Q, j < 8 -, an entry is three loads at a
+// wave-uniform offset; 32 x (4 doublings + 2 additions) on the complete formulas, then the generator part from the
+// resident tables (no entry is the identity, no digit is special).  The result is projective.
+S2K_DEV pt29r row_double_mult(const pt29r& Q1, uint32_t (*tab)[8][64], const uint32_t* __restrict__ prep, size_t stride, uint32_t sig,
+                              uint32_t pf, gt_view gt, const fer_consts& k, uint32_t lane) {
+  const fer one = k.j == 0 ? 1u : 0u;
+  const fer beta = fer_from_words(FE_BETA, k);
+  {
+    const pt29r D = pt29r_double(Q1, k);
+    pt29r cur = Q1;
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      if (j) cur = pt29r_add(cur, D, k);
+      tab[0][j][lane] = cur.x;
+      tab[1][j][lane] = fer_norm(cur.y, k);
+      tab[2][j][lane] = cur.z;
+      tab[3][j][lane] = fer_mul(cur.x, beta, k);
+    }
+  }
+  // |k1|, |k2| odd, < 2^129 (sc_split_glv_odd in the preparation kernel)
+  sc k1 = sc_zero(), k2 = sc_zero();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    k1.v[w] = prep[(size_t)(8 + w) * stride + sig];
+    k2.v[w] = prep[(size_t)(12 + w) * stride + sig];
+  }
+  k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;
+  k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;
+  const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
+  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+  auto entry_of = [&](uint32_t w, bool lam, bool sneg) -> pt29r {   // the entry of digit w (signed odd: 2w - 15), or its image
+    const bool neg = sneg != (w < 8u);                              // under the endomorphism, negated with the scalar's sign
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w < 8u) ? (7u - w) : (w - 8u)));
+    pt29r a;
+    a.x = tab[lam ? 3 : 0][e][lane];
+    a.y = tab[1][e][lane];
+    a.z = tab[2][e][lane];
+    if (neg) a.y = fer_negate(a.y, 1, k);                           // [2]: the addition normalises y
+    return a;
+  };
+  pt29r acc = pt29r_add(entry_of(8u, false, neg1), entry_of(8u, true, neg2), k);   // the top digits are +1 (w = 8)
+#pragma unroll 1
+  for (int i = 31; i >= 0; --i) {
+    const uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+    const pt29r a1 = entry_of(w1, false, neg1), a2 = entry_of(w2, true, neg2);   // (in flight during the doublings)
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) acc = pt29r_double(acc, k);
+    acc = pt29r_add(acc, a1, k);
+    acc = pt29r_add(acc, a2, k);
+  }
+  uint32_t u[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
+  apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
+#pragma unroll 1
+  for (uint32_t w = 0; w < gt.windows; ++w) {
+    pt29r q;
+    q.x = fer_from_words(g.x.v, k);
+    q.y = fer_from_words(g.y.v, k);
+    q.z = one;
+    if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));   // in flight during the addition
+    acc = pt29r_add(acc, q, k);
+  }
+  return acc;
+}
+
+// PublicKey.Verify (secec/ecdsa.go:171, 392-470) with one WAVEFRONT per signature: the small-batch ladder
 __global__ void __launch_bounds__(256)
 k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep,
              gt_view gt, uint8_t* __restrict__ out, size_t stride) {
@@ -1037,86 +1136,20 @@ k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restr
   load_be32(xw, pub + (size_t)sig * 64);
   load_be32(yw, pub + (size_t)sig * 64 + 32);
   bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
-  const fer one = k.j == 0 ? 1u : 0u;
-  pt29r T[8];
-  T[0].x = fer_from_words(xw, k);
-  T[0].y = fer_from_words(yw, k);
-  T[0].z = one;
+  __shared__ uint32_t tab_all[4][4][8][64];
+  pt29r Q1;
+  Q1.x = fer_from_words(xw, k);
+  Q1.y = fer_from_words(yw, k);
+  Q1.z = k.j == 0 ? 1u : 0u;
   {   // y^2 == x^3 + 7 (point_s11n.go:298-307)
-    const fer x2 = fer_mul(T[0].x, T[0].x, k);
-    const fer seven = k.j == 0 ? 7u : 0u;
-    const fer rhs = fer_mul_plus(x2, T[0].x, seven, k);
-    const fer lhs = fer_mul(T[0].y, T[0].y, k);
-    ok = ok && fer_is_zero(fer_add(lhs, fer_negate(rhs, 1, k)), k);
+    const fer lhs = fer_mul(Q1.y, Q1.y, k);
+    ok = ok && fer_is_zero(fer_add(lhs, fer_negate(fer_curve_rhs(Q1.x, k), 1, k)), k);
   }
   if (!ok) {                                                    // (wave-uniform)
     if (lane == 0) out[sig] = 0;
     return;
   }
-  // ---- table: odd multiples, projective ----
-  {
-    const pt29r D = pt29r_double(T[0], k);
-#pragma unroll
-    for (int j = 1; j < 8; ++j) T[j] = pt29r_add(T[j - 1], D, k);
-  }
-  const fer beta = fer_from_words(FE_BETA, k);
-  // ---- ladder over |k1|, |k2| (odd, < 2^129: sc_split_glv_odd in the preparation kernel) ----
-  sc k1 = sc_zero(), k2 = sc_zero();
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    k1.v[w] = prep[(size_t)(8 + w) * stride + sig];
-    k2.v[w] = prep[(size_t)(12 + w) * stride + sig];
-  }
-  k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;
-  k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;
-  const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
-  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
-  auto entry_of = [&](uint32_t e, bool lam, bool neg) -> pt29r {     // +-T[e] or its image under the endomorphism
-    pt29r a = T[0];
-    switch (__builtin_amdgcn_readfirstlane((int)e)) {               // (uniform: a scalar branch)
-      case 1: a = T[1]; break;
-      case 2: a = T[2]; break;
-      case 3: a = T[3]; break;
-      case 4: a = T[4]; break;
-      case 5: a = T[5]; break;
-      case 6: a = T[6]; break;
-      case 7: a = T[7]; break;
-      default: break;
-    }
-    if (lam) a.x = fer_mul(a.x, beta, k);
-    if (neg) a.y = fer_negate(a.y, 1, k);                             // [2]: the addition normalises y
-    return a;
-  };
-  pt29r acc = pt29r_add(entry_of(0, false, neg1), entry_of(0, true, neg2), k);   // the top digits are +1
-#pragma unroll 1
-  for (int i = 31; i >= 0; --i) {
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) acc = pt29r_double(acc, k);
-    const uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-      const uint32_t w = t ? w2 : w1;
-      const bool neg = (t ? neg2 : neg1) != (w < 8u);
-      const uint32_t e = (w < 8u) ? (7u - w) : (w - 8u);
-      acc = pt29r_add(acc, entry_of(e, t != 0, neg), k);
-    }
-  }
-  // ---- generator part: u1 * G from the resident tables (no entry is the identity, no digit is special) ----
-  {
-    uint32_t u[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
-    apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
-#pragma unroll 1
-    for (uint32_t w = 0; w < gt.windows; ++w) {
-      pt29r q;
-      q.x = fer_from_words(g.x.v, k);
-      q.y = fer_from_words(g.y.v, k);
-      q.z = one;
-      if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));   // in flight during the addition
-      acc = pt29r_add(acc, q, k);
-    }
-  }
+  const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
   // ---- verdict: R != infinity and x(R) mod n == r (ecdsa.go:450-465), x(R) = X / Z ----
   uint8_t verdict = 0;
   if (!fer_is_zero(acc.z, k)) {
@@ -1250,6 +1283,51 @@ k_schnorr_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __rest
   prep[(size_t)16 * stride + i] = f;
 }
 
+// SchnorrPublicKey.Verify (schnorr.go:221-253) with one WAVEFRONT per signature (small batches), behind
+// k_schnorr_prep.  lift_x of the key and of r - the point R would have to be - run as ONE chain of row products (rows 0, 1:
+// the key; rows 2, 3: r): the signature is valid iff s G - e P is the point (r, even y), compared projectively, so there
+// is no inversion.
+__global__ void __launch_bounds__(256)
+k_schnorr_row(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig64, const uint32_t* __restrict__ prep,
+              gt_view gt, uint8_t* __restrict__ out, size_t stride) {
+  const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (sig >= n) return;                                         // (whole waves)
+  const fer_consts k = fer_setup(lane);
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  uint32_t xw[8], rw[8];
+  load_be32(xw, pk + (size_t)sig * 32);
+  load_be32(rw, sig64 + (size_t)sig * 64);
+  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw);            // (PF_OK: r < p, s < n)
+  __shared__ uint32_t tab_all[4][4][8][64];
+  const fer xP = fer_from_words(xw, k), xR = fer_from_words(rw, k);
+  const fer c = fer_curve_rhs(fer_sel2(k, xP, xR), k);
+  const fer y = fer_sqrt_chain(c, k);
+  const bool is_root = fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);     // (row by row)
+  const bool odd = fer_is_odd(y, k);
+  const fer y_even = fer_norm(odd ? fer_negate(y, 1, k) : y, k);
+  const uint64_t roots = __builtin_amdgcn_ballot_w64(is_root);
+  ok = ok && (roots & 1u) && ((roots >> 32) & 1u);              // both lifts exist (lane 0: the key, lane 32: r)
+  if (!ok) {                                                    // (wave-uniform)
+    if (lane == 0) out[sig] = 0;
+    return;
+  }
+  fer yP, yR;
+  fer_halves(y_even, yP, yR);
+  pt29r Q1;
+  Q1.x = xP;
+  Q1.y = yP;
+  Q1.z = k.j == 0 ? 1u : 0u;
+  const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
+  // R = s G - e P is finite, x(R) = r and y(R) is even: X = r Z and Y = y_r Z with Z != 0
+  uint8_t verdict = 0;
+  if (!fer_is_zero(acc.z, k)) {
+    const bool mx = fer_is_zero(fer_add(acc.x, fer_negate(fer_mul(xR, acc.z, k), 1, k)), k);
+    const bool my = fer_is_zero(fer_add(fer_norm(acc.y, k), fer_negate(fer_mul(yR, acc.z, k), 1, k)), k);
+    verdict = (mx && my) ? 1 : 0;
+  }
+  if (lane == 0) out[sig] = verdict;
+}
+
 // SchnorrPublicKey.Verify (schnorr.go:221-253) with complete formulas
 S2K_DEV uint8_t schnorr_verify_complete(size_t idx, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig,
                                         const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offs,
@@ -1287,6 +1365,49 @@ k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
   for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < count; w += gridDim.x * 256) {
     size_t idx = all_n ? w : wl[w];
     out[idx] = schnorr_verify_complete(idx, pk, sig, msgs, offs, msg_len, gt, qt, stride);
+  }
+}
+
+// RecoverPublicKey (ecdsa.go:244-282) with one WAVEFRONT per item (small batches), behind k_scalar_prep (u1 = -e/r,
+// u2 = s/r, the recovery id in the flags) and in front of k_affine_finish<MODE_RECOVER>: R = (r or r + n, the root of the
+// asked parity) by a chain of row products, Q = u1 G + u2 R on the complete formulas, handed over as the Jacobian triple
+// (X Z, Y Z^2, Z) the finish kernel expects.  Items without a key get ok = 0 here (their record stays zero).
+__global__ void __launch_bounds__(256)
+k_recover_row(uint32_t n, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep, gt_view gt,
+              uint32_t* __restrict__ fin, uint8_t* __restrict__ out, size_t stride) {
+  const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (sig >= n) return;                                         // (whole waves)
+  const fer_consts k = fer_setup(lane);
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  const uint32_t rid = (pf >> 8) & 3u;
+  uint32_t xw[8];
+  load_be32(xw, rsig + (size_t)sig * 32);
+  bool ok = (pf & PF_OK) != 0;                                  // (r, s in range, id < 4, r + n < p where the id asks for it)
+  if (ok && (rid & 2u)) u256_add(xw, xw, SC_N);
+  __shared__ uint32_t tab_all[4][4][8][64];
+  pt29r Q1;
+  Q1.x = fer_from_words(xw, k);
+  Q1.z = k.j == 0 ? 1u : 0u;
+  const fer c = fer_curve_rhs(Q1.x, k);
+  const fer y = fer_sqrt_chain(c, k);
+  ok = ok && fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);
+  if (!ok) {                                                    // (wave-uniform)
+    if (lane == 0) out[sig] = 0;
+    return;
+  }
+  Q1.y = fer_norm(fer_is_odd(y, k) != ((rid & 1u) != 0) ? fer_negate(y, 1, k) : y, k);
+  const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
+  if (fer_is_zero(acc.z, k)) {                                  // identity: NewPublicKeyFromPoint fails (secec.go:206-209)
+    if (lane == 0) out[sig] = 0;
+    return;
+  }
+  const fer zz = fer_mul(acc.z, acc.z, k);
+  const fe29 X = fer_to_fe29(fer_mul(acc.x, acc.z, k)), Y = fer_to_fe29(fer_mul(fer_norm(acc.y, k), zz, k)), Z = fer_to_fe29(acc.z);
+  if (lane == 0) {
+    fq_store(fin, stride, sig, 0, X);
+    fq_store(fin, stride, sig, 1, Y);
+    fq_store(fin, stride, sig, 2, Z);
+    out[sig] = VERDICT_PENDING;
   }
 }
 
@@ -2297,9 +2418,11 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     prof_mark(ctx, st, 4);
   } else if (row) {
     // small batches: a wave per signature on the complete formulas (k_verify_row); nothing is left for the worklist kernel
+    // (a lane of the preparation per signature: sharing an inversion between PREP_M signatures saves instructions and
+    // costs latency - 94 us for six in a row, 45 for one - and latency is all a call of this size has)
     wait_all(st);
-    k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r,
-                                                (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
+    k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                            (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
@@ -2646,6 +2769,23 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   // affine results, [4] the worklist)
   prof_mark(ctx, st, 0);
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  if (n <= ctx->row_max) {
+    // small batches: a wave per item, one lane of the preparation and of the finish per item (k_recover_row)
+    k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, dig, r, s, rid, 0u, prep, pref, smont, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_recover_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, r, prep, s2k_internal_gt(ctx), fin, (uint8_t*)d_ok, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    k_affine_finish<MODE_RECOVER><<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, nullptr, fin, (uint8_t*)d_ok, stride,
+                                                                            (uint8_t*)d_pub65);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 4);
+    prof_mark(ctx, st, 5);
+    return ctx_leave(ctx, st);
+  }
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
@@ -2741,6 +2881,8 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   ctx->kg_counters = nullptr;
   ctx->last_wl_count = wl_count;
   bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
+  const bool row = n <= ctx->row_max && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
+  if (row) grouped = false;
   if (grouped) {
     rc = s2k_internal_key_reserve(ctx, n, 32);
     if (rc == S2K_ERR_NOMEM) grouped = false;      // no room for per-key tables: the general ladder for everything
@@ -2772,6 +2914,18 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
+  } else if (row) {
+    // small batches: a wave per signature, nothing left for the finish and worklist kernels (k_schnorr_row)
+    k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_schnorr_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, pk, sig, prep, s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    prof_mark(ctx, st, 4);
+    prof_mark(ctx, st, 5);
+    return ctx_leave(ctx, st);
   } else {
     k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
     HIP_TRY(ctx, hipGetLastError());

@@ -299,3 +299,120 @@ def test_small_batch_ladder_agrees_with_the_lane_ladder(oracle):
     t = [eng.ecdsa_verify_batch_submit(*arrs), eng.ecdsa_verify_batch_submit(*arrs)]
     assert np.array_equal(t[1].wait(), exp) and np.array_equal(t[0].wait(), exp)
     eng.close()
+
+
+def test_small_batch_schnorr_ladder_agrees_with_the_lane_ladder(oracle):
+    """k_schnorr_row (a wave per signature: both lifts as one chain of row products, s G - e P compared projectively with
+    (r, even y)) and the lane-per-signature kernels give the verdicts of the oracle and of the pure-Python BIP-340 on the
+    reference's vector file, on signed messages of many lengths with every parse failure (r >= p, s >= n, key >= p), on
+    keys that are no x coordinate, s = 0, r that is no x coordinate, and on valid signatures whose R was replaced by -R (odd
+    y: the only thing that tells them apart is the parity check)."""
+    import secp256k1_voi_amd as S
+    from conftest import load_golden
+    H = bytes.fromhex
+    eng = S.Engine(0)
+    d = load_golden("bip340.json")["cases"]
+    sets = [([H(c["public_key"]) for c in d], [H(c["message"]) for c in d], [H(c["signature"]) for c in d], [int(c["valid"]) for c in d])]
+    rnd = random.Random(510)
+    pk, msg, sig = [], [], []
+    for i in range(700):
+        dd = rnd.randrange(1, R.N)
+        P = R.mul(dd, R.G)
+        m = rnd.randbytes(rnd.choice([0, 1, 31, 32, 33, 55, 56, 63, 64, 65, 119, 120, 200]))
+        s = R.schnorr_sign(dd, m, rnd.randbytes(32))
+        p = b32(P[0])
+        kind = i % 10
+        if kind == 1:
+            s = s[:32] + b32((int.from_bytes(s[32:], "big") + 1) % R.N)
+        elif kind == 2:
+            m = m + b"x"
+        elif kind == 3:
+            s = b32(R.P + 5) + s[32:]                     # r >= p
+        elif kind == 4:
+            p = b32(R.P + (i % 3))                        # key >= p
+        elif kind == 5:
+            s = s[:32] + b32(R.N)                         # s >= n
+        elif kind == 6:
+            s = s[:32] + b32(0)                           # s = 0
+        elif kind == 7:                                   # a key / an r that is no x coordinate
+            x = rnd.randrange(R.P)
+            while pow((x**3 + 7) % R.P, (R.P - 1) // 2, R.P) == 1:
+                x = rnd.randrange(R.P)
+            if i % 20 == 7:
+                p = b32(x)
+            else:
+                s = b32(x) + s[32:]
+        pk.append(p); msg.append(m); sig.append(s)
+    exp = [max(0, oracle.schnorr_verify(p, m, s)) for p, m, s in zip(pk, msg, sig)]
+    assert exp == [int(R.schnorr_verify(p, m, s)) for p, m, s in zip(pk, msg, sig)] and 0 < sum(exp) < len(exp)
+    sets.append((pk, msg, sig, exp))
+    # s G - e P = -lift_x(r): x matches, y is odd.  From a valid (r, s) under key d with challenge e: R = k G; the signature
+    # (r, s') with s' = -k + e d gives s' G - e P = -R (the challenge hashes r, P, m only).
+    pk, msg, sig = [], [], []
+    for i in range(64):
+        dd = rnd.randrange(1, R.N)
+        P = R.mul(dd, R.G)
+        if P[1] & 1:
+            dd = R.N - dd
+        m = rnd.randbytes(32)
+        sg = R.schnorr_sign(dd, m, rnd.randbytes(32))
+        r, s = sg[:32], int.from_bytes(sg[32:], "big")
+        e = int.from_bytes(R.tagged_hash("BIP0340/challenge", r, b32(P[0]), m), "big") % R.N
+        kk = (s - e * dd) % R.N                           # R = kk G (even y)
+        s2 = (-kk + e * dd) % R.N
+        pk.append(b32(P[0])); msg.append(m); sig.append(r + b32(s2))
+        pk.append(b32(P[0])); msg.append(m); sig.append(sg)
+    exp = [max(0, oracle.schnorr_verify(p, m, s)) for p, m, s in zip(pk, msg, sig)]
+    assert exp == [0, 1] * 64
+    sets.append((pk, msg, sig, exp))
+    for row_max in (8192, 0):
+        eng.set_small_batch_max(row_max)
+        for pk, msg, sig, exp in sets:
+            assert eng.schnorr_verify_batch(pk, msg, sig).tolist() == exp, row_max
+            for n in (1, 5):
+                assert eng.schnorr_verify_batch(pk[:n], msg[:n], sig[:n]).tolist() == exp[:n], (row_max, n)
+    eng.close()
+
+
+def test_small_batch_recovery_ladder_agrees_with_the_lane_ladder(oracle):
+    """k_recover_row (a wave per item: the root of R as a chain of row products, Q = -e/r G + s/r R on the complete formulas,
+    the finish kernel's shared inversion) and the lane-per-signature kernels give the oracle's keys on the Wycheproof sets
+    under every recovery id 0 .. 4 (the reference's RecoverPublicKey has no vectors of its own: SURVEY 8c) and on random
+    signatures with r, s at the range boundaries (0, n, p - n and their neighbours: the ids that ask for r + n)."""
+    import secp256k1_voi_amd as S
+    from conftest import load_golden
+    H = bytes.fromhex
+    eng = S.Engine(0)
+    sets = []
+    for fn in ("wycheproof_ecdsa_sha256.json", "wycheproof_ecdsa_sha512.json"):
+        dig, rr, ss, ids = [], [], [], []
+        for c in load_golden(fn)["cases"]:
+            rs = oracle.parse_asn1_signature(H(c["sig"]))
+            if rs is None:
+                continue
+            for rid in range(5):
+                dig.append(H(c["digest"])[:32]); rr.append(rs[0]); ss.append(rs[1]); ids.append(rid)
+        sets.append((dig, rr, ss, ids))
+    rnd = random.Random(1010)
+    dig, rr, ss, ids = [], [], [], []
+    for i in range(1500):
+        d = rnd.randrange(1, R.N)
+        dg = rnd.randbytes(32)
+        r, s = R.ecdsa_sign(d, dg, rnd.randrange(1, R.N))
+        if i % 7 == 0:
+            r = rnd.choice([0, R.N, R.N + 1, 1, 2, R.P - R.N - 1, R.P - R.N, R.P - R.N + 1])
+        if i % 11 == 0:
+            s = rnd.choice([0, R.N, 1])
+        dig.append(dg); rr.append(b32(r)); ss.append(b32(s)); ids.append(rnd.randrange(4))
+    sets.append((dig, rr, ss, ids))
+    for dig, rr, ss, ids in sets:
+        exp = [oracle.ecdsa_recover(a, b, c, d) for a, b, c, d in zip(dig, rr, ss, ids)]
+        assert 0 < sum(e is not None for e in exp) < len(exp)
+        for row_max in (8192, 0):
+            eng.set_small_batch_max(row_max)
+            for lo, hi in ((0, len(dig)), (0, 1), (3, 8)):
+                pub, ok = eng.ecdsa_recover_batch(dig[lo:hi], rr[lo:hi], ss[lo:hi], ids[lo:hi])
+                got = [bytes(p) if k else None for p, k in zip(pub, ok)]
+                assert got == exp[lo:hi], (row_max, lo, hi)
+                assert all(bytes(p) == bytes(65) for p, k in zip(pub, ok) if not k)
+    eng.close()

@@ -36,6 +36,26 @@ def main():
         same = bool(np.array_equal(res["row"][1], res["lane"][1]))
         rows.append({"log2_n": lg, "row_ms": round(res["row"][0], 4), "lane_ms": round(res["lane"][0], 4), "same_verdicts": same, "valid": int(res["row"][1].sum())})
         print(json.dumps(rows[-1]), flush=True)
+    # BIP-340 verification and key recovery of the same sizes, host arrays to host results (synchronous calls)
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    pk, msgs, sig = synth_schnorr_batch(eng, 4096, 4096, 9)
+    rid = np.zeros(4096, np.uint8)
+    hw = {k: np.ascontiguousarray(w[k][:4096]) for k in ("digest", "r", "s")}
+    for lg in (0, 6, 10, 11, 12):
+        n = 1 << lg
+        row = {"log2_n": lg}
+        for name, rm in (("row", 1 << 20), ("lane", 0)):
+            eng.set_small_batch_max(rm)
+            for what, call in (("schnorr", lambda: eng.schnorr_verify_batch(pk[:n], msgs[:n], sig[:n])),
+                               ("recover", lambda: eng.ecdsa_recover_batch(hw["digest"][:n], hw["r"][:n], hw["s"][:n], rid[:n])[1])):
+                ts = []
+                for i in range(25):
+                    t0 = time.perf_counter()
+                    res = call()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                row["%s_%s_ms" % (what, name)] = round(float(np.median(ts[5:])), 4)
+                row["%s_%s_ok" % (what, name)] = int(np.asarray(res).sum())
+        print(json.dumps(row), flush=True)
     eng.close()
 
 
