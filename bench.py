@@ -350,11 +350,32 @@ def batch_sweep(eng, pub, digest, r, s, cpu):
         if cpu_1 and cross_one is None and rate > cpu_1:
             cross_one = n
         del arrs
+    # the other two per-signature entry points at the reference's own size (1024 per call: BASELINE config 1's shape)
+    small = {}
+    try:
+        from secp256k1_voi_amd.synth import synth_schnorr_batch
+        m = 1024
+        pk, msgs, sig = synth_schnorr_batch(eng, m, m, 77)
+        rid = np.zeros(m, np.uint8)
+        for key, call in (("schnorr_1024_ms", lambda: eng.schnorr_verify_batch(pk, msgs, sig)),
+                          ("recover_1024_ms", lambda: eng.ecdsa_recover_batch(digest[:m], r[:m], s[:m], rid)[1])):
+            ts = []
+            for _ in range(12):
+                t0 = time.perf_counter()
+                res = call()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            assert key != "schnorr_1024_ms" or bool(np.asarray(res).all()), "BIP-340 call of 1024 signatures rejected a valid signature"
+            small[key] = median(ts[3:])
+    except AssertionError:
+        raise
+    except Exception as e:   # noqa: BLE001 - a side measurement
+        small["small_calls_error"] = "%s: %s" % (type(e).__name__, e)
     return {"log2_n": sorted(rows), "ms": [rows[k] for k in sorted(rows)], "n_from_which_a_call_beats_all_host_threads": cross_all,
-            "n_from_which_a_call_beats_one_host_thread": cross_one,
+            "n_from_which_a_call_beats_one_host_thread": cross_one, **small,
             "note": "ms[i] = one synchronous s2k_ecdsa_verify_batch call of 2^log2_n[i] signatures, page-locked host memory to host verdicts, median of 5-9 calls per size (signatures/s = 2^log2_n / ms); "
-                    "a 1024-signature call costs what the smallest row says (launch and transfer latencies, not arithmetic); the "
-                    "streaming entry points (pcie_inclusive.pipelined) hide those from 2^17 per batch on"}
+                    "up to 2^12 signatures the wave-per-signature ladders run (k_verify_row / k_schnorr_row / k_recover_row, DESIGN 4d), above it the "
+                    "kernels of the headline; schnorr_1024_ms / recover_1024_ms: one s2k_schnorr_verify_batch / s2k_ecdsa_recover_batch call of 1024 "
+                    "items from pageable host arrays; the streaming entry points (pcie_inclusive.pipelined) hide launch and transfer latencies from 2^17 per batch on"}
 
 
 # ---------------------------------------------------------------------------------------------

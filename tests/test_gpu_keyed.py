@@ -382,12 +382,18 @@ def test_schnorr_exceptional_ladders_on_tables(eng, oracle):
     pk = np.frombuffer(b"".join(pks), np.uint8).reshape(-1, 32)
     mm = np.frombuffer(b"".join(msgs), np.uint8).reshape(-1, 32)
     sg = np.frombuffer(b"".join(sigs), np.uint8).reshape(-1, 64)
-    for mode in (S.KEYS_OFF, S.KEYS_AUTO):
-        eng.set_key_grouping(mode)
-        got = eng.schnorr_verify_batch(pk, mm, sg)
-        assert not got.any()
-        st = eng.key_grouping_stats()
-        assert st["complete"] >= len(pk) - 8       # (a random r that is no x-coordinate is rejected before the ladder matters)
+    eng.set_key_grouping(S.KEYS_OFF)
+    assert not eng.schnorr_verify_batch(pk, mm, sg).any()      # 1024 signatures: the wave-per-signature ladder, complete formulas
+    eng.set_small_batch_max(0)                                 # ... and the lane kernels with their worklist
+    try:
+        for mode in (S.KEYS_OFF, S.KEYS_AUTO):
+            eng.set_key_grouping(mode)
+            got = eng.schnorr_verify_batch(pk, mm, sg)
+            assert not got.any()
+            st = eng.key_grouping_stats()
+            assert st["complete"] >= len(pk) - 8       # (a random r that is no x-coordinate is rejected before the ladder matters)
+    finally:
+        eng.set_small_batch_max(4096)
     for j in range(0, len(pk), 97):
         assert oracle.schnorr_verify(bytes(pk[j]), bytes(mm[j]), bytes(sg[j])) != 1
     eng.set_key_grouping(S.KEYS_AUTO)
