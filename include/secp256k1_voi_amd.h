@@ -351,6 +351,7 @@ void s2k_group_destroy(s2k_group *g);
 size_t s2k_group_size(const s2k_group *g);
 const char *s2k_group_last_error(const s2k_group *g);
 int s2k_group_set_key_grouping(s2k_group *g, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables);
+int s2k_group_set_small_batch_max(s2k_group *g, uint32_t max_n);   /* s2k_ctx_set_small_batch_max on every member (a member's shard is what counts as the batch) */
 int s2k_group_ecdsa_verify_batch(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32, const uint8_t *r,
                                  const uint8_t *s, uint32_t flags, uint8_t *valid);
 int s2k_group_ecdsa_verify_batch_submit(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32,

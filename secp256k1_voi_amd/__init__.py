@@ -268,6 +268,7 @@ def load_library() -> C.CDLL:
     lib.s2k_group_last_error.argtypes = [vp]
     lib.s2k_group_last_error.restype = C.c_char_p
     lib.s2k_group_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
+    lib.s2k_group_set_small_batch_max.argtypes = [vp, u32]
     lib.s2k_group_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
     lib.s2k_group_multi_scalar_mult.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_group_keyset_create.argtypes = [vp, sz, vp, ci, vp]
@@ -359,7 +360,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ecdsa_verify_encoded_batch",
     "s2k_ecdsa_verify_batch_submit", "s2k_ecdsa_verify_encoded_batch_submit", "s2k_wait", "s2k_poll", "s2k_wait_all",
     "s2k_device_count", "s2k_group_create", "s2k_group_destroy", "s2k_group_size", "s2k_group_last_error",
-    "s2k_group_set_key_grouping", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
+    "s2k_group_set_key_grouping", "s2k_group_set_small_batch_max", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
     "s2k_group_ecdsa_verify_encoded_batch", "s2k_group_ecdsa_verify_encoded_batch_submit",
     "s2k_group_member_stats", "s2k_group_schnorr_batch_verify_rlc", "s2k_group_multi_scalar_mult",
     "s2k_group_keyset_create", "s2k_group_keyset_destroy", "s2k_group_keyset_size", "s2k_group_keyset_layout", "s2k_group_keyset_device_bytes",
@@ -1105,6 +1106,9 @@ class Group(_TicketOwner):
 
     def set_key_grouping(self, mode: int = KEYS_AUTO, min_group: int = 0, hash_bits: int = 0, max_tables: int = 0):
         self._check(self._lib.s2k_group_set_key_grouping(self._h, int(mode), int(min_group), int(hash_bits), int(max_tables)))
+
+    def set_small_batch_max(self, max_n: int):
+        self._check(self._lib.s2k_group_set_small_batch_max(self._h, int(max_n)))
 
     def gt_wait(self) -> int:
         """block until every member's device has its wide generator tables (s2k_group_gt_wait); the smallest width in use"""

@@ -349,6 +349,16 @@ int s2k_group_set_key_grouping(s2k_group* g, int mode, uint32_t min_group, uint3
   return S2K_OK;
 }
 
+int s2k_group_set_small_batch_max(s2k_group* g, uint32_t max_n) {
+  if (!g) return S2K_ERR_ARG;
+  group_wait_idle(g);
+  for (member* me : g->members) {
+    const int rc = s2k_ctx_set_small_batch_max(me->ctx, max_n);
+    if (rc) return gfail(g, rc, "%s", s2k_last_error(me->ctx));
+  }
+  return S2K_OK;
+}
+
 static int group_submit(s2k_group* g, size_t n, const shard_job& proto, s2k_ticket* ticket) {
   const size_t D = g->members.size();
   // contiguous index shards, rounded up to whole workgroups so that no member gets a ragged tail but the last

@@ -4,6 +4,7 @@ of the same code is tests/fer_model.py (CPU).  Reference symbols served: fiat Mu
 (secp256k1montgomery.go:87,750,844), addComplete / doubleComplete (point_projective.go:24,208)."""
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -299,6 +300,13 @@ def test_small_batch_ladder_agrees_with_the_lane_ladder(oracle):
     t = [eng.ecdsa_verify_batch_submit(*arrs), eng.ecdsa_verify_batch_submit(*arrs)]
     assert np.array_equal(t[1].wait(), exp) and np.array_equal(t[0].wait(), exp)
     eng.close()
+    # a group: each member's shard (here 2 x 1024 of the 2048) is what counts as the batch
+    g = S.Group([0, 0])
+    arrs, exp, rm = next(b for b in batches if len(b[1]) == 2048)
+    for row_max in (4096, 0):
+        g.set_small_batch_max(row_max)
+        assert np.array_equal(g.ecdsa_verify_batch(*arrs, reject_malleable=rm), exp), row_max
+    g.close()
 
 
 def test_small_batch_schnorr_ladder_agrees_with_the_lane_ladder(oracle):
@@ -416,3 +424,12 @@ def test_small_batch_recovery_ladder_agrees_with_the_lane_ladder(oracle):
                 assert got == exp[lo:hi], (row_max, lo, hi)
                 assert all(bytes(p) == bytes(65) for p, k in zip(pub, ok) if not k)
     eng.close()
+
+
+def test_graft_entry_smoke():
+    """what the driver runs before the bench: __graft_entry__.smoke() (its assertions name paths by their statistics, which a
+    change of the dispatch can break without any verdict being wrong)"""
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
