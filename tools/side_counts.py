@@ -8,7 +8,9 @@ BIP-340 verification at 2^20 items.
 `run`: three calls of s2k_ecdsa_recover_batch and of s2k_schnorr_verify_batch on 2^20 synthetic items of 2^16 keys.
 `summarize`: SQ_INSTS_VALU x 64 / items per dispatch of k_verify_fast<RECOVER> (template argument 2), <SCHNORR_KEYED> (6) and
 <SCHNORR> (1, the general ladder: the run is repeated with the key grouping off), averaged over the dispatches; bench.py prices
-the live duration of those kernels with them (recover_2p20.roofline, schnorr_per_signature_2p20.roofline)."""
+the live duration of those kernels with them (recover_2p20.roofline, schnorr_per_signature_2p20.roofline).  The same for the
+wave-per-signature ladders of small calls (k_verify_row, k_schnorr_row, k_recover_row; 1024 items per dispatch): there the
+figure is WAVE instructions per item - one wave works on one item -, what DESIGN 4d prices their latency with."""
 import csv
 import glob
 import json
@@ -37,20 +39,37 @@ def run():
         for _ in range(3):
             v = eng.schnorr_verify_batch(pk, msgs, sig)
         print("schnorr valid", int(v.sum()))
+    eng.set_key_grouping(S.KEYS_ADAPTIVE)
+    m = 1024
+    for _ in range(3):
+        v = eng.ecdsa_verify_batch(pub[:m], dig[:m], r[:m], s[:m])
+        v2 = eng.schnorr_verify_batch(pk[:m], msgs[:m], sig[:m])
+        q, ok = eng.ecdsa_recover_batch(dig[:m], r[:m], s[:m], rid[:m])
+    print("small calls", int(v.sum()), int(v2.sum()), int(ok.sum()))
+
+
+ROW_KERNELS = ("k_verify_row", "k_schnorr_row", "k_recover_row")
 
 
 def summarize(d, head):
     acc = {}
+    rowk = {}
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
             name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(" ", "")
             key = KERNELS.get(name)
             if key and row["Counter_Name"] == "SQ_INSTS_VALU":
                 acc.setdefault(key, []).append(float(row["Counter_Value"]))
+            if name in ROW_KERNELS and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
+                rowk.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU of tools/side_counts.py run: 2^20 items of 2^16 keys per dispatch, wave-instructions x 64 / items, "
                      "averaged over the dispatches", "items_per_dispatch": N, "head": head}
     for key, vals in sorted(acc.items()):
         out[key] = {"valu_instr_per_item": sum(vals) / len(vals) * 64.0 / N, "dispatches": len(vals)}
+    for name, c in sorted(rowk.items()):
+        v, w = c.get("SQ_INSTS_VALU", []), c.get("SQ_WAVES", [])
+        if v and w:
+            out[name] = {"valu_wave_instr_per_item": sum(v) / sum(w), "waves_per_dispatch": sum(w) / len(w), "dispatches": len(v)}
     print(json.dumps(out, indent=1))
 
 
