@@ -83,10 +83,10 @@ S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
   }
 }
 
-// Largest batch the wave-per-signature ladder (k_verify_row, engine.hip) takes: above it the lane-per-signature kernels win
-// (profiles/r05_small_batch_ab.txt: 0.24 against 0.65 ms up to 1024 signatures - one wave per SIMD -, 0.78 against 1.07 ms
-// at 8192, 1.39 against 1.09 at 16384 device-resident; from host memory 0.30 against 0.70 ms up to 1024, 0.56 against 0.70
-// at 4096, 0.89 against 0.75 at 8192).
+// Largest batch the wave-per-signature ladders (k_verify_row / k_schnorr_row / k_recover_row, engine.hip) take: above it the
+// lane-per-signature kernels win (profiles/r05_small_batch_ab.txt, ECDSA: 0.19 against 0.68 ms up to 1024 signatures - one wave
+// per SIMD -, 0.41 against 0.7-1.1 at 4096, 0.71 against 1.08 at 8192, 1.31 against 1.10 at 16384 device-resident; from host
+// memory 0.28 against 0.74 ms at 1024, 0.50 against 0.75 at 4096, 0.77 against 0.78 at 8192).
 #ifndef S2K_ROW_MAX_DEFAULT
 #define S2K_ROW_MAX_DEFAULT 4096
 #endif
