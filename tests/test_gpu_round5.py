@@ -211,6 +211,7 @@ def test_generator_table_widths_give_identical_verdicts(eng, oracle):
         assert np.array_equal(e.ecdsa_verify_batch(*arrs), exp), width
         e.set_key_grouping(S.KEYS_ADAPTIVE)
         assert np.array_equal(e.ecdsa_verify_batch(*(a[:4096] for a in arrs), force_complete=True), exp[:4096]), width
+        assert np.array_equal(e.ecdsa_verify_batch(*(a[:1000] for a in arrs)), exp[:1000]), width      # (the wave-per-signature ladder)
         assert [bytes(x) for x in np.asarray(e.scalar_base_mult_batch(ks))] == base_exp, width
         assert e.ecdsa_verify_encoded_batch(*wp).tolist() == wp_exp, width
         e.close()
