@@ -1371,10 +1371,10 @@ k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
 // RecoverPublicKey (ecdsa.go:244-282) with one WAVEFRONT per item (small batches), behind k_scalar_prep (u1 = -e/r,
 // u2 = s/r, the recovery id in the flags) and in front of k_affine_finish<MODE_RECOVER>: R = (r or r + n, the root of the
 // asked parity) by a chain of row products, Q = u1 G + u2 R on the complete formulas, handed over as the Jacobian triple
-// (X Z, Y Z^2, Z) the finish kernel expects.  Items without a key get ok = 0 here (their record stays zero).
+// (X Z, Y Z^2, Z) the finish kernel expects.  Items without a key get ok = 0 and the zero record here.
 __global__ void __launch_bounds__(256)
 k_recover_row(uint32_t n, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep, gt_view gt,
-              uint32_t* __restrict__ fin, uint8_t* __restrict__ out, size_t stride) {
+              uint32_t* __restrict__ fin, uint8_t* __restrict__ out, uint8_t* __restrict__ out_pts, size_t stride) {
   const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (sig >= n) return;                                         // (whole waves)
   const fer_consts k = fer_setup(lane);
@@ -1391,14 +1391,22 @@ k_recover_row(uint32_t n, const uint8_t* __restrict__ rsig, const uint32_t* __re
   const fer c = fer_curve_rhs(Q1.x, k);
   const fer y = fer_sqrt_chain(c, k);
   ok = ok && fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);
+  auto no_key = [&]() {                                         // ok = 0 and the zero record (RecoverPublicKey's error)
+    uint8_t* rec = out_pts + (size_t)sig * 65;
+    rec[lane] = 0;
+    if (lane == 0) {
+      rec[64] = 0;
+      out[sig] = 0;
+    }
+  };
   if (!ok) {                                                    // (wave-uniform)
-    if (lane == 0) out[sig] = 0;
+    no_key();
     return;
   }
   Q1.y = fer_norm(fer_is_odd(y, k) != ((rid & 1u) != 0) ? fer_negate(y, 1, k) : y, k);
   const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
   if (fer_is_zero(acc.z, k)) {                                  // identity: NewPublicKeyFromPoint fails (secec.go:206-209)
-    if (lane == 0) out[sig] = 0;
+    no_key();
     return;
   }
   const fer zz = fer_mul(acc.z, acc.z, k);
@@ -2352,7 +2360,6 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   uint32_t* smont = ws + WS_SMONT * stride;
   uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
   uint32_t* wl = wl_count + 64;
-  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
@@ -2361,6 +2368,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   // (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed instead
   const bool row = n <= ctx->row_max && !kvf && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
   if (row) grouped = false;
+  else HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));      // (the row ladder has no worklist: one launch less)
   ctx->kg_note_dst = nullptr;
   if (grouped && ctx->kg_mode == S2K_KEYS_ADAPTIVE && n >= KG_ADAPT_MIN_BATCH) grouped = kg_adaptive_decide(ctx);
   if (grouped) {
@@ -2370,7 +2378,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     if (rc == S2K_ERR_NOMEM) grouped = false;
     else if (rc) return rc;
   }
-  ctx->last_wl_count = wl_count;
+  ctx->last_wl_count = row ? nullptr : wl_count;
   prof_mark(ctx, st, 0);
   if (grouped) {
     // Signatures of keys that occur often enough: per-key tables (keyed.hip) and the short ladder; the
@@ -2768,15 +2776,15 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   // (stage times, s2k_ctx_profile_read_stages: [0] the scalar preparation, [2] the ladder, [3] the shared inversions of the
   // affine results, [4] the worklist)
   prof_mark(ctx, st, 0);
-  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   if (n <= ctx->row_max) {
-    // small batches: a wave per item, one lane of the preparation and of the finish per item (k_recover_row)
+    // small batches: a wave per item, one lane of the preparation and of the finish per item (k_recover_row; it writes the
+    // zero records itself and has no worklist: two launches less)
     k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, dig, r, s, rid, 0u, prep, pref, smont, stride);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_recover_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, r, prep, s2k_internal_gt(ctx), fin, (uint8_t*)d_ok, stride);
+    k_recover_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, r, prep, s2k_internal_gt(ctx), fin, (uint8_t*)d_ok,
+                                                           (uint8_t*)d_pub65, stride);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     k_affine_finish<MODE_RECOVER><<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, nullptr, fin, (uint8_t*)d_ok, stride,
@@ -2786,6 +2794,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
     prof_mark(ctx, st, 5);
     return ctx_leave(ctx, st);
   }
+  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
@@ -2877,12 +2886,12 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   // keys repeat -, [2] the ladder over per-key tables or the general one, [3] what the key tables left + the shared inversions,
   // [4] the worklist)
   prof_mark(ctx, st, 0);
-  HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   ctx->kg_counters = nullptr;
-  ctx->last_wl_count = wl_count;
   bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
   const bool row = n <= ctx->row_max && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
   if (row) grouped = false;
+  else HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
+  ctx->last_wl_count = row ? nullptr : wl_count;
   if (grouped) {
     rc = s2k_internal_key_reserve(ctx, n, 32);
     if (rc == S2K_ERR_NOMEM) grouped = false;      // no room for per-key tables: the general ladder for everything
