@@ -2216,6 +2216,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->rlc_save) (void)hipFree(ctx->rlc_save);
   if (ctx->io) (void)hipFree(ctx->io);
+  if (ctx->h_small) (void)hipHostFree(ctx->h_small);
   if (ctx->clk) (void)hipFree(ctx->clk);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   if (ctx->s_aux && !ctx->streams_shared) (void)hipStreamDestroy(ctx->s_aux);
@@ -2820,6 +2821,44 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   return ctx_leave(ctx, st);
 }
 
+}  // extern "C"
+// Small synchronous calls from host memory (up to the small-batch threshold, s2k_ctx_set_small_batch_max): the inputs are
+// copied by the CPU into a page-locked block that the kernels read in place, and the kernels write the results there - no
+// DMA transfer at all.  The five transfers of a 1024-signature call cost 45 us of its 0.23 ms, more than its 160 KB take
+// either way.  `count` pieces of `sizes[i]` bytes, 256-byte aligned; host[i] / dev[i]: the same piece as the CPU and as the
+// device address it.  (Synchronous entry points only: the block is free again when the call returns.)
+static int ctx_small_block(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** host, uint8_t** dev) {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) total += (sizes[i] + 255) & ~(size_t)255;
+  if (total > ctx->h_small_bytes) {
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    ctx->h_small = ctx->d_small = nullptr;
+    ctx->h_small_bytes = 0;
+    const size_t want = (total + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    void *h = nullptr, *d = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&h, want, hipHostMallocDefault));
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipHostFree(h);
+      return fail(ctx, S2K_ERR_HIP, "hipHostGetDevicePointer failed for the small-call block");
+    }
+    ctx->h_small = (uint8_t*)h;
+    ctx->d_small = (uint8_t*)d;
+    ctx->h_small_bytes = want;
+  }
+  size_t off = 0;
+  for (int i = 0; i < count; ++i) {
+    host[i] = ctx->h_small + off;
+    dev[i] = ctx->d_small + off;
+    off += (sizes[i] + 255) & ~(size_t)255;
+  }
+  return S2K_OK;
+}
+static bool ctx_small_call(const s2k_ctx* ctx, size_t n, uint32_t flags) {
+  static const bool off = [] { const char* v = getenv("S2K_SMALL_CALLS_DMA"); return v && atoi(v) != 0; }();   // (A/B knob)
+  return !off && n <= ctx->row_max && !(flags & (S2K_ECDSA_FORCE_COMPLETE | S2K_ECDSA_FORCE_WORKLIST));
+}
+extern "C" {
 int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const uint8_t* r, const uint8_t* s,
                             const uint8_t* recid, uint32_t flags, uint8_t* pub65, uint8_t* ok) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
@@ -2828,6 +2867,26 @@ int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const ui
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ctx_streams(ctx);
   if (rc) return rc;
+  if (ctx_small_call(ctx, n, flags)) {
+    const size_t sizes[6] = {n * 32, n * 32, n * 32, n, n * 65, n};
+    uint8_t *h[6], *d[6];
+    rc = ctx_small_block(ctx, sizes, 6, h, d);
+    if (rc) return rc;
+    memcpy(h[0], dig, n * 32);
+    memcpy(h[1], r, n * 32);
+    memcpy(h[2], s, n * 32);
+    memcpy(h[3], recid, n);
+    rc = s2k_ecdsa_recover_batch_device(ctx, n, d[0], d[1], d[2], d[3], flags, d[4], d[5], ctx->s_comp);
+    if (rc) {
+      s2k_internal_drain(ctx);
+      return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+    memcpy(pub65, h[4], n * 65);
+    memcpy(ok, h[5], n);
+    ctx->have_last = false;
+    return S2K_OK;
+  }
   // staged in the context's buffers on its compute stream (no allocation per call)
   const size_t sizes[6] = {n * 32, n * 32, n * 32, n, n * 65, n};
   uint8_t* d[6];
@@ -3253,7 +3312,31 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   if (n == 0) return S2K_OK;
   if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
-  int rc = verify_batch_enqueue(ctx, n, pub, dig, r, s, flags, valid, /*one_shot=*/false);
+  int rc;
+  if (ctx_small_call(ctx, n, flags) && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF)) {
+    // (ctx_small_block: the wave-per-signature ladder reads the caller's bytes from page-locked memory and writes the verdicts
+    // there - no DMA transfers)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = ctx_streams(ctx);
+    if (rc) return rc;
+    const size_t sizes[5] = {n * 64, n * 32, n * 32, n * 32, n};
+    uint8_t *h[5], *d[5];
+    rc = ctx_small_block(ctx, sizes, 5, h, d);
+    if (rc) return rc;
+    memcpy(h[0], pub, n * 64);
+    memcpy(h[1], dig, n * 32);
+    memcpy(h[2], r, n * 32);
+    memcpy(h[3], s, n * 32);
+    rc = s2k_ecdsa_verify_batch_device(ctx, n, d[0], d[1], d[2], d[3], flags, d[4], ctx->s_comp);
+    if (rc) {
+      s2k_internal_drain(ctx);
+      return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+    memcpy(valid, h[4], n);
+    return S2K_OK;
+  }
+  rc = verify_batch_enqueue(ctx, n, pub, dig, r, s, flags, valid, /*one_shot=*/false);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
   return S2K_OK;
@@ -3603,6 +3686,24 @@ int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const ui
   int rc = ctx_streams(ctx);
   if (rc) return rc;
   const size_t sizes[5] = {n * 32, total ? total : 16, (n + 1) * sizeof(uint64_t), n * 64, n};
+  if (ctx_small_call(ctx, n, flags) && total <= ((size_t)1 << 20)) {       // (ctx_small_block: no DMA transfers)
+    uint8_t *h[5], *dv[5];
+    rc = ctx_small_block(ctx, sizes, 5, h, dv);
+    if (rc) return rc;
+    memcpy(h[0], pk, n * 32);
+    if (total) memcpy(h[1], msgs, total);
+    if (msg_offsets) memcpy(h[2], msg_offsets, (n + 1) * sizeof(uint64_t));
+    memcpy(h[3], sig, n * 64);
+    rc = s2k_schnorr_verify_batch_device(ctx, n, dv[0], dv[1], msg_offsets ? dv[2] : nullptr, msg_len, dv[3], flags, dv[4], ctx->s_comp);
+    if (rc) {
+      s2k_internal_drain(ctx);
+      return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+    memcpy(valid, h[4], n);
+    ctx->have_last = false;
+    return S2K_OK;
+  }
   uint8_t* d[5];
   rc = ctx_stage(ctx, sizes, 5, d);
   if (rc) return rc;

@@ -106,6 +106,10 @@ struct s2k_ctx {
   // stream, events that chain them (created on first use)
   void* io = nullptr;
   size_t io_bytes = 0;
+  // small synchronous host calls (ctx_small_block, engine.hip): a page-locked block the kernels read and write in place
+  uint8_t* h_small = nullptr;
+  uint8_t* d_small = nullptr;   // the same block as the device addresses it
+  size_t h_small_bytes = 0;
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   // A child context of submit / wait owns buffers, not streams: its copy stream is its parent's, its two compute streams
   // those of its LANE (even tickets: the parent's own; odd tickets: a second pair).  Within a lane tickets run their kernels
