@@ -2827,7 +2827,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
 // DMA transfer at all.  The five transfers of a 1024-signature call cost 45 us of its 0.23 ms, more than its 160 KB take
 // either way.  `count` pieces of `sizes[i]` bytes, 256-byte aligned; host[i] / dev[i]: the same piece as the CPU and as the
 // device address it.  (Synchronous entry points only: the block is free again when the call returns.)
-static int ctx_small_block(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** host, uint8_t** dev) {
+__attribute__((visibility("hidden"))) int s2k_internal_small_block(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** host, uint8_t** dev) {
   size_t total = 0;
   for (int i = 0; i < count; ++i) total += (sizes[i] + 255) & ~(size_t)255;
   if (total > ctx->h_small_bytes) {
@@ -2854,7 +2854,7 @@ static int ctx_small_block(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t
   }
   return S2K_OK;
 }
-static bool ctx_small_call(const s2k_ctx* ctx, size_t n, uint32_t flags) {
+__attribute__((visibility("hidden"))) bool s2k_internal_small_call(const s2k_ctx* ctx, size_t n, uint32_t flags) {
   static const bool off = [] { const char* v = getenv("S2K_SMALL_CALLS_DMA"); return v && atoi(v) != 0; }();   // (A/B knob)
   return !off && n <= ctx->row_max && !(flags & (S2K_ECDSA_FORCE_COMPLETE | S2K_ECDSA_FORCE_WORKLIST));
 }
@@ -2867,10 +2867,10 @@ int s2k_ecdsa_recover_batch(s2k_ctx* ctx, size_t n, const uint8_t* dig, const ui
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ctx_streams(ctx);
   if (rc) return rc;
-  if (ctx_small_call(ctx, n, flags)) {
+  if (s2k_internal_small_call(ctx, n, flags)) {
     const size_t sizes[6] = {n * 32, n * 32, n * 32, n, n * 65, n};
     uint8_t *h[6], *d[6];
-    rc = ctx_small_block(ctx, sizes, 6, h, d);
+    rc = s2k_internal_small_block(ctx, sizes, 6, h, d);
     if (rc) return rc;
     memcpy(h[0], dig, n * 32);
     memcpy(h[1], r, n * 32);
@@ -3313,7 +3313,7 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
   if (n == 0) return S2K_OK;
   if (!pub || !dig || !r || !s || !valid) return fail(ctx, S2K_ERR_ARG, "null buffer");
   int rc;
-  if (ctx_small_call(ctx, n, flags) && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF)) {
+  if (s2k_internal_small_call(ctx, n, flags) && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF)) {
     // (ctx_small_block: the wave-per-signature ladder reads the caller's bytes from page-locked memory and writes the verdicts
     // there - no DMA transfers)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3321,7 +3321,7 @@ int s2k_ecdsa_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pub, const uin
     if (rc) return rc;
     const size_t sizes[5] = {n * 64, n * 32, n * 32, n * 32, n};
     uint8_t *h[5], *d[5];
-    rc = ctx_small_block(ctx, sizes, 5, h, d);
+    rc = s2k_internal_small_block(ctx, sizes, 5, h, d);
     if (rc) return rc;
     memcpy(h[0], pub, n * 64);
     memcpy(h[1], dig, n * 32);
@@ -3686,9 +3686,9 @@ int s2k_schnorr_verify_batch(s2k_ctx* ctx, size_t n, const uint8_t* pk, const ui
   int rc = ctx_streams(ctx);
   if (rc) return rc;
   const size_t sizes[5] = {n * 32, total ? total : 16, (n + 1) * sizeof(uint64_t), n * 64, n};
-  if (ctx_small_call(ctx, n, flags) && total <= ((size_t)1 << 20)) {       // (ctx_small_block: no DMA transfers)
+  if (s2k_internal_small_call(ctx, n, flags) && total <= ((size_t)1 << 20)) {       // (ctx_small_block: no DMA transfers)
     uint8_t *h[5], *dv[5];
-    rc = ctx_small_block(ctx, sizes, 5, h, dv);
+    rc = s2k_internal_small_block(ctx, sizes, 5, h, dv);
     if (rc) return rc;
     memcpy(h[0], pk, n * 32);
     if (total) memcpy(h[1], msgs, total);

@@ -313,6 +313,9 @@ int s2k_internal_pipe_retire(s2k_ctx* ctx, s2k_ctx::pipe_slot& sl);             
 void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, uint64_t* ticket);
 void s2k_internal_drain(s2k_ctx* ctx);                                                          // after an error: nothing left in flight
 bool s2k_internal_host_pinned(const void* p, size_t bytes);
+// small synchronous host calls without DMA transfers (engine.hip: ctx_small_block)
+bool s2k_internal_small_call(const s2k_ctx* ctx, size_t n, uint32_t flags);
+int s2k_internal_small_block(s2k_ctx* ctx, const size_t* sizes, int count, uint8_t** host, uint8_t** dev);
 
 // Synchronous host-pointer entry points are transfer, kernels, answer in series.  Two verifiers (two contexts on two host
 // threads) that take whole batches alternately could hide one's transfer behind the other's kernels, but left alone they fall

@@ -233,9 +233,13 @@ int s2k_is_valid_signature_encoding_bip0066(const uint8_t* d, size_t n) {
 // false from Verify).
 // Enqueue only (all work ends on ctx->s_comp; verdicts go to h_out, asynchronously when that is page-locked);
 // one_shot: the whole batch in one piece (submit / wait).
+// small_out: a synchronous call of up to the small-batch threshold takes its bytes without DMA transfers (s2k_internal_small_block:
+// the parse kernel reads the caller's strings from a page-locked block, the verdicts are written there); *small_out is then where
+// the caller finds them after the wait, else NULL.
 static int encoded_enqueue_inner(s2k_ctx* ctx, size_t n, const uint8_t* pubs, const uint64_t* pub_off, const uint8_t* digests,
                                  const uint64_t* dig_off, const uint8_t* sigs, const uint64_t* sig_off, int encoding, size_t digest_len,
-                                 uint32_t flags, uint8_t* h_out, bool one_shot) {
+                                 uint32_t flags, uint8_t* h_out, bool one_shot, const uint8_t** small_out = nullptr) {
+  if (small_out) *small_out = nullptr;
   const bool bip66 = (flags & S2K_ECDSA_BIP0066) != 0;
   const bool recoverable = encoding == S2K_ENCODING_COMPACT_RECOVERABLE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -251,6 +255,35 @@ static int encoded_enqueue_inner(s2k_ctx* ctx, size_t n, const uint8_t* pubs, co
   uint8_t* io = (uint8_t*)ctx->io;
   rc = ctx_streams(ctx);
   if (rc) return rc;
+  if (small_out && !one_shot && s2k_internal_small_call(ctx, n, flags) && pub_bytes + dig_bytes + sig_bytes <= ((size_t)1 << 20) &&
+      (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF)) {
+    const size_t sizes[7] = {pub_bytes, dig_bytes, sig_bytes, (n + 1) * 8, (n + 1) * 8, (n + 1) * 8, n};
+    uint8_t *h[7], *d[7];
+    rc = s2k_internal_small_block(ctx, sizes, 7, h, d);
+    if (rc) return rc;
+    memcpy(h[0], pubs, pub_bytes);
+    memcpy(h[1], digests, dig_bytes);
+    memcpy(h[2], sigs, sig_bytes);
+    memcpy(h[3], pub_off, (n + 1) * 8);
+    memcpy(h[4], dig_off, (n + 1) * 8);
+    memcpy(h[5], sig_off, (n + 1) * 8);
+    k_parse_encoded<<<(unsigned)((n + 255) / 256), 256, 0, ctx->s_comp>>>(
+        0u, (uint32_t)n, d[0], (const uint64_t*)d[3], d[1], (const uint64_t*)d[4], d[2], (const uint64_t*)d[5], encoding,
+        (uint32_t)digest_len, bip66 ? 1 : 0, (flags & S2K_ECDSA_REJECT_MALLEABLE) ? 1 : 0, io + o_xy, io + o_dg, io + o_r, io + o_s,
+        recoverable ? io + o_id : nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    if (recoverable) {
+      rc = s2k_ecdsa_recover_batch_device(ctx, n, io + o_dg, io + o_r, io + o_s, io + o_id, 0u, io + o_rec, io + o_ok, ctx->s_comp);
+      if (rc) return rc;
+      k_recovered_equals<<<(unsigned)((n + 255) / 256), 256, 0, ctx->s_comp>>>((uint32_t)n, io + o_xy, io + o_rec, io + o_ok, d[6]);
+      HIP_TRY(ctx, hipGetLastError());
+    } else {
+      rc = s2k_ecdsa_verify_batch_device(ctx, n, io + o_xy, io + o_dg, io + o_r, io + o_s, flags & S2K_ECDSA_REJECT_MALLEABLE, d[6], ctx->s_comp);
+      if (rc) return rc;
+    }
+    *small_out = h[6];
+    return S2K_OK;
+  }
   // the offset arrays go up whole (24 bytes per item); the byte strings follow chunk by chunk, each
   // copy overlapping the parse + verification of the previous chunk (same scheme as
   // s2k_ecdsa_verify_batch; chunks are two full rounds of k_verify_fast)
@@ -316,12 +349,15 @@ int s2k_ecdsa_verify_encoded_batch(s2k_ctx* ctx, size_t n, const uint8_t* pubs, 
   if (n == 0) return S2K_OK;
   int rc = encoded_check_args(ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, &digest_len, &flags, valid);
   if (rc) return rc;
-  rc = encoded_enqueue_inner(ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, digest_len, flags, valid, /*one_shot=*/false);
+  const uint8_t* small_out = nullptr;
+  rc = encoded_enqueue_inner(ctx, n, pubs, pub_off, digests, dig_off, sigs, sig_off, encoding, digest_len, flags, valid, /*one_shot=*/false,
+                             &small_out);
   if (rc) {
     s2k_internal_drain(ctx);
     return rc;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+  if (small_out) memcpy(valid, small_out, n);
   return S2K_OK;
 }
 
