@@ -469,6 +469,49 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
   }
 }
 
+// The same for ONE signature, its own inversion, the result in 17 words (u1 | k1 | k2 | flags: the planes' layout): the
+// preparation wave of the wave-per-signature kernels (k_verify_row, k_recover_row).
+S2K_DEV void scalar_prep_one(size_t i, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
+                             const uint8_t* __restrict__ recid, uint32_t flags, uint32_t* __restrict__ out17) {
+  sc x;
+  load_be32(x.v, (recid ? rsig : ssig) + i * 32);      // the value whose inverse is needed
+  if (!(sc_is_canonical_raw(x.v) && !sc_is_zero(x))) {   // (rejected below)
+    x = sc_zero();
+    x.v[0] = 1;
+  }
+  const sc26 s_inv_m = sc26_mont_inv(sc26_to_mont(sc26_from_sc(x)));     // x^-1 * R
+  sc r, s;
+  uint32_t e_raw[8];
+  load_be32(r.v, rsig + i * 32);
+  load_be32(s.v, ssig + i * 32);
+  load_be32(e_raw, dig + i * 32);
+  bool ok = sc_is_canonical_raw(r.v) && !sc_is_zero(r) && sc_is_canonical_raw(s.v) && !sc_is_zero(s);
+  if (flags & S2K_ECDSA_REJECT_MALLEABLE) ok = ok && !sc_is_gt_half_n(s);
+  const sc e = sc_reduce_once(e_raw);
+  sc u1, u2;
+  uint32_t rid = 0;
+  if (recid) {
+    rid = recid[i];
+    ok = ok && rid < 4 && (!(rid & 2u) || u256_lt(r.v, FE_P_MINUS_N));     // RecoverPoint (point_s11n.go:245-282)
+    u1 = sc26_to_sc(sc26_mm(sc26_from_sc(sc_neg(e)), s_inv_m));   // -e / r
+    u2 = sc26_to_sc(sc26_mm(sc26_from_sc(s), s_inv_m));           //  s / r
+  } else {
+    u1 = sc26_to_sc(sc26_mm(sc26_from_sc(e), s_inv_m));
+    u2 = sc26_to_sc(sc26_mm(sc26_from_sc(r), s_inv_m));
+  }
+  sc k1, k2;
+  bool neg1, neg2;
+  sc_split_glv_odd(u2, k1, neg1, k2, neg2);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) out17[w] = u1.v[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) out17[8 + w] = k1.v[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) out17[12 + w] = k2.v[w];
+  out17[16] = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) | (k1.v[4] ? PF_K1_B128 : 0) | (k2.v[4] ? PF_K2_B128 : 0) |
+              ((rid & 3u) << 8);
+}
+
 // ---------------------------------------------------------------------------------------
 // Fast path, kernel 2: per-lane table, ladder, generator part, final comparison.
 // Per-lane table {1,3,..,15}*Q brought to one common Z (no inversion): build A_j = A_{j-1} + 2Q
@@ -1056,33 +1099,38 @@ S2K_DEV fer fer_curve_rhs(fer x, const fer_consts& k) {
   return fer_mul_plus(fer_mul(x, x, k), x, seven, k);
 }
 
-// u * G + k1 * Q + k2 * lambda(Q) for ONE signature on the whole wave (Q affine and on the curve; u, |k1|, |k2|, signs from
-// the planes of the preparation kernel): the table of the key lives in LDS, one 256-byte line per coordinate of an entry
-// (lane l of the wave at word l) - x, y, z and lambda's x (beta * x) of (2j + 1) Q, j < 8 -, an entry is three loads at a
-// wave-uniform offset; 32 x (4 doublings + 2 additions) on the complete formulas, then the generator part from the
-// resident tables (no entry is the identity, no digit is special).  The result is projective.
-S2K_DEV pt29r row_double_mult(const pt29r& Q1, uint32_t (*tab)[8][64], const uint32_t* __restrict__ prep, size_t stride, uint32_t sig,
-                              uint32_t pf, gt_view gt, const fer_consts& k, uint32_t lane) {
-  const fer one = k.j == 0 ? 1u : 0u;
+// The wave-per-signature kernels.  A block is four signature waves and one PREPARATION wave: lanes 0..3 of the
+// fifth wave run the scalar arithmetic of the block's four signatures (s^-1, u1, u2, the odd GLV split: one lane's chain of
+// 55 us) into LDS while the signature waves do what does not depend on it - key checks, square roots, the key's table -, then
+// the block meets at one barrier.  One launch per call.
+//
+// row_table: the table of the key in LDS, one 256-byte line per coordinate of an entry (lane l of the wave at word l) - x, y,
+// z and lambda's x (beta * x) of (2j + 1) Q, j < 8; an entry is three loads at a wave-uniform offset.
+S2K_DEV void row_table(const pt29r& Q1, uint32_t (*tab)[8][64], const fer_consts& k, uint32_t lane) {
   const fer beta = fer_from_words(FE_BETA, k);
-  {
-    const pt29r D = pt29r_double(Q1, k);
-    pt29r cur = Q1;
+  const pt29r D = pt29r_double(Q1, k);
+  pt29r cur = Q1;
 #pragma unroll 1
-    for (int j = 0; j < 8; ++j) {
-      if (j) cur = pt29r_add(cur, D, k);
-      tab[0][j][lane] = cur.x;
-      tab[1][j][lane] = fer_norm(cur.y, k);
-      tab[2][j][lane] = cur.z;
-      tab[3][j][lane] = fer_mul(cur.x, beta, k);
-    }
+  for (int j = 0; j < 8; ++j) {
+    if (j) cur = pt29r_add(cur, D, k);
+    tab[0][j][lane] = cur.x;
+    tab[1][j][lane] = fer_norm(cur.y, k);
+    tab[2][j][lane] = cur.z;
+    tab[3][j][lane] = fer_mul(cur.x, beta, k);
   }
-  // |k1|, |k2| odd, < 2^129 (sc_split_glv_odd in the preparation kernel)
+}
+// u * G + k1 * Q + k2 * lambda(Q) for ONE signature on the whole wave, Q's table in `tab`, u | k1 | k2 | flags in the 17 words
+// `p` (LDS): 32 x (4 doublings + 2 additions) on the complete formulas, then the generator part from the resident tables (no
+// entry is the identity, no digit is special).  The result is projective.
+S2K_DEV pt29r row_ladder(uint32_t (*tab)[8][64], const uint32_t* p, gt_view gt, const fer_consts& k, uint32_t lane) {
+  const fer one = k.j == 0 ? 1u : 0u;
+  const uint32_t pf = p[16];
+  // |k1|, |k2| odd, < 2^129 (sc_split_glv_odd)
   sc k1 = sc_zero(), k2 = sc_zero();
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    k1.v[w] = prep[(size_t)(8 + w) * stride + sig];
-    k2.v[w] = prep[(size_t)(12 + w) * stride + sig];
+    k1.v[w] = p[8 + w];
+    k2.v[w] = p[12 + w];
   }
   k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;
   k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;
@@ -1110,7 +1158,7 @@ S2K_DEV pt29r row_double_mult(const pt29r& Q1, uint32_t (*tab)[8][64], const uin
   }
   uint32_t u[8];
 #pragma unroll
-  for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
+  for (int w = 0; w < 8; ++w) u[w] = p[w];
   apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
 #pragma unroll 1
   for (uint32_t w = 0; w < gt.windows; ++w) {
@@ -1123,33 +1171,62 @@ S2K_DEV pt29r row_double_mult(const pt29r& Q1, uint32_t (*tab)[8][64], const uin
   }
   return acc;
 }
+// a^(p-2), the chain of fe29_inv (Invert, internal/field/field_invert.go:11), in row products
+S2K_DEV fer fer_inv_chain(fer a, const fer_consts& k) {
+  const fer x2 = fer_mul(fer_mul(a, a, k), a, k);
+  const fer x3 = fer_mul(fer_mul(x2, x2, k), a, k);
+  const fer x6 = fer_mul(fer_sqr_n(x3, 3, k), x3, k);
+  const fer x9 = fer_mul(fer_sqr_n(x6, 3, k), x3, k);
+  const fer x11 = fer_mul(fer_sqr_n(x9, 2, k), x2, k);
+  const fer x22 = fer_mul(fer_sqr_n(x11, 11, k), x11, k);
+  const fer x44 = fer_mul(fer_sqr_n(x22, 22, k), x22, k);
+  const fer x88 = fer_mul(fer_sqr_n(x44, 44, k), x44, k);
+  const fer x176 = fer_mul(fer_sqr_n(x88, 88, k), x88, k);
+  const fer x220 = fer_mul(fer_sqr_n(x176, 44, k), x44, k);
+  const fer x223 = fer_mul(fer_sqr_n(x220, 3, k), x3, k);
+  fer t = fer_mul(fer_sqr_n(x223, 23, k), x22, k);
+  t = fer_mul(fer_sqr_n(t, 5, k), a, k);
+  t = fer_mul(fer_sqr_n(t, 3, k), x2, k);
+  return fer_mul(fer_sqr_n(t, 2, k), a, k);
+}
 
 // PublicKey.Verify (secec/ecdsa.go:171, 392-470) with one WAVEFRONT per signature: the small-batch ladder
-__global__ void __launch_bounds__(256)
-k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep,
-             gt_view gt, uint8_t* __restrict__ out, size_t stride) {
-  const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (sig >= n) return;                                         // (whole waves)
-  const fer_consts k = fer_setup(lane);
-  const uint32_t pf = prep[(size_t)16 * stride + sig];
-  uint32_t xw[8], yw[8];
-  load_be32(xw, pub + (size_t)sig * 64);
-  load_be32(yw, pub + (size_t)sig * 64 + 32);
-  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
+__global__ void __launch_bounds__(320)
+k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig,
+             const uint8_t* __restrict__ ssig, uint32_t flags, gt_view gt, uint8_t* __restrict__ out) {
   __shared__ uint32_t tab_all[4][4][8][64];
-  pt29r Q1;
-  Q1.x = fer_from_words(xw, k);
-  Q1.y = fer_from_words(yw, k);
-  Q1.z = k.j == 0 ? 1u : 0u;
-  {   // y^2 == x^3 + 7 (point_s11n.go:298-307)
-    const fer lhs = fer_mul(Q1.y, Q1.y, k);
-    ok = ok && fer_is_zero(fer_add(lhs, fer_negate(fer_curve_rhs(Q1.x, k), 1, k)), k);
+  __shared__ uint32_t prep_s[4][20];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (wave == 4) {                                              // the preparation wave
+    const uint32_t i = blockIdx.x * 4 + lane;
+    if (lane < 4 && i < n) scalar_prep_one(i, dig, rsig, ssig, nullptr, flags, prep_s[lane]);
+    __syncthreads();
+    return;
   }
-  if (!ok) {                                                    // (wave-uniform)
+  const uint32_t sig = blockIdx.x * 4 + wave;
+  const fer_consts k = fer_setup(lane);
+  bool ok = sig < n;
+  if (ok) {
+    uint32_t xw[8], yw[8];
+    load_be32(xw, pub + (size_t)sig * 64);
+    load_be32(yw, pub + (size_t)sig * 64 + 32);
+    ok = fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
+    pt29r Q1;
+    Q1.x = fer_from_words(xw, k);
+    Q1.y = fer_from_words(yw, k);
+    Q1.z = k.j == 0 ? 1u : 0u;
+    // y^2 == x^3 + 7 (point_s11n.go:298-307)
+    ok = ok && fer_is_zero(fer_add(fer_mul(Q1.y, Q1.y, k), fer_negate(fer_curve_rhs(Q1.x, k), 1, k)), k);
+    if (ok) row_table(Q1, tab_all[wave], k, lane);              // (wave-uniform)
+  }
+  __syncthreads();
+  if (sig >= n) return;
+  const uint32_t* p = prep_s[wave];
+  if (!(ok && (p[16] & PF_OK))) {
     if (lane == 0) out[sig] = 0;
     return;
   }
-  const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
+  const pt29r acc = row_ladder(tab_all[wave], p, gt, k, lane);
   // ---- verdict: R != infinity and x(R) mod n == r (ecdsa.go:450-465), x(R) = X / Z ----
   uint8_t verdict = 0;
   if (!fer_is_zero(acc.z, k)) {
@@ -1283,41 +1360,76 @@ k_schnorr_prep(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __rest
   prep[(size_t)16 * stride + i] = f;
 }
 
-// SchnorrPublicKey.Verify (schnorr.go:221-253) with one WAVEFRONT per signature (small batches), behind
-// k_schnorr_prep.  lift_x of the key and of r - the point R would have to be - run as ONE chain of row products (rows 0, 1:
-// the key; rows 2, 3: r): the signature is valid iff s G - e P is the point (r, even y), compared projectively, so there
-// is no inversion.
-__global__ void __launch_bounds__(256)
-k_schnorr_row(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig64, const uint32_t* __restrict__ prep,
-              gt_view gt, uint8_t* __restrict__ out, size_t stride) {
-  const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (sig >= n) return;                                         // (whole waves)
-  const fer_consts k = fer_setup(lane);
-  const uint32_t pf = prep[(size_t)16 * stride + sig];
-  uint32_t xw[8], rw[8];
-  load_be32(xw, pk + (size_t)sig * 32);
-  load_be32(rw, sig64 + (size_t)sig * 64);
-  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw);            // (PF_OK: r < p, s < n)
+// SchnorrPublicKey.Verify (schnorr.go:221-253) with one WAVEFRONT per signature (small batches; the block's fifth
+// wave hashes the challenges and splits -e meanwhile).  lift_x of the key and of r - the point R would have to be - run as
+// ONE chain of row products (rows 0, 1: the key; rows 2, 3: r): the signature is valid iff s G - e P is the point (r, even
+// y), compared projectively, so there is no inversion.
+// FUSED: five waves as described; the hashing makes that instance a 248-register kernel (two waves per SIMD), enough for up
+// to 1024 signatures (1280 waves).  !FUSED (larger calls): four waves behind k_schnorr_prep, whose planes they read - 62 registers.
+template <bool FUSED>
+__global__ void __launch_bounds__(FUSED ? 320 : 256)
+k_schnorr_row(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig64, const uint8_t* __restrict__ msgs,
+              const uint64_t* __restrict__ offs, uint32_t msg_len, const uint32_t* __restrict__ prep, size_t stride, gt_view gt,
+              uint8_t* __restrict__ out) {
   __shared__ uint32_t tab_all[4][4][8][64];
-  const fer xP = fer_from_words(xw, k), xR = fer_from_words(rw, k);
-  const fer c = fer_curve_rhs(fer_sel2(k, xP, xR), k);
-  const fer y = fer_sqrt_chain(c, k);
-  const bool is_root = fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);     // (row by row)
-  const bool odd = fer_is_odd(y, k);
-  const fer y_even = fer_norm(odd ? fer_negate(y, 1, k) : y, k);
-  const uint64_t roots = __builtin_amdgcn_ballot_w64(is_root);
-  ok = ok && (roots & 1u) && ((roots >> 32) & 1u);              // both lifts exist (lane 0: the key, lane 32: r)
-  if (!ok) {                                                    // (wave-uniform)
+  __shared__ uint32_t prep_s[4][20];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if constexpr (!FUSED) {
+    const uint32_t i = blockIdx.x * 4 + wave;
+    if (lane < 17 && i < n) prep_s[wave][lane] = prep[(size_t)lane * stride + i];
+  }
+  if (FUSED && wave == 4) {                                     // the preparation wave (k_schnorr_prep for four signatures)
+    const uint32_t i = blockIdx.x * 4 + lane;
+    if (lane < 4 && i < n) {
+      sc s, e;
+      const bool ok = schnorr_parse(i, pk, sig64, msgs, offs, msg_len, s, e);     // (r < p, s < n)
+      sc k1, k2;
+      bool neg1, neg2;
+      sc_split_glv_odd(sc_neg(e), k1, neg1, k2, neg2);          // schnorr.go:244
+      uint32_t* o = prep_s[lane];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) o[w] = s.v[w];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) o[8 + w] = k1.v[w];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) o[12 + w] = k2.v[w];
+      o[16] = (ok ? PF_OK : 0) | (neg1 ? PF_NEG1 : 0) | (neg2 ? PF_NEG2 : 0) | (k1.v[4] ? PF_K1_B128 : 0) | (k2.v[4] ? PF_K2_B128 : 0);
+    }
+    __syncthreads();
+    return;
+  }
+  const uint32_t sig = blockIdx.x * 4 + wave;
+  const fer_consts k = fer_setup(lane);
+  bool ok = sig < n;
+  fer xR = 0, yR = 0;
+  if (ok) {
+    uint32_t xw[8], rw[8];
+    load_be32(xw, pk + (size_t)sig * 32);
+    load_be32(rw, sig64 + (size_t)sig * 64);
+    ok = fe_is_canonical_raw(xw);
+    const fer xP = fer_from_words(xw, k);
+    xR = fer_from_words(rw, k);
+    const fer c = fer_curve_rhs(fer_sel2(k, xP, xR), k);
+    const fer y = fer_sqrt_chain(c, k);
+    const bool is_root = fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);     // (row by row)
+    const bool odd = fer_is_odd(y, k);
+    const fer y_even = fer_norm(odd ? fer_negate(y, 1, k) : y, k);
+    const uint64_t roots = __builtin_amdgcn_ballot_w64(is_root);
+    ok = ok && (roots & 1u) && ((roots >> 32) & 1u);            // both lifts exist (lane 0: the key, lane 32: r)
+    pt29r Q1;
+    Q1.x = xP;
+    fer_halves(y_even, Q1.y, yR);
+    Q1.z = k.j == 0 ? 1u : 0u;
+    if (ok) row_table(Q1, tab_all[wave], k, lane);              // (wave-uniform)
+  }
+  __syncthreads();
+  if (sig >= n) return;
+  const uint32_t* p = prep_s[wave];
+  if (!(ok && (p[16] & PF_OK))) {
     if (lane == 0) out[sig] = 0;
     return;
   }
-  fer yP, yR;
-  fer_halves(y_even, yP, yR);
-  pt29r Q1;
-  Q1.x = xP;
-  Q1.y = yP;
-  Q1.z = k.j == 0 ? 1u : 0u;
-  const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
+  const pt29r acc = row_ladder(tab_all[wave], p, gt, k, lane);
   // R = s G - e P is finite, x(R) = r and y(R) is even: X = r Z and Y = y_r Z with Z != 0
   uint8_t verdict = 0;
   if (!fer_is_zero(acc.z, k)) {
@@ -1368,54 +1480,68 @@ k_schnorr_fallback(const uint32_t* __restrict__ wl_count, const uint32_t* __rest
   }
 }
 
-// RecoverPublicKey (ecdsa.go:244-282) with one WAVEFRONT per item (small batches), behind k_scalar_prep (u1 = -e/r,
-// u2 = s/r, the recovery id in the flags) and in front of k_affine_finish<MODE_RECOVER>: R = (r or r + n, the root of the
-// asked parity) by a chain of row products, Q = u1 G + u2 R on the complete formulas, handed over as the Jacobian triple
-// (X Z, Y Z^2, Z) the finish kernel expects.  Items without a key get ok = 0 and the zero record here.
-__global__ void __launch_bounds__(256)
-k_recover_row(uint32_t n, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep, gt_view gt,
-              uint32_t* __restrict__ fin, uint8_t* __restrict__ out, uint8_t* __restrict__ out_pts, size_t stride) {
-  const uint32_t sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (sig >= n) return;                                         // (whole waves)
-  const fer_consts k = fer_setup(lane);
-  const uint32_t pf = prep[(size_t)16 * stride + sig];
-  const uint32_t rid = (pf >> 8) & 3u;
-  uint32_t xw[8];
-  load_be32(xw, rsig + (size_t)sig * 32);
-  bool ok = (pf & PF_OK) != 0;                                  // (r, s in range, id < 4, r + n < p where the id asks for it)
-  if (ok && (rid & 2u)) u256_add(xw, xw, SC_N);
+// RecoverPublicKey (ecdsa.go:244-282) with one WAVEFRONT per item (small batches; the block's fifth wave computes
+// u1 = -e/r, u2 = s/r meanwhile): R = (r or r + n, the root of the asked parity) by a chain of row products, Q = u1 G + u2 R
+// on the complete formulas, 1/Z by the inversion chain in row products, the 65-byte record written by the wave.  Items
+// without a key get ok = 0 and the zero record.
+__global__ void __launch_bounds__(320)
+k_recover_row(uint32_t n, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
+              const uint8_t* __restrict__ recid, gt_view gt, uint8_t* __restrict__ out, uint8_t* __restrict__ out_pts) {
   __shared__ uint32_t tab_all[4][4][8][64];
-  pt29r Q1;
-  Q1.x = fer_from_words(xw, k);
-  Q1.z = k.j == 0 ? 1u : 0u;
-  const fer c = fer_curve_rhs(Q1.x, k);
-  const fer y = fer_sqrt_chain(c, k);
-  ok = ok && fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);
+  __shared__ uint32_t prep_s[4][20];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (wave == 4) {                                              // the preparation wave
+    const uint32_t i = blockIdx.x * 4 + lane;
+    if (lane < 4 && i < n) scalar_prep_one(i, dig, rsig, ssig, recid, 0u, prep_s[lane]);
+    __syncthreads();
+    return;
+  }
+  const uint32_t sig = blockIdx.x * 4 + wave;
+  const fer_consts k = fer_setup(lane);
+  bool ok = sig < n;
+  if (ok) {
+    const uint32_t rid = recid[sig];
+    uint32_t xw[8];
+    load_be32(xw, rsig + (size_t)sig * 32);
+    if (rid & 2u) u256_add(xw, xw, SC_N);                       // (that r + n < p holds is the preparation wave's check)
+    pt29r Q1;
+    Q1.x = fer_from_words(xw, k);
+    Q1.z = k.j == 0 ? 1u : 0u;
+    const fer c = fer_curve_rhs(Q1.x, k);
+    const fer y = fer_sqrt_chain(c, k);
+    ok = fer_is_zero(fer_add(fer_mul(y, y, k), fer_negate(c, 1, k)), k);
+    Q1.y = fer_norm(fer_is_odd(y, k) != ((rid & 1u) != 0) ? fer_negate(y, 1, k) : y, k);
+    if (ok) row_table(Q1, tab_all[wave], k, lane);              // (wave-uniform)
+  }
+  __syncthreads();
+  if (sig >= n) return;
+  uint8_t* rec = out_pts + (size_t)sig * 65;
   auto no_key = [&]() {                                         // ok = 0 and the zero record (RecoverPublicKey's error)
-    uint8_t* rec = out_pts + (size_t)sig * 65;
     rec[lane] = 0;
     if (lane == 0) {
       rec[64] = 0;
       out[sig] = 0;
     }
   };
-  if (!ok) {                                                    // (wave-uniform)
+  const uint32_t* p = prep_s[wave];
+  if (!(ok && (p[16] & PF_OK))) {                               // (r, s in range, id < 4, r + n < p where the id asks for it)
     no_key();
     return;
   }
-  Q1.y = fer_norm(fer_is_odd(y, k) != ((rid & 1u) != 0) ? fer_negate(y, 1, k) : y, k);
-  const pt29r acc = row_double_mult(Q1, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, k, lane);
+  const pt29r acc = row_ladder(tab_all[wave], p, gt, k, lane);
   if (fer_is_zero(acc.z, k)) {                                  // identity: NewPublicKeyFromPoint fails (secec.go:206-209)
     no_key();
     return;
   }
-  const fer zz = fer_mul(acc.z, acc.z, k);
-  const fe29 X = fer_to_fe29(fer_mul(acc.x, acc.z, k)), Y = fer_to_fe29(fer_mul(fer_norm(acc.y, k), zz, k)), Z = fer_to_fe29(acc.z);
+  const fer zi = fer_inv_chain(acc.z, k);
+  uint32_t xw[8], yw[8];
+  fe29_to_words(xw, fe29_normalize(fer_to_fe29(fer_mul(acc.x, zi, k))));
+  fe29_to_words(yw, fe29_normalize(fer_to_fe29(fer_mul(fer_norm(acc.y, k), zi, k))));
   if (lane == 0) {
-    fq_store(fin, stride, sig, 0, X);
-    fq_store(fin, stride, sig, 1, Y);
-    fq_store(fin, stride, sig, 2, Z);
-    out[sig] = VERDICT_PENDING;
+    rec[0] = 0x04;
+    store_be32_unaligned(rec + 1, xw);
+    store_be32_unaligned(rec + 33, yw);
+    out[sig] = 1;
   }
 }
 
@@ -2427,16 +2553,11 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     prof_mark(ctx, st, 4);
   } else if (row) {
     // small batches: a wave per signature on the complete formulas (k_verify_row); nothing is left for the worklist kernel
-    // (a lane of the preparation per signature: sharing an inversion between PREP_M signatures saves instructions and
-    // costs latency - 94 us for six in a row, 45 for one - and latency is all a call of this size has)
     wait_all(st);
-    k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, (const uint8_t*)d_dig, (const uint8_t*)d_r,
-                                                            (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
-    HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_verify_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                          s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    k_verify_row<<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                          (const uint8_t*)d_s, flags, s2k_internal_gt(ctx), (uint8_t*)d_valid);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
@@ -2778,19 +2899,12 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   // affine results, [4] the worklist)
   prof_mark(ctx, st, 0);
   if (n <= ctx->row_max) {
-    // small batches: a wave per item, one lane of the preparation and of the finish per item (k_recover_row; it writes the
-    // zero records itself and has no worklist: two launches less)
-    k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, dig, r, s, rid, 0u, prep, pref, smont, stride);
-    HIP_TRY(ctx, hipGetLastError());
+    // small batches: a wave per item, one launch (k_recover_row: preparation, ladder, inversion and record)
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_recover_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, r, prep, s2k_internal_gt(ctx), fin, (uint8_t*)d_ok,
-                                                           (uint8_t*)d_pub65, stride);
+    k_recover_row<<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, dig, r, s, rid, s2k_internal_gt(ctx), (uint8_t*)d_ok, (uint8_t*)d_pub65);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
-    k_affine_finish<MODE_RECOVER><<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, nullptr, fin, (uint8_t*)d_ok, stride,
-                                                                            (uint8_t*)d_pub65);
-    HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 4);
     prof_mark(ctx, st, 5);
     return ctx_leave(ctx, st);
@@ -2983,12 +3097,21 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
   } else if (row) {
-    // small batches: a wave per signature, nothing left for the finish and worklist kernels (k_schnorr_row)
-    k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
-    HIP_TRY(ctx, hipGetLastError());
-    prof_mark(ctx, st, 1);
-    prof_mark(ctx, st, 2);
-    k_schnorr_row<<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, pk, sig, prep, s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    // small batches: a wave per signature, nothing left for the finish and worklist kernels (k_schnorr_row): one launch up to
+    // 1024 signatures, the preparation kernel in front above
+    if (n <= 1024) {
+      prof_mark(ctx, st, 1);
+      prof_mark(ctx, st, 2);
+      k_schnorr_row<true><<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, nullptr, 0,
+                                                                   s2k_internal_gt(ctx), (uint8_t*)d_valid);
+    } else {
+      k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+      HIP_TRY(ctx, hipGetLastError());
+      prof_mark(ctx, st, 1);
+      prof_mark(ctx, st, 2);
+      k_schnorr_row<false><<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride,
+                                                                    s2k_internal_gt(ctx), (uint8_t*)d_valid);
+    }
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
