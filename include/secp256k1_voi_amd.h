@@ -296,8 +296,8 @@ int s2k_wait_all(s2k_ctx *ctx);
  * s2k_schnorr_verify_batch and s2k_ecdsa_recover_batch (and their _device / _submit forms) therefore run ladders that spend
  * a whole wavefront on each item (k_verify_row / k_schnorr_row / k_recover_row: the row arithmetic of fe29r.h, complete
  * formulas), and the synchronous host forms move their bytes without DMA transfers (the CPU copies them into a page-locked
- * block the kernels read and write in place): host to host 0.20 instead of 0.74 ms for 1024 ECDSA signatures, 0.20 instead of
- * 0.83 for BIP-340, 0.30 instead of 0.87 for recovery - the reference's own shape is a loop of single PublicKey.Verify calls (secec/ecdsa.go:171; BASELINE config 1
+ * block the kernels read and write in place): host to host 0.20 instead of 0.74 ms for 1024 ECDSA signatures, 0.19 instead of
+ * 0.83 for BIP-340, 0.24 instead of 0.87 for recovery - the reference's own shape is a loop of single PublicKey.Verify calls (secec/ecdsa.go:171; BASELINE config 1
  * verifies 1024).  Same results (tests/test_gpu_round5.py::test_small_batch_*).  A grouping mode set by name
  * (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed at every size; the default (S2K_KEYS_ADAPTIVE) and S2K_KEYS_OFF take these
  * ladders. */
