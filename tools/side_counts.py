@@ -60,7 +60,8 @@ def summarize(d, head):
             key = KERNELS.get(name)
             if key and row["Counter_Name"] == "SQ_INSTS_VALU":
                 acc.setdefault(key, []).append(float(row["Counter_Value"]))
-            if name in ROW_KERNELS and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
+            base = name.split("<")[0]
+            if base in ROW_KERNELS and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
                 rowk.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU of tools/side_counts.py run: 2^20 items of 2^16 keys per dispatch, wave-instructions x 64 / items, "
                      "averaged over the dispatches", "items_per_dispatch": N, "head": head}
@@ -69,7 +70,9 @@ def summarize(d, head):
     for name, c in sorted(rowk.items()):
         v, w = c.get("SQ_INSTS_VALU", []), c.get("SQ_WAVES", [])
         if v and w:
-            out[name] = {"valu_wave_instr_per_item": sum(v) / sum(w), "waves_per_dispatch": sum(w) / len(w), "dispatches": len(v)}
+            # (1024 items per dispatch; five waves per four items since the preparation wave joined the kernels: its instructions
+            # - one lane's scalar arithmetic for four signatures - are in the sum)
+            out[name] = {"valu_wave_instr_per_item": sum(v) / (1024.0 * len(v)), "waves_per_dispatch": sum(w) / len(w), "dispatches": len(v)}
     print(json.dumps(out, indent=1))
 
 
