@@ -373,8 +373,8 @@ def batch_sweep(eng, pub, digest, r, s, cpu):
     return {"log2_n": sorted(rows), "ms": [rows[k] for k in sorted(rows)], "n_from_which_a_call_beats_all_host_threads": cross_all,
             "n_from_which_a_call_beats_one_host_thread": cross_one, **small,
             "note": "ms[i] = one synchronous s2k_ecdsa_verify_batch call of 2^log2_n[i] signatures, page-locked host memory to host verdicts, median of 5-9 calls per size (signatures/s = 2^log2_n / ms); "
-                    "up to 2^12 signatures the wave-per-signature ladders run (k_verify_row / k_schnorr_row / k_recover_row, DESIGN 4d) and the bytes "
-                    "move without DMA transfers (a page-locked block the kernels read and write in place), above it the kernels of the headline; "
+                    "up to 3072 signatures the wave-per-signature ladders run (k_verify_row / k_schnorr_row / k_recover_row, DESIGN 4d) and the bytes "
+                    "move without DMA transfers (a page-locked block the kernels read and write in place), up to 2^15 four lanes per signature (k_verify_quad), above it the kernels of the headline; "
                     "schnorr_1024_ms / recover_1024_ms: one s2k_schnorr_verify_batch / s2k_ecdsa_recover_batch call of 1024 "
                     "items from pageable host arrays; the streaming entry points (pcie_inclusive.pipelined) hide launch and transfer latencies from 2^17 per batch on"}
 

@@ -292,7 +292,7 @@ int s2k_wait(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_poll(s2k_ctx *ctx, s2k_ticket ticket);
 int s2k_wait_all(s2k_ctx *ctx);
 /* Small batches.  A call of up to a few thousand signatures leaves the device empty whatever it runs, and costs the latency
- * of ONE signature's ladder; for batches of up to max_n items (default 4096; 0 = never) s2k_ecdsa_verify_batch,
+ * of ONE signature's ladder; for batches of up to max_n items (default 3072; 0 = never) s2k_ecdsa_verify_batch,
  * s2k_schnorr_verify_batch and s2k_ecdsa_recover_batch (and their _device / _submit forms) therefore run ladders that spend
  * a whole wavefront on each item (k_verify_row / k_schnorr_row / k_recover_row: the row arithmetic of fe29r.h, complete
  * formulas), and the synchronous host forms move their bytes without DMA transfers (the CPU copies them into a page-locked
@@ -302,6 +302,10 @@ int s2k_wait_all(s2k_ctx *ctx);
  * (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed at every size; the default (S2K_KEYS_ADAPTIVE) and S2K_KEYS_OFF take these
  * ladders. */
 int s2k_ctx_set_small_batch_max(s2k_ctx *ctx, uint32_t max_n);
+/* ECDSA batches above that threshold and up to max_n signatures (default 32768; 0 = never) run a ladder with FOUR lanes per
+ * signature (k_verify_quad, pt29q.h): calls of this size fill neither kind of kernel, and what they cost is the latency of one
+ * wave's ladder - half as long this way as with a lane per signature.  Same verdicts (tests/test_gpu_round5.py). */
+int s2k_ctx_set_mid_batch_max(s2k_ctx *ctx, uint32_t max_n);
 /* Times of a ticket on the device's clock, for placement diagnostics (s2k_group_member_stats_ex): after
  * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records when its host-to-device copies start and end and when its
  * verdicts are ready; s2k_ticket_times gives ms[0] = the copies, ms[1] = first copy to verdicts for one of the last eight
@@ -353,6 +357,7 @@ size_t s2k_group_size(const s2k_group *g);
 const char *s2k_group_last_error(const s2k_group *g);
 int s2k_group_set_key_grouping(s2k_group *g, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables);
 int s2k_group_set_small_batch_max(s2k_group *g, uint32_t max_n);   /* s2k_ctx_set_small_batch_max on every member (a member's shard is what counts as the batch) */
+int s2k_group_set_mid_batch_max(s2k_group *g, uint32_t max_n);     /* s2k_ctx_set_mid_batch_max on every member */
 int s2k_group_ecdsa_verify_batch(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32, const uint8_t *r,
                                  const uint8_t *s, uint32_t flags, uint8_t *valid);
 int s2k_group_ecdsa_verify_batch_submit(s2k_group *g, size_t n, const uint8_t *pub_xy, const uint8_t *digest32,

@@ -269,6 +269,7 @@ def load_library() -> C.CDLL:
     lib.s2k_group_last_error.restype = C.c_char_p
     lib.s2k_group_set_key_grouping.argtypes = [vp, ci, u32, u32, u32]
     lib.s2k_group_set_small_batch_max.argtypes = [vp, u32]
+    lib.s2k_group_set_mid_batch_max.argtypes = [vp, u32]
     lib.s2k_group_schnorr_batch_verify_rlc.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp]
     lib.s2k_group_multi_scalar_mult.argtypes = [vp, sz, vp, vp, vp]
     lib.s2k_group_keyset_create.argtypes = [vp, sz, vp, ci, vp]
@@ -334,6 +335,7 @@ def load_library() -> C.CDLL:
     lib.s2k_group_host_free.argtypes = [vp, vp]
     lib.s2k_group_host_free.restype = None
     lib.s2k_ctx_set_small_batch_max.argtypes = [vp, u32]
+    lib.s2k_ctx_set_mid_batch_max.argtypes = [vp, u32]
     lib.s2k_ctx_create_ex.argtypes = [ci, ci, u32, C.POINTER(vp)]
     lib.s2k_set_generator_table_budget.argtypes = [sz]
     lib.s2k_set_generator_table_budget.restype = None
@@ -360,7 +362,7 @@ EXPORTED_SYMBOLS = [
     "s2k_ecdsa_verify_encoded_batch",
     "s2k_ecdsa_verify_batch_submit", "s2k_ecdsa_verify_encoded_batch_submit", "s2k_wait", "s2k_poll", "s2k_wait_all",
     "s2k_device_count", "s2k_group_create", "s2k_group_destroy", "s2k_group_size", "s2k_group_last_error",
-    "s2k_group_set_key_grouping", "s2k_group_set_small_batch_max", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
+    "s2k_group_set_key_grouping", "s2k_group_set_small_batch_max", "s2k_group_set_mid_batch_max", "s2k_group_ecdsa_verify_batch", "s2k_group_ecdsa_verify_batch_submit", "s2k_group_wait",
     "s2k_group_ecdsa_verify_encoded_batch", "s2k_group_ecdsa_verify_encoded_batch_submit",
     "s2k_group_member_stats", "s2k_group_schnorr_batch_verify_rlc", "s2k_group_multi_scalar_mult",
     "s2k_group_keyset_create", "s2k_group_keyset_destroy", "s2k_group_keyset_size", "s2k_group_keyset_layout", "s2k_group_keyset_device_bytes",
@@ -379,7 +381,7 @@ EXPORTED_SYMBOLS = [
     "s2k_device_pci_bus_id", "s2k_device_numa_node", "s2k_bind_thread_to_node", "s2k_topology_prefer_node", "s2k_topology_node_count",
     "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
     "s2k_group_member_stats_ex", "s2k_group_gt_wait", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
-    "s2k_ctx_set_small_batch_max", "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
+    "s2k_ctx_set_small_batch_max", "s2k_ctx_set_mid_batch_max", "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
 ]
 
 
@@ -530,6 +532,10 @@ class Engine(_TicketOwner):
     def set_small_batch_max(self, max_n: int):
         """batches of up to max_n signatures take the wave-per-signature ladder (s2k_ctx_set_small_batch_max; 0: never)"""
         self._check(self._lib.s2k_ctx_set_small_batch_max(self._h, int(max_n)))
+
+    def set_mid_batch_max(self, max_n: int):
+        """ECDSA batches above the small-batch threshold and up to max_n take the four-lanes-per-signature ladder (0: never)"""
+        self._check(self._lib.s2k_ctx_set_mid_batch_max(self._h, int(max_n)))
 
     def gt_wait(self) -> int:
         """block until the background build of the wide generator tables has ended; the window bits in use then"""
@@ -1109,6 +1115,9 @@ class Group(_TicketOwner):
 
     def set_small_batch_max(self, max_n: int):
         self._check(self._lib.s2k_group_set_small_batch_max(self._h, int(max_n)))
+
+    def set_mid_batch_max(self, max_n: int):
+        self._check(self._lib.s2k_group_set_mid_batch_max(self._h, int(max_n)))
 
     def gt_wait(self) -> int:
         """block until every member's device has its wide generator tables (s2k_group_gt_wait); the smallest width in use"""

@@ -28,6 +28,7 @@
 #include "lane_tables.h"
 #include "pt29.h"
 #include "fe29r.h"
+#include "pt29q.h"
 #include "complete_path.h"
 #include "point.h"
 #include "sc.h"
@@ -1241,6 +1242,110 @@ k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restr
     verdict = match ? 1 : 0;
   }
   if (lane == 0) out[sig] = verdict;
+}
+
+// PublicKey.Verify with FOUR LANES per signature (pt29q.h: a point is X | Y | Z | Z on the lanes of a quad, a layer of the
+// complete formulas one lane product): the ladder for calls between the wave-per-signature kernels and the lane-per-signature
+// ones - a doubling is 550 dependent instructions where a lane needs 1 070, so a lone wave is through its 16
+// signatures in half the time, at twice the instructions per signature.  Behind k_scalar_prep (one lane per signature).
+// The key's table - (2j + 1) Q, j < 8, projective - lives in LDS, tab[wave][entry][limb][lane]: the lanes of a quad hold
+// x | y | z | beta * x of the entry (lane 3's copy of z is not read by an addition; lambda's image reads its x from there).
+__global__ void __launch_bounds__(256)
+k_verify_quad(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep,
+              gt_view gt, uint8_t* __restrict__ out, size_t stride) {
+  __shared__ uint32_t tab_all[4][8][9][64];
+  const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+  uint32_t (*tab)[9][64] = tab_all[threadIdx.x >> 6];
+  const uint32_t sig0 = (blockIdx.x * 256 + threadIdx.x) >> 2;
+  const bool live = sig0 < n;
+  const uint32_t sig = live ? sig0 : n - 1;                     // (idle quads redo the last signature: no divergence, no store)
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  uint32_t xw[8], yw[8];
+  load_be32(xw, pub + (size_t)sig * 64);
+  load_be32(yw, pub + (size_t)sig * 64 + 32);
+  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
+  fe29 qx = fe29_from_words(xw), qy = fe29_from_words(yw);
+  {   // y^2 == x^3 + 7 (point_s11n.go:298-307); an invalid key is replaced by G, its verdict is 0
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
+    rhs.n[0] += 7;
+    if (!fe29_eq(fe29_sqr(qy), rhs)) ok = false;
+    if (!ok) {
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
+    }
+  }
+  const fe29 beta = fe29_from_words(FE_BETA), one = fe29_one();
+  // ---- table ----
+  {
+    fe29 cur = fe29_pick(q >= 2, fe29_pick(q == 1, qx, qy), one);                  // x | y | 1 | 1
+    const fe29 D = pt29q_double(cur, q);
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      if (j) cur = pt29q_add(cur, D, q);
+      const fe29 bx = fe29_mul(fe29_qperm<S2K_QP(0, 0, 0, 0)>(cur), beta);
+      const fe29 st = fe29_pick(q == 3, cur, bx);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) tab[j][i][lane] = st.n[i];
+    }
+  }
+  // ---- ladder over |k1|, |k2| (odd, < 2^129) ----
+  sc k1 = sc_zero(), k2 = sc_zero();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    k1.v[w] = prep[(size_t)(8 + w) * stride + sig];
+    k2.v[w] = prep[(size_t)(12 + w) * stride + sig];
+  }
+  k1.v[4] = (pf & PF_K1_B128) ? 1u : 0u;
+  k2.v[4] = (pf & PF_K2_B128) ? 1u : 0u;
+  const bool neg1 = pf & PF_NEG1, neg2 = pf & PF_NEG2;
+  digit_stream d1 = ds_init(k1), d2 = ds_init(k2);
+  const uint32_t col3 = lane | 3u;
+  auto entry_of = [&](uint32_t w, bool lam, bool sneg) -> fe29 {   // this lane's coordinate of the entry of digit w (2w - 15)
+    const bool neg = sneg != (w < 8u);
+    const uint32_t e = (w < 8u) ? (7u - w) : (w - 8u);
+    const uint32_t col = (lam && q == 0) ? col3 : lane;            // lambda's image: x from the quad's fourth slot
+    fe29 a;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.n[i] = tab[e][i][col];
+    return fe29_normalize_weak(fe29_cond_negate1(a, neg && q == 1));
+  };
+  fe29 acc = pt29q_add(entry_of(8u, false, neg1), entry_of(8u, true, neg2), q);     // the top digits are +1 (w = 8)
+#pragma unroll 1
+  for (int i = 31; i >= 0; --i) {
+    const uint32_t w1 = ds_next(d1), w2 = ds_next(d2);
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) acc = pt29q_double(acc, q);
+    acc = pt29q_add(acc, entry_of(w1, false, neg1), q);
+    acc = pt29q_add(acc, entry_of(w2, true, neg2), q);
+  }
+  // ---- generator part ----
+  {
+    uint32_t u[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
+    apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
+#pragma unroll 1
+    for (uint32_t w = 0; w < gt.windows; ++w) {
+      const fe29 qc = fe29_pick(q >= 2, fe29_pick(q == 1, fe29_from_words(g.x.v), fe29_from_words(g.y.v)), one);
+      if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));
+      acc = pt29q_add(acc, qc, q);
+    }
+  }
+  // ---- verdict: R != infinity and x(R) mod n == r (ecdsa.go:450-465), x(R) = X / Z ----
+  const pt29 R = pt29q_gather(acc);
+  uint8_t verdict = 0;
+  if (ok && !fe29_is_zero(R.z)) {
+    uint32_t rw[8];
+    load_be32(rw, rsig + (size_t)sig * 32);
+    bool match = fe29_eq(R.x, fe29_mul(fe29_from_words(rw), R.z));
+    if (u256_lt(rw, FE_P_MINUS_N)) {
+      uint32_t r2[8];
+      u256_add(r2, rw, SC_N);
+      match = match || fe29_eq(R.x, fe29_mul(fe29_from_words(r2), R.z));
+    }
+    verdict = match ? 1 : 0;
+  }
+  if (live && q == 0) out[sig] = verdict;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2494,8 +2599,11 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   // small batches: a wave per signature beats any table (k_verify_row); a grouping mode somebody asked for by name
   // (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed instead
   const bool row = n <= ctx->row_max && !kvf && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
-  if (row) grouped = false;
-  else HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));      // (the row ladder has no worklist: one launch less)
+  // ... and up to quad_max four lanes per signature (k_verify_quad): half the latency of the lane kernels for calls that fill
+  // neither
+  const bool quad = !row && n <= ctx->quad_max && !kvf && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
+  if (row || quad) grouped = false;
+  else HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));      // (these ladders have no worklist: one launch less)
   ctx->kg_note_dst = nullptr;
   if (grouped && ctx->kg_mode == S2K_KEYS_ADAPTIVE && n >= KG_ADAPT_MIN_BATCH) grouped = kg_adaptive_decide(ctx);
   if (grouped) {
@@ -2505,7 +2613,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     if (rc == S2K_ERR_NOMEM) grouped = false;
     else if (rc) return rc;
   }
-  ctx->last_wl_count = row ? nullptr : wl_count;
+  ctx->last_wl_count = (row || quad) ? nullptr : wl_count;
   prof_mark(ctx, st, 0);
   if (grouped) {
     // Signatures of keys that occur often enough: per-key tables (keyed.hip) and the short ladder; the
@@ -2551,6 +2659,21 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                                                                   stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 4);
+  } else if (quad) {
+    // four lanes per signature on the complete formulas (k_verify_quad), behind a preparation with one lane per signature
+    wait_all(st);
+    k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, (const uint8_t*)d_dig, (const uint8_t*)d_r,
+                                                            (const uint8_t*)d_s, nullptr, flags, prep, pref, smont, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_verify_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
+                                                             s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    prof_mark(ctx, st, 4);
+    prof_mark(ctx, st, 5);
+    return ctx_leave(ctx, st);
   } else if (row) {
     // small batches: a wave per signature on the complete formulas (k_verify_row); nothing is left for the worklist kernel
     wait_all(st);
@@ -3599,6 +3722,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   sl.ctx->kg_hash_bits = ctx->kg_hash_bits;
   sl.ctx->kg_max_tables = ctx->kg_max_tables;
   sl.ctx->row_max = ctx->row_max;
+  sl.ctx->quad_max = ctx->quad_max;
   sl.direct = host_pinned(valid, n);
   if (!sl.direct && sl.h_valid_bytes < n) {
     if (sl.h_valid) (void)hipHostFree(sl.h_valid);
@@ -3777,6 +3901,12 @@ int s2k_wait_all(s2k_ctx* ctx) {
 int s2k_ctx_set_small_batch_max(s2k_ctx* ctx, uint32_t max_n) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
   ctx->row_max = max_n;
+  return S2K_OK;
+}
+// ECDSA batches above that and up to max_n take the four-lanes-per-signature ladder (k_verify_quad); 0 switches it off.
+int s2k_ctx_set_mid_batch_max(s2k_ctx* ctx, uint32_t max_n) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  ctx->quad_max = max_n;
   return S2K_OK;
 }
 // Per-ticket times on the device's clock (for placement diagnostics, s2k_group_member_stats_ex): enable, submit, wait, ask.

@@ -87,8 +87,14 @@ S2K_DEV void store_be32_unaligned(uint8_t* p, const uint32_t in[8]) {
 // lane-per-signature kernels win (profiles/r05_small_batch_ab.txt, ECDSA: 0.19 against 0.68 ms up to 1024 signatures - one wave
 // per SIMD -, 0.41 against 0.7-1.1 at 4096, 0.71 against 1.08 at 8192, 1.31 against 1.10 at 16384 device-resident; from host
 // memory 0.28 against 0.74 ms at 1024, 0.50 against 0.75 at 4096, 0.77 against 0.78 at 8192).
+// Largest batch the four-lanes-per-signature ladder (k_verify_quad) takes, above the row kernels' threshold
+// (profiles/r05_mid_batch_ab.txt: 0.35 ms for anything from 2^11 to 2^14 signatures - one wave per SIMD at 2^14 -, 0.61 at 2^15,
+// 1.10 at 2^16; the lane kernels 0.59-0.72 over that range, the row kernels 0.26 at 2^11 and 0.42 at 2^12).
+#ifndef S2K_QUAD_MAX_DEFAULT
+#define S2K_QUAD_MAX_DEFAULT 32768
+#endif
 #ifndef S2K_ROW_MAX_DEFAULT
-#define S2K_ROW_MAX_DEFAULT 4096
+#define S2K_ROW_MAX_DEFAULT 3072
 #endif
 
 // ---- host side ----
@@ -138,6 +144,7 @@ struct s2k_ctx {
   size_t msm_prof_cap = 0, msm_prof_used = 0;
   bool msm_prof_on = false;
   // repeated-key path (keyed.hip): grouping arrays and per-key tables, grown on demand
+  uint32_t quad_max = S2K_QUAD_MAX_DEFAULT;   // ... and up to this many the four-lanes-per-signature ladder (s2k_ctx_set_mid_batch_max)
   uint32_t row_max = S2K_ROW_MAX_DEFAULT;   // batches of up to this many signatures take the wave-per-signature ladder (s2k_ctx_set_small_batch_max)
   int kg_mode = S2K_KEYS_ADAPTIVE;
   uint32_t kg_min_group = 0, kg_hash_bits = 0, kg_max_tables = KG_MAX_TABLES_DEFAULT;

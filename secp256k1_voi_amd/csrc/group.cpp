@@ -359,6 +359,16 @@ int s2k_group_set_small_batch_max(s2k_group* g, uint32_t max_n) {
   return S2K_OK;
 }
 
+int s2k_group_set_mid_batch_max(s2k_group* g, uint32_t max_n) {
+  if (!g) return S2K_ERR_ARG;
+  group_wait_idle(g);
+  for (member* me : g->members) {
+    const int rc = s2k_ctx_set_mid_batch_max(me->ctx, max_n);
+    if (rc) return gfail(g, rc, "%s", s2k_last_error(me->ctx));
+  }
+  return S2K_OK;
+}
+
 static int group_submit(s2k_group* g, size_t n, const shard_job& proto, s2k_ticket* ticket) {
   const size_t D = g->members.size();
   // contiguous index shards, rounded up to whole workgroups so that no member gets a ragged tail but the last

@@ -103,7 +103,7 @@ static int gpu_part(void) {
   for (int i = 0; i < N; i += 8) dig[i * 32 + 5] ^= 0x40;
   /* 4096 signatures would take the wave-per-signature ladder; this part is about the per-key tables (the small-batch
    * ladder runs the same batch further down) */
-  CHECK(s2k_ctx_set_small_batch_max(ctx, 0) == S2K_OK, "s2k_ctx_set_small_batch_max");
+  CHECK(s2k_ctx_set_small_batch_max(ctx, 0) == S2K_OK && s2k_ctx_set_mid_batch_max(ctx, 0) == S2K_OK, "s2k_ctx_set_small_batch_max");
   rc = s2k_ecdsa_verify_batch(ctx, N, pub, dig, r, s, S2K_ECDSA_REJECT_MALLEABLE, valid);
   CHECK(rc == S2K_OK, "s2k_ecdsa_verify_batch");
   int good = 0, wrong = 0;
@@ -125,6 +125,11 @@ static int gpu_part(void) {
   memset(valid2, 0xff, N);
   rc = s2k_ecdsa_verify_batch(ctx, N, pub, dig, r, s, S2K_ECDSA_REJECT_MALLEABLE, valid2);
   CHECK(rc == S2K_OK && memcmp(valid, valid2, N) == 0, "same verdicts from the wave-per-signature ladder");
+  CHECK(s2k_ctx_set_small_batch_max(ctx, 0) == S2K_OK && s2k_ctx_set_mid_batch_max(ctx, 32768) == S2K_OK, "s2k_ctx_set_mid_batch_max");
+  memset(valid2, 0xff, N);
+  rc = s2k_ecdsa_verify_batch(ctx, N, pub, dig, r, s, S2K_ECDSA_REJECT_MALLEABLE, valid2);
+  CHECK(rc == S2K_OK && memcmp(valid, valid2, N) == 0, "same verdicts from the four-lanes-per-signature ladder");
+  CHECK(s2k_ctx_set_small_batch_max(ctx, 3072) == S2K_OK, "s2k_ctx_set_small_batch_max");
   CHECK(s2k_ctx_key_grouping_stats(ctx, st) == S2K_OK && st[0] == 0 && st[1] == 0, "grouping statistics (off)");
   CHECK(s2k_ctx_set_key_grouping(ctx, 7, 0, 0, 0) == S2K_ERR_ARG, "bad grouping mode refused");
   CHECK(s2k_ctx_set_key_grouping(ctx, S2K_KEYS_AUTO, 0, 0, 0) == S2K_OK, "grouping back on");

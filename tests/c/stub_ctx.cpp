@@ -139,6 +139,7 @@ void s2k_ctx_destroy(s2k_ctx* c) {
 int s2k_stub_live_contexts(void) { return g_live_contexts.load(); }
 int s2k_ctx_set_key_grouping(s2k_ctx*, int, uint32_t, uint32_t, uint32_t) { return S2K_OK; }
 int s2k_ctx_set_small_batch_max(s2k_ctx*, uint32_t) { return S2K_OK; }
+int s2k_ctx_set_mid_batch_max(s2k_ctx*, uint32_t) { return S2K_OK; }
 int s2k_ctx_ticket_timing(s2k_ctx* c, int e) {
   c->timing = e != 0;
   return S2K_OK;

@@ -35,6 +35,7 @@ if backend == "nccl":
 else:
     dist.init_process_group(backend, rank=rank, world_size=world)
 eng = S.Engine(0)
+eng.set_mid_batch_max(0)     # (2^14 signatures per rank would take the four-lanes-per-signature ladder; this worker reports the grouped path's statistics)
 n = 1 << log2n
 out = {"rank": rank, "backend": dist.get_backend()}
 

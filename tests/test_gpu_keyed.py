@@ -393,7 +393,7 @@ def test_schnorr_exceptional_ladders_on_tables(eng, oracle):
             st = eng.key_grouping_stats()
             assert st["complete"] >= len(pk) - 8       # (a random r that is no x-coordinate is rejected before the ladder matters)
     finally:
-        eng.set_small_batch_max(4096)
+        eng.set_small_batch_max(3072)
     for j in range(0, len(pk), 97):
         assert oracle.schnorr_verify(bytes(pk[j]), bytes(mm[j]), bytes(sg[j])) != 1
     eng.set_key_grouping(S.KEYS_AUTO)

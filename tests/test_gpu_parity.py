@@ -18,8 +18,9 @@ H = bytes.fromhex
 @pytest.fixture(scope="module", params=["lane", "wave"])
 def eng(request):
     """Every test of this file runs twice: with the lane-per-signature kernels at every size ("lane": s2k_ctx_set_small_batch_max
-    0 - most vector sets here have fewer than 4097 items and would otherwise never reach them), and with the context's default
-    ("wave": calls of up to 4096 items take the wave-per-signature ladders)."""
+    and s2k_ctx_set_mid_batch_max 0 - most vector sets here have fewer than 3073 items and would otherwise never reach them), and
+    with the context's default ("wave": calls of up to 3072 items take the wave-per-signature ladders, ECDSA calls of up to 32768
+    the four-lanes-per-signature one)."""
     # torch first: it bundles its own HIP runtime, and the runtime that is loaded first serves
     # the whole process (the engine library then binds to the same one)
     import torch
@@ -29,6 +30,7 @@ def eng(request):
     e = S.Engine(0)
     if request.param == "lane":
         e.set_small_batch_max(0)
+        e.set_mid_batch_max(0)
     return e
 
 

@@ -837,9 +837,9 @@ def test_adaptive_key_grouping(oracle):
         assert np.array_equal(eng.ecdsa_verify_batch(*lone), ref_lone)
         st = eng.key_grouping_stats()
         assert st["keyed"] == 0 and st["general"] == n, (k, st)
-    idx = np.arange(n).reshape(16, n // 16)[:, :1024].reshape(-1)     # (key of signature i: i mod n / 16) 1024 keys, 16 each
-    small = [np.ascontiguousarray(a[idx]) for a in shared]            # below 2^16: neither learned from nor skipped
-    assert np.array_equal(eng.ecdsa_verify_batch(*small), ref_shared[idx]) and eng.key_grouping_stats()["tables"] == 1024
+    idx = np.arange(n).reshape(16, n // 16)[:, :3072].reshape(-1)     # (key of signature i: i mod n / 16) 3072 keys, 16 each
+    small = [np.ascontiguousarray(a[idx]) for a in shared]            # 49152 signatures, below 2^16: neither learned from nor skipped
+    assert np.array_equal(eng.ecdsa_verify_batch(*small), ref_shared[idx]) and eng.key_grouping_stats()["tables"] == 3072
     for k in range(15):                                 # not looked at - even where there would be something to find
         arrs, ref = (lone, ref_lone) if k < 8 else (shared, ref_shared)
         assert np.array_equal(eng.ecdsa_verify_batch(*arrs), ref)

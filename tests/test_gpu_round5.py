@@ -212,6 +212,7 @@ def test_generator_table_widths_give_identical_verdicts(eng, oracle):
         e.set_key_grouping(S.KEYS_ADAPTIVE)
         assert np.array_equal(e.ecdsa_verify_batch(*(a[:4096] for a in arrs), force_complete=True), exp[:4096]), width
         assert np.array_equal(e.ecdsa_verify_batch(*(a[:1000] for a in arrs)), exp[:1000]), width      # (the wave-per-signature ladder)
+        assert np.array_equal(e.ecdsa_verify_batch(*(a[:9000] for a in arrs)), exp[:9000]), width      # (four lanes per signature)
         assert [bytes(x) for x in np.asarray(e.scalar_base_mult_batch(ks))] == base_exp, width
         assert e.ecdsa_verify_encoded_batch(*wp).tolist() == wp_exp, width
         e.close()
@@ -240,7 +241,7 @@ def test_generator_tables_degrade_under_a_budget():
 
 
 def test_small_batch_ladder_agrees_with_the_lane_ladder(oracle):
-    """k_verify_row (a wave per signature on the complete formulas, the default for batches of up to 4096 signatures) and the
+    """k_verify_row (a wave per signature on the complete formulas, the default for batches of up to 3072 signatures), k_verify_quad (four lanes per signature, up to 32768) and the
     lane-per-signature kernels give the oracle's verdicts on the reference's vectors and on boundary-value inputs: Wycheproof
     sha256 + sha512 (parsed by the oracle's ParseASN1Signature), the RFC 6979 signatures with shifted digests, random
     batches of 1 .. 5000 signatures with damage and the low-s rule, and the structured fuzz of test_gpu_parity (every field of
@@ -290,12 +291,19 @@ def test_small_batch_ladder_agrees_with_the_lane_ladder(oracle):
                 arrs[f - 1][i] = v
     for rm in (False, True):
         batches.append((arrs, oracle.ecdsa_verify_batch(*arrs, reject_malleable=rm, nthreads=8), rm))
-    for row_max in (8192, 0):
+    for row_max, quad_max in ((8192, 0), (0, 1 << 20), (0, 0)):      # wave per signature / four lanes per signature / lane per signature
         eng.set_small_batch_max(row_max)
+        eng.set_mid_batch_max(quad_max)
         for arrs, exp, rm in batches:
             got = eng.ecdsa_verify_batch(*arrs, reject_malleable=rm)
-            assert np.array_equal(got, exp), (row_max, len(exp), rm, np.nonzero(got != exp)[0][:8])
-    # the same through submit / wait (child contexts inherit the setting)
+            assert np.array_equal(got, exp), (row_max, quad_max, len(exp), rm, np.nonzero(got != exp)[0][:8])
+    # the same through submit / wait (child contexts inherit the settings)
+    for row_max, quad_max in ((8192, 0), (0, 1 << 20)):
+        eng.set_small_batch_max(row_max)
+        eng.set_mid_batch_max(quad_max)
+        arrs, exp, rm = batches[0]
+        t = [eng.ecdsa_verify_batch_submit(*arrs), eng.ecdsa_verify_batch_submit(*arrs)]
+        assert np.array_equal(t[1].wait(), exp) and np.array_equal(t[0].wait(), exp)
     eng.set_small_batch_max(8192)
     arrs, exp, rm = batches[0]
     t = [eng.ecdsa_verify_batch_submit(*arrs), eng.ecdsa_verify_batch_submit(*arrs)]
@@ -304,7 +312,7 @@ def test_small_batch_ladder_agrees_with_the_lane_ladder(oracle):
     # a group: each member's shard (here 2 x 1024 of the 2048) is what counts as the batch
     g = S.Group([0, 0])
     arrs, exp, rm = next(b for b in batches if len(b[1]) == 2048)
-    for row_max in (4096, 0):
+    for row_max in (4096, 0):             # (0: the members' shards take the four-lanes-per-signature ladder)
         g.set_small_batch_max(row_max)
         assert np.array_equal(g.ecdsa_verify_batch(*arrs, reject_malleable=rm), exp), row_max
     g.close()
