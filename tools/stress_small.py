@@ -6,7 +6,8 @@ the lane-per-signature kernels.
 Every iteration draws a call size (1 .. 6000, mostly small), a key population, damage of every kind (bit flips in r / s /
 digest / key, zero and out-of-range values, foreign keys, keys that are not on the curve, BIP-340 keys and r that are no x
 coordinate, recovery ids 0 .. 4) and runs ECDSA verification, BIP-340 verification and public-key recovery three ways: the
-wave-per-signature ladder (threshold above the size), the lane kernels (threshold 0), and the oracle; synchronously and, every
+wave-per-signature ladder (threshold above the size), four lanes per signature (ECDSA; the other two entry points take the lane
+kernels then), the lane kernels (both thresholds 0), and the oracle; synchronously and, every
 fourth iteration, as two tickets in flight.  Prints one line per iteration; exits non-zero on the first mismatch."""
 import os
 import sys
@@ -66,8 +67,9 @@ def main():
         exp_s = np.array([1 if O.schnorr_verify(bytes(pk[j]), bytes(msgs[j]), bytes(sig[j])) == 1 else 0 for j in range(m)], dtype=np.uint8)
         exp_r = [O.ecdsa_recover(bytes(dig[j]), bytes(r[j]), bytes(s[j]), int(rid[j])) for j in range(n)]
         bad = []
-        for name, row_max in (("wave", 1 << 20), ("lane", 0)):
+        for name, row_max, quad_max in (("wave", 1 << 20, 0), ("quad", 0, 1 << 20), ("lane", 0, 0)):
             eng.set_small_batch_max(row_max)
+            eng.set_mid_batch_max(quad_max)
             if it % 4 == 3:
                 t = [eng.ecdsa_verify_batch_submit(pub, dig, r, s, reject_malleable=rm) for _ in range(2)]
                 got_v = t[1].wait()
