@@ -1244,38 +1244,18 @@ k_verify_row(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restr
   if (lane == 0) out[sig] = verdict;
 }
 
-// PublicKey.Verify with FOUR LANES per signature (pt29q.h: a point is X | Y | Z | Z on the lanes of a quad, a layer of the
-// complete formulas one lane product): the ladder for calls between the wave-per-signature kernels and the lane-per-signature
-// ones - a doubling is 550 dependent instructions where a lane needs 1 070, so a lone wave is through its 16
-// signatures in half the time, at twice the instructions per signature.  Behind k_scalar_prep (one lane per signature).
-// The key's table - (2j + 1) Q, j < 8, projective - lives in LDS, tab[wave][entry][limb][lane]: the lanes of a quad hold
-// x | y | z | beta * x of the entry (lane 3's copy of z is not read by an addition; lambda's image reads its x from there).
-__global__ void __launch_bounds__(256)
-k_verify_quad(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep,
-              gt_view gt, uint8_t* __restrict__ out, size_t stride) {
-  __shared__ uint32_t tab_all[4][8][9][64];
-  const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
-  uint32_t (*tab)[9][64] = tab_all[threadIdx.x >> 6];
-  const uint32_t sig0 = (blockIdx.x * 256 + threadIdx.x) >> 2;
-  const bool live = sig0 < n;
-  const uint32_t sig = live ? sig0 : n - 1;                     // (idle quads redo the last signature: no divergence, no store)
-  const uint32_t pf = prep[(size_t)16 * stride + sig];
-  uint32_t xw[8], yw[8];
-  load_be32(xw, pub + (size_t)sig * 64);
-  load_be32(yw, pub + (size_t)sig * 64 + 32);
-  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
-  fe29 qx = fe29_from_words(xw), qy = fe29_from_words(yw);
-  {   // y^2 == x^3 + 7 (point_s11n.go:298-307); an invalid key is replaced by G, its verdict is 0
-    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
-    rhs.n[0] += 7;
-    if (!fe29_eq(fe29_sqr(qy), rhs)) ok = false;
-    if (!ok) {
-      qx = fe29_from_words(FE_GX);
-      qy = fe29_from_words(FE_GY);
-    }
-  }
+// FOUR LANES per signature (pt29q.h: a point is X | Y | Z | Z on the lanes of a quad, a layer of the complete formulas one lane
+// product): the ladders for calls between the wave-per-signature kernels and the lane-per-signature ones - a
+// doubling is 550 dependent instructions where a lane needs 1 070, so a lone wave is through its 16 signatures in half the
+// time, at twice the instructions per signature.  Behind the preparation kernels (one lane per signature).
+// quad_double_mult: u G + k1 Q + k2 lambda(Q) for the quad's signature, Q = (qx, qy) affine and on the curve; u | k1 | k2 | flags
+// from the preparation's planes.  The key's table - (2j + 1) Q, j < 8, projective - lives in LDS, tab[entry][limb][lane]: the
+// lanes of a quad hold x | y | z | beta * x of the entry (lane 3's copy of z is not read by an addition; lambda's image reads its
+// x from there).  Returns this lane's coordinate of the result.
+S2K_DEV fe29 quad_double_mult(const fe29& qx, const fe29& qy, uint32_t (*tab)[9][64], const uint32_t* __restrict__ prep, size_t stride,
+                              uint32_t sig, uint32_t pf, gt_view gt, uint32_t lane) {
+  const uint32_t q = lane & 3u;
   const fe29 beta = fe29_from_words(FE_BETA), one = fe29_one();
-  // ---- table ----
   {
     fe29 cur = fe29_pick(q >= 2, fe29_pick(q == 1, qx, qy), one);                  // x | y | 1 | 1
     const fe29 D = pt29q_double(cur, q);
@@ -1288,7 +1268,7 @@ k_verify_quad(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
       for (int i = 0; i < 9; ++i) tab[j][i][lane] = st.n[i];
     }
   }
-  // ---- ladder over |k1|, |k2| (odd, < 2^129) ----
+  // |k1|, |k2| odd, < 2^129
   sc k1 = sc_zero(), k2 = sc_zero();
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
@@ -1318,19 +1298,44 @@ k_verify_quad(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     acc = pt29q_add(acc, entry_of(w1, false, neg1), q);
     acc = pt29q_add(acc, entry_of(w2, true, neg2), q);
   }
-  // ---- generator part ----
-  {
-    uint32_t u[8];
+  uint32_t u[8];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
-    apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
+  for (int w = 0; w < 8; ++w) u[w] = prep[(size_t)w * stride + sig];
+  apt g = gt_load(gt, 0, gt_next_digit(u, gt.bits));
 #pragma unroll 1
-    for (uint32_t w = 0; w < gt.windows; ++w) {
-      const fe29 qc = fe29_pick(q >= 2, fe29_pick(q == 1, fe29_from_words(g.x.v), fe29_from_words(g.y.v)), one);
-      if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));
-      acc = pt29q_add(acc, qc, q);
+  for (uint32_t w = 0; w < gt.windows; ++w) {
+    const fe29 qc = fe29_pick(q >= 2, fe29_pick(q == 1, fe29_from_words(g.x.v), fe29_from_words(g.y.v)), one);
+    if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));
+    acc = pt29q_add(acc, qc, q);
+  }
+  return acc;
+}
+
+// PublicKey.Verify (secec/ecdsa.go:171, 392-470), four lanes per signature; behind k_scalar_prep
+__global__ void __launch_bounds__(256)
+k_verify_quad(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep,
+              gt_view gt, uint8_t* __restrict__ out, size_t stride) {
+  __shared__ uint32_t tab_all[4][8][9][64];
+  const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+  const uint32_t sig0 = (blockIdx.x * 256 + threadIdx.x) >> 2;
+  const bool live = sig0 < n;
+  const uint32_t sig = live ? sig0 : n - 1;                     // (idle quads redo the last signature: no divergence, no store)
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  uint32_t xw[8], yw[8];
+  load_be32(xw, pub + (size_t)sig * 64);
+  load_be32(yw, pub + (size_t)sig * 64 + 32);
+  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw) && fe_is_canonical_raw(yw);
+  fe29 qx = fe29_from_words(xw), qy = fe29_from_words(yw);
+  {   // y^2 == x^3 + 7 (point_s11n.go:298-307); an invalid key is replaced by G, its verdict is 0
+    fe29 rhs = fe29_mul(fe29_sqr(qx), qx);
+    rhs.n[0] += 7;
+    if (!fe29_eq(fe29_sqr(qy), rhs)) ok = false;
+    if (!ok) {
+      qx = fe29_from_words(FE_GX);
+      qy = fe29_from_words(FE_GY);
     }
   }
+  const fe29 acc = quad_double_mult(qx, qy, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, lane);
   // ---- verdict: R != infinity and x(R) mod n == r (ecdsa.go:450-465), x(R) = X / Z ----
   const pt29 R = pt29q_gather(acc);
   uint8_t verdict = 0;
@@ -1346,6 +1351,92 @@ k_verify_quad(uint32_t n, const uint8_t* __restrict__ pub, const uint8_t* __rest
     verdict = match ? 1 : 0;
   }
   if (live && q == 0) out[sig] = verdict;
+}
+
+// SchnorrPublicKey.Verify (schnorr.go:221-253), four lanes per signature; behind k_schnorr_prep.  The two lifts - of the key and of
+// r, the point R would have to be - run side by side on the lanes of the quad (lanes 0, 2: the key; lanes 1, 3: r), one chain of
+// lane products; valid iff s G - e P is finite and equals (r, even y), compared projectively.
+__global__ void __launch_bounds__(256)
+k_schnorr_quad(uint32_t n, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig64, const uint32_t* __restrict__ prep,
+               gt_view gt, uint8_t* __restrict__ out, size_t stride) {
+  __shared__ uint32_t tab_all[4][8][9][64];
+  const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+  const uint32_t sig0 = (blockIdx.x * 256 + threadIdx.x) >> 2;
+  const bool live = sig0 < n;
+  const uint32_t sig = live ? sig0 : n - 1;
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  uint32_t xw[8], rw[8];
+  load_be32(xw, pk + (size_t)sig * 32);
+  load_be32(rw, sig64 + (size_t)sig * 64);
+  bool ok = (pf & PF_OK) && fe_is_canonical_raw(xw);            // (PF_OK: r < p, s < n)
+  fe29 xP = fe29_from_words(xw);
+  const fe29 xR = fe29_from_words(rw);
+  const fe29 xin = fe29_pick((q & 1u) != 0, xP, xR);
+  fe29 c = fe29_mul(fe29_sqr(xin), xin);
+  c.n[0] += 7;
+  fe29 y;
+  const bool has = fe29_sqrt(y, c);
+  y = fe29_normalize(y);
+  y = fe29_pick((y.n[0] & 1u) != 0, y, fe29_normalize_weak(fe29_negate(y, 1)));       // the even root
+  const int hasP = __builtin_amdgcn_mov_dpp(has ? 1 : 0, S2K_QP(0, 0, 0, 0), 0xF, 0xF, true);
+  const int hasR = __builtin_amdgcn_mov_dpp(has ? 1 : 0, S2K_QP(1, 1, 1, 1), 0xF, 0xF, true);
+  ok = ok && hasP && hasR;
+  fe29 yP = fe29_qperm<S2K_QP(0, 0, 0, 0)>(y);
+  const fe29 yR = fe29_qperm<S2K_QP(1, 1, 1, 1)>(y);
+  if (!ok) {                                                    // keep the arithmetic on the curve; the verdict is 0
+    xP = fe29_from_words(FE_GX);
+    yP = fe29_from_words(FE_GY);
+  }
+  const fe29 acc = quad_double_mult(xP, yP, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, lane);
+  const pt29 R = pt29q_gather(acc);
+  uint8_t verdict = 0;
+  if (ok && !fe29_is_zero(R.z))
+    verdict = (fe29_eq(R.x, fe29_mul(xR, R.z)) && fe29_eq(R.y, fe29_mul(yR, R.z))) ? 1 : 0;
+  if (live && q == 0) out[sig] = verdict;
+}
+
+// RecoverPublicKey (ecdsa.go:244-282), four lanes per item; between k_scalar_prep (u1 = -e/r, u2 = s/r, the id in the flags) and
+// k_affine_finish<MODE_RECOVER>, which gets the Jacobian triple (X Z, Y Z^2, Z) it expects.  Items without a key: ok = 0 (their
+// record was zeroed before).
+__global__ void __launch_bounds__(256)
+k_recover_quad(uint32_t n, const uint8_t* __restrict__ rsig, const uint32_t* __restrict__ prep, gt_view gt, uint32_t* __restrict__ fin,
+               uint8_t* __restrict__ out, size_t stride) {
+  __shared__ uint32_t tab_all[4][8][9][64];
+  const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+  const uint32_t sig0 = (blockIdx.x * 256 + threadIdx.x) >> 2;
+  const bool live = sig0 < n;
+  const uint32_t sig = live ? sig0 : n - 1;
+  const uint32_t pf = prep[(size_t)16 * stride + sig];
+  const uint32_t rid = (pf >> 8) & 3u;
+  uint32_t xw[8];
+  load_be32(xw, rsig + (size_t)sig * 32);
+  bool ok = (pf & PF_OK) != 0;                                  // (r, s in range, id < 4, r + n < p where the id asks for it)
+  if (ok && (rid & 2u)) u256_add(xw, xw, SC_N);
+  fe29 qx = fe29_from_words(xw);
+  fe29 c = fe29_mul(fe29_sqr(qx), qx);
+  c.n[0] += 7;
+  fe29 qy;
+  ok = fe29_sqrt(qy, c) && ok;
+  qy = fe29_normalize(qy);
+  qy = fe29_pick(((qy.n[0] & 1u) != 0) != ((rid & 1u) != 0), qy, fe29_normalize_weak(fe29_negate(qy, 1)));
+  if (!ok) {
+    qx = fe29_from_words(FE_GX);
+    qy = fe29_from_words(FE_GY);
+  }
+  const fe29 acc = quad_double_mult(qx, qy, tab_all[threadIdx.x >> 6], prep, stride, sig, pf, gt, lane);
+  const pt29 R = pt29q_gather(acc);
+  const bool finite = !fe29_is_zero(R.z);                       // identity: NewPublicKeyFromPoint fails (secec.go:206-209)
+  if (live && q == 0) {
+    if (ok && finite) {
+      const fe29 zz = fe29_sqr(R.z);
+      fq_store(fin, stride, sig, 0, fe29_mul(R.x, R.z));
+      fq_store(fin, stride, sig, 1, fe29_mul(R.y, zz));
+      fq_store(fin, stride, sig, 2, R.z);
+      out[sig] = VERDICT_PENDING;
+    } else {
+      out[sig] = 0;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -3032,6 +3123,23 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
     prof_mark(ctx, st, 5);
     return ctx_leave(ctx, st);
   }
+  if (n <= ctx->quad_max) {
+    // four lanes per item (k_recover_quad) between a preparation and a finish with one lane per item
+    k_scalar_prep<<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, dig, r, s, rid, 0u, prep, pref, smont, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));      // items without a key keep the zero record
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_recover_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, r, prep, s2k_internal_gt(ctx), fin, (uint8_t*)d_ok, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    k_affine_finish<MODE_RECOVER><<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, nullptr, fin, (uint8_t*)d_ok, stride,
+                                                                            (uint8_t*)d_pub65);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 4);
+    prof_mark(ctx, st, 5);
+    return ctx_leave(ctx, st);
+  }
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
@@ -3185,9 +3293,10 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   ctx->kg_counters = nullptr;
   bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
   const bool row = n <= ctx->row_max && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
-  if (row) grouped = false;
+  const bool quad = !row && n <= ctx->quad_max && (ctx->kg_mode == S2K_KEYS_ADAPTIVE || ctx->kg_mode == S2K_KEYS_OFF);
+  if (row || quad) grouped = false;
   else HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
-  ctx->last_wl_count = row ? nullptr : wl_count;
+  ctx->last_wl_count = (row || quad) ? nullptr : wl_count;
   if (grouped) {
     rc = s2k_internal_key_reserve(ctx, n, 32);
     if (rc == S2K_ERR_NOMEM) grouped = false;      // no room for per-key tables: the general ladder for everything
@@ -3219,6 +3328,18 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
+  } else if (quad) {
+    // four lanes per signature (k_schnorr_quad) behind the preparation kernel; nothing left for the finish and worklist kernels
+    k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 1);
+    prof_mark(ctx, st, 2);
+    k_schnorr_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, pk, sig, prep, s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    HIP_TRY(ctx, hipGetLastError());
+    prof_mark(ctx, st, 3);
+    prof_mark(ctx, st, 4);
+    prof_mark(ctx, st, 5);
+    return ctx_leave(ctx, st);
   } else if (row) {
     // small batches: a wave per signature, nothing left for the finish and worklist kernels (k_schnorr_row): one launch up to
     // 1024 signatures, the preparation kernel in front above

@@ -385,6 +385,7 @@ def test_schnorr_exceptional_ladders_on_tables(eng, oracle):
     eng.set_key_grouping(S.KEYS_OFF)
     assert not eng.schnorr_verify_batch(pk, mm, sg).any()      # 1024 signatures: the wave-per-signature ladder, complete formulas
     eng.set_small_batch_max(0)                                 # ... and the lane kernels with their worklist
+    eng.set_mid_batch_max(0)
     try:
         for mode in (S.KEYS_OFF, S.KEYS_AUTO):
             eng.set_key_grouping(mode)
@@ -394,6 +395,7 @@ def test_schnorr_exceptional_ladders_on_tables(eng, oracle):
             assert st["complete"] >= len(pk) - 8       # (a random r that is no x-coordinate is rejected before the ladder matters)
     finally:
         eng.set_small_batch_max(3072)
+        eng.set_mid_batch_max(32768)
     for j in range(0, len(pk), 97):
         assert oracle.schnorr_verify(bytes(pk[j]), bytes(mm[j]), bytes(sg[j])) != 1
     eng.set_key_grouping(S.KEYS_AUTO)

@@ -382,12 +382,13 @@ def test_small_batch_schnorr_ladder_agrees_with_the_lane_ladder(oracle):
     exp = [max(0, oracle.schnorr_verify(p, m, s)) for p, m, s in zip(pk, msg, sig)]
     assert exp == [0, 1] * 64
     sets.append((pk, msg, sig, exp))
-    for row_max in (8192, 0):
+    for row_max, quad_max in ((8192, 0), (0, 1 << 20), (0, 0)):      # wave / four lanes / lane per signature
         eng.set_small_batch_max(row_max)
+        eng.set_mid_batch_max(quad_max)
         for pk, msg, sig, exp in sets:
-            assert eng.schnorr_verify_batch(pk, msg, sig).tolist() == exp, row_max
+            assert eng.schnorr_verify_batch(pk, msg, sig).tolist() == exp, (row_max, quad_max)
             for n in (1, 5):
-                assert eng.schnorr_verify_batch(pk[:n], msg[:n], sig[:n]).tolist() == exp[:n], (row_max, n)
+                assert eng.schnorr_verify_batch(pk[:n], msg[:n], sig[:n]).tolist() == exp[:n], (row_max, quad_max, n)
     eng.close()
 
 
@@ -425,12 +426,13 @@ def test_small_batch_recovery_ladder_agrees_with_the_lane_ladder(oracle):
     for dig, rr, ss, ids in sets:
         exp = [oracle.ecdsa_recover(a, b, c, d) for a, b, c, d in zip(dig, rr, ss, ids)]
         assert 0 < sum(e is not None for e in exp) < len(exp)
-        for row_max in (8192, 0):
+        for row_max, quad_max in ((8192, 0), (0, 1 << 20), (0, 0)):  # wave / four lanes / lane per item
             eng.set_small_batch_max(row_max)
+            eng.set_mid_batch_max(quad_max)
             for lo, hi in ((0, len(dig)), (0, 1), (3, 8)):
                 pub, ok = eng.ecdsa_recover_batch(dig[lo:hi], rr[lo:hi], ss[lo:hi], ids[lo:hi])
                 got = [bytes(p) if k else None for p, k in zip(pub, ok)]
-                assert got == exp[lo:hi], (row_max, lo, hi)
+                assert got == exp[lo:hi], (row_max, quad_max, lo, hi)
                 assert all(bytes(p) == bytes(65) for p, k in zip(pub, ok) if not k)
     eng.close()
 

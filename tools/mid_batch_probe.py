@@ -38,6 +38,33 @@ def main():
             row = {"keys": keys_name, "log2_n": lg, **{k + "_ms": round(v[0], 4) for k, v in res.items()}, "same_verdicts": bool(same),
                    "valid": int(res["lane"][1].sum())}
             print(json.dumps(row), flush=True)
+    # BIP-340 verification and public-key recovery of the same sizes, host arrays to host results
+    from secp256k1_voi_amd.synth import synth_schnorr_batch
+    for lg in (12, 13, 14, 15):
+        n = 1 << lg
+        pk, msgs, sig = synth_schnorr_batch(eng, n, n, 9 + lg)
+        pub, dig, r, s = synth_batch(eng, n, n, seed=200 + lg)
+        rid = np.zeros(n, np.uint8)
+        row = {"log2_n": lg}
+        keep = {}
+        for name, qm in (("quad", 1 << 20), ("lane", 0)):
+            eng.set_small_batch_max(0)
+            eng.set_mid_batch_max(qm)
+            for what, call in (("schnorr", lambda: eng.schnorr_verify_batch(pk, msgs, sig)),
+                               ("recover", lambda: eng.ecdsa_recover_batch(dig, r, s, rid))):
+                ts = []
+                for i in range(15):
+                    t0 = time.perf_counter()
+                    res = call()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                row["%s_%s_ms" % (what, name)] = round(float(np.median(ts[4:])), 4)
+                keep[(what, name)] = res
+        row["same"] = bool(np.array_equal(keep[("schnorr", "quad")], keep[("schnorr", "lane")]) and
+                           np.array_equal(keep[("recover", "quad")][0], keep[("recover", "lane")][0]) and
+                           np.array_equal(keep[("recover", "quad")][1], keep[("recover", "lane")][1]))
+        row["schnorr_valid"] = int(np.asarray(keep[("schnorr", "quad")]).sum())
+        row["recovered"] = int(np.asarray(keep[("recover", "quad")][1]).sum())
+        print(json.dumps(row), flush=True)
     eng.close()
 
 
