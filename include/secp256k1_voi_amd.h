@@ -302,9 +302,10 @@ int s2k_wait_all(s2k_ctx *ctx);
  * (S2K_KEYS_AUTO / S2K_KEYS_ALWAYS) is obeyed at every size; the default (S2K_KEYS_ADAPTIVE) and S2K_KEYS_OFF take these
  * ladders. */
 int s2k_ctx_set_small_batch_max(s2k_ctx *ctx, uint32_t max_n);
-/* ECDSA batches above that threshold and up to max_n signatures (default 32768; 0 = never) run a ladder with FOUR lanes per
- * signature (k_verify_quad, pt29q.h): calls of this size fill neither kind of kernel, and what they cost is the latency of one
- * wave's ladder - half as long this way as with a lane per signature.  Same verdicts (tests/test_gpu_round5.py). */
+/* Batches above that threshold and up to max_n items (default 32768; 0 = never) run ladders with FOUR lanes per signature
+ * (k_verify_quad / k_schnorr_quad / k_recover_quad, pt29q.h): calls of this size fill neither kind of kernel, and what they cost
+ * is the latency of one wave's ladder - half as long this way as with a lane per signature (0.35 instead of 0.6-0.7 ms for
+ * 2^12 .. 2^14 ECDSA signatures).  Same results (tests/test_gpu_round5.py). */
 int s2k_ctx_set_mid_batch_max(s2k_ctx *ctx, uint32_t max_n);
 /* Times of a ticket on the device's clock, for placement diagnostics (s2k_group_member_stats_ex): after
  * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records when its host-to-device copies start and end and when its
