@@ -46,14 +46,22 @@ def run():
         v2 = eng.schnorr_verify_batch(pk[:m], msgs[:m], sig[:m])
         q, ok = eng.ecdsa_recover_batch(dig[:m], r[:m], s[:m], rid[:m])
     print("small calls", int(v.sum()), int(v2.sum()), int(ok.sum()))
+    m = 16384                             # four lanes per signature (k_verify_quad / k_schnorr_quad / k_recover_quad)
+    for _ in range(3):
+        v = eng.ecdsa_verify_batch(pub[:m], dig[:m], r[:m], s[:m])
+        v2 = eng.schnorr_verify_batch(pk[:m], msgs[:m], sig[:m])
+        q, ok = eng.ecdsa_recover_batch(dig[:m], r[:m], s[:m], rid[:m])
+    print("mid-size calls", int(v.sum()), int(v2.sum()), int(ok.sum()))
 
 
 ROW_KERNELS = ("k_verify_row", "k_schnorr_row", "k_recover_row")
+QUAD_KERNELS = ("k_verify_quad", "k_schnorr_quad", "k_recover_quad")
 
 
 def summarize(d, head):
     acc = {}
     rowk = {}
+    quadk = {}
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
             name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(" ", "")
@@ -61,6 +69,8 @@ def summarize(d, head):
             if key and row["Counter_Name"] == "SQ_INSTS_VALU":
                 acc.setdefault(key, []).append(float(row["Counter_Value"]))
             base = name.split("<")[0]
+            if base in QUAD_KERNELS and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
+                quadk.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
             if base in ROW_KERNELS and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_WAVES"):
                 rowk.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU of tools/side_counts.py run: 2^20 items of 2^16 keys per dispatch, wave-instructions x 64 / items, "
@@ -73,6 +83,11 @@ def summarize(d, head):
             # (1024 items per dispatch; five waves per four items since the preparation wave joined the kernels: its instructions
             # - one lane's scalar arithmetic for four signatures - are in the sum)
             out[name] = {"valu_wave_instr_per_item": sum(v) / (1024.0 * len(v)), "waves_per_dispatch": sum(w) / len(w), "dispatches": len(v)}
+    for name, c in sorted(quadk.items()):
+        v, w = c.get("SQ_INSTS_VALU", []), c.get("SQ_WAVES", [])
+        if v and w:     # 16384 items per dispatch, 16 per wave
+            out[name] = {"valu_wave_instr_per_item": sum(v) / (16384.0 * len(v)), "valu_wave_instr_per_wave": sum(v) / sum(w),
+                         "waves_per_dispatch": sum(w) / len(w), "dispatches": len(v)}
     print(json.dumps(out, indent=1))
 
 
