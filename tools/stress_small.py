@@ -1,7 +1,7 @@
 """Randomised differential run of the wave-per-signature ladders (small calls) against the CPU oracle and against
 the lane-per-signature kernels.
 
-    python tools/stress_small.py [iterations] [seed]
+    python tools/stress_small.py [iterations] [seed] [max_n]
 
 Every iteration draws a call size (1 .. 6000, mostly small), a key population, damage of every kind (bit flips in r / s /
 digest / key, zero and out-of-range values, foreign keys, keys that are not on the curve, BIP-340 keys and r that are no x
@@ -32,6 +32,7 @@ def b32(v):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 6000        # (above 6000: the mid-size range of the four-lanes-per-signature ladders)
     O.build()
     eng = S.Engine(0)
     threads = os.cpu_count() or 1
@@ -40,6 +41,8 @@ def main():
     for it in range(iters):
         rng = np.random.default_rng(seed0 * 100019 + it)
         n = int(rng.choice([rng.integers(1, 9), rng.integers(1, 300), rng.integers(300, 2000), rng.integers(2000, 6000)]))
+        if max_n > 6000:
+            n = int(rng.integers(3000, max_n))
         nk = int(rng.choice([1, max(1, n // 7), n]))
         pub, dig, r, s = synth_batch(eng, n, nk, seed=int(rng.integers(1 << 30)))
         dmg = rng.integers(0, int(rng.choice([8, 30, 300])), size=n)
