@@ -185,7 +185,8 @@ int s2k_ecdsa_verify_batch_device(s2k_ctx *ctx, size_t n, const void *d_pub_xy, 
 int s2k_ctx_set_key_grouping(s2k_ctx *ctx, int mode, uint32_t min_group, uint32_t hash_bits, uint32_t max_tables);
 /* After the last s2k_ecdsa_verify_batch_device call has finished (synchronises the device):
  * stats[0] signatures verified from per-key tables, [1] tables built, [2] signatures through the
- * general kernel, [3] signatures re-done by the complete-formula kernel. */
+ * general kernel, [3] signatures re-done by the complete-formula kernel.  All zero after a call that took the ladders of
+ * small or mid-size batches (s2k_ctx_set_small_batch_max / s2k_ctx_set_mid_batch_max): they neither group nor have a worklist. */
 int s2k_ctx_key_grouping_stats(s2k_ctx *ctx, uint32_t stats[4]);
 /* State of S2K_KEYS_ADAPTIVE, without synchronising: out[0] consecutive observed calls that found no group, [1] calls
  * still to be verified without looking, [2] calls verified without looking so far, [3] calls that looked again after a
