@@ -470,6 +470,14 @@ k_scalar_prep(uint32_t n, uint32_t T, const uint8_t* __restrict__ dig, const uin
   }
 }
 
+// Lanes of k_scalar_prep for n signatures: PREP_M signatures share a lane's inversion where that saves instructions that
+// matter (2^20: a third of the kernel), but a call that cannot fill the chip anyway is better off with the latency of fewer
+// signatures per lane - up to 2^16 lanes (a wave on every SIMD) are used before signatures start to share one (94 us for six in
+// a row, 55 for one).
+static inline uint32_t prep_lanes(size_t n) {
+  const size_t shared = (n + PREP_M - 1) / PREP_M, wide = n < ((size_t)1 << 16) ? n : ((size_t)1 << 16);
+  return (uint32_t)(shared > wide ? shared : wide);
+}
 // The same for ONE signature, its own inversion, the result in 17 words (u1 | k1 | k2 | flags: the planes' layout): the
 // preparation wave of the wave-per-signature kernels (k_verify_row, k_recover_row).
 S2K_DEV void scalar_prep_one(size_t i, const uint8_t* __restrict__ dig, const uint8_t* __restrict__ rsig, const uint8_t* __restrict__ ssig,
@@ -2683,7 +2691,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
   uint32_t* smont = ws + WS_SMONT * stride;
   uint32_t* wl_count = ws + WS_LANE_WORDS * stride;
   uint32_t* wl = wl_count + 64;
-  const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  const uint32_t T = prep_lanes(n);
   const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   uint64_t* clk = ctx->prof_on ? ctx->clk : nullptr;
   bool grouped = ctx->kg_mode != S2K_KEYS_OFF && n >= KG_MIN_BATCH;
@@ -2721,7 +2729,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                          // the same kernels on shifted pointers
                          for (int c = 0; c < arrivals->count; ++c) {
                            const size_t lo = arrivals->lo[c], cnt = arrivals->cnt[c];
-                           const uint32_t Tc = (uint32_t)((cnt + PREP_M - 1) / PREP_M);
+                           const uint32_t Tc = prep_lanes(cnt);
                            (void)hipStreamWaitEvent(aux, arrivals->ev[c], 0);
                            k_scalar_prep<<<(Tc + 63) / 64, 64, 0, aux>>>((uint32_t)cnt, Tc, (const uint8_t*)d_dig + lo * 32,
                                                                          (const uint8_t*)d_r + lo * 32, (const uint8_t*)d_s + lo * 32,
@@ -2959,7 +2967,7 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   ctx->last_wl_count = wl_count;
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(d_valid, 0, n, st));       // signatures naming no key of the set stay invalid
-  const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  const uint32_t T = prep_lanes(n);
   const uint32_t kvf = (flags & S2K_ECDSA_FORCE_WORKLIST) ? KVF_FORCE_WORKLIST : 0u;
   // second stream: scalar preparation and generator part; caller's: the sort by key index
   // (stage times, s2k_ctx_profile_read_stages: [0] + [1] the sort with the second stream's work beside it, [2] the ladder)
@@ -3014,6 +3022,24 @@ int s2k_ecdsa_verify_batch_keyset(s2k_ctx* ctx, const s2k_keyset* ks, size_t n, 
   int rc = ctx_streams(ctx);
   if (rc) return rc;
   const size_t sizes[5] = {n * 4, n * 32, n * 32, n * 32, n};
+  if (s2k_internal_small_call(ctx, n, flags)) {             // (s2k_internal_small_block: no DMA transfers)
+    uint8_t *h[5], *dv[5];
+    rc = s2k_internal_small_block(ctx, sizes, 5, h, dv);
+    if (rc) return rc;
+    memcpy(h[0], key_index, n * 4);
+    memcpy(h[1], dig, n * 32);
+    memcpy(h[2], r, n * 32);
+    memcpy(h[3], s, n * 32);
+    rc = s2k_ecdsa_verify_batch_keyset_device(ctx, ks, n, dv[0], dv[1], dv[2], dv[3], flags, dv[4], ctx->s_comp);
+    if (rc) {
+      s2k_internal_drain(ctx);
+      return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comp));
+    memcpy(valid, h[4], n);
+    ctx->have_last = false;
+    return S2K_OK;
+  }
   uint8_t* d[5];
   rc = ctx_stage(ctx, sizes, 5, d);
   if (rc) return rc;
@@ -3141,7 +3167,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
     return ctx_leave(ctx, st);
   }
   HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
-  const uint32_t T = (uint32_t)((n + PREP_M - 1) / PREP_M);
+  const uint32_t T = prep_lanes(n);
   k_scalar_prep<<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, dig, r, s, rid, 0u, prep, pref, smont, stride);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));      // items without a key keep the zero record
