@@ -71,6 +71,9 @@ def parse_args():
                          "timed region (both for profiling those kernels under the driver's settings; not the headline)")
     ap.add_argument("--full", action="store_true", help="print the line with its explanations (as rounds 1-4 did) instead of the compact form")
     ap.add_argument("--write-notes", action="store_true", help="refresh bench_notes.json (the explanations, by path) from this run")
+    ap.add_argument("--rank-timeout", type=float, default=600.0,
+                    help="launcher (--gpus N without torchrun): seconds every rank has to report ready (process group, context, wide tables) "
+                         "before the launch is abandoned and the missing ranks are named")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="test hook: allow more ranks than devices (rank r -> device r mod count, gloo collectives)")
     return ap.parse_args()
@@ -95,16 +98,76 @@ def launch(args):
     s.close()
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(args.gpus),
                 "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
-    procs = []
+    # Every rank is a fresh child of this process (which never touches a GPU).  The children's stderr comes through here line by
+    # line, so that the launcher knows each rank's last words and when it said "ready" (process group up, context created, wide
+    # tables built).  First rank to exit non-zero, or --rank-timeout seconds without every rank ready: the siblings are ended -
+    # they would otherwise sit in init_process_group / the first all-gather until the collective's own timeout - and the
+    # launcher says WHICH rank, with what code and what it printed last.
+    import threading
+    procs, last_line, ready = [], {}, set()
+    lock = threading.Lock()
+
+    def pump(rank, pipe):
+        for raw in iter(pipe.readline, b""):
+            text = raw.decode("utf-8", "replace").rstrip("\n")
+            with lock:
+                if text.strip():
+                    last_line[rank] = text
+                if text.startswith("bench.py: rank %d ready" % rank):
+                    ready.add(rank)
+            sys.stderr.write(text + "\n")
+            sys.stderr.flush()
+        pipe.close()
+
     for rank in range(args.gpus):
-        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), S2K_BENCH_LAUNCHED="1")
         if ndev and ndev < args.gpus:
             e["S2K_BENCH_DEVICE"] = str(rank % ndev)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e, stderr=subprocess.PIPE)
+        threading.Thread(target=pump, args=(rank, p.stderr), daemon=True).start()
+        procs.append(p)
+
+    def end_all(but=None):
+        for r, p in enumerate(procs):
+            if r != but and p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5.0
+        for r, p in enumerate(procs):
+            if r != but and p.poll() is None:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+
+    t0 = time.time()
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if failed:
+            r, c = failed[0]
+            time.sleep(0.2)                          # (its last lines are still on their way through the pipe)
+            with lock:
+                words = last_line.get(r, "(nothing on stderr)")
+            print("bench.py: rank %d exited with code %d; its last stderr line: %s" % (r, c, words), file=sys.stderr)
+            end_all(but=r)
+            print("bench.py: ended the other %d rank(s)" % (len(procs) - 1), file=sys.stderr)
+            rc = c if c > 0 else 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        with lock:
+            n_ready = len(ready)
+            missing = [r for r in range(args.gpus) if r not in ready]
+        if n_ready < args.gpus and time.time() - t0 > args.rank_timeout:
+            with lock:
+                words = {r: last_line.get(r, "(nothing on stderr)") for r in missing}
+            print("bench.py: after %.0f s rank(s) %s have not reported ready; last stderr lines: %s" % (args.rank_timeout, missing, words), file=sys.stderr)
+            end_all()
+            rc = 124
+            break
+        time.sleep(0.05)
     return rc
 
 
@@ -245,7 +308,7 @@ PROSE_KEYS = ("note", "check", "method", "sample", "threads_note", "peak_def", "
               "counts_note", "def")
 LIST_KEYS = ("ms_each", "ms_per_batch_each", "thread_probe", "per_call_ms", "ms_rounds", "ms_rounds_every_call", "ms_rounds_off", "static_recount")
 NESTED_ROOFLINE_DROPS = ("bound", "unit", "peak", "hbm", "counts_head")     # constants the top-level roofline states once
-LAST_KEYS = ("distinct_keys", "general_path_same_batch", "keyset_resident", "pcie_inclusive", "batch_sweep", "roofline", "cpu_baseline")
+LAST_KEYS = ("distinct_keys", "general_path_same_batch", "keyset_resident", "pcie_inclusive", "batch_sweep", "small_call", "roofline", "cpu_baseline")
 DROP_ORDER = ("worst_case_equal_points", "worst_case_ladder_collision", "forced_worklist", "worst_case_all_fallback", "resident_two_contexts",
               "keyset_resident_chunk_tables", "keyset_resident_joint_tables_4bit", "msm_2p22", "encoded_2p20", "key_grouping")
 LINE_BUDGET = 7700
@@ -379,6 +442,96 @@ def batch_sweep(eng, pub, digest, r, s, cpu):
                     "items from pageable host arrays; the streaming entry points (pcie_inclusive.pipelined) hide launch and transfer latencies from 2^17 per batch on"}
 
 
+def small_call(eng, S, torch, d_pub, d_dig, d_r, d_s, sweep):
+    """The small-call ladders in the record: a 1024-signature call's times, the row kernel against the issue
+    roofline (wave instructions per item from the committed PMC pass, kernel time from HIP events of THIS run), and the
+    crossovers row -> quad -> lane measured on THIS box (device-resident calls, each ladder forced in turn) beside the defaults
+    the library ships (engine_internal.h: S2K_ROW_MAX_DEFAULT / S2K_QUAD_MAX_DEFAULT)."""
+    row_def, quad_def = 3072, 32768
+    cfg = eng._lib.s2k_build_config().decode()
+    for tok in cfg.split():
+        if tok.startswith("ROW_MAX="):
+            row_def = int(tok.split("=")[1])
+        if tok.startswith("QUAD_MAX="):
+            quad_def = int(tok.split("=")[1])
+    st = torch.cuda.current_stream().cuda_stream
+    d_valid = torch.zeros(1 << 17, dtype=torch.uint8, device=d_pub.device)
+
+    def timed(n, reps=9):
+        ts = []
+        for _ in range(reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.ecdsa_verify_batch_device(n, d_pub.data_ptr(), d_dig.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), d_valid.data_ptr(), 0, st)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        assert int(d_valid[:n].sum().item()) == n, "small call: a batch of valid signatures did not verify"
+        return median(ts[2:])
+
+    sizes = [1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072]
+    ms = {"row": [], "quad": [], "lane": []}
+    try:
+        for n in sizes:
+            for kind, (rmax, qmax) in (("row", (1 << 30, 0)), ("quad", (0, 1 << 30)), ("lane", (0, 0))):
+                if kind == "row" and n > 16384:
+                    ms[kind].append(None)              # (a wave per signature beyond this: milliseconds, and not in question)
+                    continue
+                eng.set_small_batch_max(rmax)
+                eng.set_mid_batch_max(qmax)
+                ms[kind].append(timed(n, 5))
+        # one 1024-signature call through the row kernel, HIP events around the kernel
+        eng.set_small_batch_max(row_def)
+        eng.set_mid_batch_max(quad_def)
+        eng.profile(True)
+        for _ in range(20):
+            eng.ecdsa_verify_batch_device(1024, d_pub.data_ptr(), d_dig.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), d_valid.data_ptr(), 0, st)
+        pr = eng.profile_read_stages(cap=32)
+        eng.profile(False)
+    finally:
+        eng.set_small_batch_max(row_def)
+        eng.set_mid_batch_max(quad_def)
+    kernel_ms = median(pr["fast_each"]) if pr["fast_each"] else None
+
+    def crossover(a, b):                                   # smallest size from which ladder b is the faster one and stays so
+        best = None
+        for i in range(len(sizes) - 1, -1, -1):
+            if ms[a][i] is None:
+                best = sizes[i] if best is None else best
+                continue
+            if ms[b][i] is not None and ms[b][i] < ms[a][i]:
+                best = sizes[i]
+            else:
+                break
+        return best
+
+    x_rq, x_ql = crossover("row", "quad"), crossover("quad", "lane")
+    out = {"n": 1024, "ecdsa_ms": (sweep or {}).get("ms", [None] * 5)[4] if (sweep or {}).get("log2_n", [None] * 5)[4] == 10 else None,
+           "schnorr_ms": (sweep or {}).get("schnorr_1024_ms"), "recover_ms": (sweep or {}).get("recover_1024_ms"),
+           "device_resident_ecdsa_ms": ms["row"][0],
+           "crossovers": {"sizes": sizes, "row_ms": ms["row"], "quad_ms": ms["quad"], "lane_ms": ms["lane"],
+                          "row_to_quad_measured": x_rq, "quad_to_lane_measured": x_ql, "row_max_default": row_def, "quad_max_default": quad_def},
+           "note": "ecdsa_ms / schnorr_ms / recover_ms: one synchronous host call of 1024 items (batch_sweep); crossovers: device-resident "
+                   "calls with each ladder forced (s2k_ctx_set_small_batch_max / _mid_batch_max), median of 5; *_measured = the smallest size "
+                   "from which the next ladder is faster on this box, beside the shipped defaults (a quad ladder takes sizes above "
+                   "row_max up to quad_max)"}
+    side = load_profile_json("r06_side_counts.json") or load_profile_json("r05_side_counts.json")
+    wi = ((side or {}).get("k_verify_row") or {}).get("valu_wave_instr_per_item")
+    if wi and kernel_ms:
+        peak_wave_instr = SIMDS * PEAK_CLOCK_HZ / 4.0      # one wave64 VALU instruction per 4 cycles per SIMD
+        out["roofline"] = {"kernel": "k_verify_row", "kernel_ms": kernel_ms, "wave_instr_per_item": wi,
+                           "frac": wi * 1024 / (kernel_ms * 1e-3) / peak_wave_instr, "waves": 1280,
+                           "frac_def": "VALU wave-instructions per signature (PMC, profiles/r05_side_counts.json: the signature's wave and its share of "
+                                       "the preparation wave) x 1024 / kernel time (HIP events) / (1024 SIMDs x 2.4 GHz / 4 cycles); 1280 waves on "
+                                       "1024 SIMDs: the call is one wave deep, what is not issue is the latency of one wave's ladder"}
+    off = []
+    for name, meas, dflt in (("row_max", x_rq, row_def), ("quad_max", x_ql, quad_def)):
+        if meas and (meas > 2 * dflt or dflt > 2 * meas):
+            off.append("%s: measured crossover %d against the default %d" % (name, meas, dflt))
+    if off:
+        out["crossovers_off_by_more_than_2x"] = off
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 def worker(args):
     import numpy as np
@@ -399,6 +552,12 @@ def worker(args):
     if shared_device:
         local_rank = int(os.environ["S2K_BENCH_DEVICE"])
     backend = os.environ.get("S2K_DIST_BACKEND", "nccl")
+    if os.environ.get("S2K_BENCH_TEST_FAIL_RANK") == str(rank) and world > 1:   # test hook (tests/test_bench_cpu.py): this rank dies before it joins the group
+        print("bench.py: rank %d: S2K_BENCH_TEST_FAIL_RANK (test hook): leaving before init_process_group" % rank, file=sys.stderr, flush=True)
+        return 3
+    if str(rank) in os.environ.get("S2K_BENCH_TEST_HANG_RANK", "").split(",") and world > 1:   # test hook: this rank never gets ready
+        print("bench.py: rank %d: S2K_BENCH_TEST_HANG_RANK (test hook): sleeping" % rank, file=sys.stderr, flush=True)
+        time.sleep(3600)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -431,6 +590,10 @@ def worker(args):
     eng.gt_wait()                                  # the timed steps run on the tables a long-lived context has: the wide ones
     gt_wait_s = time.perf_counter() - t_c0
     gt_now = eng.gt_info()
+    if world > 1:                                  # (the launcher's watchdog waits for this line from every rank)
+        print("bench.py: rank %d ready (device %d, %d-bit generator tables%s, NUMA node %d, %.1f s)"
+              % (rank, local_rank, gt_now["bits"], "" if gt_now["bits"] == gt_now["target_bits"] or not gt_now["target_bits"] else " of %d wanted" % gt_now["target_bits"],
+                 numa_node, time.perf_counter() - t_c0), file=sys.stderr, flush=True)
     if args.key_grouping == "off":
         eng.set_key_grouping(S.KEYS_OFF)
     pub, digest, r, s = synth_batch(eng, n, n_keys, seed=0x5EC9 + rank)
@@ -531,8 +694,11 @@ def worker(args):
         splits = splits.view(world, 3).cpu().tolist()
         nodes = torch.zeros(world, dtype=torch.float64, device=t.device)
         dist.all_gather_into_tensor(nodes, torch.tensor([float(numa_node)], dtype=torch.float64, device=t.device))
+        gtb = torch.zeros(world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(gtb, torch.tensor([float(gt_now["bits"])], dtype=torch.float64, device=t.device))
         multi = {"per_rank_ms": [x * 1e3 / args.steps for x in every.cpu().tolist()],
                  "per_rank_numa_node": [int(x) for x in nodes.cpu().tolist()],
+                 "per_rank_gt_bits": [int(x) for x in gtb.cpu().tolist()],
                  "per_rank_local_ms": [x[0] for x in splits], "collective_ms": [x[1] for x in splits],
                  "per_rank_step_ms_diagnostic_pass": [x[2] for x in splits],
                  "value_without_collective": n * world / (max(x[0] for x in splits) * 1e-3),
@@ -775,6 +941,16 @@ def worker(args):
             except Exception as e:
                 line["batch_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 rc = 1
+        if not args.no_extras and world == 1:
+            try:
+                line["small_call"] = small_call(eng, S, torch, d_pub, d_dig, d_r, d_s, line.get("batch_sweep"))
+                if line["small_call"].get("crossovers_off_by_more_than_2x"):
+                    line["config"]["small_call_thresholds"] = line["small_call"]["crossovers_off_by_more_than_2x"]
+            except AssertionError as e:
+                line["small_call"] = {"error": str(e) or "assertion failed"}
+                rc = 1
+            except Exception as e:
+                line["small_call"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(compact_line(line, args), flush=True)
     if dist is not None:
         dist.barrier()

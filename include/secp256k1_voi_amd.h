@@ -85,7 +85,8 @@ enum {
  * s2k_ctx_create returns as soon as a narrow table (20-bit windows, 0.8 GiB) is built - under 0.1 s - and a background
  * thread builds the wide one (26-bit windows, 40 GiB, 3 s; 24 or 22 bits when the device has less than twice that free or
  * s2k_set_generator_table_budget says so; none when even those do not fit): calls made meanwhile run on the narrow table
- * (about 2 % slower), the first launch after the build uses the wide one.  Verdicts do not depend on the width.
+ * (about 2 % slower), the first CALL that starts after the build uses the wide one (a call never changes tables between its
+ * launches).  Verdicts do not depend on the width.  A context's child contexts (submit / wait) use its width.
  * s2k_ctx_create_ex: gt_bits 0 = as above; 16 .. 26 = tables of exactly that width for this context, built before the call
  * returns (S2K_ERR_NOMEM when the device cannot hold them); flags S2K_CTX_WAIT_TABLES = automatic width, but return only
  * when the background build has ended.  s2k_ctx_gt_info: info[0] window bits in use now, [1] bits being aimed for (0: none),
@@ -102,6 +103,10 @@ void s2k_set_table_memory_budgets(size_t keyset_free_bytes, size_t key_table_byt
 int s2k_ctx_gt_info(s2k_ctx *ctx, uint64_t info[4]);
 const char *s2k_ctx_gt_note(s2k_ctx *ctx);
 int s2k_ctx_gt_wait(s2k_ctx *ctx);
+/* Test hook: the next s2k_ecdsa_verify_batch_device call of this (automatic) context makes the table of `bits` the one the
+ * device's automatic contexts use BETWEEN its ladder launch and its worklist launch - the worst moment for the background
+ * build to publish.  A call uses one table for all its launches, so its verdicts must not change.  One shot; 0 disarms. */
+int s2k_debug_gt_swap_in_call(s2k_ctx *ctx, int bits);
 void s2k_ctx_destroy(s2k_ctx *ctx);
 const char *s2k_last_error(const s2k_ctx *ctx);
 const char *s2k_version(void);
@@ -309,9 +314,11 @@ int s2k_ctx_set_small_batch_max(s2k_ctx *ctx, uint32_t max_n);
  * 2^12 .. 2^14 ECDSA signatures).  Same results (tests/test_gpu_round5.py). */
 int s2k_ctx_set_mid_batch_max(s2k_ctx *ctx, uint32_t max_n);
 /* Times of a ticket on the device's clock, for placement diagnostics (s2k_group_member_stats_ex): after
- * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records when its host-to-device copies start and end and when its
- * verdicts are ready; s2k_ticket_times gives ms[0] = the copies, ms[1] = first copy to verdicts for one of the last eight
- * retired tickets (S2K_PENDING and zeros otherwise). */
+ * s2k_ctx_ticket_timing(ctx, 1) every submitted ticket records three moments on the device's clock: t0 = its first host-to-device
+ * copy is about to start, t1 = its last copy has ended, t2 = its verdicts are in host memory.  t0 <= t1 <= t2 by construction
+ * (the stream that delivers the verdicts waits for the marker behind the copies), also when several contexts share the
+ * device's hardware queues.  s2k_ticket_times gives ms[0] = t1 - t0 (the copies), ms[1] = t2 - t0 (first copy to verdicts), so
+ * 0 < ms[0] <= ms[1], for one of the last eight retired tickets (S2K_PENDING and zeros otherwise). */
 int s2k_ctx_ticket_timing(s2k_ctx *ctx, int enable);
 int s2k_ticket_times(s2k_ctx *ctx, s2k_ticket ticket, double ms[2]);
 /* s2k_ecdsa_verify_batch_keyset in the same form: signatures that name their key by its index in a key set of this context
@@ -354,6 +361,8 @@ int s2k_topology_node_count(const char *sysfs_root);
 int s2k_topology_numa_node_of_pci(const char *sysfs_root, const char *bus_id);
 int s2k_topology_node_cpus(const char *sysfs_root, int node, int *cpus, size_t cap);
 int s2k_group_create(const int *devices, size_t n_devices, s2k_group **out);
+/* ... with the members' generator table width and context flags as s2k_ctx_create_ex takes them (0, 0 = s2k_group_create) */
+int s2k_group_create_ex(const int *devices, size_t n_devices, int gt_bits, uint32_t flags, s2k_group **out);
 void s2k_group_destroy(s2k_group *g);
 size_t s2k_group_size(const s2k_group *g);
 const char *s2k_group_last_error(const s2k_group *g);
@@ -378,9 +387,10 @@ int s2k_group_ecdsa_verify_encoded_batch_submit(s2k_group *g, size_t n, const ui
  * submit to its verdicts (host clock), device index. */
 int s2k_group_member_stats(s2k_group *g, double *stats /* 4 * members */);
 /* The same and more, stats[m * 8 + 0..7]: signatures, first index, host milliseconds, device index, NUMA node of the device
- * (-1 unknown), CPUs the member's thread is bound to (0: not bound), and of the last finished shard the milliseconds of its
- * host-to-device copies and the milliseconds from its first copy to its verdicts, on the device's clock (the first call
- * switches that timing on: zero until a shard has been submitted after it).  Placement: every member's thread binds itself
+ * (-1 unknown), CPUs the member's thread is bound to (0: not bound), and of the last finished shard [6] the milliseconds of its
+ * host-to-device copies and [7] the milliseconds from its first copy to its verdicts, on the device's clock as
+ * s2k_ticket_times defines them: 0 < [6] <= [7] for every member, whatever shares its device (the first call switches that
+ * timing on: zero until a shard has been submitted after it).  Placement: every member's thread binds itself
  * to the CPUs of its device's NUMA node (sysfs; no-op on one node, when the node is unknown or the cpuset forbids it). */
 int s2k_group_member_stats_ex(s2k_group *g, double *stats /* 8 * members */);
 /* Blocks until the wide generator tables of every member's device are in (s2k_ctx_gt_wait per member); returns the smallest
@@ -607,6 +617,39 @@ int s2k_ct_ecdh(const uint8_t priv32[32], const uint8_t pub65[65], uint8_t share
  * or s == 0 (draw another nonce, as the reference does). */
 int s2k_ct_ecdsa_sign_raw(const uint8_t priv32[32], const uint8_t digest32[32], const uint8_t nonce32[32],
                           uint8_t r32[32], uint8_t s32[32], uint8_t *recovery_id);
+/* ---- single operations of Point / Scalar / field.Element: constant time, host CPU ----------------------------------
+ * What the reference's Point / Scalar / field.Element METHODS bind to.  One call, one operation, no context, no
+ * device: the batched GPU forms further down (s2k_point_add_batch, s2k_fn_op_batch, s2k_fp_op_batch) are variable time and
+ * cost a device round trip - they are batch offerings for public data, never the binding of a method that may see a secret
+ * (Scalar.Invert of a nonce, ecdsa.go:371).  No branch or address depends on an operand's VALUE, including whether a point is
+ * the identity.  Points are 65-byte records, scalars / elements 32-byte canonical big-endian; an operand the reference's type
+ * cannot hold (off-curve or non-canonical: its constructors return errors, point.go:192-216, scalar.go:135, field.go:153) is
+ * S2K_ERR_ARG.  ctrl follows the reference: 0 selects the first alternative, anything else the second. */
+int s2k_ct_point_add(const uint8_t a65[65], const uint8_t b65[65], uint8_t out65[65]);        /* Point.Add, point.go:62 */
+int s2k_ct_point_double(const uint8_t a65[65], uint8_t out65[65]);                             /* Point.Double, point.go:73 */
+int s2k_ct_point_subtract(const uint8_t a65[65], const uint8_t b65[65], uint8_t out65[65]);   /* Point.Subtract, point.go:83 */
+int s2k_ct_point_negate(const uint8_t a65[65], uint8_t out65[65]);                             /* Point.Negate, point.go:89 */
+int s2k_ct_point_conditional_negate(const uint8_t a65[65], uint64_t ctrl, uint8_t out65[65]); /* Point.ConditionalNegate, point.go:102 */
+int s2k_ct_point_conditional_select(const uint8_t a65[65], const uint8_t b65[65], uint64_t ctrl,
+                                    uint8_t out65[65]);                                        /* Point.ConditionalSelect, point.go:115 */
+int s2k_ct_point_equal(const uint8_t a65[65], const uint8_t b65[65], uint64_t *out);          /* Point.Equal, point.go:133: 1 / 0 */
+int s2k_ct_point_is_identity(const uint8_t a65[65], uint64_t *out);                            /* Point.IsIdentity, point.go:148 */
+int s2k_ct_point_is_y_odd(const uint8_t a65[65], uint64_t *out);                               /* Point.IsYOdd, point.go:155 */
+/* op: S2K_OP_MUL / SQR / ADD / SUB / NEG / INV (below) - Scalar.Multiply / Square / Add / Subtract / Negate (scalar.go:66-93),
+ * Scalar.Invert (scalar_invert.go:11; 0 -> 0).  b32 is read by MUL / ADD / SUB only. */
+int s2k_ct_scalar_op(int op, const uint8_t a32[32], const uint8_t b32[32], uint8_t out32[32]);
+int s2k_ct_scalar_conditional_select(const uint8_t a32[32], const uint8_t b32[32], uint64_t ctrl, uint8_t out32[32]); /* scalar.go:176 */
+int s2k_ct_scalar_conditional_negate(const uint8_t a32[32], uint64_t ctrl, uint8_t out32[32]);                        /* scalar.go:168 */
+/* what: 0 Scalar.IsZero (scalar.go:187), 1 Scalar.IsGreaterThanHalfN (:196), 2 Scalar.Equal (:182, reads b32): *out = 1 / 0 */
+#define S2K_SCALAR_IS_ZERO 0
+#define S2K_SCALAR_IS_GT_HALF_N 1
+#define S2K_SCALAR_EQUAL 2
+int s2k_ct_scalar_predicate(int what, const uint8_t a32[32], const uint8_t b32[32], uint64_t *out);
+/* Scalar.SetBytes (scalar.go:123): out = src mod n; *did_reduce (may be NULL) = 1 iff src >= n.  Accepts any 32 bytes. */
+int s2k_ct_scalar_set_bytes(const uint8_t src32[32], uint8_t out32[32], uint64_t *did_reduce);
+/* field.Element: S2K_OP_MUL / SQR / ADD / SUB / NEG (internal/field/field.go:61-104), S2K_OP_INV (field_invert.go:11; 0 -> 0),
+ * S2K_OP_SQRT (field_sqrt_ratio.go:14: *flag = 1 iff a is a square, out = a^((p+1)/4) then, 0 otherwise; flag required). */
+int s2k_ct_fe_op(int op, const uint8_t a32[32], const uint8_t b32[32], uint8_t out32[32], uint64_t *flag);
 /* Test instrumentation: field multiplications executed by the calling thread in s2k_ct_* since the
  * previous call of this function.  The count is the same for every scalar (tests/test_ct_cpu.py). */
 uint64_t s2k_ct_debug_fe_mul_count(void);

@@ -261,6 +261,8 @@ def load_library() -> C.CDLL:
     lib.s2k_wait_all.argtypes = [vp]
     lib.s2k_device_count.restype = ci
     lib.s2k_group_create.argtypes = [C.POINTER(ci), sz, C.POINTER(vp)]
+    lib.s2k_group_create_ex.argtypes = [C.POINTER(ci), sz, ci, u32, C.POINTER(vp)]
+    lib.s2k_debug_gt_swap_in_call.argtypes = [vp, ci]
     lib.s2k_group_destroy.argtypes = [vp]
     lib.s2k_group_destroy.restype = None
     lib.s2k_group_size.argtypes = [vp]
@@ -316,6 +318,22 @@ def load_library() -> C.CDLL:
     lib.s2k_ct_scalar_base_mult.argtypes = [C.c_char_p, C.c_char_p]
     lib.s2k_ct_ecdh.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     lib.s2k_ct_debug_fe_mul_count.restype = C.c_uint64
+    cp, pu64 = C.c_char_p, C.POINTER(C.c_uint64)
+    lib.s2k_ct_point_add.argtypes = [cp, cp, cp]
+    lib.s2k_ct_point_double.argtypes = [cp, cp]
+    lib.s2k_ct_point_subtract.argtypes = [cp, cp, cp]
+    lib.s2k_ct_point_negate.argtypes = [cp, cp]
+    lib.s2k_ct_point_conditional_negate.argtypes = [cp, C.c_uint64, cp]
+    lib.s2k_ct_point_conditional_select.argtypes = [cp, cp, C.c_uint64, cp]
+    lib.s2k_ct_point_equal.argtypes = [cp, cp, pu64]
+    lib.s2k_ct_point_is_identity.argtypes = [cp, pu64]
+    lib.s2k_ct_point_is_y_odd.argtypes = [cp, pu64]
+    lib.s2k_ct_scalar_op.argtypes = [ci, cp, cp, cp]
+    lib.s2k_ct_scalar_conditional_select.argtypes = [cp, cp, C.c_uint64, cp]
+    lib.s2k_ct_scalar_conditional_negate.argtypes = [cp, C.c_uint64, cp]
+    lib.s2k_ct_scalar_predicate.argtypes = [ci, cp, cp, pu64]
+    lib.s2k_ct_scalar_set_bytes.argtypes = [cp, cp, pu64]
+    lib.s2k_ct_fe_op.argtypes = [ci, cp, cp, cp, pu64]
     lib.s2k_ct_multi_scalar_mult.argtypes = [sz, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.s2k_device_pci_bus_id.argtypes = [ci, C.c_char_p, sz]
     lib.s2k_device_numa_node.argtypes = [ci]
@@ -382,6 +400,11 @@ EXPORTED_SYMBOLS = [
     "s2k_topology_numa_node_of_pci", "s2k_topology_node_cpus", "s2k_ctx_ticket_timing", "s2k_ticket_times",
     "s2k_group_member_stats_ex", "s2k_group_gt_wait", "s2k_group_shard_size", "s2k_group_host_alloc", "s2k_group_host_free",
     "s2k_ctx_set_small_batch_max", "s2k_ctx_set_mid_batch_max", "s2k_ctx_create_ex", "s2k_set_generator_table_budget", "s2k_set_table_memory_budgets", "s2k_ctx_gt_info", "s2k_ctx_gt_note", "s2k_ctx_gt_wait",
+    "s2k_group_create_ex", "s2k_debug_gt_swap_in_call",
+    "s2k_ct_point_add", "s2k_ct_point_double", "s2k_ct_point_subtract", "s2k_ct_point_negate", "s2k_ct_point_conditional_negate",
+    "s2k_ct_point_conditional_select", "s2k_ct_point_equal", "s2k_ct_point_is_identity", "s2k_ct_point_is_y_odd",
+    "s2k_ct_scalar_op", "s2k_ct_scalar_conditional_select", "s2k_ct_scalar_conditional_negate", "s2k_ct_scalar_predicate",
+    "s2k_ct_scalar_set_bytes", "s2k_ct_fe_op",
 ]
 
 
@@ -443,6 +466,56 @@ def ct_multi_scalar_mult(scalars, points):
     if rc == -4:
         raise MemoryError("s2k_ct_multi_scalar_mult: out of memory")
     return out.raw if rc == 0 else None
+
+
+# ---- single operations, constant time, host CPU (s2k_ct_point_* / s2k_ct_scalar_* / s2k_ct_fe_op): what the reference's
+# Point / Scalar / field.Element methods bind to.  A malformed operand raises ValueError (the reference's constructors fail).
+def _ct_out(fn, n, *args):
+    out = C.create_string_buffer(n)
+    rc = fn(*args, out)
+    if rc != 0:
+        raise ValueError(f"{fn.__name__}: operand the reference's type cannot hold ({rc})")
+    return out.raw
+
+
+def _ct_flag(fn, *args) -> int:
+    v = C.c_uint64(7)
+    rc = fn(*args, C.byref(v))
+    if rc != 0:
+        raise ValueError(f"{fn.__name__}: operand the reference's type cannot hold ({rc})")
+    return int(v.value)
+
+
+def ct_point_add(a65, b65): return _ct_out(load_library().s2k_ct_point_add, 65, bytes(a65), bytes(b65))
+def ct_point_double(a65): return _ct_out(load_library().s2k_ct_point_double, 65, bytes(a65))
+def ct_point_subtract(a65, b65): return _ct_out(load_library().s2k_ct_point_subtract, 65, bytes(a65), bytes(b65))
+def ct_point_negate(a65): return _ct_out(load_library().s2k_ct_point_negate, 65, bytes(a65))
+def ct_point_conditional_negate(a65, ctrl): return _ct_out(load_library().s2k_ct_point_conditional_negate, 65, bytes(a65), int(ctrl))
+def ct_point_conditional_select(a65, b65, ctrl): return _ct_out(load_library().s2k_ct_point_conditional_select, 65, bytes(a65), bytes(b65), int(ctrl))
+def ct_point_equal(a65, b65): return _ct_flag(load_library().s2k_ct_point_equal, bytes(a65), bytes(b65))
+def ct_point_is_identity(a65): return _ct_flag(load_library().s2k_ct_point_is_identity, bytes(a65))
+def ct_point_is_y_odd(a65): return _ct_flag(load_library().s2k_ct_point_is_y_odd, bytes(a65))
+def ct_scalar_op(op, a32, b32=None): return _ct_out(load_library().s2k_ct_scalar_op, 32, int(op), bytes(a32), None if b32 is None else bytes(b32))
+def ct_scalar_conditional_select(a32, b32, ctrl): return _ct_out(load_library().s2k_ct_scalar_conditional_select, 32, bytes(a32), bytes(b32), int(ctrl))
+def ct_scalar_conditional_negate(a32, ctrl): return _ct_out(load_library().s2k_ct_scalar_conditional_negate, 32, bytes(a32), int(ctrl))
+def ct_scalar_predicate(what, a32, b32=None): return _ct_flag(load_library().s2k_ct_scalar_predicate, int(what), bytes(a32), None if b32 is None else bytes(b32))
+
+
+def ct_scalar_set_bytes(src32):
+    """Scalar.SetBytes -> (src mod n, did_reduce)"""
+    out, did = C.create_string_buffer(32), C.c_uint64(7)
+    if load_library().s2k_ct_scalar_set_bytes(bytes(src32), out, C.byref(did)) != 0:
+        raise ValueError("s2k_ct_scalar_set_bytes")
+    return out.raw, int(did.value)
+
+
+def ct_fe_op(op, a32, b32=None):
+    """field.Element operation -> (out, flag); flag is 1 except for OP_SQRT of a non-square"""
+    out, flag = C.create_string_buffer(32), C.c_uint64(7)
+    rc = load_library().s2k_ct_fe_op(int(op), bytes(a32), None if b32 is None else bytes(b32), out, C.byref(flag))
+    if rc != 0:
+        raise ValueError(f"s2k_ct_fe_op: operand the reference's type cannot hold ({rc})")
+    return out.raw, int(flag.value)
 
 
 def ct_scalar_base_mult(k: bytes) -> bytes:
@@ -528,6 +601,11 @@ class Engine(_TicketOwner):
         self._check(self._lib.s2k_ctx_gt_info(self._h, info))
         return {"bits": int(info[0]), "target_bits": int(info[1]), "building": bool(info[2]), "bytes": int(info[3]),
                 "note": self._lib.s2k_ctx_gt_note(self._h).decode()}
+
+    def debug_gt_swap_in_call(self, bits: int):
+        """test hook (s2k_debug_gt_swap_in_call): the next ecdsa_verify_batch publishes the `bits`-wide generator table for the
+        device's automatic contexts between its ladder launch and its worklist launch"""
+        self._check(self._lib.s2k_debug_gt_swap_in_call(self._h, int(bits)))
 
     def set_small_batch_max(self, max_n: int):
         """batches of up to max_n signatures take the wave-per-signature ladder (s2k_ctx_set_small_batch_max; 0: never)"""
@@ -1074,13 +1152,14 @@ class Group(_TicketOwner):
     """Several devices behind one process (s2k_group): one context and one host thread per listed device, contiguous
     index shards, verdicts written straight into the result array."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, gt_bits: int = 0, wait_tables: bool = False):
+        """gt_bits / wait_tables: as Engine's (s2k_group_create_ex): every member, and its child contexts, on that table width."""
         self._lib = load_library()
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         h = C.c_void_p()
-        rc = self._lib.s2k_group_create(devs, len(devices), C.byref(h))
+        rc = self._lib.s2k_group_create_ex(devs, len(devices), int(gt_bits), CTX_WAIT_TABLES if wait_tables else 0, C.byref(h))
         if rc != 0:
-            raise EngineError(f"s2k_group_create failed ({rc})")
+            raise EngineError(f"s2k_group_create_ex failed ({rc})")
         self._h = h
         self.devices = list(devices)
         import weakref

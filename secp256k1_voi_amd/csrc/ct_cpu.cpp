@@ -587,6 +587,75 @@ void ct_scalar_base_mult(pt& v, const sc& s) {
   }
 }
 
+
+// a^((p+1)/4) with the addition chain of the inversion's prefix (Element.Sqrt, internal/field/field_sqrt_ratio.go:14:
+// p = 3 mod 4, so this is a square root whenever one exists); returns the mask "r^2 == a"
+u64 fe_sqrt(fe& r, const fe& a) {
+  fe x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t;
+  fe_sqr(t, a); fe_mul(x2, t, a);
+  fe_sqr(t, x2); fe_mul(x3, t, a);
+  fe_sqr_n(t, x3, 3); fe_mul(x6, t, x3);
+  fe_sqr_n(t, x6, 3); fe_mul(x9, t, x3);
+  fe_sqr_n(t, x9, 2); fe_mul(x11, t, x2);
+  fe_sqr_n(t, x11, 11); fe_mul(x22, t, x11);
+  fe_sqr_n(t, x22, 22); fe_mul(x44, t, x22);
+  fe_sqr_n(t, x44, 44); fe_mul(x88, t, x44);
+  fe_sqr_n(t, x88, 88); fe_mul(x176, t, x88);
+  fe_sqr_n(t, x176, 44); fe_mul(x220, t, x44);
+  fe_sqr_n(t, x220, 3); fe_mul(x223, t, x3);
+  fe_sqr_n(t, x223, 23); fe_mul(t, t, x22);
+  fe_sqr_n(t, t, 6); fe_mul(t, t, x2);
+  fe_sqr_n(r, t, 2);
+  fe chk;
+  fe_sqr(chk, r);
+  fe_sub(chk, chk, a);
+  return is_zero256(chk);
+}
+
+// 65-byte record -> point WITHOUT branching on what the record holds (the single-operation calls: an operand may be an
+// intermediate value of a secret computation, and whether it is the identity is then a secret too).  Returns the mask
+// "the record is a Point the reference can hold": the identity record, or 0x04 || X || Y canonical and on the curve
+// (SetUncompressedBytes, point_s11n.go:178-201).  The caller branches on THAT only (a malformed record is a usage error).
+u64 pt_from_record_ct(pt& p, const uint8_t* rec) {
+  u64 body = 0;
+  for (int i = 1; i < 65; ++i) body |= rec[i];
+  const u64 is_id = mask_eq(rec[0], 0x00) & ~mask_nonzero(body);
+  u256 t;
+  from_be(p.x, rec + 1);
+  from_be(p.y, rec + 33);
+  const u64 canon = mask_nonzero(sub256(t, p.x, FP_P)) & mask_nonzero(sub256(t, p.y, FP_P));
+  fe zero = FE_ZERO;
+  cmov256(p.x, zero, ~canon);        // (the arithmetic below assumes reduced operands; the verdict is already "no")
+  cmov256(p.y, zero, ~canon);
+  fe l, r3, seven = {{7, 0, 0, 0}};
+  fe_sqr(l, p.y);
+  fe_sqr(r3, p.x);
+  fe_mul(r3, r3, p.x);
+  fe_add(r3, r3, seven);
+  fe_sub(l, l, r3);
+  const u64 is_affine = mask_eq(rec[0], 0x04) & canon & is_zero256(l);
+  p.z = FE_ONE;
+  pt id;
+  pt_identity(id);
+  pt_cmov(p, id, ~is_affine);        // (a rejected record leaves the identity behind, never an off-curve point)
+  return is_id | is_affine;
+}
+inline u64 ctrl_mask(uint64_t ctrl) { return mask_nonzero((u64)ctrl); }   // the reference's ctrl: 0 or "otherwise"
+inline u64 sc_from_be_canonical(sc& r, const uint8_t* b) {               // mask: b < n (SetCanonicalBytes, scalar.go:135)
+  u256 t;
+  from_be(r, b);
+  const u64 ok = mask_nonzero(sub256(t, r, SC_N));
+  sc_reduce_once(r, 0);
+  return ok;
+}
+inline u64 fe_from_be_canonical(fe& r, const uint8_t* b) {               // mask: b < p (NewElementFromCanonicalBytes, field.go:153)
+  u256 t;
+  from_be(r, b);
+  const u64 ok = mask_nonzero(sub256(t, r, FP_P));
+  fe zero = FE_ZERO;
+  cmov256(r, zero, ~ok);
+  return ok;
+}
 }  // namespace
 
 extern "C" {
@@ -723,6 +792,198 @@ int s2k_ct_ecdsa_sign_raw(const uint8_t priv32[32], const uint8_t digest32[32], 
   to_be(s32, s);
   if (recovery_id) *recovery_id = (uint8_t)(((rec[64] & 1) ^ (high & 1)) | ((overflow & 1) << 1));
   return bad ? S2K_ERR_ARG : S2K_OK;
+}
+
+// ---- single operations of Point / Scalar / field.Element, constant time ("single-op entry points served by
+// the CPU backend so the Go Point / Scalar methods have something to call").  The batched GPU forms (s2k_point_add_batch,
+// s2k_fn_op_batch ...) are variable time, need a context and a device round trip: right for a million public values, wrong
+// for one secret nonce.  Operands are 65-byte point records / 32-byte canonical big-endian values; a record or value the
+// reference's type cannot hold is S2K_ERR_ARG (the reference's constructors return an error for those).
+
+// v = p + q — Point.Add (point.go:62); addComplete (point_projective.go:24)
+int s2k_ct_point_add(const uint8_t a65[65], const uint8_t b65[65], uint8_t out65[65]) {
+  if (!a65 || !b65 || !out65) return S2K_ERR_ARG;
+  pt a, b, r;
+  if (~(pt_from_record_ct(a, a65) & pt_from_record_ct(b, b65))) return S2K_ERR_ARG;
+  pt_add(r, a, b);
+  pt_to_record(out65, r);
+  return S2K_OK;
+}
+// v = p + p — Point.Double (point.go:73); doubleComplete (point_projective.go:208)
+int s2k_ct_point_double(const uint8_t a65[65], uint8_t out65[65]) {
+  if (!a65 || !out65) return S2K_ERR_ARG;
+  pt a, r;
+  if (~pt_from_record_ct(a, a65)) return S2K_ERR_ARG;
+  pt_double(r, a);
+  pt_to_record(out65, r);
+  return S2K_OK;
+}
+// v = p - q — Point.Subtract (point.go:83)
+int s2k_ct_point_subtract(const uint8_t a65[65], const uint8_t b65[65], uint8_t out65[65]) {
+  if (!a65 || !b65 || !out65) return S2K_ERR_ARG;
+  pt a, b, r;
+  if (~(pt_from_record_ct(a, a65) & pt_from_record_ct(b, b65))) return S2K_ERR_ARG;
+  pt_cneg(b, ~(u64)0);
+  pt_add(r, a, b);
+  pt_to_record(out65, r);
+  return S2K_OK;
+}
+// v = p iff ctrl == 0, v = -p otherwise — Point.ConditionalNegate (point.go:102); ctrl = 1 is Point.Negate (point.go:89)
+int s2k_ct_point_conditional_negate(const uint8_t a65[65], uint64_t ctrl, uint8_t out65[65]) {
+  if (!a65 || !out65) return S2K_ERR_ARG;
+  pt a;
+  if (~pt_from_record_ct(a, a65)) return S2K_ERR_ARG;
+  pt_cneg(a, ctrl_mask(ctrl));
+  // (the operand is affine or the identity: the record is rebuilt without the inversion of pt_to_record)
+  const u64 keep = ~is_zero256(a.z);
+  uint8_t xb[32], yb[32];
+  to_be(xb, a.x);
+  to_be(yb, a.y);
+  out65[0] = (uint8_t)(0x04 & keep);
+  for (int i = 0; i < 32; ++i) {
+    out65[1 + i] = (uint8_t)(xb[i] & keep);
+    out65[33 + i] = (uint8_t)(yb[i] & keep);
+  }
+  return S2K_OK;
+}
+int s2k_ct_point_negate(const uint8_t a65[65], uint8_t out65[65]) { return s2k_ct_point_conditional_negate(a65, 1, out65); }
+// v = a iff ctrl == 0, v = b otherwise — Point.ConditionalSelect (point.go:115)
+int s2k_ct_point_conditional_select(const uint8_t a65[65], const uint8_t b65[65], uint64_t ctrl, uint8_t out65[65]) {
+  if (!a65 || !b65 || !out65) return S2K_ERR_ARG;
+  pt a, b;
+  if (~(pt_from_record_ct(a, a65) & pt_from_record_ct(b, b65))) return S2K_ERR_ARG;
+  const uint8_t m = (uint8_t)ctrl_mask(ctrl);
+  for (int i = 0; i < 65; ++i) out65[i] = (uint8_t)((a65[i] & ~m) | (b65[i] & m));
+  return S2K_OK;
+}
+// Point.Equal (point.go:133: X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1), Point.IsIdentity (:148), Point.IsYOdd (:155; 0 for the
+// identity, whose rescaled y is 0): *out = 1 or 0
+int s2k_ct_point_equal(const uint8_t a65[65], const uint8_t b65[65], uint64_t* out) {
+  if (!a65 || !b65 || !out) return S2K_ERR_ARG;
+  pt a, b;
+  if (~(pt_from_record_ct(a, a65) & pt_from_record_ct(b, b65))) return S2K_ERR_ARG;
+  fe x1z2, x2z1, y1z2, y2z1, dx, dy;
+  fe_mul(x1z2, a.x, b.z);
+  fe_mul(x2z1, b.x, a.z);
+  fe_mul(y1z2, a.y, b.z);
+  fe_mul(y2z1, b.y, a.z);
+  fe_sub(dx, x1z2, x2z1);
+  fe_sub(dy, y1z2, y2z1);
+  *out = (is_zero256(dx) & is_zero256(dy)) & 1;
+  return S2K_OK;
+}
+int s2k_ct_point_is_identity(const uint8_t a65[65], uint64_t* out) {
+  if (!a65 || !out) return S2K_ERR_ARG;
+  pt a;
+  if (~pt_from_record_ct(a, a65)) return S2K_ERR_ARG;
+  *out = is_zero256(a.z) & 1;
+  return S2K_OK;
+}
+int s2k_ct_point_is_y_odd(const uint8_t a65[65], uint64_t* out) {
+  if (!a65 || !out) return S2K_ERR_ARG;
+  pt a;
+  if (~pt_from_record_ct(a, a65)) return S2K_ERR_ARG;
+  *out = a.y.v[0] & 1 & ~is_zero256(a.z);
+  return S2K_OK;
+}
+
+// Scalar.Add / Subtract / Negate / Multiply / Square (scalar.go:66-93) and Scalar.Invert (scalar_invert.go:11; 0 -> 0):
+// op is one of S2K_OP_MUL / SQR / ADD / SUB / NEG / INV, b is read by the binary ones.  Operands canonical (< n).
+int s2k_ct_scalar_op(int op, const uint8_t a32[32], const uint8_t b32[32], uint8_t out32[32]) {
+  if (!a32 || !out32) return S2K_ERR_ARG;
+  const bool binary = op == S2K_OP_MUL || op == S2K_OP_ADD || op == S2K_OP_SUB;
+  if (!binary && op != S2K_OP_SQR && op != S2K_OP_NEG && op != S2K_OP_INV) return S2K_ERR_ARG;
+  if (binary && !b32) return S2K_ERR_ARG;
+  sc a, b = {{0, 0, 0, 0}}, r;
+  u64 ok = sc_from_be_canonical(a, a32);
+  if (binary) ok &= sc_from_be_canonical(b, b32);
+  if (~ok) return S2K_ERR_ARG;
+  switch (op) {                       // (op is public)
+    case S2K_OP_MUL: sc_mul(r, a, b); break;
+    case S2K_OP_SQR: sc_mul(r, a, a); break;
+    case S2K_OP_ADD: sc_add(r, a, b); break;
+    case S2K_OP_SUB: sc_neg(b, b); sc_add(r, a, b); break;
+    case S2K_OP_NEG: sc_neg(r, a); break;
+    default: sc_inv(r, a); break;
+  }
+  to_be(out32, r);
+  return S2K_OK;
+}
+// Scalar.ConditionalSelect (scalar.go:176): out = a iff ctrl == 0, b otherwise; Scalar.ConditionalNegate (scalar.go:168) is
+// select(a, -a, ctrl) and has its own entry so that a shim does not need two calls
+int s2k_ct_scalar_conditional_select(const uint8_t a32[32], const uint8_t b32[32], uint64_t ctrl, uint8_t out32[32]) {
+  if (!a32 || !b32 || !out32) return S2K_ERR_ARG;
+  sc a, b;
+  if (~(sc_from_be_canonical(a, a32) & sc_from_be_canonical(b, b32))) return S2K_ERR_ARG;
+  cmov256(a, b, ctrl_mask(ctrl));
+  to_be(out32, a);
+  return S2K_OK;
+}
+int s2k_ct_scalar_conditional_negate(const uint8_t a32[32], uint64_t ctrl, uint8_t out32[32]) {
+  if (!a32 || !out32) return S2K_ERR_ARG;
+  sc a, r;
+  if (~sc_from_be_canonical(a, a32)) return S2K_ERR_ARG;
+  sc_cneg(r, a, ctrl_mask(ctrl));
+  to_be(out32, r);
+  return S2K_OK;
+}
+// Scalar.Equal (scalar.go:182), IsZero (:187), IsGreaterThanHalfN (:196): *out = 1 or 0.  what: 0 = IsZero(a),
+// 1 = IsGreaterThanHalfN(a), 2 = Equal(a, b)
+int s2k_ct_scalar_predicate(int what, const uint8_t a32[32], const uint8_t b32[32], uint64_t* out) {
+  if (!a32 || !out || what < 0 || what > 2 || (what == 2 && !b32)) return S2K_ERR_ARG;
+  sc a, b = {{0, 0, 0, 0}};
+  u64 ok = sc_from_be_canonical(a, a32);
+  if (what == 2) ok &= sc_from_be_canonical(b, b32);
+  if (~ok) return S2K_ERR_ARG;
+  u64 m;
+  if (what == 0) m = is_zero256(a);
+  else if (what == 1) m = sc_gt_half_n(a);
+  else {
+    u256 d;
+    sub256(d, a, b);
+    m = is_zero256(d);
+  }
+  *out = m & 1;
+  return S2K_OK;
+}
+// Scalar.SetBytes (scalar.go:123): out = src mod n (one conditional subtraction), *did_reduce = 1 iff src >= n
+int s2k_ct_scalar_set_bytes(const uint8_t src32[32], uint8_t out32[32], uint64_t* did_reduce) {
+  if (!src32 || !out32) return S2K_ERR_ARG;
+  sc a;
+  const u64 ok = sc_from_be_canonical(a, src32);
+  to_be(out32, a);
+  if (did_reduce) *did_reduce = ~ok & 1;
+  return S2K_OK;
+}
+// field.Element: Multiply / Square / Add / Subtract / Negate (internal/field/field.go:61-104), Invert (field_invert.go:11;
+// 0 -> 0), Sqrt (field_sqrt_ratio.go:14; *flag = 1 iff a is a square, out = the root the chain gives, else out = 0).
+// Operands canonical (< p); flag may be NULL except for S2K_OP_SQRT.
+int s2k_ct_fe_op(int op, const uint8_t a32[32], const uint8_t b32[32], uint8_t out32[32], uint64_t* flag) {
+  if (!a32 || !out32) return S2K_ERR_ARG;
+  const bool binary = op == S2K_OP_MUL || op == S2K_OP_ADD || op == S2K_OP_SUB;
+  if (!binary && op != S2K_OP_SQR && op != S2K_OP_NEG && op != S2K_OP_INV && op != S2K_OP_SQRT) return S2K_ERR_ARG;
+  if ((binary && !b32) || (op == S2K_OP_SQRT && !flag)) return S2K_ERR_ARG;
+  fe a, b = FE_ZERO, r;
+  u64 ok = fe_from_be_canonical(a, a32);
+  if (binary) ok &= fe_from_be_canonical(b, b32);
+  if (~ok) return S2K_ERR_ARG;
+  u64 f = ~(u64)0;
+  switch (op) {
+    case S2K_OP_MUL: fe_mul(r, a, b); break;
+    case S2K_OP_SQR: fe_sqr(r, a); break;
+    case S2K_OP_ADD: fe_add(r, a, b); break;
+    case S2K_OP_SUB: fe_sub(r, a, b); break;
+    case S2K_OP_NEG: fe_neg(r, a); break;
+    case S2K_OP_INV: fe_inv(r, a); break;
+    default: {
+      f = fe_sqrt(r, a);
+      fe zero = FE_ZERO;
+      cmov256(r, zero, ~f);
+    }
+  }
+  to_be(out32, r);
+  if (flag) *flag = f & 1;
+  return S2K_OK;
 }
 
 }  // extern "C"

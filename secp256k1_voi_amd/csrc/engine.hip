@@ -74,8 +74,10 @@ __global__ void k_gen_gtable_bases(uint32_t* __restrict__ bases, uint32_t bits, 
   }
 }
 // one lane per entry: m * B_w by a double-and-add of bits + 1 steps (m = digit, or digit + 1 for w >= 1)
-__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, const uint32_t* __restrict__ bases, uint32_t bits, uint32_t windows) {
-  size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+// (block0: the first block of this launch - the background build launches a table window by window)
+__global__ void __launch_bounds__(256) k_gen_gtable(uint32_t* __restrict__ gt, const uint32_t* __restrict__ bases, uint32_t bits, uint32_t windows,
+                                                    uint32_t block0) {
+  size_t id = ((size_t)block0 + blockIdx.x) * 256 + threadIdx.x;
   uint32_t window = (uint32_t)(id >> bits), digit = (uint32_t)id & ((1u << bits) - 1u);
   apt b;
 #pragma unroll
@@ -2085,7 +2087,7 @@ static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const ui
     launch_prep(ctx->s_aux);
     HIP_TRY(ctx, hipGetLastError());
     if (n_first && !gp_in_prep) {
-      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, s2k_internal_gt(ctx), gp, stride);
+      k_generator_part<<<blocks_for(n_first), 256, 0, ctx->s_aux>>>(0u, n_first, prep, ctx->gt_call, gp, stride);
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -2118,7 +2120,7 @@ static int grouped_front_forked(s2k_ctx* ctx, hipStream_t st, size_t n, const ui
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_mid, 0));
   }
   if (n_first < n) {
-    k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, s2k_internal_gt(ctx), gp, stride);
+    k_generator_part<<<blocks_for(n - n_first), 256, 0, ctx->s_aux>>>(n_first, (uint32_t)n, prep, ctx->gt_call, gp, stride);
     HIP_TRY(ctx, hipGetLastError());
   }
   return S2K_OK;
@@ -2165,6 +2167,7 @@ const char* s2k_version(void) { return "secp256k1_voi_amd 0.4 (gfx950)"; }
 const char* s2k_build_config(void) {
   return "GT_BITS=" S2K_STR(S2K_GT_BITS) " GT_BITS_FIRST=" S2K_STR(S2K_GT_BITS_FIRST) " PREP_M=" S2K_STR(S2K_PREP_M)
          " QT_PACK=" S2K_STR(S2K_QT_PACK) " FAST_WAVES=" S2K_STR(S2K_FAST_WAVES) " STRIDE_PAD=" S2K_STR(S2K_STRIDE_PAD)
+         " ROW_MAX=" S2K_STR(S2K_ROW_MAX_DEFAULT) " QUAD_MAX=" S2K_STR(S2K_QUAD_MAX_DEFAULT)
          " flags=[" S2K_BUILD_FLAGS "]";
 }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
@@ -2231,48 +2234,73 @@ __attribute__((visibility("hidden"))) int s2k_internal_ensure_ws(s2k_ctx* ctx, s
 }
 
 // The resident generator tables are shared by the contexts of a device (one context per goroutine / thread is the intended
-// use): per device one registry, reference counted, the last context to go frees it.  Since round 5 a
+// use): per device one registry with its own lock, reference counted, the last context to go frees it.  A
 // registry holds tables of SEVERAL widths:
 //   * the first table (GT_BITS_FIRST = 20 bits, 0.8 GiB) is built inside the first s2k_ctx_create: < 0.1 s to a usable context;
 //   * an automatic context then starts ONE background thread per device that allocates and builds the wide table
 //     (GT_BITS_TARGET = 26 bits / 40 GiB when the device has twice that free and the budget allows, else 24 / 11 GiB, else 22 /
-//     3 GiB, else nothing) on a stream of its own, beside whatever the contexts are doing; when it is done, the next launch of
-//     every automatic context uses it (s2k_internal_gt: one atomic load per launch).  A failed allocation or build leaves the
-//     contexts on the table they have - context creation no longer depends on 43 GB being free;
-//   * s2k_ctx_create_ex with an explicit width builds exactly that table, synchronously, and uses only it (tests, A/B runs).
+//     3 GiB, else nothing) on a stream of its own, beside whatever the contexts are doing; when it is done, the next CALL of
+//     every automatic context uses it (ctx_enter loads the view once; a call never changes tables between its launches).  A
+//     failed allocation or build leaves the contexts on the table they have, and is not tried again while the registry lives;
+//   * s2k_ctx_create_ex with an explicit width uses exactly that table, built synchronously unless it exists or is being built.
+// The builder thread is never detached: the last context to go cancels it (it looks at the flag before it allocates, between
+// the windows of a table and before it publishes) and joins it; a process that exits with contexts alive does the same from an
+// atexit handler, so that no thread of this library is inside the HIP runtime while that is torn down.
 // The reference's analogue is a 510 KiB unpack at package init (point_mul_table.go:75-100).
 namespace {
 struct gtable_dev {
-  std::atomic<uint32_t*> table[GT_BITS_MAX + 1];   // by width; non-null = built and readable
+  std::mutex m;
+  std::condition_variable cv;                     // a build has ended (either kind), the builder has been kicked or cancelled
+  std::atomic<uint32_t*> table[GT_BITS_MAX + 1];  // by width; non-null = built and readable
+  bool being_built[GT_BITS_MAX + 1] = {};         // a thread is building this width outside the lock (others wait for it)
   std::atomic<int> auto_bits{0};                  // width the automatic contexts use now (0: registry empty)
   int refs = 0;
   std::atomic<bool> kicked{false};                // an entry point has enqueued its first call on the device (ctx_leave)
   int target = 0;                                 // width the background build aims for (0: none wanted / none possible)
-  bool building = false, abandoned = false;       // a builder thread is running / was left behind by the last context
+  bool building = false;                          // the builder thread is running
+  bool gave_up = false;                           // a background build failed: not tried again by later contexts of this registry
+  bool closing = false;                           // the last context is waiting for the builder to end: nobody acquires meanwhile
+  std::atomic<bool> cancel{false};                // the builder is to stop at its next look
+  std::atomic<size_t> pending{0};                 // bytes the builder is about to take from the device (s2k_internal_gt_pending_bytes)
   std::thread builder;
-  char note[200] = {0};                           // why the target is what it is (s2k_ctx_gt_info)
+  char note[200] = {0};                           // why the target is what it is (s2k_ctx_gt_note; read and written under m)
   gtable_dev() {
     for (auto& t : table) t.store(nullptr);
   }
 };
-std::mutex g_gtable_mutex;
-std::condition_variable g_gtable_cv;              // a builder has finished
 gtable_dev g_gtable[64];
 std::atomic<size_t> g_gt_budget{0};               // s2k_set_generator_table_budget: bytes per device the tables may take (0: by free memory)
 std::atomic<size_t> g_keyset_budget{0};           // s2k_set_table_memory_budgets: what counts as free for a key set's joint tables (0: what is free)
 
-// allocate and build the table of `bits` on `stream` (null: the default stream); synchronises that stream
-hipError_t gtable_build(int bits, hipStream_t stream, uint32_t** out) {
+// allocate and build the table of `bits` on `stream` (null: the default stream); synchronises that stream.  With `cancel` the
+// table is built window by window and the flag is looked at in between (hipErrorNotReady: cancelled, nothing is left allocated).
+hipError_t gtable_build(int bits, hipStream_t stream, uint32_t** out, const std::atomic<bool>* cancel = nullptr,
+                        std::atomic<size_t>* pending = nullptr) {
   const uint32_t windows = gt_windows_of(bits);
   uint32_t *table = nullptr, *bases = nullptr;
   hipError_t e = hipMalloc((void**)&table, gt_bytes_of(bits));
+  if (pending) pending->store(0);                 // (taken, or not to be had)
   if (e == hipSuccess) e = hipMalloc((void**)&bases, (windows + 1) * 64);
   if (e == hipSuccess) {
     k_gen_gtable_bases<<<1, 1, 0, stream>>>(bases, (uint32_t)bits, windows);
-    k_gen_gtable<<<(unsigned)(gt_entries_of(bits) / 256), 256, 0, stream>>>(table, bases, (uint32_t)bits, windows);
-    e = hipGetLastError();
+    const unsigned per_window = (unsigned)(((size_t)1 << bits) / 256);
+    if (!cancel) {
+      k_gen_gtable<<<per_window * windows, 256, 0, stream>>>(table, bases, (uint32_t)bits, windows, 0u);
+      e = hipGetLastError();
+    } else {
+      for (uint32_t w = 0; w < windows && e == hipSuccess; ++w) {
+        if (cancel->load()) {
+          e = hipErrorNotReady;
+          break;
+        }
+        k_gen_gtable<<<per_window, 256, 0, stream>>>(table, bases, (uint32_t)bits, windows, w * per_window);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      }
+    }
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  else (void)hipStreamSynchronize(stream);
   if (bases) (void)hipFree(bases);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -2283,22 +2311,28 @@ hipError_t gtable_build(int bits, hipStream_t stream, uint32_t** out) {
   return hipSuccess;
 }
 
-// the widest of 26 / 24 / 22 (not above GT_BITS_TARGET, above the first table) that fits: twice its size free on the device, so
-// that the tables never take more than half of what is left for key sets, workspaces and other processes; and inside the budget
-int gtable_pick_target(gtable_dev& g) {
+// does a wide table of `bits` fit NOW: twice its size free on the device, so that the tables never take more than half of
+// what is left for key sets, workspaces and other processes; and inside the budget.  Asked when the target is chosen and again
+// by the builder right before each allocation (half a second or more later).
+bool gtable_fits(int bits, size_t* free_out) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
     (void)hipGetLastError();
-    snprintf(g.note, sizeof g.note, "hipMemGetInfo failed: staying on %d bits", GT_BITS_FIRST);
-    return 0;
+    return false;
   }
+  if (free_out) *free_out = free_b;
+  const size_t need = gt_bytes_of(bits), budget = g_gt_budget.load();
+  if (budget && need + gt_bytes_of(GT_BITS_FIRST) > budget) return false;
+  return free_b >= 2 * need;
+}
+// the widest of 26 / 24 / 22 (not above `from`, above the first table) that fits; 0: none.  Caller holds g.m (the note).
+int gtable_pick_target(gtable_dev& g, int from) {
+  size_t free_b = 0;
   const size_t budget = g_gt_budget.load();
   for (int bits : {26, 24, 22}) {
-    if (bits > GT_BITS_TARGET || bits <= GT_BITS_FIRST) continue;
-    const size_t need = gt_bytes_of(bits);
-    if (budget && need + gt_bytes_of(GT_BITS_FIRST) > budget) continue;
-    if (free_b < 2 * need) continue;
-    snprintf(g.note, sizeof g.note, "%d-bit windows: %.1f GiB of %.1f GiB free%s", bits, need / 1073741824.0, free_b / 1073741824.0,
+    if (bits > from || bits > GT_BITS_TARGET || bits <= GT_BITS_FIRST) continue;
+    if (!gtable_fits(bits, &free_b)) continue;
+    snprintf(g.note, sizeof g.note, "%d-bit windows: %.1f GiB of %.1f GiB free%s", bits, gt_bytes_of(bits) / 1073741824.0, free_b / 1073741824.0,
              budget ? " (inside the budget)" : "");
     return bits;
   }
@@ -2309,73 +2343,128 @@ int gtable_pick_target(gtable_dev& g) {
 
 void gtable_builder_main(int device, int bits) {
   gtable_dev& g = g_gtable[device];
-  uint32_t* table = nullptr;
   // The allocation of tens of gigabytes holds the runtime's allocator for a second or two, and whatever another thread asks of
   // the runtime meanwhile (its first call's workspace ...) waits behind it: 0.1-0.3 s from s2k_ctx_create to the first verdict
   // became 2.3 s whenever the two collided.  So the build starts when the context's first call has been enqueued (ctx_leave),
   // or after half a second without one.
   {
-    std::unique_lock<std::mutex> lock(g_gtable_mutex);
-    g_gtable_cv.wait_for(lock, std::chrono::milliseconds(500), [&] { return g.kicked.load() || g.abandoned; });
-    if (g.abandoned) bits = GT_BITS_FIRST;         // the contexts are gone already: nothing to build
+    std::unique_lock<std::mutex> lock(g.m);
+    g.cv.wait_for(lock, std::chrono::milliseconds(500), [&] { return g.kicked.load() || g.cancel.load(); });
   }
-  hipError_t e = hipSetDevice(device);
+  hipError_t e = g.cancel.load() ? hipErrorNotReady : hipSetDevice(device);
   hipStream_t st = nullptr;
   if (e == hipSuccess) {
     int lo = 0, hi = 0;                            // lowest priority: the build yields to verification kernels
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
     e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);
   }
+  const int wanted = bits;
   int built = 0;
-  while (e == hipSuccess && bits > GT_BITS_FIRST) {   // a failed allocation: the next width down
-    if (gtable_build(bits, st, &table) == hipSuccess) {
+  uint32_t* table = nullptr;                       // ours to free unless it is published
+  std::unique_lock<std::mutex> lock(g.m);
+  while (e == hipSuccess && bits > GT_BITS_FIRST && !g.cancel.load()) {
+    if (g.table[bits].load()) {                    // a context with that explicit width built it meanwhile: use that one
       built = bits;
       break;
     }
-    bits -= 2;
+    if (g.being_built[bits]) {                     // ... or is building it right now: wait for that to end, look again
+      g.cv.wait(lock, [&] { return !g.being_built[bits] || g.cancel.load(); });
+      continue;
+    }
+    bits = gtable_pick_target(g, bits);            // (the memory may have gone since the target was chosen)
+    if (!bits) break;
+    if (g.table[bits].load() || g.being_built[bits]) continue;
+    g.being_built[bits] = true;
+    g.pending.store(gt_bytes_of(bits));
+    lock.unlock();
+    const hipError_t be = gtable_build(bits, st, &table, &g.cancel, &g.pending);
+    lock.lock();
+    g.pending.store(0);
+    g.being_built[bits] = false;
+    g.cv.notify_all();
+    if (be == hipSuccess) {
+      built = bits;
+      break;
+    }
+    table = nullptr;
+    if (be == hipErrorNotReady) break;             // cancelled
+    bits -= 2;                                     // a failed allocation or build: the next width down that fits
   }
-  if (st) (void)hipStreamDestroy(st);
-  std::lock_guard<std::mutex> lock(g_gtable_mutex);
-  if (g.abandoned) {                                // every context went away meanwhile: nobody wants the table
+  if (g.cancel.load()) {                           // every context went away meanwhile: nobody wants the table
     if (table) (void)hipFree(table);
-    g.abandoned = false;
   } else if (built) {
-    g.table[built].store(table, std::memory_order_release);
+    if (table && g.table[built].load()) {          // (never two tables of one width: the one that is there stays)
+      (void)hipFree(table);
+    } else if (table) {
+      g.table[built].store(table, std::memory_order_release);
+    }
     g.auto_bits.store(built, std::memory_order_release);
-    if (built != g.target) snprintf(g.note, sizeof g.note, "%d-bit windows (the allocation for %d bits failed)", built, g.target);
+    if (built != wanted) snprintf(g.note, sizeof g.note, "%d-bit windows (the table of %d bits could not be had)", built, wanted);
     g.target = built;
   } else {
-    snprintf(g.note, sizeof g.note, "the wide table could not be built: staying on %d bits", GT_BITS_FIRST);
+    if (e != hipSuccess || bits) snprintf(g.note, sizeof g.note, "the wide table could not be built: staying on %d bits", GT_BITS_FIRST);
     g.target = 0;
+    g.gave_up = true;
   }
   g.building = false;
-  g_gtable_cv.notify_all();
+  g.cv.notify_all();
+  lock.unlock();
+  if (st) (void)hipStreamDestroy(st);
+}
+
+// a process that exits with contexts alive: the builders are stopped and joined before static destruction and before the HIP
+// runtime's own exit handlers (registered earlier than this one, so run later)
+void gtable_at_exit() {
+  for (gtable_dev& g : g_gtable) {
+    std::thread t;
+    {
+      std::lock_guard<std::mutex> lock(g.m);
+      if (!g.builder.joinable()) continue;
+      g.cancel.store(true);
+      g.cv.notify_all();
+      t = std::move(g.builder);
+    }
+    t.join();
+  }
 }
 }  // namespace
 
 // fixed_bits == 0: the shared automatic tables (first table now, wide table in the background); else exactly that width
 static hipError_t gtable_acquire(int device, int fixed_bits) {
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-  std::unique_lock<std::mutex> lock(g_gtable_mutex);
+  static std::once_flag at_exit_once;
+  std::call_once(at_exit_once, [] { (void)atexit(gtable_at_exit); });
   gtable_dev& g = g_gtable[device];
-  g_gtable_cv.wait(lock, [&] { return !g.abandoned; });   // a builder left behind by an earlier generation of contexts finishes first
+  std::unique_lock<std::mutex> lock(g.m);
+  g.cv.wait(lock, [&] { return !g.closing; });    // (the last context of an earlier generation is still joining its builder)
   const int bits = fixed_bits ? fixed_bits : GT_BITS_FIRST;
-  if (!g.table[bits].load()) {
+  while (!g.table[bits].load()) {
+    if (g.being_built[bits]) {                     // by the builder or by another context's creation: wait, do not build a second one
+      g.cv.wait(lock, [&] { return !g.being_built[bits]; });
+      continue;
+    }
+    g.being_built[bits] = true;
+    lock.unlock();                                 // (seconds for a wide table: the contexts of this device keep working)
     uint32_t* t = nullptr;
     const hipError_t e = gtable_build(bits, nullptr, &t);
+    lock.lock();
+    g.being_built[bits] = false;
+    g.cv.notify_all();
     if (e != hipSuccess) return e;
     g.table[bits].store(t, std::memory_order_release);
   }
   if (!fixed_bits) {
     if (g.auto_bits.load() == 0) g.auto_bits.store(GT_BITS_FIRST, std::memory_order_release);
-    if (!g.building && g.target == 0 && g.auto_bits.load() == GT_BITS_FIRST && GT_BITS_TARGET > GT_BITS_FIRST) {
-      g.target = gtable_pick_target(g);
+    if (!g.building && !g.gave_up && g.target == 0 && g.auto_bits.load() == GT_BITS_FIRST && GT_BITS_TARGET > GT_BITS_FIRST) {
+      g.target = gtable_pick_target(g, GT_BITS_TARGET);
       if (g.target) {
         if (g.table[g.target].load()) {             // (built earlier for a context with that explicit width)
           g.auto_bits.store(g.target, std::memory_order_release);
         } else {
-          if (g.builder.joinable()) g.builder.join();
+          if (g.builder.joinable()) g.builder.join();   // (an earlier builder that has ended: building is false)
           g.building = true;
+          g.cancel.store(false);
+          g.pending.store(gt_bytes_of(g.target));
           g.builder = std::thread(gtable_builder_main, device, g.target);
         }
       }
@@ -2385,33 +2474,41 @@ static hipError_t gtable_acquire(int device, int fixed_bits) {
   return hipSuccess;
 }
 static void gtable_release(int device) {
-  std::unique_lock<std::mutex> lock(g_gtable_mutex);
   gtable_dev& g = g_gtable[device];
-  if (g.refs > 0 && --g.refs == 0) {
-    (void)hipSetDevice(device);
-    for (auto& t : g.table) {
-      uint32_t* p = t.exchange(nullptr);
-      if (p) (void)hipFree(p);
-    }
-    g.auto_bits.store(0);
-    g.target = 0;
-    g.kicked.store(false);
-    if (g.building) {
-      g.abandoned = true;                           // its table is freed by the builder itself when it is done
-      g_gtable_cv.notify_all();                     // (a builder still waiting for its start signal)
-    }
-    if (g.builder.joinable()) g.builder.detach();
+  std::unique_lock<std::mutex> lock(g.m);
+  if (g.refs <= 0 || --g.refs > 0) return;
+  // the last context: stop the builder (it frees what it has not published), wait for it, then free the tables
+  g.closing = true;
+  g.cancel.store(true);
+  g.cv.notify_all();
+  std::thread t = std::move(g.builder);
+  lock.unlock();
+  if (t.joinable()) t.join();
+  lock.lock();
+  (void)hipSetDevice(device);
+  for (auto& tb : g.table) {
+    uint32_t* p = tb.exchange(nullptr);
+    if (p) (void)hipFree(p);
   }
+  g.auto_bits.store(0);
+  g.target = 0;
+  g.gave_up = false;
+  g.building = false;
+  g.pending.store(0);
+  g.kicked.store(false);
+  g.cancel.store(false);
+  g.closing = false;
+  g.cv.notify_all();
 }
-// the table a launch of this moment uses
 extern "C++" __attribute__((visibility("hidden"))) void s2k_internal_gt_kick(int device) {
   gtable_dev& g = g_gtable[device];
   if (g.kicked.load(std::memory_order_relaxed)) return;         // (every call after the first: one relaxed load)
   g.kicked.store(true);
-  std::lock_guard<std::mutex> lock(g_gtable_mutex);             // (so that the notification cannot fall between the builder's test and its wait)
-  g_gtable_cv.notify_all();
+  std::lock_guard<std::mutex> lock(g.m);                        // (so that the notification cannot fall between the builder's test and its wait)
+  g.cv.notify_all();
 }
-extern "C++" __attribute__((visibility("hidden"))) gt_view s2k_internal_gt(const s2k_ctx* ctx) {
+// the table a call that starts now uses (ctx_enter: once per call)
+extern "C++" __attribute__((visibility("hidden"))) gt_view s2k_internal_gt_load(const s2k_ctx* ctx) {
   const gtable_dev& g = g_gtable[ctx->device];
   const int bits = ctx->gt_fixed ? ctx->gt_fixed : g.auto_bits.load(std::memory_order_acquire);
   gt_view v;
@@ -2419,6 +2516,37 @@ extern "C++" __attribute__((visibility("hidden"))) gt_view s2k_internal_gt(const
   v.bits = (uint32_t)bits;
   v.windows = gt_windows_of(bits);
   return v;
+}
+// bytes of device memory the background build of this device is about to allocate: whoever sizes something by what is free
+// (key-set layouts, the per-key table buffer) takes them off first
+extern "C++" __attribute__((visibility("hidden"))) size_t s2k_internal_gt_pending_bytes(int device) {
+  return device >= 0 && device < 64 ? g_gtable[device].pending.load() : 0;
+}
+// Test hook behind s2k_debug_gt_swap_in_call: make `bits` the width of the device's automatic contexts NOW (building the table
+// if the registry does not hold it) - what the background builder does at a moment nobody chooses.
+static hipError_t gtable_debug_publish(int device, int bits) {
+  gtable_dev& g = g_gtable[device];
+  std::unique_lock<std::mutex> lock(g.m);
+  while (!g.table[bits].load()) {
+    if (g.being_built[bits]) {
+      g.cv.wait(lock, [&] { return !g.being_built[bits]; });
+      continue;
+    }
+    g.being_built[bits] = true;
+    lock.unlock();
+    uint32_t* t = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = gtable_build(bits, st, &t);
+    if (st) (void)hipStreamDestroy(st);
+    lock.lock();
+    g.being_built[bits] = false;
+    g.cv.notify_all();
+    if (e != hipSuccess) return e;
+    g.table[bits].store(t, std::memory_order_release);
+  }
+  g.auto_bits.store(bits, std::memory_order_release);
+  return hipSuccess;
 }
 
 extern "C" {
@@ -2433,12 +2561,12 @@ void s2k_set_table_memory_budgets(size_t keyset_free_bytes, size_t key_table_byt
   g_keyset_budget.store(keyset_free_bytes);
   s2k_internal_key_table_limit().store(key_table_bytes);
 }
-// info[0] = window bits the context's launches use now, [1] = bits the background build aims for (0: none), [2] = 1 while it
+// info[0] = window bits the context's next call uses, [1] = bits the background build aims for (0: none), [2] = 1 while it
 // is running, [3] = bytes of generator tables the device holds for this process
 int s2k_ctx_gt_info(s2k_ctx* ctx, uint64_t info[4]) {
   if (!ctx || !info) return fail(ctx, S2K_ERR_ARG, "null argument");
-  std::lock_guard<std::mutex> lock(g_gtable_mutex);
-  const gtable_dev& g = g_gtable[ctx->device];
+  gtable_dev& g = g_gtable[ctx->device];
+  std::lock_guard<std::mutex> lock(g.m);
   info[0] = (uint64_t)(ctx->gt_fixed ? ctx->gt_fixed : g.auto_bits.load());
   info[1] = (uint64_t)(ctx->gt_fixed ? 0 : g.target);
   info[2] = g.building && !ctx->gt_fixed ? 1 : 0;
@@ -2448,14 +2576,31 @@ int s2k_ctx_gt_info(s2k_ctx* ctx, uint64_t info[4]) {
   info[3] = bytes;
   return S2K_OK;
 }
-const char* s2k_ctx_gt_note(s2k_ctx* ctx) { return ctx ? g_gtable[ctx->device].note : ""; }
+// (a copy taken under the lock, owned by the context: the builder thread rewrites the registry's note)
+const char* s2k_ctx_gt_note(s2k_ctx* ctx) {
+  if (!ctx) return "";
+  gtable_dev& g = g_gtable[ctx->device];
+  std::lock_guard<std::mutex> lock(g.m);
+  snprintf(ctx->gt_note, sizeof ctx->gt_note, "%s", g.note);
+  return ctx->gt_note;
+}
 // blocks until the background build of the context's device has ended (either way); returns the window bits in use then
 int s2k_ctx_gt_wait(s2k_ctx* ctx) {
   if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
-  std::unique_lock<std::mutex> lock(g_gtable_mutex);
   gtable_dev& g = g_gtable[ctx->device];
-  g_gtable_cv.wait(lock, [&] { return !g.building; });
+  std::unique_lock<std::mutex> lock(g.m);
+  g.cv.wait(lock, [&] { return !g.building; });
   return ctx->gt_fixed ? ctx->gt_fixed : g.auto_bits.load();
+}
+// Test hook (tests/test_gpu_round6.py): the next s2k_ecdsa_verify_batch_device call of this (automatic) context publishes the
+// table of `bits` for the device's automatic contexts BETWEEN its ladder launch and its worklist launch - the moment the
+// background build must not be visible inside a call.  One shot; 0 disarms.
+int s2k_debug_gt_swap_in_call(s2k_ctx* ctx, int bits) {
+  if (!ctx) return fail(nullptr, S2K_ERR_ARG, "ctx is NULL");
+  if (bits != 0 && (bits < 16 || bits > GT_BITS_MAX)) return fail(ctx, S2K_ERR_ARG, "generator window width %d: 0 or 16 .. %d", bits, GT_BITS_MAX);
+  if (ctx->gt_fixed && bits) return fail(ctx, S2K_ERR_ARG, "a context with an explicit table width never changes tables");
+  ctx->dbg_gt_swap = bits;
+  return S2K_OK;
 }
 }  // extern "C"
 
@@ -2680,7 +2825,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     wait_all(st);
     k_ecdsa_verify<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                                   (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
-                                                  s2k_internal_gt(ctx), qt, stride);
+                                                  ctx->gt_call, qt, stride);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
@@ -2734,27 +2879,27 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
                            k_scalar_prep<<<(Tc + 63) / 64, 64, 0, aux>>>((uint32_t)cnt, Tc, (const uint8_t*)d_dig + lo * 32,
                                                                          (const uint8_t*)d_r + lo * 32, (const uint8_t*)d_s + lo * 32,
                                                                          nullptr, flags, prep + lo, pref + lo, smont + lo, stride);
-                           k_generator_part<<<blocks_for(cnt), 256, 0, aux>>>((uint32_t)lo, (uint32_t)(lo + cnt), prep, s2k_internal_gt(ctx), gp, stride);
+                           k_generator_part<<<blocks_for(cnt), 256, 0, aux>>>((uint32_t)lo, (uint32_t)(lo + cnt), prep, ctx->gt_call, gp, stride);
                          }
                        },
                        &kg, /*gp_in_prep=*/arrivals != nullptr);
     if (rc) return rc;
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                                   qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl,
+                                                                   qt, fin, ctx->gt_call, (uint8_t*)d_valid, wl_count, wl,
                                                                    stride, nullptr, clk, kg);
     HIP_TRY(ctx, hipGetLastError());
     if (kg.nparts > 1) {   // the other side of the split, once its tables (third stream) are there
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_part1, 0));
       kg.part = 1;
       k_verify_fast<MODE_ECDSA_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                                     qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl,
+                                                                     qt, fin, ctx->gt_call, (uint8_t*)d_valid, wl_count, wl,
                                                                      stride, nullptr, nullptr, kg);
       HIP_TRY(ctx, hipGetLastError());
     }
     prof_mark(ctx, st, 3);
     k_verify_fast<MODE_ECDSA_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                                  qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl,
+                                                                  qt, fin, ctx->gt_call, (uint8_t*)d_valid, wl_count, wl,
                                                                   stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 4);
@@ -2767,7 +2912,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
     k_verify_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep,
-                                                             s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+                                                             ctx->gt_call, (uint8_t*)d_valid, stride);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
@@ -2779,7 +2924,7 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
     k_verify_row<<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, (const uint8_t*)d_pub, (const uint8_t*)d_dig, (const uint8_t*)d_r,
-                                                          (const uint8_t*)d_s, flags, s2k_internal_gt(ctx), (uint8_t*)d_valid);
+                                                          (const uint8_t*)d_s, flags, ctx->gt_call, (uint8_t*)d_valid);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
@@ -2793,15 +2938,23 @@ static int verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pub, const 
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
     k_verify_fast<MODE_ECDSA><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, (const uint8_t*)d_pub, (const uint8_t*)d_r, prep, qt, fin,
-                                                             s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk,
+                                                             ctx->gt_call, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk,
                                                              key_groups{});
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
   }
+  if (ctx->dbg_gt_swap) {   // test hook: the wide table appears HERE, between the ladder and the kernel that finishes its tagged lanes
+    const int bits = ctx->dbg_gt_swap;
+    ctx->dbg_gt_swap = 0;
+    HIP_TRY(ctx, gtable_debug_publish(ctx->device, bits));
+#ifdef S2K_DEBUG_GT_PER_LAUNCH   // (variant build that restores the fault of round 5 - a view per launch - to show the test sees it)
+    ctx->gt_call = s2k_internal_gt_load(ctx);
+#endif
+  }
   k_verify_fallback<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (const uint8_t*)d_pub, (const uint8_t*)d_dig,
                                         (const uint8_t*)d_r, (const uint8_t*)d_s, flags, (uint8_t*)d_valid,
-                                        s2k_internal_gt(ctx), qt, stride);
+                                        ctx->gt_call, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
@@ -2872,6 +3025,8 @@ int s2k_keyset_create_ex(s2k_ctx* ctx, size_t n_keys, const uint8_t* pub_xy, int
     if (w == 0) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t promised = s2k_internal_gt_pending_bytes(ctx->device);   // what the background table build is about to take
+        free_b -= promised < free_b ? promised : free_b;
         if (free_b > pretend_free) free_b = pretend_free;
         if (s2k_internal_keyset_joint_bytes(n_keys, 5) + s2k_internal_keyset_joint_scratch_bytes(n_keys, 5) <= free_b / 2) w = 5;
         else if (s2k_internal_keyset_joint_bytes(n_keys, 4) <= free_b / 2) w = 4;
@@ -2977,7 +3132,7 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
   k_scalar_prep<<<(T + 63) / 64, 64, 0, ctx->s_aux>>>((uint32_t)n, T, (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s,
                                                       nullptr, flags, prep, pref, smont, stride);
-  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, s2k_internal_gt(ctx), gp, stride);
+  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, ctx->gt_call, gp, stride);
   rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "launch failed");
   key_groups kg{};
   if (rc == S2K_OK) rc = s2k_internal_keyset_sort(ctx, ks->base, ks->n, n, (const uint32_t*)d_key_index, st, &kg);
@@ -2992,21 +3147,21 @@ int s2k_ecdsa_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, siz
   prof_mark(ctx, st, 2);
   if (ks->joint && ks->jw == 6)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT6><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
-                                                                           s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+                                                                           ctx->gt_call, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else if (ks->joint && ks->jw == 5)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT5><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
-                                                                           s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+                                                                           ctx->gt_call, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else if (ks->joint)
     k_verify_fast<MODE_ECDSA_KEYSET_JOINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin,
-                                                                          s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
+                                                                          ctx->gt_call, (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   else
-    k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, s2k_internal_gt(ctx),
+    k_verify_fast<MODE_ECDSA_KEYSET><<<blocks_for(n), 256, 0, st>>>((uint32_t)n | kvf, nullptr, (const uint8_t*)d_r, prep, qt, fin, ctx->gt_call,
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, clk, kg);
   prof_mark(ctx, st, 3);
   HIP_TRY(ctx, hipGetLastError());
   k_verify_fallback_keyset<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, ks->base + off[0], (const uint32_t*)d_key_index,
                                                                     (const uint8_t*)d_dig, (const uint8_t*)d_r, (const uint8_t*)d_s, flags,
-                                                                    (uint8_t*)d_valid, s2k_internal_gt(ctx), qt, stride);
+                                                                    (uint8_t*)d_valid, ctx->gt_call, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 4);
   prof_mark(ctx, st, 5);
@@ -3131,7 +3286,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
                 *rid = (const uint8_t*)d_recid;
   if (flags & S2K_ECDSA_FORCE_COMPLETE) {
     k_recover_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, dig, r, s, rid, (uint8_t*)d_ok,
-                                                      (uint8_t*)d_pub65, s2k_internal_gt(ctx), qt, stride);
+                                                      (uint8_t*)d_pub65, ctx->gt_call, qt, stride);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
@@ -3142,7 +3297,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
     // small batches: a wave per item, one launch (k_recover_row: preparation, ladder, inversion and record)
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_recover_row<<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, dig, r, s, rid, s2k_internal_gt(ctx), (uint8_t*)d_ok, (uint8_t*)d_pub65);
+    k_recover_row<<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, dig, r, s, rid, ctx->gt_call, (uint8_t*)d_ok, (uint8_t*)d_pub65);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
@@ -3156,7 +3311,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
     HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));      // items without a key keep the zero record
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_recover_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, r, prep, s2k_internal_gt(ctx), fin, (uint8_t*)d_ok, stride);
+    k_recover_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, r, prep, ctx->gt_call, fin, (uint8_t*)d_ok, stride);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     k_affine_finish<MODE_RECOVER><<<(unsigned)((n + 63) / 64), 64, 0, st>>>((uint32_t)n, (uint32_t)n, nullptr, fin, (uint8_t*)d_ok, stride,
@@ -3173,7 +3328,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   HIP_TRY(ctx, hipMemsetAsync(d_pub65, 0, n * 65, st));      // items without a key keep the zero record
   prof_mark(ctx, st, 1);
   prof_mark(ctx, st, 2);
-  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, s2k_internal_gt(ctx),
+  k_verify_fast<MODE_RECOVER><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, nullptr, r, prep, qt, fin, ctx->gt_call,
                                                              (uint8_t*)d_ok, wl_count, wl, stride, (uint8_t*)d_pub65, ctx->prof_on ? ctx->clk : nullptr,
                                                              key_groups{});
   HIP_TRY(ctx, hipGetLastError());
@@ -3186,7 +3341,7 @@ int s2k_ecdsa_recover_batch_device(s2k_ctx* ctx, size_t n, const void* d_dig, co
   }
   prof_mark(ctx, st, 4);
   k_recover_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, dig, r, s, rid, (uint8_t*)d_ok, (uint8_t*)d_pub65,
-                                                              s2k_internal_gt(ctx), qt, stride);
+                                                              ctx->gt_call, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
@@ -3308,7 +3463,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   const uint64_t* offs = (const uint64_t*)d_msg_offsets;
   if (flags & S2K_ECDSA_FORCE_COMPLETE) {
     k_schnorr_fallback<<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len,
-                                                      (uint8_t*)d_valid, s2k_internal_gt(ctx), qt, stride);
+                                                      (uint8_t*)d_valid, ctx->gt_call, qt, stride);
     HIP_TRY(ctx, hipGetLastError());
     return ctx_leave(ctx, st);
   }
@@ -3340,18 +3495,18 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     if (rc) return rc;
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
+    k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gt_call,
                                                                      (uint8_t*)d_valid, wl_count, wl, stride, nullptr, ctx->prof_on ? ctx->clk : nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     if (kg.nparts > 1) {
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_part1, 0));
       kg.part = 1;
-      k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
+      k_verify_fast<MODE_SCHNORR_KEYED><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gt_call,
                                                                        (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
       HIP_TRY(ctx, hipGetLastError());
     }
-    k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
+    k_verify_fast<MODE_SCHNORR_LEFT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gt_call,
                                                                     (uint8_t*)d_valid, wl_count, wl, stride, nullptr, nullptr, kg);
     HIP_TRY(ctx, hipGetLastError());
   } else if (quad) {
@@ -3360,7 +3515,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_schnorr_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, pk, sig, prep, s2k_internal_gt(ctx), (uint8_t*)d_valid, stride);
+    k_schnorr_quad<<<(unsigned)((n + 63) / 64), 256, 0, st>>>((uint32_t)n, pk, sig, prep, ctx->gt_call, (uint8_t*)d_valid, stride);
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
     prof_mark(ctx, st, 4);
@@ -3373,14 +3528,14 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
       prof_mark(ctx, st, 1);
       prof_mark(ctx, st, 2);
       k_schnorr_row<true><<<(unsigned)((n + 3) / 4), 320, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, nullptr, 0,
-                                                                   s2k_internal_gt(ctx), (uint8_t*)d_valid);
+                                                                   ctx->gt_call, (uint8_t*)d_valid);
     } else {
       k_schnorr_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
       HIP_TRY(ctx, hipGetLastError());
       prof_mark(ctx, st, 1);
       prof_mark(ctx, st, 2);
       k_schnorr_row<false><<<(unsigned)((n + 3) / 4), 256, 0, st>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride,
-                                                                    s2k_internal_gt(ctx), (uint8_t*)d_valid);
+                                                                    ctx->gt_call, (uint8_t*)d_valid);
     }
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 3);
@@ -3392,7 +3547,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
     HIP_TRY(ctx, hipGetLastError());
     prof_mark(ctx, st, 1);
     prof_mark(ctx, st, 2);
-    k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, s2k_internal_gt(ctx),
+    k_verify_fast<MODE_SCHNORR><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, pk, sig, prep, qt, fin, ctx->gt_call,
                                                                (uint8_t*)d_valid, wl_count, wl, stride, nullptr, ctx->prof_on ? ctx->clk : nullptr,
                                                                key_groups{});
     HIP_TRY(ctx, hipGetLastError());
@@ -3405,7 +3560,7 @@ int s2k_schnorr_verify_batch_device(s2k_ctx* ctx, size_t n, const void* d_pk, co
   }
   prof_mark(ctx, st, 4);
   k_schnorr_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, pk, sig, msgs, offs, (uint32_t)msg_len,
-                                                              (uint8_t*)d_valid, s2k_internal_gt(ctx), qt, stride);
+                                                              (uint8_t*)d_valid, ctx->gt_call, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   prof_mark(ctx, st, 5);
   return ctx_leave(ctx, st);
@@ -3483,7 +3638,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
   k_schnorr_prep<<<blocks_for(n), 256, 0, ctx->s_aux>>>((uint32_t)n, pk, sig, msgs, offs, (uint32_t)msg_len, prep, stride);
-  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, s2k_internal_gt(ctx), gp, stride);
+  k_generator_part<<<blocks_for(n), 256, 0, ctx->s_aux>>>(0u, (uint32_t)n, prep, ctx->gt_call, gp, stride);
   rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "launch failed");
   key_groups kg{};
   if (rc == S2K_OK) rc = s2k_internal_keyset_sort(ctx, ks->base, ks->n, n, (const uint32_t*)d_key_index, st, &kg);
@@ -3495,7 +3650,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
   kg.gp = gp;
   kg.jtab = ks->joint;
 #define S2K_SKS_LAUNCH(M) \
-  k_verify_fast<M><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, set_keys, sig, prep, qt, fin, s2k_internal_gt(ctx), (uint8_t*)d_valid, wl_count, wl, stride, \
+  k_verify_fast<M><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, set_keys, sig, prep, qt, fin, ctx->gt_call, (uint8_t*)d_valid, wl_count, wl, stride, \
                                                   nullptr, nullptr, kg)
   if (ks->joint && ks->jw == 6) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT6);
   else if (ks->joint && ks->jw == 5) S2K_SKS_LAUNCH(MODE_SCHNORR_KEYSET_JOINT5);
@@ -3510,7 +3665,7 @@ int s2k_schnorr_verify_batch_keyset_device(s2k_ctx* ctx, const s2k_keyset* ks, s
   }
   // (the worklist kernel re-does its lanes from the x-only key: lift_x gives the even-y point whatever the set's Y says)
   k_schnorr_worklist<<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, pk, sig, msgs, offs, (uint32_t)msg_len, (uint8_t*)d_valid,
-                                                              s2k_internal_gt(ctx), qt, stride);
+                                                              ctx->gt_call, qt, stride);
   HIP_TRY(ctx, hipGetLastError());
   return ctx_leave(ctx, st);
 }
@@ -3826,7 +3981,7 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
       ctx->lane1_aux = b;
     }
     s2k_ctx* child = nullptr;
-    rc = s2k_ctx_create(ctx->device, &child);
+    rc = s2k_ctx_create_ex(ctx->device, ctx->gt_fixed, 0, &child);   // the parent's table width, explicit or automatic
     if (rc) return fail(ctx, rc, "submit: child context: %s", s2k_last_error(nullptr));
     child->s_copy = ctx->s_copy;
     child->s_comp = (odd_lane && !one_lane) ? ctx->lane1_comp : ctx->s_comp;
@@ -3885,7 +4040,14 @@ __attribute__((visibility("hidden"))) int s2k_internal_pipe_slot(s2k_ctx* ctx, s
   return S2K_OK;
 }
 __attribute__((visibility("hidden"))) void s2k_internal_pipe_issue(s2k_ctx* ctx, s2k_ctx::pipe_slot* sl, s2k_ticket* ticket) {
-  if (sl->timed) sl->timed = hipEventRecord(sl->t_copied, ctx->s_copy) == hipSuccess && hipEventRecord(sl->t_end, sl->ctx->s_comp) == hipSuccess;
+  // s2k_ctx_ticket_timing: t_begin (s2k_internal_pipe_slot) and t_copied bracket the ticket's transfers on the copy stream; the
+  // compute stream WAITS for t_copied before t_end is recorded behind the verdicts, so that first copy start <= last copy end
+  // <= verdicts holds on the device's clock however the runtime multiplexes the streams onto hardware queues (eight members on
+  // one device: a marker could be processed after another stream's later one).  Costs the ticket nothing
+  // while the timing is off.
+  if (sl->timed)
+    sl->timed = hipEventRecord(sl->t_copied, ctx->s_copy) == hipSuccess && hipStreamWaitEvent(sl->ctx->s_comp, sl->t_copied, 0) == hipSuccess &&
+                hipEventRecord(sl->t_end, sl->ctx->s_comp) == hipSuccess;
   if (hipEventRecord(sl->done, sl->ctx->s_comp) != hipSuccess) {    // behind the ticket's last operation (on its lane's stream)
     // no event to wait on: the ticket is made to finish here, so that s2k_wait finds it done (or reports this failure)
     const hipError_t e = hipGetLastError();
@@ -4165,7 +4327,7 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
   uint32_t* status = (uint32_t*)(io + o_status);
   if (impl == S2K_IMPL_COMPLETE) {
     k_point_fallback<true><<<blocks_for(n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_out,
-                                                          s2k_internal_gt(ctx), qt, stride, status);
+                                                          ctx->gt_call, qt, stride, status);
     HIP_TRY(ctx, hipGetLastError());
   } else {
     HIP_TRY(ctx, hipMemsetAsync(wl_count, 0, sizeof(uint32_t), st));
@@ -4173,14 +4335,14 @@ int s2k_double_scalar_mult_basepoint_batch_ex(s2k_ctx* ctx, uint32_t impl, size_
     k_hot_prep<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, d_u1, io + o_u2, io + o_pts, io + o_pub, prep, stride, wl_count, wl,
                                               status);
     HIP_TRY(ctx, hipGetLastError());
-    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, fin, s2k_internal_gt(ctx),
+    k_verify_fast<MODE_POINT><<<blocks_for(n), 256, 0, st>>>((uint32_t)n, io + o_pub, nullptr, prep, qt, fin, ctx->gt_call,
                                                              io + o_ok, wl_count, wl, stride, io + o_out, nullptr, key_groups{});
     HIP_TRY(ctx, hipGetLastError());
     const uint32_t T = (uint32_t)((n + FIN_M - 1) / FIN_M);
     k_affine_finish<MODE_RECOVER><<<(T + 63) / 64, 64, 0, st>>>((uint32_t)n, T, nullptr, fin, io + o_ok, stride, io + o_out);
     HIP_TRY(ctx, hipGetLastError());
     k_point_fallback<false><<<fallback_blocks(ctx, n), 256, 0, st>>>(wl_count, wl, (uint32_t)n, d_u1, io + o_u2, io + o_pts,
-                                                                     io + o_out, s2k_internal_gt(ctx), qt, stride, status);
+                                                                     io + o_out, ctx->gt_call, qt, stride, status);
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t h_status = 0;

@@ -41,8 +41,9 @@ inline constexpr uint32_t gt_windows_of(int bits) { return (uint32_t)((256 + bit
 inline constexpr size_t gt_entries_of(int bits) { return (size_t)gt_windows_of(bits) << bits; }
 inline constexpr size_t gt_bytes_of(int bits) { return gt_entries_of(bits) * 64; }
 
-// what a kernel gets: the table and its geometry, by value (a call may see the narrow table in one launch and the wide one
-// in the next: every launch is consistent in itself, and the tables hold the same group elements)
+// what a kernel gets: the table and its geometry, by value.  A CALL uses one view for all its launches (s2k_ctx::gt_call,
+// loaded by ctx_enter): the ladder kernels leave lanes for the worklist kernel whose tags name an entry of the table they ran
+// on (WL_DOUBLE_LAST, engine.hip), so the background build may publish the wide table between two calls, never inside one.
 struct gt_view {
   const uint32_t* p;
   uint32_t bits, windows;
@@ -102,6 +103,9 @@ struct s2k_ctx {
   int device = -1;
   bool gt_held = false;         // this context holds a reference on its device's generator tables (gtable_acquire)
   int gt_fixed = 0;             // s2k_ctx_create_ex with an explicit width: only the table of that width is used (0: the widest ready)
+  gt_view gt_call = {nullptr, 0, 0};   // the generator table of the call being enqueued: loaded ONCE per call (ctx_enter), passed to every launch of it
+  int dbg_gt_swap = 0;          // test hook (s2k_debug_gt_swap_in_call): publish this width between the ladder and the worklist launch of the next call
+  char gt_note[200] = {0};      // s2k_ctx_gt_note's answer (copied under the registry's lock)
   void* ws = nullptr;           // workspace of the verification path
   size_t ws_bytes = 0;
   void* msm_ws = nullptr;       // workspace of the multi-scalar multiplication
@@ -219,7 +223,8 @@ inline std::atomic<size_t>& s2k_internal_key_table_limit() {   // s2k_set_table_
   static std::atomic<size_t> v{0};
   return v;
 }
-gt_view s2k_internal_gt(const s2k_ctx* ctx);   // engine.hip: the generator table a launch of this moment uses
+gt_view s2k_internal_gt_load(const s2k_ctx* ctx);   // engine.hip: the generator table a call that starts now uses (one load per call)
+size_t s2k_internal_gt_pending_bytes(int device);   // engine.hip: device memory the background table build is about to allocate
 
 inline thread_local char g_err[512];
 
@@ -262,6 +267,7 @@ static inline size_t lane_stride(size_t n) { return ((n + 63) & ~(size_t)63) + S
 
 // Serialisation of the calls of one context across streams (see s2k_ctx::ev_done).
 inline int ctx_enter(s2k_ctx* ctx, hipStream_t st) {
+  ctx->gt_call = s2k_internal_gt_load(ctx);   // every launch of this call reads this view and no other
   if (ctx->have_last && ctx->last_stream != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_done, 0));
   return S2K_OK;
 }

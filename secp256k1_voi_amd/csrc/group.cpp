@@ -51,6 +51,7 @@ struct member {
   s2k_group* group = nullptr;
   size_t index = 0;                // position in the group (its key set in a s2k_group_keyset)
   int device = -1;
+  int gt_bits = 0;                 // s2k_group_create_ex: the members' generator table width (0: automatic)
   s2k_ctx* ctx = nullptr;
   int create_rc = S2K_OK;
   char create_err[256] = {0};
@@ -159,7 +160,7 @@ void member_main(member* me) {
     me->numa_node = s2k_device_numa_node(me->device);
     me->bound_cpus = s2k_bind_thread_to_node(me->numa_node);
     s2k_ctx* ctx = nullptr;
-    const int rc = s2k_ctx_create(me->device, &ctx);
+    const int rc = s2k_ctx_create_ex(me->device, me->gt_bits, 0, &ctx);
     std::lock_guard<std::mutex> lock(me->m);
     me->ctx = ctx;
     me->create_rc = rc;
@@ -268,10 +269,16 @@ void member_main(member* me) {
 
 extern "C" {
 
-int s2k_group_create(const int* devices, size_t n_devices, s2k_group** out) {
+int s2k_group_create(const int* devices, size_t n_devices, s2k_group** out) { return s2k_group_create_ex(devices, n_devices, 0, 0, out); }
+
+// gt_bits / flags: what s2k_ctx_create_ex takes, applied to every member (0, 0: automatic tables).  The members' child contexts
+// (submit / wait) inherit the width, so a group asked for a narrow table never allocates a wide one behind the caller's back.
+int s2k_group_create_ex(const int* devices, size_t n_devices, int gt_bits, uint32_t flags, s2k_group** out) {
   if (!out) return S2K_ERR_ARG;
   *out = nullptr;
   if (!devices || n_devices == 0 || n_devices > 1024) return S2K_ERR_ARG;
+  if (gt_bits != 0 && (gt_bits < 16 || gt_bits > 26)) return S2K_ERR_ARG;
+  if (flags & ~(uint32_t)S2K_CTX_WAIT_TABLES) return S2K_ERR_ARG;
   const int count = s2k_device_count();
   if (count <= 0) return S2K_ERR_NO_DEVICE;
   for (size_t i = 0; i < n_devices; ++i)
@@ -287,6 +294,7 @@ int s2k_group_create(const int* devices, size_t n_devices, s2k_group** out) {
     me->group = g;
     me->index = i;
     me->device = devices[i];
+    me->gt_bits = gt_bits;
     g->members.push_back(me);
     me->th = std::thread(member_main, me);
   }
@@ -304,6 +312,7 @@ int s2k_group_create(const int* devices, size_t n_devices, s2k_group** out) {
     s2k_group_destroy(g);
     return rc;
   }
+  if (flags & S2K_CTX_WAIT_TABLES) (void)s2k_group_gt_wait(g);
   *out = g;
   return S2K_OK;
 }

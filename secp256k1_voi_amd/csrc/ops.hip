@@ -641,7 +641,7 @@ static int point_op(s2k_ctx* ctx, int op, size_t n, const uint8_t* k1, const uin
   HIP_TRY(ctx, dst.alloc(16));
   HIP_TRY(ctx, hipMemset(dst.p, 0, 16));
   k_point_op<<<blocks_for(n), 256>>>(op, (uint32_t)n, (const uint8_t*)dk1.p, (const uint8_t*)dpa.p, (const uint8_t*)dpb.p,
-                                     (uint8_t*)dout.p, s2k_internal_gt(ctx), (uint32_t*)dst.p);
+                                     (uint8_t*)dout.p, s2k_internal_gt_load(ctx), (uint32_t*)dst.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
   uint32_t h_status = 0;
@@ -812,7 +812,7 @@ int s2k_generator_window_bits(void) { return GT_BITS_TARGET; }
 
 int s2k_debug_gtable_entry(s2k_ctx* ctx, unsigned i, unsigned d, uint8_t* out64) {
   if (!ctx || !out64) return fail(ctx, S2K_ERR_ARG, "null argument");
-  const gt_view gt = s2k_internal_gt(ctx);
+  const gt_view gt = s2k_internal_gt_load(ctx);
   if (i >= gt.windows || d >= (1u << gt.bits)) return fail(ctx, S2K_ERR_ARG, "index out of range");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dev_buf o;

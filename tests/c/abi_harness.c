@@ -66,6 +66,25 @@ static int cpu_part(void) {
   memcpy(bad, g, 65);
   bad[64] ^= 1;
   CHECK(s2k_ct_scalar_mult(k, bad, out) == S2K_ERR_ARG, "off-curve point refused");
+  /* the single operations a Go Point / Scalar method binds to: G + G = 2G = Double(G), 2G + G = 3G, 3G - G = 2G; 2 * 2^-1 = 1 */
+  {
+    uint8_t g2[65], g3[65], t[65], two[32] = {0}, inv[32], one[32] = {0}, prod[32];
+    uint64_t f = 9;
+    CHECK(s2k_ct_point_add(g, g, g2) == S2K_OK && s2k_ct_point_double(g, t) == S2K_OK && memcmp(g2, t, 65) == 0, "G + G = Double(G)");
+    hex(x, G2X);
+    CHECK(g2[0] == 4 && memcmp(g2 + 1, x, 32) == 0, "G + G = 2G");
+    CHECK(s2k_ct_point_add(g2, g, g3) == S2K_OK, "2G + G");
+    hex(x, G3X);
+    CHECK(memcmp(g3 + 1, x, 32) == 0, "2G + G = 3G");
+    CHECK(s2k_ct_point_subtract(g3, g, t) == S2K_OK && s2k_ct_point_equal(t, g2, &f) == S2K_OK && f == 1, "3G - G = 2G");
+    CHECK(s2k_ct_point_subtract(g, g, t) == S2K_OK && s2k_ct_point_is_identity(t, &f) == S2K_OK && f == 1, "G - G = 0");
+    CHECK(s2k_ct_point_add(g, bad, t) == S2K_ERR_ARG, "off-curve operand refused");
+    two[31] = 2;
+    one[31] = 1;
+    CHECK(s2k_ct_scalar_op(S2K_OP_INV, two, NULL, inv) == S2K_OK && s2k_ct_scalar_op(S2K_OP_MUL, two, inv, prod) == S2K_OK &&
+              memcmp(prod, one, 32) == 0, "2 * Invert(2) = 1");
+    CHECK(s2k_ct_scalar_predicate(S2K_SCALAR_IS_GT_HALF_N, inv, NULL, &f) == S2K_OK && f == 1, "1/2 = (n + 1) / 2 > n / 2");
+  }
   /* DER: 30 06 02 01 01 02 01 01 is (r, s) = (1, 1) */
   const uint8_t der[8] = {0x30, 0x06, 0x02, 0x01, 0x01, 0x02, 0x01, 0x01};
   uint8_t r[32], s[32];

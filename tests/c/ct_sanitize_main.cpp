@@ -82,6 +82,72 @@ int main() {
     bad += s2k_ct_multi_scalar_mult(33, ks, ps, out) != S2K_ERR_ARG;
     bad += s2k_ct_multi_scalar_mult(2, nullptr, ps, out) != S2K_ERR_ARG;
   }
+  // the single operations: every entry point on exact-size heap buffers (an overread is a report), group identities as the check
+  {
+    auto heap = [](const uint8_t* src, size_t n) {
+      uint8_t* p = new uint8_t[n];
+      memcpy(p, src, n);
+      return p;
+    };
+    uint8_t ident[65] = {0};
+    for (int it = 0; it < 30; ++it) {
+      for (int i = 0; i < 32; ++i) {
+        k[i] = (uint8_t)next();
+        d[i] = (uint8_t)next();
+      }
+      k[0] &= 0x7f;
+      d[0] &= 0x7f;
+      if (it == 0) memset(k, 0, 32);
+      uint8_t pa[65], pb[65];
+      bad += s2k_ct_scalar_base_mult(k, pa) != 0;
+      bad += s2k_ct_scalar_base_mult(d, pb) != 0;
+      uint8_t *A = heap(pa, 65), *B = heap(pb, 65), *O = new uint8_t[65], *O2 = new uint8_t[65], *K = heap(k, 32), *D = heap(d, 32), *S32 = new uint8_t[32],
+              *T32 = new uint8_t[32];
+      uint64_t f = 9, g = 9;
+      // (k + d) G = k G + d G; a - b + b = a; 2a = a + a; -(-a) = a
+      bad += s2k_ct_scalar_op(S2K_OP_ADD, K, D, S32) != 0;
+      bad += s2k_ct_scalar_base_mult(S32, out) != 0;
+      bad += s2k_ct_point_add(A, B, O) != 0 || memcmp(O, out, 65) != 0;
+      bad += s2k_ct_point_subtract(O, B, O2) != 0 || memcmp(O2, A, 65) != 0;
+      bad += s2k_ct_point_double(A, O) != 0 || s2k_ct_point_add(A, A, O2) != 0 || memcmp(O, O2, 65) != 0;
+      bad += s2k_ct_point_negate(A, O) != 0 || s2k_ct_point_conditional_negate(O, 1, O2) != 0 || memcmp(O2, A, 65) != 0;
+      bad += s2k_ct_point_add(A, O, O2) != 0 || memcmp(O2, ident, 65) != 0;
+      bad += s2k_ct_point_conditional_select(A, B, 0, O) != 0 || memcmp(O, A, 65) != 0;
+      bad += s2k_ct_point_conditional_select(A, B, 7, O) != 0 || memcmp(O, B, 65) != 0;
+      bad += s2k_ct_point_equal(A, A, &f) != 0 || f != 1 || s2k_ct_point_equal(A, B, &f) != 0 || f != (uint64_t)(memcmp(A, B, 65) == 0);
+      bad += s2k_ct_point_is_identity(A, &f) != 0 || f != (uint64_t)(it == 0) || s2k_ct_point_is_y_odd(A, &g) != 0 || g != (uint64_t)(A[64] & 1);
+      // scalars: a * a^-1 = 1 (a != 0), a - a = 0, a + (-a) = 0, select / negate / predicates
+      bad += s2k_ct_scalar_op(S2K_OP_INV, D, nullptr, S32) != 0 || s2k_ct_scalar_op(S2K_OP_MUL, D, S32, T32) != 0;
+      bad += s2k_ct_scalar_predicate(S2K_SCALAR_IS_ZERO, D, nullptr, &f) != 0;
+      uint8_t one[32] = {0};
+      one[31] = 1;
+      if (!f) bad += memcmp(T32, one, 32) != 0;
+      bad += s2k_ct_scalar_op(S2K_OP_SUB, D, D, S32) != 0 || s2k_ct_scalar_predicate(S2K_SCALAR_IS_ZERO, S32, nullptr, &f) != 0 || f != 1;
+      bad += s2k_ct_scalar_op(S2K_OP_NEG, D, nullptr, S32) != 0 || s2k_ct_scalar_op(S2K_OP_ADD, D, S32, T32) != 0;
+      bad += s2k_ct_scalar_predicate(S2K_SCALAR_IS_ZERO, T32, nullptr, &f) != 0 || f != 1;
+      bad += s2k_ct_scalar_conditional_negate(D, 1, T32) != 0 || memcmp(T32, S32, 32) != 0;
+      bad += s2k_ct_scalar_conditional_select(K, D, 1, T32) != 0 || memcmp(T32, D, 32) != 0;
+      bad += s2k_ct_scalar_predicate(S2K_SCALAR_EQUAL, K, D, &f) != 0 || f != (uint64_t)(memcmp(K, D, 32) == 0);
+      bad += s2k_ct_scalar_predicate(S2K_SCALAR_IS_GT_HALF_N, D, nullptr, &f) != 0 || s2k_ct_scalar_predicate(S2K_SCALAR_IS_GT_HALF_N, S32, nullptr, &g) != 0;
+      bad += s2k_ct_scalar_op(S2K_OP_SQR, D, nullptr, S32) != 0 || s2k_ct_scalar_op(S2K_OP_MUL, D, D, T32) != 0 || memcmp(S32, T32, 32) != 0;
+      bad += s2k_ct_scalar_set_bytes(D, S32, &f) != 0 || f != 0 || memcmp(S32, D, 32) != 0;
+      // field: x(A) * x(A)^-1 = 1; y(A)^2 has a root and it is +-y(A)
+      if (it) {
+        bad += s2k_ct_fe_op(S2K_OP_INV, A + 1, nullptr, S32, nullptr) != 0 || s2k_ct_fe_op(S2K_OP_MUL, A + 1, S32, T32, &f) != 0 || memcmp(T32, one, 32) != 0;
+        bad += s2k_ct_fe_op(S2K_OP_SQR, A + 33, nullptr, S32, nullptr) != 0 || s2k_ct_fe_op(S2K_OP_SQRT, S32, nullptr, T32, &f) != 0 || f != 1;
+        bad += s2k_ct_fe_op(S2K_OP_NEG, T32, nullptr, S32, nullptr) != 0 || (memcmp(T32, A + 33, 32) != 0 && memcmp(S32, A + 33, 32) != 0);
+        bad += s2k_ct_fe_op(S2K_OP_ADD, A + 1, A + 33, S32, nullptr) != 0 || s2k_ct_fe_op(S2K_OP_SUB, S32, A + 33, T32, nullptr) != 0 || memcmp(T32, A + 1, 32) != 0;
+      }
+      // malformed operands: rejected
+      O[0] = 0x04;
+      memset(O + 1, 0xFF, 64);
+      bad += s2k_ct_point_add(A, O, O2) != S2K_ERR_ARG || s2k_ct_point_is_identity(O, &f) != S2K_ERR_ARG;
+      memset(S32, 0xFF, 32);
+      bad += s2k_ct_scalar_op(S2K_OP_INV, S32, nullptr, T32) != S2K_ERR_ARG || s2k_ct_fe_op(S2K_OP_INV, S32, nullptr, T32, nullptr) != S2K_ERR_ARG;
+      bad += s2k_ct_scalar_set_bytes(S32, T32, &f) != 0 || f != 1;
+      delete[] A; delete[] B; delete[] O; delete[] O2; delete[] K; delete[] D; delete[] S32; delete[] T32;
+    }
+  }
   (void)s2k_ct_debug_fe_mul_count();
   printf("%s\n", bad ? "FAILED" : "ok");
   return bad != 0;

@@ -107,7 +107,9 @@ int s2k_device_pci_bus_id(int device, char* out, size_t len) {
   return S2K_OK;
 }
 const char* s2k_last_error(const s2k_ctx* ctx) { return ctx ? ctx->err : g_err; }
-int s2k_ctx_create(int device, s2k_ctx** out) {
+int s2k_ctx_create_ex(int device, int gt_bits, uint32_t flags, s2k_ctx** out);
+int s2k_ctx_create(int device, s2k_ctx** out) { return s2k_ctx_create_ex(device, 0, 0, out); }
+int s2k_ctx_create_ex(int device, int /*gt_bits*/, uint32_t /*flags*/, s2k_ctx** out) {
   if (device == 3) {                   // device 3 of the stub machine always fails: the group's error path
     snprintf(g_err, sizeof g_err, "stub: device 3 is broken");
     return S2K_ERR_HIP;

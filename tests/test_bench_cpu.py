@@ -18,6 +18,36 @@ def test_bench_launcher_refuses_without_devices():
     assert "--oversubscribe" in p.stderr
 
 
+def test_bench_launcher_names_the_rank_that_died():
+    """one rank exits before init_process_group (test hook) - the launcher ends its siblings, names the
+    rank, its exit code and its last stderr line, and returns non-zero within seconds instead of leaving the others blocked
+    in the rendezvous until the collective's own timeout.  No GPU needed: the surviving rank is still importing / waiting
+    for its peer when it is ended."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["S2K_BENCH_TEST_FAIL_RANK"] = "1"
+    env["S2K_BENCH_TEST_HANG_RANK"] = "0"              # (stands for "blocked in the rendezvous": this box has no GPU to get that far)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--oversubscribe",
+                        "--no-cpu-baseline", "--no-extras", "--no-pcie"], env=env, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-1500:])
+    assert "rank 1 exited with code 3" in p.stderr and "S2K_BENCH_TEST_FAIL_RANK" in p.stderr, p.stderr[-1500:]
+    assert "ended the other 1 rank(s)" in p.stderr
+    assert took < 60, took
+    assert p.stdout.strip() == ""                      # no bench line from a launch that failed
+
+
+def test_bench_launcher_times_out_on_ranks_that_never_get_ready():
+    """... and ranks that hang before they are ready (the hook S2K_BENCH_TEST_HANG_RANK) are named after --rank-timeout seconds."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["S2K_BENCH_TEST_HANG_RANK"] = "0,1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--oversubscribe",
+                        "--rank-timeout", "8", "--no-cpu-baseline", "--no-extras", "--no-pcie"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124, (p.returncode, p.stderr[-1500:])
+    assert "have not reported ready" in p.stderr and "[0, 1]" in p.stderr, p.stderr[-1500:]
+
+
 def test_bench_line_fits_the_drivers_record():
     """The driver keeps an 8 KB tail of stdout: bench.py's compact form carries numbers only - the prose
     goes to bench_notes.json by path -, puts what must survive LAST, rounds to six digits, and names what it had to drop.

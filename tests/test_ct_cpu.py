@@ -185,6 +185,147 @@ def test_ct_operation_count_is_scalar_independent(S):
     assert len(counts) == 1, counts
 
 
+# ---- single operations (s2k_ct_point_* / s2k_ct_scalar_* / s2k_ct_fe_op): what Point / Scalar / field.Element methods bind to ----
+N_HEX = "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141"
+HALF_N = 0x7fffffffffffffffffffffffffffffff5d576e7357a4501ddfe92f46681b20a0
+IDENT = bytes(65)
+
+
+def rec(pt):
+    return IDENT if pt is None else b"\x04" + b32(pt[0]) + b32(pt[1])
+
+
+def test_ct_scalar_single_ops_boundaries_and_oracle(S, oracle):
+    """scalar_test.go:27-41 (SetBytes / SetCanonicalBytes on N, N+1, N+2, N+2^128), :76-95 (IsGreaterThanHalfN around N/2),
+    and every arithmetic method against the oracle on boundary and random scalars (scalar.go:66-93, scalar_invert.go:11)."""
+    geq_n = [R.N, R.N + 1, R.N + 2, R.N + 2**128]
+    for v, red in zip(geq_n, [0, 1, 2, 2**128]):
+        assert S.ct_scalar_set_bytes(b32(v)) == (b32(red), 1)
+        for fn in (lambda: S.ct_scalar_op(S.OP_NEG, b32(v)), lambda: S.ct_scalar_op(S.OP_ADD, b32(1), b32(v)),
+                   lambda: S.ct_scalar_predicate(0, b32(v)), lambda: S.ct_scalar_conditional_select(b32(1), b32(v), 0)):
+            with pytest.raises(ValueError):            # SetCanonicalBytes: errNonCanonicalEncoding
+                fn()
+    assert S.ct_scalar_set_bytes(b32(R.N - 1)) == (b32(R.N - 1), 0)
+    for v, gt in ((HALF_N, 0), (HALF_N - 1, 0), (HALF_N + 1, 1), (HALF_N + 2, 1), (0, 0), (R.N - 1, 1)):
+        assert S.ct_scalar_predicate(1, b32(v)) == gt == int(oracle.fn_is_gt_half_n(b32(v)))
+    assert S.ct_scalar_predicate(0, b32(0)) == 1 and S.ct_scalar_predicate(0, b32(1)) == 0
+    rnd = random.Random(61)
+    vals = [0, 1, 2, R.N - 1, R.N - 2, HALF_N, HALF_N + 1, 2**128, 2**128 - 1, 2**255, R.LAMBDA] + [rnd.randrange(R.N) for _ in range(40)]
+    for a in vals:
+        A = b32(a)
+        assert S.ct_scalar_op(S.OP_NEG, A) == oracle.fn_neg(A) == b32(-a % R.N)
+        assert S.ct_scalar_op(S.OP_SQR, A) == oracle.fn_mul(A, A)
+        assert S.ct_scalar_op(S.OP_INV, A) == oracle.fn_inv(A) == b32(pow(a, -1, R.N) if a else 0)
+        assert S.ct_scalar_conditional_negate(A, 0) == A and S.ct_scalar_conditional_negate(A, 1) == b32(-a % R.N)
+        assert S.ct_scalar_conditional_negate(A, 2**63) == b32(-a % R.N)          # ctrl: anything but 0
+        for b in rnd.sample(vals, 6):
+            B = b32(b)
+            assert S.ct_scalar_op(S.OP_MUL, A, B) == oracle.fn_mul(A, B) == b32(a * b % R.N)
+            assert S.ct_scalar_op(S.OP_ADD, A, B) == oracle.fn_add(A, B) == b32((a + b) % R.N)
+            assert S.ct_scalar_op(S.OP_SUB, A, B) == oracle.fn_sub(A, B) == b32((a - b) % R.N)
+            assert S.ct_scalar_conditional_select(A, B, 0) == A and S.ct_scalar_conditional_select(A, B, 1) == B
+            assert S.ct_scalar_predicate(2, A, B) == int(a == b)
+    # Sum / Product of scalar_test.go:43-64 are loops over Add / Multiply: 1 + 1 + 1 = 3, 2 * 3 = 6
+    three = S.ct_scalar_op(S.OP_ADD, S.ct_scalar_op(S.OP_ADD, b32(1), b32(1)), b32(1))
+    assert three == b32(3) and S.ct_scalar_op(S.OP_MUL, b32(2), b32(3)) == b32(6)
+    with pytest.raises(ValueError):
+        S.ct_scalar_op(99, b32(1), b32(1))
+    with pytest.raises(ValueError):
+        S.ct_scalar_op(S.OP_MUL, b32(1), None)
+
+
+def test_ct_fe_single_ops_vs_oracle(S, oracle):
+    """field.Element methods (field.go:61-104, Invert, Sqrt) on the field's boundary values (field_test.go:29-41: p is not a
+    canonical encoding) and random elements, against the oracle and big integers."""
+    rnd = random.Random(62)
+    for v in (R.P, R.P + 1, 2**256 - 1):
+        with pytest.raises(ValueError):
+            S.ct_fe_op(S.OP_SQR, b32(v))
+    vals = [0, 1, 2, 7, R.P - 1, R.P - 2, 2**255, 0x1000003D0, 0x1000003D1, 2**256 - 0x1000003D1 - 1] + [rnd.randrange(R.P) for _ in range(40)]
+    squares = 0
+    for a in vals:
+        A = b32(a)
+        assert S.ct_fe_op(S.OP_SQR, A) == (oracle.fp_sqr(A), 1)
+        assert S.ct_fe_op(S.OP_NEG, A) == (oracle.fp_neg(A), 1)
+        assert S.ct_fe_op(S.OP_INV, A) == (oracle.fp_inv(A), 1) == (b32(pow(a, -1, R.P) if a else 0), 1)
+        root, ok = S.ct_fe_op(S.OP_SQRT, A)
+        o_root, o_ok = oracle.fp_sqrt(A)
+        assert (root, ok) == (bytes(o_root), int(o_ok))
+        if ok:
+            squares += 1
+            assert pow(int.from_bytes(root, "big"), 2, R.P) == a
+        else:
+            assert root == b32(0)
+        for b in rnd.sample(vals, 5):
+            B = b32(b)
+            assert S.ct_fe_op(S.OP_MUL, A, B)[0] == oracle.fp_mul(A, B) == b32(a * b % R.P)
+            assert S.ct_fe_op(S.OP_ADD, A, B)[0] == oracle.fp_add(A, B)
+            assert S.ct_fe_op(S.OP_SUB, A, B)[0] == oracle.fp_sub(A, B)
+    assert 10 < squares < len(vals) - 10
+
+
+def test_ct_point_single_ops_properties_and_oracle(S, oracle):
+    """point_test.go:136-213: a + 0 = 0 + a = a, a + a = 2a, a + b = b + a, 2 * 0 = 0, a - 0 = a, 0 - a = -a, a - a = 0,
+    a - b = a + (-b); every result also against the oracle's complete formulas and the affine big-integer group law;
+    Equal / IsIdentity / IsYOdd / ConditionalSelect / ConditionalNegate (point.go:102-160); malformed records are errors."""
+    rnd = random.Random(63)
+    pts = [R.mul(rnd.randrange(1, R.N), R.G) for _ in range(12)] + [R.G, R.mul(R.N - 1, R.G), R.mul(2, R.G)]
+    for a in pts:
+        A, negA = rec(a), rec((a[0], R.P - a[1]))
+        assert S.ct_point_add(A, IDENT) == A == S.ct_point_add(IDENT, A)
+        assert S.ct_point_add(A, A) == S.ct_point_double(A) == oracle.point_double(A) == rec(R.add(a, a))
+        assert S.ct_point_subtract(A, IDENT) == A and S.ct_point_subtract(IDENT, A) == negA == S.ct_point_negate(A)
+        assert S.ct_point_subtract(A, A) == IDENT == S.ct_point_add(A, negA)
+        assert S.ct_point_negate(A) == oracle.point_neg(A)
+        assert S.ct_point_conditional_negate(A, 0) == A and S.ct_point_conditional_negate(A, 5) == negA
+        assert S.ct_point_equal(A, A) == 1 and S.ct_point_equal(A, negA) == 0 and S.ct_point_equal(A, IDENT) == 0
+        assert S.ct_point_is_identity(A) == 0 and S.ct_point_is_y_odd(A) == (a[1] & 1)
+        for b in rnd.sample(pts, 4):
+            B = rec(b)
+            ab = S.ct_point_add(A, B)
+            assert ab == S.ct_point_add(B, A) == oracle.point_add(A, B) == rec(R.add(a, b))
+            assert S.ct_point_subtract(A, B) == S.ct_point_add(A, S.ct_point_negate(B)) == rec(R.add(a, (b[0], R.P - b[1])))
+            assert S.ct_point_conditional_select(A, B, 0) == A and S.ct_point_conditional_select(A, B, 1) == B
+            assert S.ct_point_equal(A, B) == int(a == b)
+    assert S.ct_point_double(IDENT) == IDENT == S.ct_point_negate(IDENT) == S.ct_point_add(IDENT, IDENT)
+    assert S.ct_point_is_identity(IDENT) == 1 and S.ct_point_is_y_odd(IDENT) == 0 and S.ct_point_equal(IDENT, IDENT) == 1
+    g = rec(R.G)
+    bad = [b"\x04" + b32(R.G[0]) + b32(R.G[1] ^ 1),            # off the curve
+           b"\x04" + b32(R.G[0]) + b32(R.P + 1),               # non-canonical y
+           b"\x04" + b32(R.P) + b32(0),                         # non-canonical x
+           b"\x02" + g[1:], b"\x00" + g[1:], b"\x04" + bytes(64),   # wrong tag, identity tag with a body, (0, 0)
+           b"\x00" * 64 + b"\x01"]
+    for rec_bad in bad:
+        for fn in (lambda: S.ct_point_add(g, rec_bad), lambda: S.ct_point_add(rec_bad, g), lambda: S.ct_point_double(rec_bad),
+                   lambda: S.ct_point_negate(rec_bad), lambda: S.ct_point_equal(g, rec_bad), lambda: S.ct_point_is_identity(rec_bad),
+                   lambda: S.ct_point_conditional_select(g, rec_bad, 0), lambda: S.ct_point_subtract(rec_bad, g)):
+            with pytest.raises(ValueError):
+                fn()
+
+
+def test_ct_single_ops_operation_count_is_value_independent(S):
+    """The field multiplications of a single operation do not depend on the operands' values - identity or not, equal or
+    opposite points, zero or dense scalars."""
+    rnd = random.Random(64)
+    a, b = rec(R.mul(rnd.randrange(1, R.N), R.G)), rec(R.mul(rnd.randrange(1, R.N), R.G))
+    nb = rec((int.from_bytes(b[1:33], "big"), R.P - int.from_bytes(b[33:], "big")))
+    lib = S.load_library()
+    counts = set()
+    for x, y in ((a, b), (a, a), (b, nb), (IDENT, a), (a, IDENT), (IDENT, IDENT)):
+        lib.s2k_ct_debug_fe_mul_count()
+        S.ct_point_add(x, y)
+        counts.add(lib.s2k_ct_debug_fe_mul_count())
+    assert len(counts) == 1, counts
+    counts = set()
+    for x in (a, IDENT, rec(R.G)):
+        lib.s2k_ct_debug_fe_mul_count()
+        S.ct_point_double(x)
+        S.ct_point_equal(x, a)
+        S.ct_point_is_identity(x)
+        counts.add(lib.s2k_ct_debug_fe_mul_count())
+    assert len(counts) == 1, counts
+
+
 def test_ct_machine_code_has_no_data_dependent_branches(S):
     """The constant-time claim at the level that matters: the COMPILED functions.  Optimisers turn
     `mask = (w == j)` scans back into compare-and-branch chains and secret-indexed loads (clang did, before
@@ -214,7 +355,13 @@ def test_ct_machine_code_has_no_data_dependent_branches(S):
               "pt_double": 0, "pt_to_record": 0, "sc_split_glv": 0, "fe_inv": 2, "fe_sqr_n": 1, "sc_inv": 3, "sc_reduce_wide": 0,
               "s2k_ct_scalar_mult": 3, "s2k_ct_scalar_base_mult": 2, "s2k_ct_ecdh": 6, "s2k_ct_ecdsa_sign_raw": 6,
               # loops over the (public) number of terms and over the 32 scalar bytes; allocation / argument checks
-              "ct_multi_scalar_mult": 8, "s2k_ct_multi_scalar_mult": 24}
+              "ct_multi_scalar_mult": 8, "s2k_ct_multi_scalar_mult": 24,
+              # single operations: NULL checks, the validity of the operands' ENCODING, the public op code, fixed loops
+              "pt_from_record_ct": 2, "fe_sqrt": 2, "s2k_ct_point_add": 4, "s2k_ct_point_double": 3, "s2k_ct_point_subtract": 4,
+              "s2k_ct_point_conditional_negate": 4, "s2k_ct_point_negate": 4, "s2k_ct_point_conditional_select": 6,
+              "s2k_ct_point_equal": 4, "s2k_ct_point_is_identity": 3, "s2k_ct_point_is_y_odd": 3, "s2k_ct_scalar_op": 16,
+              "s2k_ct_scalar_conditional_select": 4, "s2k_ct_scalar_conditional_negate": 3, "s2k_ct_scalar_predicate": 10,
+              "s2k_ct_scalar_set_bytes": 3, "s2k_ct_fe_op": 20}
     for name, lim in limits.items():
         assert counts.get(name, 0) <= lim, (name, counts.get(name))
     # nothing that looks like a switch over a 4-bit window value
