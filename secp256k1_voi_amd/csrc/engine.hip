@@ -2703,6 +2703,7 @@ void s2k_ctx_destroy(s2k_ctx* ctx) {
   if (ctx->ev_part0) (void)hipEventDestroy(ctx->ev_part0);
   if (ctx->ev_part1) (void)hipEventDestroy(ctx->ev_part1);
   if (ctx->s_aux2) (void)hipStreamDestroy(ctx->s_aux2);
+  if (ctx->s_msm_tail) (void)hipStreamDestroy(ctx->s_msm_tail);
   if (ctx->kg) (void)hipFree(ctx->kg);
   if (ctx->ktab) (void)hipFree(ctx->ktab);
   if (ctx->xkeys) (void)hipFree(ctx->xkeys);

@@ -157,6 +157,7 @@ struct s2k_ctx {
   hipStream_t s_aux = nullptr;       // scalar preparation runs here, beside the grouping and the table kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_part0 = nullptr, ev_part1 = nullptr;
   hipStream_t s_aux2 = nullptr;      // two-part flow: the second half of the tables is built here, beside the first half's ladder
+  hipStream_t s_msm_tail = nullptr;  // multi-scalar multiplication in two parts (msm.hip): the upper windows' tail, beside the lower windows' bucket pass
   uint32_t kg_parts = 1;             // 1: all tables, then all ladders; 2: the two-part flow (S2K_KEYED_PARTS; measured slower)
   uint32_t gp_first_percent = 60;    // share of k_generator_part launched beside k_key_chain (the rest: after k_key_odd)
   void* kg = nullptr;

@@ -44,6 +44,9 @@ namespace {
 #ifndef S2K_MSM_WAVES
 #define S2K_MSM_WAVES 4   // waves per SIMD the bucket pass is built for (127 VGPRs) and sized to fill once
 #endif
+#ifndef S2K_MSM_SPLIT_DEFAULT
+#define S2K_MSM_SPLIT_DEFAULT 0   // windows in the lower part of the two-part bucket pass (msm_core; 0: one part - measured: DESIGN.md section 6)
+#endif
 #ifndef S2K_MSM_CHUNK_LOG2
 #define S2K_MSM_CHUNK_LOG2 3   // default of the buckets per reduction chunk (log2); S2K_MSM_CHUNK_LOG2 in the environment overrides it
 #endif
@@ -385,6 +388,13 @@ k_msm_coarse_scatter_staged(uint32_t n, size_t nstride, msm_geom g, const uint32
     pairs[gbase[b] + (k - lofs[b])] = stage[k];
   }
 }
+// The bucket pass runs in one or two PARTS (msm_core): part B = the windows below `split_key / nb` (the list positions below
+// offset[split_key]), part A = the windows from there up, each cut into its own ranges - L_B entries per lane for the lanes
+// [0, nlanesB), L_A for the lanes [nlanesB, nlanes) - so that either part fills the chip by itself.  One part: split_key = 0,
+// nlanesB = 0, everything is part A.
+struct msm_parts {
+  uint32_t split_key, nlanesB, nlanes, L_A, L_B;
+};
 // one workgroup per coarse bucket: pairs -> list (term index | sign << 31, grouped by key), offset[key], lanekey[range];
 // the last workgroup also writes offset[nkeys] = total.  The sorted piece of the list is put together in LDS and written out in
 // order (scattered 4-byte stores straight to memory cost six times the list's size in write traffic); a coarse
@@ -393,7 +403,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__(FS_THREADS)
 k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict__ mbase, uint32_t total_slot,
                 const typename msm_pair<WIDE>::type* __restrict__ pairs, uint32_t* __restrict__ offset,
-                uint32_t* __restrict__ list, uint32_t L, uint32_t* __restrict__ lanekey) {
+                uint32_t* __restrict__ list, msm_parts P, uint32_t* __restrict__ lanekey) {
   typedef msm_pair<WIDE> PR;
   __shared__ uint32_t h[FINE], part[FINE], stage[FS_STAGE];
   const uint32_t b = blockIdx.x, t = threadIdx.x;
@@ -429,9 +439,13 @@ k_msm_fine_sort(uint32_t ncoarse, uint32_t nblk_pad, const uint32_t* __restrict_
     offset[key] = off;
     if (b + 1 == ncoarse && t == FINE - 1) offset[key + 1] = hi;
     h[t] = staged ? off - lo : off;                      // running cursor of key t
-    // the bucket pass cuts the list into ranges of L entries: the key of every range start that falls into this bucket
-    // (saves each of its lanes a binary search of offset[], 19 dependent loads with the whole chip waiting)
-    for (uint32_t k = (off + L - 1) / L; (uint64_t)k * L < (uint64_t)off + mine; ++k) lanekey[k] = (uint32_t)key;
+    // the bucket pass cuts each part of the list into ranges of L entries: the key of every range start that falls into this
+    // bucket (saves each of its lanes a binary search of offset[], 19 dependent loads with the whole chip waiting).  Part A
+    // starts where the coarse bucket of split_key starts (split_key is a multiple of FINE: the scanned matrix has the position).
+    const bool in_b = key < P.split_key;
+    const uint32_t start = in_b || !P.split_key ? 0u : mbase[(size_t)(P.split_key >> FINE_BITS) * nblk_pad];
+    const uint32_t L = in_b ? P.L_B : P.L_A, lane0 = in_b ? 0u : P.nlanesB, rel = off - start;
+    for (uint32_t k = (rel + L - 1) / L; (uint64_t)k * L < (uint64_t)rel + mine; ++k) lanekey[lane0 + k] = (uint32_t)key;
   }
   __syncthreads();
   for (uint32_t j = lo + t; j < hi; j += FS_THREADS * U) {
@@ -531,33 +545,45 @@ S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t stride, size_t 
   for (int w = 0; w < 9; ++w) p.zzz.n[w] = base[(size_t)(27 + w) * stride + slot];
   return p;
 }
+template <int PAD_KIB>
 __global__ void __launch_bounds__(256, S2K_MSM_WAVES)
-k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, const uint32_t* __restrict__ offset,
                  const uint32_t* __restrict__ lanekey, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
-                 uint32_t* __restrict__ xsum, uint32_t part, uint32_t split_key) {
-  // part 0: the whole list.  Two-part flow (msm_core): part 1 = the keys from split_key on (the upper windows), part 2 =
-  // the keys below it; the one range that holds the split position takes part in both, each side up to the split - which
-  // is a bucket border, so no piece is cut by it.
-  const uint32_t lane = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t total = offset[nkeys];
-  const uint64_t lo64 = (uint64_t)lane * L;
-  if (lo64 >= total) return;
-  uint32_t lo = (uint32_t)lo64, hi = total - lo > L ? lo + L : total;
-  uint32_t key = lanekey[lane];                            // offset[key] <= lo < offset[key + 1] (k_msm_fine_sort)
-  if (part) {
-    const uint32_t split_pos = offset[split_key];
-    if (part == 1) {
-      if (hi <= split_pos) return;
-      if (lo < split_pos) {                                // starts at the split: the first non-empty bucket from split_key on
-        lo = split_pos;
-        key = split_key;
-        while (offset[key + 1] <= lo) ++key;
-      }
-    } else {
-      if (lo >= split_pos) return;
-      if (hi > split_pos) hi = split_pos;
+                 uint32_t* __restrict__ xsum) {
+  // which = 0: part A (the list from offset[split_key] on; everything when there is one part), 1: part B (the list below it).
+  // The split is a bucket border, so no piece is cut by it.  PAD_KIB: a block of LDS the kernel owns and never uses - 48 KiB
+  // let three workgroups into a CU's 160 KiB and keep a fourth out, 72 KiB two: msm_core launches part B that way, so that
+  // every SIMD keeps wave slots and registers free for the tail of part A, which runs beside it.
+  if constexpr (PAD_KIB > 0) {
+    __shared__ uint32_t pad[PAD_KIB * 256];
+    if (which == 0xffffffffu) {                            // (never: the block only has to exist)
+      pad[threadIdx.x] = nkeys;
+      __syncthreads();
+      xsum[0] = pad[(threadIdx.x + 1) & 255];
     }
   }
+  const uint32_t lane = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t split_pos = offset[P.split_key];          // (0 when there is one part)
+  uint32_t L, limit, gl;
+  uint64_t lo64;
+  if (which) {
+    if (lane >= P.nlanesB) return;
+    L = P.L_B;
+    lo64 = (uint64_t)lane * L;
+    limit = split_pos;
+    gl = lane;
+  } else {
+    if (lane >= P.nlanes - P.nlanesB) return;
+    L = P.L_A;
+    lo64 = (uint64_t)split_pos + (uint64_t)lane * L;
+    limit = offset[nkeys];
+    gl = P.nlanesB + lane;
+  }
+  if (lo64 >= limit) return;
+  const uint32_t lo = (uint32_t)lo64, hi = limit - lo > L ? lo + L : limit;
+  uint32_t key = lanekey[gl];                              // offset[key] <= lo < offset[key + 1] (k_msm_fine_sort)
+  const uint32_t nlanes = P.nlanes;
+  const uint32_t lane_slot = gl;
   uint32_t border = offset[key + 1];                       // > lo
   bool open_left = offset[key] < lo;
   bool fresh = true;                                       // the next point starts a piece
@@ -567,7 +593,7 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
     if (j == border) {                                     // a bucket ends here: flush, next non-empty bucket
-      xz_store(xsum, stride, open_left ? (size_t)nkeys + lane : (size_t)key, acc);
+      xz_store(xsum, stride, open_left ? (size_t)nkeys + lane_slot : (size_t)key, acc);
       open_left = false;
       fresh = true;
       do {
@@ -592,7 +618,7 @@ k_msm_accumulate(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
   // the last piece: left edge if it came in from the previous range (then it may go on as well: a range inside one
   // bucket), right edge if it goes on into the next range, else a whole bucket
   const bool open_right = border > hi;
-  xz_store(xsum, stride, open_left ? (size_t)nkeys + lane : (open_right ? (size_t)nkeys + nlanes + lane : (size_t)key), acc);
+  xz_store(xsum, stride, open_left ? (size_t)nkeys + lane_slot : (open_right ? (size_t)nkeys + nlanes + lane_slot : (size_t)key), acc);
 }
 // the piece in `slot` (the list entries [first, end) of one bucket) as a projective point; ZZ = 0: walked again, complete formulas
 S2K_DEV pt29 msm_piece(const uint32_t* __restrict__ xsum, size_t stride, size_t slot, uint32_t first, uint32_t end,
@@ -609,10 +635,22 @@ S2K_DEV pt29 msm_piece(const uint32_t* __restrict__ xsum, size_t stride, size_t 
   }
   return acc;
 }
-// piece of the bucket [b, e) in range k
-S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, size_t stride, uint32_t nkeys, uint32_t nlanes, uint32_t L, uint32_t b,
+// the ranges of the part a key belongs to: first lane, list position of its first range, entries per range
+struct msm_part_of {
+  uint32_t lane0, start, L;
+};
+S2K_DEV msm_part_of msm_part_for(const msm_parts& P, uint32_t key, const uint32_t* __restrict__ offset) {
+  msm_part_of r;
+  const bool in_b = key < P.split_key;
+  r.lane0 = in_b ? 0u : P.nlanesB;
+  r.start = in_b ? 0u : offset[P.split_key];
+  r.L = in_b ? P.L_B : P.L_A;
+  return r;
+}
+// piece of the bucket [b, e) in range k (a global lane number)
+S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, size_t stride, uint32_t nkeys, uint32_t nlanes, const msm_part_of& pp, uint32_t b,
                           uint32_t e, uint32_t k, uint32_t k_lo, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw) {
-  const uint64_t r0 = (uint64_t)k * L, r1 = r0 + L;
+  const uint64_t r0 = (uint64_t)pp.start + (uint64_t)(k - pp.lane0) * pp.L, r1 = r0 + pp.L;
   const uint32_t first = b > r0 ? b : (uint32_t)r0, end = e < r1 ? e : (uint32_t)r1;
   // the first range's piece is a right edge (the bucket starts in it or at its border and goes on), the others' left edges
   return msm_piece(xsum, stride, k == k_lo ? (size_t)nkeys + nlanes + k : (size_t)nkeys + k, first, end, list, ptw);
@@ -620,10 +658,11 @@ S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, size_t stride, uint
 // one lane per key: sums[key] = the bucket as a projective point - the identity for an empty bucket, the converted piece
 // for a bucket inside one range, the sum of its pieces for a bucket that crosses range borders (one addition for an ordinary
 // bucket; buckets spread over more than STITCH_SERIAL ranges are queued for k_msm_stitch_big)
-__global__ void __launch_bounds__(256)
-k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+__global__ void __launch_bounds__(256, 4)     // (128 registers: a wave fits beside the lower part's bucket pass)
+k_msm_stitch(msm_parts P, uint32_t nkeys, size_t stride, const uint32_t* __restrict__ offset,
              const uint32_t* __restrict__ xsum, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
              uint32_t* __restrict__ sums, uint32_t* __restrict__ big /* [0] count, [1 ..] keys */, uint32_t key_lo, uint32_t key_hi) {
+  __builtin_amdgcn_s_setprio(3);   // (beside the lower part's bucket pass these waves issue first: they are few and the call waits for them)
   const uint32_t key = key_lo + blockIdx.x * 256 + threadIdx.x;      // the keys [key_lo, key_hi) of this launch
   if (key >= key_hi) return;
   const uint32_t b = offset[key], e = offset[key + 1];
@@ -631,7 +670,8 @@ k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const u
     pt_store(sums, stride, key, pt29_identity());
     return;
   }
-  const uint32_t k_lo = b / L, k_hi = (e - 1) / L;
+  const msm_part_of pp = msm_part_for(P, key, offset);
+  const uint32_t k_lo = pp.lane0 + (b - pp.start) / pp.L, k_hi = pp.lane0 + (e - 1 - pp.start) / pp.L;
   if (k_lo == k_hi) {
     pt_store(sums, stride, key, msm_piece(xsum, stride, key, b, e, list, ptw));
     return;
@@ -643,14 +683,14 @@ k_msm_stitch(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const u
       return;
     }                                       // more oversized buckets than the queue holds: serial after all
   }
-  pt29 r = msm_piece_of(xsum, stride, nkeys, nlanes, L, b, e, k_lo, k_lo, list, ptw);
+  pt29 r = msm_piece_of(xsum, stride, nkeys, P.nlanes, pp, b, e, k_lo, k_lo, list, ptw);
 #pragma unroll 1
-  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, nlanes, L, b, e, k, k_lo, list, ptw));
+  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, P.nlanes, pp, b, e, k, k_lo, list, ptw));
   pt_store(sums, stride, key, r);
 }
 // one workgroup per queued bucket: the threads take the pieces round robin, then a tree in LDS
 __global__ void __launch_bounds__(256)
-k_msm_stitch_big(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, const uint32_t* __restrict__ offset,
+k_msm_stitch_big(msm_parts P, uint32_t nkeys, size_t stride, const uint32_t* __restrict__ offset,
                  const uint32_t* __restrict__ xsum, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
                  uint32_t* __restrict__ sums, const uint32_t* __restrict__ big) {
   __shared__ uint32_t sh[PT_WORDS][128];
@@ -658,11 +698,12 @@ k_msm_stitch_big(uint32_t L, uint32_t nkeys, uint32_t nlanes, size_t stride, con
   for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
     const uint32_t key = big[1 + q];
     const uint32_t b = offset[key], e = offset[key + 1];
-    const uint32_t k_lo = b / L, k_hi = (e - 1) / L;
+    const msm_part_of pp = msm_part_for(P, key, offset);
+    const uint32_t k_lo = pp.lane0 + (b - pp.start) / pp.L, k_hi = pp.lane0 + (e - 1 - pp.start) / pp.L;
     pt29 r = pt29_identity();
 #pragma unroll 1
     for (uint32_t k = k_lo + threadIdx.x; k <= k_hi; k += 256)
-      r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, nlanes, L, b, e, k, k_lo, list, ptw));
+      r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, P.nlanes, pp, b, e, k, k_lo, list, ptw));
     for (uint32_t half = 128; half >= 1; half >>= 1) {
       __syncthreads();
       if (threadIdx.x >= half && threadIdx.x < 2 * half) pt_store(&sh[0][0], 128, threadIdx.x - half, r);
@@ -818,13 +859,16 @@ S2K_DEV void fold_quad_tree(uint32_t* sh, uint32_t groups, uint32_t GS, uint32_t
   __syncthreads();
 }
 __global__ void __launch_bounds__(256, 4)      // 128 registers: 4 waves per SIMD, 1024 of the 1152 workgroups resident at once
-k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ lvl, size_t lstride) {
+k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restrict__ lvl, size_t lstride, uint32_t s_lo, uint32_t ns) {
+  __builtin_amdgcn_s_setprio(3);   // (beside the lower part's bucket pass these waves issue first: they are few and the call waits for them)
+  // the slots [s_lo, s_lo + ns) of this launch: 64 row blocks and 64 column blocks per slot (the whole key range: s_lo = 0, ns = 9)
   __shared__ uint32_t sh[PT_WORDS * 128];
   const uint32_t t = threadIdx.x;
-  if (blockIdx.x < FOLD_ROW_BLOCKS) {
+  if (blockIdx.x < 64 * ns) {
     // two rows per workgroup, 128 threads each: two keys per thread and one level of the tree a lane per addition (128
     // additions per level), then 128 partials in LDS (row r: slots 64 r ..) and six levels by quads
-    const uint32_t half_id = t >> 7, u = t & 127u, row = 2 * blockIdx.x + half_id;
+    const uint32_t rb = 64 * s_lo + blockIdx.x;          // row block: rows 2 rb, 2 rb + 1
+    const uint32_t half_id = t >> 7, u = t & 127u, row = 2 * rb + half_id;
     const size_t k0 = (size_t)row * 256 + u;
     pt29 acc = pt29_add(pt_load(sums, stride, k0), pt_load(sums, stride, k0 + 128));
     if (u >= 64) pt_store(sh, 128, half_id * 64 + (u - 64), acc);
@@ -833,13 +877,13 @@ k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restric
     __syncthreads();
     if (u < 64) pt_store(sh, 128, half_id * 64 + u, acc);
     fold_quad_tree(sh, 2, 64, 1, 32, t);
-    if (t < 2) pt_store(lvl, lstride, 2 * blockIdx.x + t, pt_load(sh, 128, t * 64));
+    if (t < 2) pt_store(lvl, lstride, 2 * rb + t, pt_load(sh, 128, t * 64));
   } else {
     // block of 128 rows x 4 columns: thread (hg, lc) sums rows 2 hg, 2 hg + 1 of column 4 lb + lc; the tree over the 64 hg:
     // one level a lane per addition (128 additions), then 128 partials in LDS (slot 4 hg + lc) and five levels by quads.
     // (Eight columns and four rows per thread had two more additions on every lane's chain: the column blocks ended 15 us
     // after the row blocks.)
-    const uint32_t cb = blockIdx.x - FOLD_ROW_BLOCKS, blk = cb >> 6, lb = cb & 63u, hg = t >> 2, lc = t & 3u;
+    const uint32_t cb = blockIdx.x - 64 * ns, blk = s_lo + (cb >> 6), lb = cb & 63u, hg = t >> 2, lc = t & 3u;
     const size_t k0 = ((size_t)blk * 128 + 2 * hg) * 256 + 4 * lb + lc;
     pt29 acc = pt29_add(pt_load(sums, stride, k0), pt_load(sums, stride, k0 + 256));
     if (hg >= 32) pt_store(sh, 128, (hg - 32) * 4 + lc, acc);
@@ -861,14 +905,19 @@ S2K_DEV uint32_t fold_members(uint32_t ws, uint32_t b) {
   }
   return b < 8 ? 128u : 1u;      // weights 1 .. 256: bit 8 is the weight 256 alone
 }
+S2K_DEV uint32_t fold_ws_of(uint32_t idx, uint32_t w_lo, uint32_t nwp, uint32_t s_lo) { return idx < nwp ? w_lo + idx : 8u + s_lo + (idx - nwp); }
 S2K_DEV uint32_t fold_member_slot(uint32_t ws, uint32_t b, uint32_t m) {
   const uint32_t w = b < 8 ? (((m >> b) << (b + 1)) | (1u << b) | (m & ((1u << b) - 1u))) : 256u;
   return ws < 8 ? ws * 128 + w : FOLD_COL0 + (ws - 8) * 256 + (w - 1);
 }
 __global__ void __launch_bounds__(1024)
-k_msm_planes(uint32_t* __restrict__ lvl, size_t lstride) {
+k_msm_planes(uint32_t* __restrict__ lvl, size_t lstride, uint32_t w_lo, uint32_t nwp, uint32_t s_lo) {
+  __builtin_amdgcn_s_setprio(3);   // (beside the lower part's bucket pass these waves issue first: they are few and the call waits for them)
+  // the weighted sums of this launch: the row sums of the windows [w_lo, w_lo + nwp), then the column sums of the slots from s_lo
+  // on (grid: (windows + slots) x FOLD_BITS; everything: 0, 8, 0 and 17 x 9 workgroups)
   __shared__ uint32_t sh[PT_WORDS * 8];
-  const uint32_t ws = blockIdx.x / FOLD_BITS, b = blockIdx.x % FOLD_BITS, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t idx = blockIdx.x / FOLD_BITS, ws = fold_ws_of(idx, w_lo, nwp, s_lo);
+  const uint32_t b = blockIdx.x % FOLD_BITS, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const fer_consts k = fer_setup(lane);
   const uint32_t M = fold_members(ws, b);
   pt29r acc = pt29r_identity(k);
@@ -887,8 +936,9 @@ k_msm_planes(uint32_t* __restrict__ lvl, size_t lstride) {
 }
 // one wave per weighted sum: sum_b 2^b plane_b
 __global__ void __launch_bounds__(64)
-k_msm_plane_horner(uint32_t* __restrict__ lvl, size_t lstride) {
-  const uint32_t ws = blockIdx.x;
+k_msm_plane_horner(uint32_t* __restrict__ lvl, size_t lstride, uint32_t w_lo, uint32_t nwp, uint32_t s_lo) {
+  __builtin_amdgcn_s_setprio(3);   // (beside the lower part's bucket pass these waves issue first: they are few and the call waits for them)
+  const uint32_t ws = fold_ws_of(blockIdx.x, w_lo, nwp, s_lo);
   const fer_consts k = fer_setup(threadIdx.x);
   int b = (int)FOLD_BITS - 1;
   while (b > 0 && fold_members(ws, (uint32_t)b) == 0) --b;
@@ -900,27 +950,42 @@ k_msm_plane_horner(uint32_t* __restrict__ lvl, size_t lstride) {
   }
   pt29r_store(lvl, lstride, FOLD_WS0 + ws, acc, k);
 }
-// result = sum_w 2^(16 w) S_w, S_w = 256 RW_w + CW_w (CW_7 = the column sums of both blocks of the top window).  Eight waves
-// form the eight S_w side by side (eight doublings and one or two additions each), then wave 0 runs the recurrence over
-// the windows: 112 doublings and 7 additions that wait for each other.
+// result = sum_w 2^(16 w) S_w, S_w = 256 RW_w + CW_w (CW_7 = the column sums of both blocks of the top window).  The waves
+// [w_lo, w_hi) form their S_w side by side (eight doublings and one or two additions each), then wave w_hi - 1 runs the
+// recurrence over those windows: 16 doublings and an addition per window, all waiting for each other.
+// One launch: w_lo = 0, w_hi = 8.  Two parts (msm_core): the launch of the upper windows ends with 16 more doublings and leaves
+// its point in the carry slot (carry_out); the launch of the lower windows starts from carry + S_(w_hi - 1) (carry_in).
 __global__ void __launch_bounds__(512)
-k_msm_final16(const uint32_t* __restrict__ lvl, size_t lstride, uint8_t* __restrict__ out65, int affine) {
+k_msm_final16(uint32_t* __restrict__ lvl, size_t lstride, uint8_t* __restrict__ out65, int affine, uint32_t w_lo, uint32_t w_hi,
+              int carry_in, int carry_out) {
+  __builtin_amdgcn_s_setprio(3);   // (beside the lower part's bucket pass these waves issue first: they are few and the call waits for them)
   __shared__ uint32_t sh[PT_WORDS * 8];
-  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t wave = threadIdx.x >> 6, top = w_hi - 1u;
   const fer_consts k = fer_setup(threadIdx.x & 63u);
-  pt29r accr = pt29r_load(lvl, lstride, FOLD_WS0 + wave, k);
+  const bool active = wave >= w_lo && wave < w_hi;         // (wave-uniform)
+  pt29r accr = pt29r_identity(k);
+  if (active) {
+    accr = pt29r_load(lvl, lstride, FOLD_WS0 + wave, k);
 #pragma unroll 1
-  for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
-  accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 8 + wave, k), k);
-  if (wave == 7) accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 16, k), k);
-  if (wave != 7) pt29r_store(sh, 8, wave, accr, k);
+    for (int t = 0; t < 8; ++t) accr = pt29r_double(accr, k);
+    accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 8 + wave, k), k);
+    if (wave == 7) accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_WS0 + 16, k), k);
+    if (wave != top) pt29r_store(sh, 8, wave, accr, k);
+  }
   __syncthreads();
-  if (wave != 7) return;                       // (whole waves)
+  if (wave != top) return;                     // (whole waves)
+  if (carry_in) accr = pt29r_add(accr, pt29r_load(lvl, lstride, FOLD_END, k), k);
 #pragma unroll 1
-  for (int w = 6; w >= 0; --w) {
+  for (int w = (int)top - 1; w >= (int)w_lo; --w) {
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) accr = pt29r_double(accr, k);
     accr = pt29r_add(accr, pt29r_load(sh, 8, (uint32_t)w, k), k);
+  }
+  if (carry_out) {
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) accr = pt29r_double(accr, k);
+    pt29r_store(lvl, lstride, FOLD_END, accr, k);
+    return;
   }
   const pt29 acc = pt29r_gather(accr, k);
   if ((threadIdx.x & 63u) != 0) return;
@@ -996,7 +1061,7 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
   m.cap = n;
   {
     const size_t pairs_max = n * (size_t)g.nw, by_len = (pairs_max + MSM_L_MIN - 1) / MSM_L_MIN;
-    m.lanes_cap = (uint32_t)(by_len < msm_lanes_target() ? by_len : msm_lanes_target()) + 1;
+    m.lanes_cap = 2 * ((uint32_t)(by_len < msm_lanes_target() ? by_len : msm_lanes_target()) + 1);   // (two parts, each with up to the target)
     m.sum_stride = align_up(m.nkeys + 2 * (size_t)m.lanes_cap, 64);
   }
   // status word, then the queue of oversized buckets (counter + keys), zeroed with the counters
@@ -1036,15 +1101,56 @@ int msm_setup(s2k_ctx* ctx, size_t n, size_t aux_bytes, msm_ws& m) {
 }
 
 // buckets -> result, given scw / ptw / flag already filled and status/count/cursor zeroed
+// the second stream of a multi-scalar call (the point half of the front end; the upper part's tail in the two-part flow)
+static int msm_second_stream(s2k_ctx* ctx, hipStream_t* out) {
+  if (!ctx->s_msm_tail) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) hi = 0;
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->s_msm_tail, hipStreamNonBlocking, hi));
+  }
+  *out = ctx->s_msm_tail;
+  return S2K_OK;
+}
 int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65, bool affine = true) {
   const msm_geom& g = m.g;
   if (n > m.cap) return fail(ctx, S2K_ERR_ARG, "internal: more terms than the multiscalar workspace was carved for");
   const uint32_t nsortblk = (uint32_t)((n + m.sort_terms - 1) / m.sort_terms);  // <= m.nsortblk: the matrix columns beyond stay zero
-  // ranges of the bucket pass: as long as it takes for the lanes to fill the chip once
-  const size_t pairs_max = n * (size_t)g.nw;
-  size_t L = (pairs_max + msm_lanes_target() - 1) / msm_lanes_target();
-  if (L < MSM_L_MIN) L = MSM_L_MIN;
-  const uint32_t nlanes = (uint32_t)((pairs_max + L - 1) / L);                   // <= m.lanes_cap
+  static const bool fold_off = getenv("S2K_MSM_OLD_REDUCE") != nullptr;      // A/B hook: the round-3 reduction (chunks of 8 buckets, quads)
+  const bool fold16 = g.c == 16 && !fold_off && m.nslots + 1 > FOLD_END;
+  // Two parts, top-down (16-bit windows, large inputs): the bucket pass of the windows from `wsplit` up
+  // first; their stitching, row / column sums, bit planes and their share of the recurrence over the windows (all of it
+  // serial or latency bound: 0.3 ms for the whole key range) then run on a second stream BESIDE the bucket pass of the lower
+  // windows, which is launched three workgroups per CU (a block of LDS it never touches keeps the fourth out) so that every
+  // SIMD has a wave slot and 128 VGPRs free for them; what is left behind the bucket pass is the tail of `wsplit` windows,
+  // and the recurrence continues from the point the upper part left in the carry slot.  Each part is cut into its own
+  // ranges (msm_parts), so either fills the chip by itself - round 3's attempt gave a part a SUBSET of the ranges of the
+  // whole list and no room for the tail kernels, and was slower than one part.  S2K_MSM_SPLIT_WINDOW overrides (0: one part).
+  static const int split_env = [] {
+    const char* e = getenv("S2K_MSM_SPLIT_WINDOW");
+    return e ? atoi(e) : S2K_MSM_SPLIT_DEFAULT;
+  }();
+  static const uint32_t b_wgs_per_cu = [] {   // S2K_MSM_B_WGS: workgroups per CU of the lower part's bucket pass (2 .. 4)
+    const char* e = getenv("S2K_MSM_B_WGS");
+    const int v = e ? atoi(e) : 2;
+    return (uint32_t)(v < 2 ? 2 : (v > 4 ? 4 : v));
+  }();
+  const uint32_t wsplit = (fold16 && n >= ((size_t)1 << 17) && split_env > 0 && split_env < (int)g.nw) ? (uint32_t)split_env : 0u;
+  // ranges of the bucket pass: as long as it takes for the lanes of a part to fill the chip once
+  msm_parts P;
+  {
+    const size_t pairs_a = n * (size_t)(g.nw - wsplit), pairs_b = n * (size_t)wsplit;
+    const size_t target_a = msm_lanes_target(), target_b = (size_t)msm_lanes_target() * b_wgs_per_cu / 4;
+    size_t la = (pairs_a + target_a - 1) / target_a, lb = wsplit ? (pairs_b + target_b - 1) / target_b : MSM_L_MIN;
+    if (la < MSM_L_MIN) la = MSM_L_MIN;
+    if (lb < MSM_L_MIN) lb = MSM_L_MIN;
+    P.split_key = wsplit * g.nb;
+    P.L_A = (uint32_t)la;
+    P.L_B = (uint32_t)lb;
+    P.nlanesB = wsplit ? (uint32_t)((pairs_b + lb - 1) / lb) : 0u;
+    P.nlanes = P.nlanesB + (uint32_t)((pairs_a + la - 1) / la);                  // <= m.lanes_cap
+  }
+  if (P.nlanes > m.lanes_cap) return fail(ctx, S2K_ERR_ARG, "internal: more ranges than the multiscalar workspace was carved for");
+  const uint32_t nlanes_a = P.nlanes - P.nlanesB;
   // sort: coarse partition (counts -> scan -> scatter), then one workgroup per coarse bucket
   msm_prof_mark(ctx, st, 1);
   k_msm_coarse_count<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, m.sort_terms);
@@ -1052,47 +1158,36 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   const size_t mat_words = (size_t)m.ncoarse * m.nblk_pad;
   const unsigned scan_blocks = (unsigned)(mat_words / 1024);
   if (scan_blocks > 8192) return fail(ctx, S2K_ERR_ARG, "batch too large for the multiscalar sort");
+  // (one launch with a chained look-back instead of these three - every workgroup publishing its sum and adding up the sums
+  // before it - was measured at + 0.4 ms: 1152 workgroups polling each other's words with agent-scope acquires; profiles/r06_msm_attempts.txt)
   k_msm_scan_blocks<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum);
   k_msm_scan_top<<<1, 1024, 0, st>>>(m.bsum, scan_blocks, m.matrix + mat_words);
   k_msm_scan_apply<<<scan_blocks, 256, 0, st>>>(m.matrix, m.bsum, m.matrix);
   HIP_TRY(ctx, hipGetLastError());
   if (m.wide) {
     k_msm_coarse_scatter<true><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint2*)m.pairs, m.sort_terms);
-    k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list, (uint32_t)L, m.lanekey);
+    k_msm_fine_sort<true><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint2*)m.pairs, m.offset, m.list, P, m.lanekey);
   } else {
     if (m.sort_terms == SORT_TERMS_STAGED)
       k_msm_coarse_scatter_staged<<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs, m.sort_terms);
     else
       k_msm_coarse_scatter<false><<<nsortblk, SORT_THREADS, 0, st>>>((uint32_t)n, m.cap, g, m.scw, m.flag, m.ncoarse, m.nblk_pad, m.matrix, (uint32_t*)m.pairs, m.sort_terms);
-    k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list, (uint32_t)L, m.lanekey);
+    k_msm_fine_sort<false><<<m.ncoarse, FS_THREADS, 0, st>>>(m.ncoarse, m.nblk_pad, m.matrix, (uint32_t)mat_words, (const uint32_t*)m.pairs, m.offset, m.list, P, m.lanekey);
   }
   HIP_TRY(ctx, hipGetLastError());
   msm_prof_mark(ctx, st, 2);
-  // Two-part flow (S2K_MSM_SPLIT_WINDOW=ws, OFF by default; 16-bit windows, large inputs): the bucket pass of the windows
-  // from ws up first; their stitching, reduction, tree and their share of the Horner recurrence then on the second stream
-  // beside the bucket pass of the lower windows, and the caller's stream continues the recurrence from the carried point.
-  // Built, tested (same results) and MEASURED SLOWER: 2^20 inputs 1.82 ms in one part, 1.93 / 1.91 / 1.88 / 1.88 / 2.05 ms
-  // split at window 1 / 2 / 3 / 4 / 6.  Two reasons.  The lanes of a part are a SUBSET of the ranges (the ranges are cut
-  // from the whole list), so the lower part runs at under one wave per SIMD, i.e. at half the issue rate; and the tail
-  // kernels find no room beside the bucket pass anyway: its waves hold 3 x 134 of a SIMD's 512 VGPRs, the tail kernels need
-  // 113 to 140, and because every range is equally long no wave of the bucket pass ends before all of them do.
-  static const int split_env = [] {   // S2K_MSM_SPLIT_WINDOW (0 = single part)
-    const char* e = getenv("S2K_MSM_SPLIT_WINDOW");
-    return e ? atoi(e) : 0;
-  }();
-  const uint32_t ws = (g.c == 16 && n >= ((size_t)1 << 17) && split_env > 0 && split_env < (int)g.nw) ? (uint32_t)split_env : 0u;
   uint32_t* big2 = m.big + (STITCH_BIG_CAP + 1);
-  static const bool fold_off = getenv("S2K_MSM_OLD_REDUCE") != nullptr;      // A/B hook: the round-3 reduction (chunks of 8 buckets, quads)
-  const bool fold16 = g.c == 16 && ws == 0 && !fold_off && m.nslots + 1 >= FOLD_END;
-  auto tail = [&](hipStream_t s_, uint32_t slot_lo, uint32_t slot_hi, uint32_t* big) -> int {   // stitch, reduce, tree of the slots [slot_lo, slot_hi)
+  // stitch and reduce the slots [slot_lo, slot_hi) (the windows [w_lo, w_hi)) on stream s_
+  auto tail = [&](hipStream_t s_, uint32_t slot_lo, uint32_t slot_hi, uint32_t w_lo, uint32_t w_hi, uint32_t* big) -> int {
     const uint32_t key_lo = slot_lo * g.nb, key_hi = slot_hi == g.nslot ? (uint32_t)m.nkeys : slot_hi * g.nb;
-    k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
-    k_msm_stitch_big<<<64, 256, 0, s_>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big);
+    k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>(P, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
+    k_msm_stitch_big<<<64, 256, 0, s_>>>(P, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big);
     HIP_TRY(ctx, hipGetLastError());
-    if (fold16 && slot_lo == 0 && slot_hi == g.nslot) {   // 16-bit windows, whole key range: row / column sums, bit planes (above)
-      k_msm_fold<<<FOLD_ROW_BLOCKS + FOLD_COL_BLOCKS, 256, 0, s_>>>(m.sums, m.sum_stride, m.partial, m.nslots + 1);
-      k_msm_planes<<<FOLD_NWS * FOLD_BITS, 1024, 0, s_>>>(m.partial, m.nslots + 1);
-      k_msm_plane_horner<<<FOLD_NWS, 64, 0, s_>>>(m.partial, m.nslots + 1);
+    if (fold16) {   // 16-bit windows: row / column sums, bit planes (above)
+      const uint32_t ns = slot_hi - slot_lo, nwp = w_hi - w_lo;
+      k_msm_fold<<<128 * ns, 256, 0, s_>>>(m.sums, m.sum_stride, m.partial, m.nslots + 1, slot_lo, ns);
+      k_msm_planes<<<(nwp + ns) * FOLD_BITS, 1024, 0, s_>>>(m.partial, m.nslots + 1, w_lo, nwp, slot_lo);
+      k_msm_plane_horner<<<nwp + ns, 64, 0, s_>>>(m.partial, m.nslots + 1, w_lo, nwp, slot_lo);
       HIP_TRY(ctx, hipGetLastError());
       return S2K_OK;
     }
@@ -1105,42 +1200,53 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     HIP_TRY(ctx, hipGetLastError());
     return S2K_OK;
   };
-  if (ws == 0) {
-    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum, 0u, 0u);
+  if (wsplit == 0) {
+    k_msm_accumulate<0><<<blocks_for(nlanes_a), 256, 0, st>>>(P, 0u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
     HIP_TRY(ctx, hipGetLastError());
     msm_prof_mark(ctx, st, 3);
-    int rc = tail(st, 0, g.nslot, m.big);
+    int rc = tail(st, 0, g.nslot, 0, g.nw, m.big);
     if (rc) return rc;
     msm_prof_mark(ctx, st, 4);
     if (fold16)
-      k_msm_final16<<<1, 512, 0, st>>>(m.partial, m.nslots + 1, d_out65, affine ? 1 : 0);
+      k_msm_final16<<<1, 512, 0, st>>>(m.partial, m.nslots + 1, d_out65, affine ? 1 : 0, 0u, 8u, 0, 0);
     else
       k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, g.nw, 0u);
     HIP_TRY(ctx, hipGetLastError());
   } else {
-    int rc = ctx_aux_streams(ctx);
+    int rc = ctx_aux_streams(ctx);                    // (the fork / join events)
     if (rc) return rc;
-    const uint32_t split_key = ws * g.nb;
-    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum, 1u, split_key);
+    hipStream_t s2 = nullptr;                         // the upper part's tail: a stream of its own, served first when a slot frees up
+    rc = msm_second_stream(ctx, &s2);
+    if (rc) return rc;
+    k_msm_accumulate<0><<<blocks_for(nlanes_a), 256, 0, st>>>(P, 0u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, ctx->ev_fork, 0));
-    k_msm_accumulate<<<blocks_for(nlanes), 256, 0, st>>>((uint32_t)L, (uint32_t)m.nkeys, nlanes, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum, 2u, split_key);
-    rc = hipGetLastError() == hipSuccess ? S2K_OK : fail(ctx, S2K_ERR_HIP, "k_msm_accumulate launch failed");
-    if (rc == S2K_OK) rc = tail(ctx->s_aux, ws, g.nslot, big2);
+    HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    // the tail of the upper part first (so that it is in its queue when the first part ends), then the lower part's bucket pass
+    rc = tail(s2, wsplit, g.nslot, wsplit, g.nw, big2);
     if (rc == S2K_OK) {
-      k_msm_final<<<1, 64, 0, ctx->s_aux>>>(g, m.partial, d_out65, 0, g.nw, ws);     // upper windows -> carry slot
-      if (hipGetLastError() != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "k_msm_final launch failed");
+      k_msm_final16<<<1, 512, 0, s2>>>(m.partial, m.nslots + 1, d_out65, 0, wsplit, 8u, 0, 1);     // upper windows -> carry slot
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "k_msm_final16 launch failed");
+    }
+    if (rc == S2K_OK) {
+      // (a block of LDS per workgroup keeps the others out of the CU: 48 KiB - three fit 160 KiB -, 72 KiB - two)
+      const unsigned nb_ = blocks_for(P.nlanesB);
+      if (b_wgs_per_cu >= 4)
+        k_msm_accumulate<0><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+      else if (b_wgs_per_cu == 3)
+        k_msm_accumulate<48><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+      else
+        k_msm_accumulate<72><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "k_msm_accumulate launch failed");
     }
     msm_prof_mark(ctx, st, 3);
-    if (rc == S2K_OK) rc = tail(st, 0, ws, m.big);
-    ctx_aux_join(ctx, st);            // error or not: nothing stays in flight on the second stream alone
-    if (rc) {
-      (void)ctx_leave(ctx, st);
-      return rc;
-    }
+    if (rc == S2K_OK) rc = tail(st, 0, wsplit, 0, wsplit, m.big);
+    // error or not: nothing stays in flight on the second stream alone
+    (void)hipEventRecord(ctx->ev_join, s2);
+    (void)hipStreamWaitEvent(st, ctx->ev_join, 0);
+    if (rc) return rc;
     msm_prof_mark(ctx, st, 4);
-    k_msm_final<<<1, 64, 0, st>>>(g, m.partial, d_out65, affine ? 1 : 0, ws, 0u);
+    k_msm_final16<<<1, 512, 0, st>>>(m.partial, m.nslots + 1, d_out65, affine ? 1 : 0, 0u, wsplit, 1, 0);
     HIP_TRY(ctx, hipGetLastError());
   }
   msm_prof_mark(ctx, st, 5);
@@ -1493,6 +1599,8 @@ int s2k_multi_scalar_mult_device(s2k_ctx* ctx, size_t n, const void* d_scalars, 
   if (rc) return rc;
   msm_prof_mark(ctx, st, 0);
   HIP_TRY(ctx, hipMemsetAsync(ctx->msm_ws, 0, m.zero_bytes, st));
+  // (the front end moves 275 MB in 0.075 ms - it is bound by that, not by its arithmetic: splitting it into a scalar kernel in
+  // front of the sort and a point kernel beside it on a second stream was measured 0.03 ms SLOWER, profiles/r06_msm_attempts.txt)
   k_msm_parse<<<blocks_for(n), 256, 0, st>>>((uint32_t)n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, m.scw,
                                              m.ptw, m.flag, m.status);
   HIP_TRY(ctx, hipGetLastError());
