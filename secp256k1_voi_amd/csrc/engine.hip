@@ -536,6 +536,9 @@ S2K_DEV void scalar_prep_one(size_t i, const uint8_t* __restrict__ dig, const ui
 // Waves per SIMD the joint-table key-set ladder is built for.  Measured (tools/gpu_joint_waves.sh, same box, two runs each):
 // 3 waves (150 VGPRs, no spills) 1.743 / 1.746 ms, 4 waves (128 VGPRs, 21 spilled) 1.733 / 1.743 ms - the kernel is at the
 // clock the chip gives it (1.89-2.02 GHz under 8 GB of table fetches per launch) either way; 3 stays.
+#ifndef S2K_JOINT_PREFETCH
+#define S2K_JOINT_PREFETCH 1   // the wide joint ladders ask for the next table entry before they add the current one
+#endif
 #ifndef S2K_JOINT_WAVES
 #define S2K_JOINT_WAVES 3
 #endif
@@ -855,8 +858,10 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
         // magnitude 2 (NE - 1 - w) + 1, else positive with magnitude 2 (w - NE) + 1
         using J = kjw_geom<JW>;
         constexpr uint32_t WM = (1u << JW) - 1u, NE = (uint32_t)J::NE;
-#pragma unroll 1
-        for (int c = 0; c < J::POS; ++c) {
+        // The entry of position c + 1 is asked for BEFORE the addition of position c (S2K_JOINT_PREFETCH, default on): a joint
+        // table is 0.8 / 2.75 MiB per key and a lookup is a 64-byte read from HBM more often than not - issued behind the
+        // addition, its latency stood between every two additions of a wave.
+        auto next_entry = [&](int c, bool& n1_out) -> uint32_t {
           const uint32_t w1 = a[0] & WM, w2 = b[0] & WM;
 #pragma unroll
           for (int w = 0; w < 3; ++w) {
@@ -867,11 +872,31 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           b[3] >>= JW;
           const bool n1 = neg1 != (w1 < NE), n2 = neg2 != (w2 < NE);
           const uint32_t ea = (w1 < NE) ? (NE - 1u - w1) : (w1 - NE), eb = (w2 < NE) ? (NE - 1u - w2) : (w2 - NE);
-          const uint32_t j = (((uint32_t)c * NE + ea) * NE + eb) * 2u + (n1 != n2 ? 1u : 0u);
+          n1_out = n1;
+          return (((uint32_t)c * NE + ea) * NE + eb) * 2u + (n1 != n2 ? 1u : 0u);
+        };
+#if S2K_JOINT_PREFETCH
+        bool n1_cur;
+        jw_raw raw = jw_fetch(jt + (size_t)next_entry(0, n1_cur) * J::EQ);
+#pragma unroll 1
+        for (int c = 0; c < J::POS; ++c) {
+          const jw_raw cur = raw;
+          const bool n1 = n1_cur;
+          if (c + 1 < J::POS) raw = jw_fetch(jt + (size_t)next_entry(c + 1, n1_cur) * J::EQ);
+          fe29 x, y;
+          jw_point(cur, x, y);
+          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
+        }
+#else
+#pragma unroll 1
+        for (int c = 0; c < J::POS; ++c) {
+          bool n1;
+          const uint32_t j = next_entry(c, n1);
           fe29 x, y;
           jw_load(jt + (size_t)j * J::EQ, x, y);
           xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
         }
+#endif
       } else {
 #pragma unroll 1
       for (int c = 0; c < KS_CHUNKS; ++c) {

@@ -150,6 +150,20 @@ S2K_DEV void jw_load(const uint4* __restrict__ e, fe29& x, fe29& y) {
   x = fe29_from_words(xw);
   y = fe29_from_words(yw);
 }
+// the same in two steps: the 64 bytes asked for (in flight while the previous addition runs), the limbs cut when they are wanted
+struct jw_raw {
+  uint4 a, b, c, d;
+};
+S2K_DEV jw_raw jw_fetch(const uint4* __restrict__ e) {
+  jw_raw r;
+  r.a = e[0]; r.b = e[1]; r.c = e[2]; r.d = e[3];
+  return r;
+}
+S2K_DEV void jw_point(const jw_raw& r, fe29& x, fe29& y) {
+  const uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w}, yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
+  x = fe29_from_words(xw);
+  y = fe29_from_words(yw);
+}
 // one field element parked in the first three quads of a joint entry's slot (the build's prefix products)
 S2K_DEV void je_store1(uint4* __restrict__ e, const fe29& v) {
   e[0] = make_uint4(v.n[0], v.n[1], v.n[2], v.n[3]);
