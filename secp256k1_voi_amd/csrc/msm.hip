@@ -47,6 +47,9 @@ namespace {
 #ifndef S2K_MSM_SPLIT_DEFAULT
 #define S2K_MSM_SPLIT_DEFAULT 0   // windows in the lower part of the two-part bucket pass (msm_core; 0: one part - measured: DESIGN.md section 6)
 #endif
+#ifndef S2K_MSM_BORDER_AHEAD
+#define S2K_MSM_BORDER_AHEAD 1   // the bucket pass loads the border after the next one bucket ahead
+#endif
 #ifndef S2K_MSM_CHUNK_LOG2
 #define S2K_MSM_CHUNK_LOG2 3   // default of the buckets per reduction chunk (log2); S2K_MSM_CHUNK_LOG2 in the environment overrides it
 #endif
@@ -585,6 +588,12 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
   const uint32_t nlanes = P.nlanes;
   const uint32_t lane_slot = gl;
   uint32_t border = offset[key + 1];                       // > lo
+  // the border AFTER that one, asked for one bucket ahead (S2K_MSM_BORDER_AHEAD, default on): some lane of a wave meets a
+  // border in two trips of three, and the load of the next border was a dependent one the whole wave waited for - 11.6 % of
+  // the kernel's wave cycles were spent waiting for memory (profiles/r06_msm_attempts.txt)
+#if S2K_MSM_BORDER_AHEAD
+  uint32_t border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];
+#endif
   bool open_left = offset[key] < lo;
   bool fresh = true;                                       // the next point starts a piece
   xyzz29 acc = xyzz29_from_affine(fe29_zero(), fe29_zero());
@@ -596,10 +605,18 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
       xz_store(xsum, stride, open_left ? (size_t)nkeys + lane_slot : (size_t)key, acc);
       open_left = false;
       fresh = true;
+#if S2K_MSM_BORDER_AHEAD
+      do {
+        ++key;
+        border = border2;
+        border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];
+      } while (border <= j);
+#else
       do {
         ++key;
         border = offset[key + 1];
       } while (border <= j);
+#endif
     }
     const msm_rec r_nxt = msm_load_rec(ptw, e_nxt);        // entry 0 when past the end: a valid address
     const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;

@@ -13,7 +13,7 @@ def main():
     acc = defaultdict(list)
     for fn in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
-            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             if name.startswith("k_"):
                 acc[(name, row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):
