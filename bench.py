@@ -1116,6 +1116,10 @@ def multiscalar_roofline(eng, which, call_ms, stages, units, dominant, dominant_
     kernel_ms = st_ms[dominant_stage]
     roof = {"bound": "valu", "kernel": dominant, "kernel_ms": kernel_ms, "stages_ms": st_ms, "unit": "Tlane-op/s",
             "peak": VALU_PEAK_LANE_OPS / 1e12, "peak_def": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per 4 cycles per SIMD"}
+    if prof and dominant not in prof["kernels"]:       # (a kernel that became a template since: k_msm_accumulate -> k_msm_accumulate<0>)
+        alias = [k for k in prof["kernels"] if k.split("<")[0] == dominant.split("<")[0]]
+        if alias:
+            prof["kernels"][dominant] = prof["kernels"][alias[0]]
     if prof and dominant in prof["kernels"]:
         kk = prof["kernels"][dominant]
         wave_instr = kk["valu_wave_instr_per_call"]
@@ -1446,7 +1450,6 @@ def extra_measurements(eng, dev, n, n_keys, step, sync, st, args, host_pub=None,
     out["msm_2p20"]["one_call_after_the_other_ms"] = median(serial)
     out["msm_2p20"]["two_calls_in_flight_note"] = ("wall time PER CALL: two contexts on two host threads and streams, %d calls each, against %d calls "
                                                    "one after the other on one context (host time included in both), median of three rounds" % (reps2, 2 * reps2))
-    eng_b.close()
     del dk, dp
 
     # (c) from HOST memory: the synchronous host-pointer call pays transfer and kernels in series; two verifiers (two contexts,

@@ -124,3 +124,58 @@ print("leaving with a live context", flush=True)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "leaving with a live context" in r.stdout
+
+
+def test_table_registry_under_concurrent_contexts(oracle):
+    """The per-device table registry from several host threads at once (never two tables of one width, a width
+    that is being built is waited for, explicit widths beside the automatic build): contexts of widths 0 / 18 / 0 / 22 / 18
+    are created, used and destroyed concurrently, twice; every verdict array equals the oracle's and the registry ends with
+    one table per width."""
+    import threading
+    import secp256k1_voi_amd as S
+    from workload import make_ecdsa_batch
+    w = make_ecdsa_batch(oracle, 3000, seed=603, corrupt_every=4)
+    exp = oracle.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"], nthreads=8)
+    keep = S.Engine(0)                                  # (holds the registry while the others come and go)
+    errors, infos = [], []
+
+    def run(bits, rounds):
+        try:
+            for _ in range(rounds):
+                e = S.Engine(0, gt_bits=bits)
+                try:
+                    e.set_small_batch_max(0)
+                    e.set_mid_batch_max(0)
+                    for _ in range(3):
+                        got = e.ecdsa_verify_batch(w["pub"], w["digest"], w["r"], w["s"])
+                        if not np.array_equal(got, exp):
+                            errors.append(("verdicts", bits))
+                    infos.append((bits, e.gt_info()))
+                finally:
+                    e.close()
+        except Exception as ex:   # noqa: BLE001 - reported below
+            errors.append((bits, repr(ex)))
+
+    try:
+        th = [threading.Thread(target=run, args=(b, 2)) for b in (0, 18, 0, 22, 18)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in th), "a context creation is stuck in the registry"
+        assert not errors, errors
+        for bits, info in infos:
+            assert info["bits"] == bits or (bits == 0 and info["bits"] in (20, 22, 24, 26)), (bits, info)
+        keep.gt_wait()
+        held = keep.gt_info()["bytes"]
+        # bytes held = a sum over DISTINCT widths (the session's other tests may have left explicit widths behind) that contains
+        # 18, 20, 22 and the width in use: a table built twice would not fit any such sum
+        import itertools
+        size = {b: ((256 + b - 1) // b) * (64 << b) for b in range(16, 27)}
+        now = keep.gt_info()["bits"]
+        must = {18, 20, 22, now}
+        rest = [b for b in size if b not in must]
+        base = sum(size[b] for b in must)
+        assert any(base + sum(size[b] for b in extra) == held for k in range(len(rest) + 1) for extra in itertools.combinations(rest, k)), (held, now)
+    finally:
+        keep.close()
