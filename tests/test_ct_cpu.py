@@ -326,6 +326,29 @@ def test_ct_single_ops_operation_count_is_value_independent(S):
     assert len(counts) == 1, counts
 
 
+def test_ct_single_ops_argument_checks(S):
+    """NULL pointers and unknown op codes are S2K_ERR_ARG (-3 ... the library's argument error), never a crash."""
+    lib = S.load_library()
+    import ctypes as C
+    g, one, out65, out32, flag = rec(R.G), b32(1), C.create_string_buffer(65), C.create_string_buffer(32), C.c_uint64(0)
+    ERR = lib.s2k_ct_point_add(None, g, out65)
+    assert ERR != 0
+    for rc in (lib.s2k_ct_point_add(g, None, out65), lib.s2k_ct_point_add(g, g, None), lib.s2k_ct_point_double(None, out65),
+               lib.s2k_ct_point_double(g, None), lib.s2k_ct_point_subtract(g, g, None), lib.s2k_ct_point_negate(None, out65),
+               lib.s2k_ct_point_conditional_select(g, None, 0, out65), lib.s2k_ct_point_equal(g, g, None),
+               lib.s2k_ct_point_is_identity(None, C.byref(flag)), lib.s2k_ct_point_is_y_odd(g, None),
+               lib.s2k_ct_scalar_op(S.OP_ADD, one, None, out32), lib.s2k_ct_scalar_op(S.OP_ADD, None, one, out32),
+               lib.s2k_ct_scalar_op(S.OP_NEG, one, None, None), lib.s2k_ct_scalar_op(S.OP_SQRT, one, None, out32), lib.s2k_ct_scalar_op(-1, one, one, out32),
+               lib.s2k_ct_scalar_conditional_select(one, None, 1, out32), lib.s2k_ct_scalar_conditional_negate(None, 1, out32),
+               lib.s2k_ct_scalar_predicate(2, one, None, C.byref(flag)), lib.s2k_ct_scalar_predicate(3, one, one, C.byref(flag)),
+               lib.s2k_ct_scalar_predicate(0, one, None, None), lib.s2k_ct_scalar_set_bytes(None, out32, None),
+               lib.s2k_ct_fe_op(S.OP_SQRT, one, None, out32, None), lib.s2k_ct_fe_op(S.OP_MUL, one, None, out32, None), lib.s2k_ct_fe_op(42, one, one, out32, None)):
+        assert rc == ERR, rc
+    # and the forms that are allowed to leave optional arguments out
+    assert lib.s2k_ct_scalar_set_bytes(one, out32, None) == 0 and out32.raw == one
+    assert lib.s2k_ct_fe_op(S.OP_INV, one, None, out32, None) == 0 and out32.raw == one
+
+
 def test_ct_machine_code_has_no_data_dependent_branches(S):
     """The constant-time claim at the level that matters: the COMPILED functions.  Optimisers turn
     `mask = (w == j)` scans back into compare-and-branch chains and secret-indexed loads (clang did, before
