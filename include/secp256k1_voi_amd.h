@@ -91,7 +91,11 @@ enum {
  * returns (S2K_ERR_NOMEM when the device cannot hold them); flags S2K_CTX_WAIT_TABLES = automatic width, but return only
  * when the background build has ended.  s2k_ctx_gt_info: info[0] window bits in use now, [1] bits being aimed for (0: none),
  * [2] 1 while the build runs, [3] bytes of tables the device holds for this process; s2k_ctx_gt_note: why (free memory,
- * budget, a failed allocation); s2k_ctx_gt_wait: block until the build has ended, returns the bits in use then. */
+ * budget, a failed allocation); s2k_ctx_gt_wait: block until the build has ended, returns the bits in use then.
+ * The builder thread is never left behind: the s2k_ctx_destroy that removes the last context of a device cancels it (it
+ * looks at the flag before it allocates, between the windows of a table and before it publishes) and joins it - 0.01-0.13 s,
+ * or the rest of the 40 GiB allocation when the destroy meets it (1.6 s; profiles/r06_ctx_lifecycle.txt) - and a process that
+ * exits with contexts alive does the same from an atexit handler, before the HIP runtime is torn down. */
 #define S2K_CTX_WAIT_TABLES 1u
 int s2k_ctx_create(int device_index, s2k_ctx **out);
 int s2k_ctx_create_ex(int device_index, int gt_bits, uint32_t flags, s2k_ctx **out);

@@ -43,6 +43,8 @@ t0 = time.time()
 for it in range(iters):
     n = rnd.choice([1, 2, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 20000, 65536, 100000,
                     rnd.randrange(1, 3000), rnd.randrange(3000, 40000)])
+    if os.environ.get("S2K_MSM_SPLIT_WINDOW") and rnd.random() < 0.5:     # the two-part flow starts at 2^17 terms = 2^16 inputs
+        n = rnd.choice([65536, 65537, 70000, 100000, 131072, 150001])
     kind = rnd.randrange(5)
     mix = rnd.random() < 0.3
     idx = [rnd.randrange(POOL if rnd.random() < 0.8 else 4) for _ in range(n)]      # sometimes only 4 distinct points
