@@ -47,6 +47,9 @@ namespace {
 #ifndef S2K_MSM_SPLIT_DEFAULT
 #define S2K_MSM_SPLIT_DEFAULT 0   // windows in the lower part of the two-part bucket pass (msm_core; 0: one part - measured: DESIGN.md section 6)
 #endif
+#ifndef S2K_MSM_UNPACK_FIRST
+#define S2K_MSM_UNPACK_FIRST 1   // the bucket pass unpacks the fetched record before it flushes a piece (see k_msm_accumulate)
+#endif
 #ifndef S2K_MSM_BORDER_AHEAD
 #define S2K_MSM_BORDER_AHEAD 1   // the bucket pass loads the border after the next one bucket ahead
 #endif
@@ -588,9 +591,10 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
   const uint32_t nlanes = P.nlanes;
   const uint32_t lane_slot = gl;
   uint32_t border = offset[key + 1];                       // > lo
-  // the border AFTER that one, asked for one bucket ahead (S2K_MSM_BORDER_AHEAD, default on): some lane of a wave meets a
-  // border in two trips of three, and the load of the next border was a dependent one the whole wave waited for - 11.6 % of
-  // the kernel's wave cycles were spent waiting for memory (profiles/r06_msm_attempts.txt)
+  // the border AFTER that one, fetched ahead (S2K_MSM_BORDER_AHEAD, default on): some lane of a wave meets a border in two
+  // trips of three, and the load of the next border was a dependent one the whole wave waited for - 11.6 % of the kernel's
+  // wave cycles were spent waiting for memory (profiles/r06_msm_attempts.txt).  It is re-fetched every trip beside the next
+  // record, so that the flush itself issues nothing but stores.
 #if S2K_MSM_BORDER_AHEAD
   uint32_t border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];
 #endif
@@ -601,27 +605,46 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
   msm_rec r_cur = msm_load_rec(ptw, e_cur);
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
-    if (j == border) {                                     // a bucket ends here: flush, next non-empty bucket
-      xz_store(xsum, stride, open_left ? (size_t)nkeys + lane_slot : (size_t)key, acc);
-      open_left = false;
-      fresh = true;
+    // Order of a trip (S2K_MSM_UNPACK_FIRST, default on): the record fetched during the previous addition is unpacked FIRST,
+    // then - at a border - the border after the next is asked for and the piece is flushed, then the next record is asked
+    // for, then the addition runs.  The memory counter of this hardware completes in order and the compiler must assume
+    // the shortest path at a merge: with the flush in front of the unpacking (rounds 3-5) a wave that met a border waited
+    // for its 36 stores to reach memory before it could touch the record it had fetched a whole addition earlier.
+    fe29 qx, qy;
+#if S2K_MSM_UNPACK_FIRST
+    msm_point_of(r_cur, e_cur, qx, qy);
+#pragma unroll
+    for (int w = 0; w < 9; ++w) asm volatile("" : "+v"(qx.n[w]), "+v"(qy.n[w]));   // (pins the unpacking HERE: left alone, the compiler sinks it below the flush)
+#endif
+    if (j == border) {                                     // a bucket ends here: next non-empty bucket, flush
+      const size_t slot = open_left ? (size_t)nkeys + lane_slot : (size_t)key;
 #if S2K_MSM_BORDER_AHEAD
-      do {
-        ++key;
-        border = border2;
-        border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];
-      } while (border <= j);
+      ++key;
+      border = border2;                                    // (fetched in an earlier trip: no load, no wait in front of the stores)
+      if (border <= j) {                                   // (an empty bucket: rare - these loads are waited for)
+        do {
+          ++key;
+          border = offset[key + 1];
+        } while (border <= j);
+      }
 #else
       do {
         ++key;
         border = offset[key + 1];
       } while (border <= j);
 #endif
+      xz_store(xsum, stride, slot, acc);
+      open_left = false;
+      fresh = true;
     }
     const msm_rec r_nxt = msm_load_rec(ptw, e_nxt);        // entry 0 when past the end: a valid address
     const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;
-    fe29 qx, qy;
+#if S2K_MSM_BORDER_AHEAD
+    border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];  // the border after the next, EVERY trip, beside the record's fetch (one cached word)
+#endif
+#if !S2K_MSM_UNPACK_FIRST
     msm_point_of(r_cur, e_cur, qx, qy);
+#endif
     if (fresh) {                                           // (a few lanes of the wave at a time: the others wait out 36 moves)
       acc = xyzz29_from_affine(qx, qy);
       fresh = false;
