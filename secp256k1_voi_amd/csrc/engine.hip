@@ -628,6 +628,8 @@ k_generator_part(uint32_t first, uint32_t n, const uint32_t* __restrict__ prep, 
     if (w + 1 < gt.windows) g = gt_load(gt, w + 1, gt_next_digit(u, gt.bits));   // in flight during this addition
     xa = xyzz29_add_affine(xa, gx, gy);
   }
+  // (two entries in flight instead of one halve the kernel's waiting - SQ_WAIT_ANY 87 M -> 46 M wave cycles - and change
+  // neither its duration nor the step's: three waves per SIMD cover it; profiles/r06_wait_shares.txt)
   const jpt29 acc = xyzz29_to_jacobian(xa);
   fq_store(gp, stride, idx, 0, acc.x);
   fq_store(gp, stride, idx, 1, acc.y);
