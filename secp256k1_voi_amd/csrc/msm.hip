@@ -698,7 +698,10 @@ S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, size_t stride, uint
 // one lane per key: sums[key] = the bucket as a projective point - the identity for an empty bucket, the converted piece
 // for a bucket inside one range, the sum of its pieces for a bucket that crosses range borders (one addition for an ordinary
 // bucket; buckets spread over more than STITCH_SERIAL ranges are queued for k_msm_stitch_big)
-__global__ void __launch_bounds__(256, 4)     // (128 registers: a wave fits beside the lower part's bucket pass)
+// (WAVES = 3: 166 registers, nothing spilled - 66 us for the whole key range; WAVES = 4: 128 registers, 29 of them spilled, 76 us,
+// but a wave fits beside the lower part's bucket pass: what the two-part flow launches on its second stream)
+template <int WAVES>
+__global__ void __launch_bounds__(256, WAVES)
 k_msm_stitch(msm_parts P, uint32_t nkeys, size_t stride, const uint32_t* __restrict__ offset,
              const uint32_t* __restrict__ xsum, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
              uint32_t* __restrict__ sums, uint32_t* __restrict__ big /* [0] count, [1 ..] keys */, uint32_t key_lo, uint32_t key_hi) {
@@ -1220,7 +1223,10 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
   // stitch and reduce the slots [slot_lo, slot_hi) (the windows [w_lo, w_hi)) on stream s_
   auto tail = [&](hipStream_t s_, uint32_t slot_lo, uint32_t slot_hi, uint32_t w_lo, uint32_t w_hi, uint32_t* big) -> int {
     const uint32_t key_lo = slot_lo * g.nb, key_hi = slot_hi == g.nslot ? (uint32_t)m.nkeys : slot_hi * g.nb;
-    k_msm_stitch<<<blocks_for(key_hi - key_lo), 256, 0, s_>>>(P, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
+    if (wsplit && s_ != st)      // (beside the lower part's bucket pass: the form that fits into the registers it leaves)
+      k_msm_stitch<4><<<blocks_for(key_hi - key_lo), 256, 0, s_>>>(P, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
+    else
+      k_msm_stitch<3><<<blocks_for(key_hi - key_lo), 256, 0, s_>>>(P, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big, key_lo, key_hi);
     k_msm_stitch_big<<<64, 256, 0, s_>>>(P, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.xsum, m.list, m.ptw, m.sums, big);
     HIP_TRY(ctx, hipGetLastError());
     if (fold16) {   // 16-bit windows: row / column sums, bit planes (above)
