@@ -179,3 +179,21 @@ def test_table_registry_under_concurrent_contexts(oracle):
         assert any(base + sum(size[b] for b in extra) == held for k in range(len(rest) + 1) for extra in itertools.combinations(rest, k)), (held, now)
     finally:
         keep.close()
+
+
+def test_group_create_ex_arguments():
+    """s2k_group_create_ex: widths outside 16 .. 26 and unknown flags are refused; the wait flag returns a group whose members
+    are on their final tables."""
+    import ctypes as C
+    import secp256k1_voi_amd as S
+    lib = S.load_library()
+    devs = (C.c_int * 1)(0)
+    h = C.c_void_p()
+    for bits, flags in ((15, 0), (27, 0), (-1, 0), (0, 2), (18, 0x80)):
+        assert lib.s2k_group_create_ex(devs, 1, bits, flags, C.byref(h)) != 0 and not h.value, (bits, flags)
+    assert lib.s2k_group_create_ex(devs, 0, 0, 0, C.byref(h)) != 0
+    g = S.Group([0], wait_tables=True)
+    try:
+        assert g.gt_wait() in (20, 22, 24, 26)
+    finally:
+        g.close()
