@@ -899,6 +899,33 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
         }
 #endif
+      } else if constexpr (JOINT && S2K_JOINT_PREFETCH) {
+        // the 4-bit joint ladder with the same lead: the 80-byte entry of position c + 1 (18 limbs) asked for before the addition
+        // of position c
+        auto next_entry4 = [&](int c, bool& n1_out) -> uint32_t {
+          const uint32_t w1 = a[0] & 15u, w2 = b[0] & 15u;
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            a[w] = (a[w] >> 4) | (a[w + 1] << 28);
+            b[w] = (b[w] >> 4) | (b[w + 1] << 28);
+          }
+          a[3] >>= 4;
+          b[3] >>= 4;
+          const bool n1 = neg1 != (w1 < 8u), n2 = neg2 != (w2 < 8u);
+          const uint32_t ea = (w1 < 8u) ? (7u - w1) : (w1 - 8u), eb = (w2 < 8u) ? (7u - w2) : (w2 - 8u);
+          n1_out = n1;
+          return (((uint32_t)c * 8u + ea) * 8u + eb) * 2u + (n1 != n2 ? 1u : 0u);
+        };
+        bool n1_nxt;
+        fe29 nx, ny;
+        je_load(jt + (size_t)next_entry4(0, n1_nxt) * KJ_ENTRY_QUADS, nx, ny);
+#pragma unroll 1
+        for (int c = 0; c < KS_CHUNKS; ++c) {
+          const fe29 x = nx, y = ny;
+          const bool n1 = n1_nxt;
+          if (c + 1 < KS_CHUNKS) je_load(jt + (size_t)next_entry4(c + 1, n1_nxt) * KJ_ENTRY_QUADS, nx, ny);
+          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
+        }
       } else {
 #pragma unroll 1
       for (int c = 0; c < KS_CHUNKS; ++c) {
