@@ -981,6 +981,9 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           }
         }
       }
+      // (the next entry asked for before the current addition - what the key-set ladders do - costs this ladder its fourth wave
+      // per SIMD: 145-147 VGPRs against 126.  Measured in both forms, four alternating pairs: the step 4.89 against 4.91 ms,
+      // the kernel 58.2 M against 57.8 M cycles under the counters - nothing, and not kept; profiles/r06_wait_shares.txt)
     }
     acc = xyzz29_to_jacobian(xa);
     // the table's points are affine on the curve isomorphic by W (keyed.hip): back on secp256k1 itself
