@@ -326,6 +326,32 @@ def test_ct_single_ops_operation_count_is_value_independent(S):
     assert len(counts) == 1, counts
 
 
+def test_ct_scalar_mult_vs_trivial_double_and_add_through_the_single_ops(S, oracle):
+    """The reference's own cross-check (point_test.go:392-416: every scalar multiplication against the trivially correct
+    double-and-add `scalarMultTrivial`), with the double-and-add run through s2k_ct_point_double / s2k_ct_point_add: the
+    single operations and the table-driven multiplications must describe the same group."""
+    rnd = random.Random(65)
+    for it in range(12):
+        k = [0, 1, 2, R.N - 1, R.LAMBDA, 2**128 + 1][it] if it < 6 else rnd.randrange(R.N)
+        P = rec(R.mul(rnd.randrange(1, R.N), R.G))
+        acc = IDENT
+        for bit in range(k.bit_length() - 1, -1, -1):
+            acc = S.ct_point_double(acc)
+            if (k >> bit) & 1:
+                acc = S.ct_point_add(acc, P)
+        want = S.ct_scalar_mult(b32(k), P)
+        assert acc == want == oracle.scalar_mult_vartime(b32(k), P), (it, k)
+        # ... and the base multiplication is the same map on G
+        if it % 3 == 0:
+            g = rec(R.G)
+            accg = IDENT
+            for bit in range(k.bit_length() - 1, -1, -1):
+                accg = S.ct_point_double(accg)
+                if (k >> bit) & 1:
+                    accg = S.ct_point_add(accg, g)
+            assert accg == S.ct_scalar_base_mult(b32(k))
+
+
 def test_ct_single_ops_argument_checks(S):
     """NULL pointers and unknown op codes are S2K_ERR_ARG (-3 ... the library's argument error), never a crash."""
     lib = S.load_library()
