@@ -47,6 +47,9 @@ namespace {
 #ifndef S2K_MSM_SPLIT_DEFAULT
 #define S2K_MSM_SPLIT_DEFAULT 0   // windows in the lower part of the two-part bucket pass (msm_core; 0: one part - measured: DESIGN.md section 6)
 #endif
+#ifndef S2K_MSM_NEGATE_LIMBS
+#define S2K_MSM_NEGATE_LIMBS 1   // negative entries of the bucket pass are negated on the limbs, not on the 32-bit words
+#endif
 #ifndef S2K_MSM_UNPACK_FIRST
 #define S2K_MSM_UNPACK_FIRST 1   // the bucket pass unpacks the fetched record before it flushes a piece (see k_msm_accumulate)
 #endif
@@ -508,20 +511,28 @@ S2K_DEV msm_rec msm_load_rec(const uint32_t* __restrict__ ptw, uint32_t entry) {
   return r;
 }
 S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
-  uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
-  uint32_t yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
+  const uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+  const uint32_t yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
+#if S2K_MSM_NEGATE_LIMBS
+  // a negative entry adds (x, -y): negated on the limbs (2p - y limb by limb, nine instructions, the result at two units like
+  // the addends of the verification ladders) - on the 32-bit words it was an eight-word add-with-carry chain per addition
+  x = fe29_from_words(xw);
+  y = fe29_cond_negate1(fe29_from_words(yw), (entry >> 31) != 0);
+#else
   // neg: p - y = ~y + p + 1 over the eight words (y in [1, p), so the result is in (0, p) and the carry out is dropped)
   constexpr uint32_t PW[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   const uint32_t M = 0u - (entry >> 31);
+  uint32_t nw[8];
   uint64_t cy = M & 1u;
 #pragma unroll
   for (int w = 0; w < 8; ++w) {
     cy += (uint64_t)(yw[w] ^ M) + (PW[w] & M);
-    yw[w] = (uint32_t)cy;
+    nw[w] = (uint32_t)cy;
     cy >>= 32;
   }
   x = fe29_from_words(xw);
-  y = fe29_from_words(yw);
+  y = fe29_from_words(nw);
+#endif
 }
 // The additions are the incomplete XYZZ mixed additions of xyzz29.h: a piece STARTS as its first point, and it is flushed
 // as it is - four coordinates, 36 words, to the slot's column of `xsum`: the hot loop pays stores only (some lane of a wave
@@ -529,7 +540,25 @@ S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
 // outside the hot loop, turns the pieces into projective points; a piece whose ZZ is 0 - it met P + P or P - P, or it
 // really sums to the identity - is walked again there with the complete formulas (msm_piece).
 constexpr int XZ_WORDS = 36;
+#ifndef S2K_MSM_XSUM_RECORDS
+#define S2K_MSM_XSUM_RECORDS 1   // a flushed piece is ONE 144-byte record (nine 16-byte stores) instead of 36 words in 36 planes
+#endif
 S2K_DEV void xz_store(uint32_t* __restrict__ base, size_t stride, size_t slot, const xyzz29& p) {
+#if S2K_MSM_XSUM_RECORDS
+  // some lane of a wave flushes in two trips of three, and the whole wave steps through the flush: 36 stores with 36 addresses
+  // were a hundred instructions of every such trip; a record is nine stores behind one address
+  (void)stride;
+  uint4* r = reinterpret_cast<uint4*>(base + slot * XZ_WORDS);
+  r[0] = make_uint4(p.x.n[0], p.x.n[1], p.x.n[2], p.x.n[3]);
+  r[1] = make_uint4(p.x.n[4], p.x.n[5], p.x.n[6], p.x.n[7]);
+  r[2] = make_uint4(p.x.n[8], p.y.n[0], p.y.n[1], p.y.n[2]);
+  r[3] = make_uint4(p.y.n[3], p.y.n[4], p.y.n[5], p.y.n[6]);
+  r[4] = make_uint4(p.y.n[7], p.y.n[8], p.zz.n[0], p.zz.n[1]);
+  r[5] = make_uint4(p.zz.n[2], p.zz.n[3], p.zz.n[4], p.zz.n[5]);
+  r[6] = make_uint4(p.zz.n[6], p.zz.n[7], p.zz.n[8], p.zzz.n[0]);
+  r[7] = make_uint4(p.zzz.n[1], p.zzz.n[2], p.zzz.n[3], p.zzz.n[4]);
+  r[8] = make_uint4(p.zzz.n[5], p.zzz.n[6], p.zzz.n[7], p.zzz.n[8]);
+#else
 #pragma unroll
   for (int w = 0; w < 9; ++w) base[(size_t)w * stride + slot] = p.x.n[w];
 #pragma unroll
@@ -538,9 +567,27 @@ S2K_DEV void xz_store(uint32_t* __restrict__ base, size_t stride, size_t slot, c
   for (int w = 0; w < 9; ++w) base[(size_t)(18 + w) * stride + slot] = p.zz.n[w];
 #pragma unroll
   for (int w = 0; w < 9; ++w) base[(size_t)(27 + w) * stride + slot] = p.zzz.n[w];
+#endif
 }
 S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t stride, size_t slot) {
   xyzz29 p;
+#if S2K_MSM_XSUM_RECORDS
+  (void)stride;
+  const uint4* r = reinterpret_cast<const uint4*>(base + slot * XZ_WORDS);
+  uint32_t v[XZ_WORDS];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const uint4 t = r[q];
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+#pragma unroll
+  for (int w = 0; w < 9; ++w) {
+    p.x.n[w] = v[w];
+    p.y.n[w] = v[9 + w];
+    p.zz.n[w] = v[18 + w];
+    p.zzz.n[w] = v[27 + w];
+  }
+#else
 #pragma unroll
   for (int w = 0; w < 9; ++w) p.x.n[w] = base[(size_t)w * stride + slot];
 #pragma unroll
@@ -549,6 +596,7 @@ S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t stride, size_t 
   for (int w = 0; w < 9; ++w) p.zz.n[w] = base[(size_t)(18 + w) * stride + slot];
 #pragma unroll
   for (int w = 0; w < 9; ++w) p.zzz.n[w] = base[(size_t)(27 + w) * stride + slot];
+#endif
   return p;
 }
 template <int PAD_KIB>
@@ -671,7 +719,7 @@ S2K_DEV pt29 msm_piece(const uint32_t* __restrict__ xsum, size_t stride, size_t 
     const uint32_t e = list[j];
     fe29 qx, qy;
     msm_point_of(msm_load_rec(ptw, e), e, qx, qy);
-    acc = pt29_add_mixed(acc, qx, qy);
+    acc = pt29_add_mixed(acc, qx, fe29_normalize_weak(qy));      // (the complete formulas take an addend of one unit)
   }
   return acc;
 }
