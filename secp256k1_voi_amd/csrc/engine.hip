@@ -536,9 +536,6 @@ S2K_DEV void scalar_prep_one(size_t i, const uint8_t* __restrict__ dig, const ui
 // Waves per SIMD the joint-table key-set ladder is built for.  Measured (tools/gpu_joint_waves.sh, same box, two runs each):
 // 3 waves (150 VGPRs, no spills) 1.743 / 1.746 ms, 4 waves (128 VGPRs, 21 spilled) 1.733 / 1.743 ms - the kernel is at the
 // clock the chip gives it (1.89-2.02 GHz under 8 GB of table fetches per launch) either way; 3 stays.
-#ifndef S2K_JOINT_PREFETCH
-#define S2K_JOINT_PREFETCH 1   // the wide joint ladders ask for the next table entry before they add the current one
-#endif
 #ifndef S2K_JOINT_WAVES
 #define S2K_JOINT_WAVES 3
 #endif
@@ -860,7 +857,7 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
         // magnitude 2 (NE - 1 - w) + 1, else positive with magnitude 2 (w - NE) + 1
         using J = kjw_geom<JW>;
         constexpr uint32_t WM = (1u << JW) - 1u, NE = (uint32_t)J::NE;
-        // The entry of position c + 1 is asked for BEFORE the addition of position c (S2K_JOINT_PREFETCH, default on): a joint
+        // The entry of position c + 1 is asked for BEFORE the addition of position c (measured both ways, profiles/r06_keyset_wait.json): a joint
         // table is 0.8 / 2.75 MiB per key and a lookup is a 64-byte read from HBM more often than not - issued behind the
         // addition, its latency stood between every two additions of a wave.
         auto next_entry = [&](int c, bool& n1_out) -> uint32_t {
@@ -877,7 +874,6 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           n1_out = n1;
           return (((uint32_t)c * NE + ea) * NE + eb) * 2u + (n1 != n2 ? 1u : 0u);
         };
-#if S2K_JOINT_PREFETCH
         bool n1_cur;
         jw_raw raw = jw_fetch(jt + (size_t)next_entry(0, n1_cur) * J::EQ);
 #pragma unroll 1
@@ -889,17 +885,7 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
           jw_point(cur, x, y);
           xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
         }
-#else
-#pragma unroll 1
-        for (int c = 0; c < J::POS; ++c) {
-          bool n1;
-          const uint32_t j = next_entry(c, n1);
-          fe29 x, y;
-          jw_load(jt + (size_t)j * J::EQ, x, y);
-          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
-        }
-#endif
-      } else if constexpr (JOINT && S2K_JOINT_PREFETCH) {
+      } else if constexpr (JOINT) {
         // the 4-bit joint ladder with the same lead: the 80-byte entry of position c + 1 (18 limbs) asked for before the addition
         // of position c
         auto next_entry4 = [&](int c, bool& n1_out) -> uint32_t {
@@ -928,23 +914,15 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
         }
       } else {
 #pragma unroll 1
-      for (int c = 0; c < KS_CHUNKS; ++c) {
-        const uint32_t w1 = a[0] & 15u, w2 = b[0] & 15u;
+        for (int c = 0; c < KS_CHUNKS; ++c) {
+          const uint32_t w1 = a[0] & 15u, w2 = b[0] & 15u;
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          a[w] = (a[w] >> 4) | (a[w + 1] << 28);
-          b[w] = (b[w] >> 4) | (b[w + 1] << 28);
-        }
-        a[3] >>= 4;
-        b[3] >>= 4;
-        if constexpr (JOINT) {
-          const bool n1 = neg1 != (w1 < 8u), n2 = neg2 != (w2 < 8u);          // signs of the two signed digits
-          const uint32_t ea = (w1 < 8u) ? (7u - w1) : (w1 - 8u), eb = (w2 < 8u) ? (7u - w2) : (w2 - 8u);
-          const uint32_t j = (((uint32_t)c * 8u + ea) * 8u + eb) * 2u + (n1 != n2 ? 1u : 0u);
-          fe29 x, y;
-          je_load(jt + (size_t)j * KJ_ENTRY_QUADS, x, y);
-          xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, n1));
-        } else {
+          for (int w = 0; w < 3; ++w) {
+            a[w] = (a[w] >> 4) | (a[w + 1] << 28);
+            b[w] = (b[w] >> 4) | (b[w + 1] << 28);
+          }
+          a[3] >>= 4;
+          b[3] >>= 4;
 #pragma unroll 1
           for (int t = 0; t < 2; ++t) {
             uint32_t w = t ? w2 : w1;
@@ -955,7 +933,6 @@ k_verify_fast(uint32_t n_and_flags, const uint8_t* __restrict__ pub, const uint8
             xa = xyzz29_add_affine(xa, x, fe29_cond_negate1(y, neg));
           }
         }
-      }
       }
     } else {
       digit_stream4 d1 = ds4_init_chunked(k1), d2 = ds4_init_chunked(k2);

@@ -47,15 +47,6 @@ namespace {
 #ifndef S2K_MSM_SPLIT_DEFAULT
 #define S2K_MSM_SPLIT_DEFAULT 0   // windows in the lower part of the two-part bucket pass (msm_core; 0: one part - measured: DESIGN.md section 6)
 #endif
-#ifndef S2K_MSM_NEGATE_LIMBS
-#define S2K_MSM_NEGATE_LIMBS 1   // negative entries of the bucket pass are negated on the limbs, not on the 32-bit words
-#endif
-#ifndef S2K_MSM_UNPACK_FIRST
-#define S2K_MSM_UNPACK_FIRST 1   // the bucket pass unpacks the fetched record before it flushes a piece (see k_msm_accumulate)
-#endif
-#ifndef S2K_MSM_BORDER_AHEAD
-#define S2K_MSM_BORDER_AHEAD 1   // the bucket pass loads the border after the next one bucket ahead
-#endif
 #ifndef S2K_MSM_CHUNK_LOG2
 #define S2K_MSM_CHUNK_LOG2 3   // default of the buckets per reduction chunk (log2); S2K_MSM_CHUNK_LOG2 in the environment overrides it
 #endif
@@ -497,8 +488,8 @@ constexpr uint32_t MSM_LANES = 256u * 4u * 64u * S2K_MSM_WAVES;      // lanes th
 constexpr uint32_t MSM_L_MIN = 8;             // shortest range
 constexpr uint32_t STITCH_SERIAL = 8, STITCH_BIG_CAP = 4096;
 
-// A list entry is a term index with the digit's sign: a negative digit adds -P = (x, p - y), formed on the 32-bit
-// words before the limbs are cut.  The record (a random 64-byte read from the term array) is fetched one addition
+// A list entry is a term index with the digit's sign: a negative digit adds -P = (x, -y), negated on the limbs
+// (msm_point_of).  The record (a random 64-byte read from the term array) is fetched one addition
 // ahead, into registers (fetching it in two halves to save registers cost more than it saved: the second half's line
 // had left the L2 by the time it was asked for, 5.4 GB fetched per 2^20-term call instead of 3.0).
 struct msm_rec {
@@ -513,41 +504,20 @@ S2K_DEV msm_rec msm_load_rec(const uint32_t* __restrict__ ptw, uint32_t entry) {
 S2K_DEV void msm_point_of(const msm_rec& r, uint32_t entry, fe29& x, fe29& y) {
   const uint32_t xw[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
   const uint32_t yw[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w};
-#if S2K_MSM_NEGATE_LIMBS
   // a negative entry adds (x, -y): negated on the limbs (2p - y limb by limb, nine instructions, the result at two units like
   // the addends of the verification ladders) - on the 32-bit words it was an eight-word add-with-carry chain per addition
   x = fe29_from_words(xw);
   y = fe29_cond_negate1(fe29_from_words(yw), (entry >> 31) != 0);
-#else
-  // neg: p - y = ~y + p + 1 over the eight words (y in [1, p), so the result is in (0, p) and the carry out is dropped)
-  constexpr uint32_t PW[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-  const uint32_t M = 0u - (entry >> 31);
-  uint32_t nw[8];
-  uint64_t cy = M & 1u;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    cy += (uint64_t)(yw[w] ^ M) + (PW[w] & M);
-    nw[w] = (uint32_t)cy;
-    cy >>= 32;
-  }
-  x = fe29_from_words(xw);
-  y = fe29_from_words(nw);
-#endif
 }
 // The additions are the incomplete XYZZ mixed additions of xyzz29.h: a piece STARTS as its first point, and it is flushed
-// as it is - four coordinates, 36 words, to the slot's column of `xsum`: the hot loop pays stores only (some lane of a wave
+// as it is - four coordinates, 36 words, one 144-byte record of `xsum` per slot: the hot loop pays stores only (some lane of a wave
 // flushes in nearly every trip, so whatever the flush does, the whole wave waits for).  k_msm_stitch, one lane per key and
 // outside the hot loop, turns the pieces into projective points; a piece whose ZZ is 0 - it met P + P or P - P, or it
 // really sums to the identity - is walked again there with the complete formulas (msm_piece).
 constexpr int XZ_WORDS = 36;
-#ifndef S2K_MSM_XSUM_RECORDS
-#define S2K_MSM_XSUM_RECORDS 1   // a flushed piece is ONE 144-byte record (nine 16-byte stores) instead of 36 words in 36 planes
-#endif
-S2K_DEV void xz_store(uint32_t* __restrict__ base, size_t stride, size_t slot, const xyzz29& p) {
-#if S2K_MSM_XSUM_RECORDS
+S2K_DEV void xz_store(uint32_t* __restrict__ base, size_t slot, const xyzz29& p) {
   // some lane of a wave flushes in two trips of three, and the whole wave steps through the flush: 36 stores with 36 addresses
   // were a hundred instructions of every such trip; a record is nine stores behind one address
-  (void)stride;
   uint4* r = reinterpret_cast<uint4*>(base + slot * XZ_WORDS);
   r[0] = make_uint4(p.x.n[0], p.x.n[1], p.x.n[2], p.x.n[3]);
   r[1] = make_uint4(p.x.n[4], p.x.n[5], p.x.n[6], p.x.n[7]);
@@ -558,21 +528,9 @@ S2K_DEV void xz_store(uint32_t* __restrict__ base, size_t stride, size_t slot, c
   r[6] = make_uint4(p.zz.n[6], p.zz.n[7], p.zz.n[8], p.zzz.n[0]);
   r[7] = make_uint4(p.zzz.n[1], p.zzz.n[2], p.zzz.n[3], p.zzz.n[4]);
   r[8] = make_uint4(p.zzz.n[5], p.zzz.n[6], p.zzz.n[7], p.zzz.n[8]);
-#else
-#pragma unroll
-  for (int w = 0; w < 9; ++w) base[(size_t)w * stride + slot] = p.x.n[w];
-#pragma unroll
-  for (int w = 0; w < 9; ++w) base[(size_t)(9 + w) * stride + slot] = p.y.n[w];
-#pragma unroll
-  for (int w = 0; w < 9; ++w) base[(size_t)(18 + w) * stride + slot] = p.zz.n[w];
-#pragma unroll
-  for (int w = 0; w < 9; ++w) base[(size_t)(27 + w) * stride + slot] = p.zzz.n[w];
-#endif
 }
-S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t stride, size_t slot) {
+S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t slot) {
   xyzz29 p;
-#if S2K_MSM_XSUM_RECORDS
-  (void)stride;
   const uint4* r = reinterpret_cast<const uint4*>(base + slot * XZ_WORDS);
   uint32_t v[XZ_WORDS];
 #pragma unroll
@@ -587,21 +545,11 @@ S2K_DEV xyzz29 xz_load(const uint32_t* __restrict__ base, size_t stride, size_t 
     p.zz.n[w] = v[18 + w];
     p.zzz.n[w] = v[27 + w];
   }
-#else
-#pragma unroll
-  for (int w = 0; w < 9; ++w) p.x.n[w] = base[(size_t)w * stride + slot];
-#pragma unroll
-  for (int w = 0; w < 9; ++w) p.y.n[w] = base[(size_t)(9 + w) * stride + slot];
-#pragma unroll
-  for (int w = 0; w < 9; ++w) p.zz.n[w] = base[(size_t)(18 + w) * stride + slot];
-#pragma unroll
-  for (int w = 0; w < 9; ++w) p.zzz.n[w] = base[(size_t)(27 + w) * stride + slot];
-#endif
   return p;
 }
 template <int PAD_KIB>
 __global__ void __launch_bounds__(256, S2K_MSM_WAVES)
-k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, const uint32_t* __restrict__ offset,
+k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, const uint32_t* __restrict__ offset,
                  const uint32_t* __restrict__ lanekey, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw,
                  uint32_t* __restrict__ xsum) {
   // which = 0: part A (the list from offset[split_key] on; everything when there is one part), 1: part B (the list below it).
@@ -639,13 +587,11 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
   const uint32_t nlanes = P.nlanes;
   const uint32_t lane_slot = gl;
   uint32_t border = offset[key + 1];                       // > lo
-  // the border AFTER that one, fetched ahead (S2K_MSM_BORDER_AHEAD, default on): some lane of a wave meets a border in two
+  // the border AFTER that one, fetched ahead: some lane of a wave meets a border in two
   // trips of three, and the load of the next border was a dependent one the whole wave waited for - 11.6 % of the kernel's
   // wave cycles were spent waiting for memory (profiles/r06_msm_attempts.txt).  It is re-fetched every trip beside the next
   // record, so that the flush itself issues nothing but stores.
-#if S2K_MSM_BORDER_AHEAD
   uint32_t border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];
-#endif
   bool open_left = offset[key] < lo;
   bool fresh = true;                                       // the next point starts a piece
   xyzz29 acc = xyzz29_from_affine(fe29_zero(), fe29_zero());
@@ -653,20 +599,17 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
   msm_rec r_cur = msm_load_rec(ptw, e_cur);
 #pragma unroll 1
   for (uint32_t j = lo; j < hi; ++j) {
-    // Order of a trip (S2K_MSM_UNPACK_FIRST, default on): the record fetched during the previous addition is unpacked FIRST,
+    // Order of a trip: the record fetched during the previous addition is unpacked FIRST,
     // then - at a border - the border after the next is asked for and the piece is flushed, then the next record is asked
     // for, then the addition runs.  The memory counter of this hardware completes in order and the compiler must assume
     // the shortest path at a merge: with the flush in front of the unpacking (rounds 3-5) a wave that met a border waited
     // for its 36 stores to reach memory before it could touch the record it had fetched a whole addition earlier.
     fe29 qx, qy;
-#if S2K_MSM_UNPACK_FIRST
     msm_point_of(r_cur, e_cur, qx, qy);
 #pragma unroll
     for (int w = 0; w < 9; ++w) asm volatile("" : "+v"(qx.n[w]), "+v"(qy.n[w]));   // (pins the unpacking HERE: left alone, the compiler sinks it below the flush)
-#endif
     if (j == border) {                                     // a bucket ends here: next non-empty bucket, flush
       const size_t slot = open_left ? (size_t)nkeys + lane_slot : (size_t)key;
-#if S2K_MSM_BORDER_AHEAD
       ++key;
       border = border2;                                    // (fetched in an earlier trip: no load, no wait in front of the stores)
       if (border <= j) {                                   // (an empty bucket: rare - these loads are waited for)
@@ -675,24 +618,13 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
           border = offset[key + 1];
         } while (border <= j);
       }
-#else
-      do {
-        ++key;
-        border = offset[key + 1];
-      } while (border <= j);
-#endif
-      xz_store(xsum, stride, slot, acc);
+      xz_store(xsum, slot, acc);
       open_left = false;
       fresh = true;
     }
     const msm_rec r_nxt = msm_load_rec(ptw, e_nxt);        // entry 0 when past the end: a valid address
     const uint32_t e_nn = j + 2 < hi ? list[j + 2] : 0u;
-#if S2K_MSM_BORDER_AHEAD
     border2 = offset[key + 2 <= nkeys ? key + 2 : nkeys];  // the border after the next, EVERY trip, beside the record's fetch (one cached word)
-#endif
-#if !S2K_MSM_UNPACK_FIRST
-    msm_point_of(r_cur, e_cur, qx, qy);
-#endif
     if (fresh) {                                           // (a few lanes of the wave at a time: the others wait out 36 moves)
       acc = xyzz29_from_affine(qx, qy);
       fresh = false;
@@ -706,12 +638,12 @@ k_msm_accumulate(msm_parts P, uint32_t which, uint32_t nkeys, size_t stride, con
   // the last piece: left edge if it came in from the previous range (then it may go on as well: a range inside one
   // bucket), right edge if it goes on into the next range, else a whole bucket
   const bool open_right = border > hi;
-  xz_store(xsum, stride, open_left ? (size_t)nkeys + lane_slot : (open_right ? (size_t)nkeys + nlanes + lane_slot : (size_t)key), acc);
+  xz_store(xsum, open_left ? (size_t)nkeys + lane_slot : (open_right ? (size_t)nkeys + nlanes + lane_slot : (size_t)key), acc);
 }
 // the piece in `slot` (the list entries [first, end) of one bucket) as a projective point; ZZ = 0: walked again, complete formulas
-S2K_DEV pt29 msm_piece(const uint32_t* __restrict__ xsum, size_t stride, size_t slot, uint32_t first, uint32_t end,
+S2K_DEV pt29 msm_piece(const uint32_t* __restrict__ xsum, size_t slot, uint32_t first, uint32_t end,
                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw) {
-  const xyzz29 x = xz_load(xsum, stride, slot);
+  const xyzz29 x = xz_load(xsum, slot);
   if (!fe29_is_zero(x.zz)) return xyzz29_to_pt29(x);
   pt29 acc = pt29_identity();
 #pragma unroll 1
@@ -736,12 +668,12 @@ S2K_DEV msm_part_of msm_part_for(const msm_parts& P, uint32_t key, const uint32_
   return r;
 }
 // piece of the bucket [b, e) in range k (a global lane number)
-S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, size_t stride, uint32_t nkeys, uint32_t nlanes, const msm_part_of& pp, uint32_t b,
+S2K_DEV pt29 msm_piece_of(const uint32_t* __restrict__ xsum, uint32_t nkeys, uint32_t nlanes, const msm_part_of& pp, uint32_t b,
                           uint32_t e, uint32_t k, uint32_t k_lo, const uint32_t* __restrict__ list, const uint32_t* __restrict__ ptw) {
   const uint64_t r0 = (uint64_t)pp.start + (uint64_t)(k - pp.lane0) * pp.L, r1 = r0 + pp.L;
   const uint32_t first = b > r0 ? b : (uint32_t)r0, end = e < r1 ? e : (uint32_t)r1;
   // the first range's piece is a right edge (the bucket starts in it or at its border and goes on), the others' left edges
-  return msm_piece(xsum, stride, k == k_lo ? (size_t)nkeys + nlanes + k : (size_t)nkeys + k, first, end, list, ptw);
+  return msm_piece(xsum, k == k_lo ? (size_t)nkeys + nlanes + k : (size_t)nkeys + k, first, end, list, ptw);
 }
 // one lane per key: sums[key] = the bucket as a projective point - the identity for an empty bucket, the converted piece
 // for a bucket inside one range, the sum of its pieces for a bucket that crosses range borders (one addition for an ordinary
@@ -764,7 +696,7 @@ k_msm_stitch(msm_parts P, uint32_t nkeys, size_t stride, const uint32_t* __restr
   const msm_part_of pp = msm_part_for(P, key, offset);
   const uint32_t k_lo = pp.lane0 + (b - pp.start) / pp.L, k_hi = pp.lane0 + (e - 1 - pp.start) / pp.L;
   if (k_lo == k_hi) {
-    pt_store(sums, stride, key, msm_piece(xsum, stride, key, b, e, list, ptw));
+    pt_store(sums, stride, key, msm_piece(xsum, key, b, e, list, ptw));
     return;
   }
   if (k_hi - k_lo > STITCH_SERIAL) {
@@ -774,9 +706,9 @@ k_msm_stitch(msm_parts P, uint32_t nkeys, size_t stride, const uint32_t* __restr
       return;
     }                                       // more oversized buckets than the queue holds: serial after all
   }
-  pt29 r = msm_piece_of(xsum, stride, nkeys, P.nlanes, pp, b, e, k_lo, k_lo, list, ptw);
+  pt29 r = msm_piece_of(xsum, nkeys, P.nlanes, pp, b, e, k_lo, k_lo, list, ptw);
 #pragma unroll 1
-  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, P.nlanes, pp, b, e, k, k_lo, list, ptw));
+  for (uint32_t k = k_lo + 1; k <= k_hi; ++k) r = pt29_add(r, msm_piece_of(xsum, nkeys, P.nlanes, pp, b, e, k, k_lo, list, ptw));
   pt_store(sums, stride, key, r);
 }
 // one workgroup per queued bucket: the threads take the pieces round robin, then a tree in LDS
@@ -794,7 +726,7 @@ k_msm_stitch_big(msm_parts P, uint32_t nkeys, size_t stride, const uint32_t* __r
     pt29 r = pt29_identity();
 #pragma unroll 1
     for (uint32_t k = k_lo + threadIdx.x; k <= k_hi; k += 256)
-      r = pt29_add(r, msm_piece_of(xsum, stride, nkeys, P.nlanes, pp, b, e, k, k_lo, list, ptw));
+      r = pt29_add(r, msm_piece_of(xsum, nkeys, P.nlanes, pp, b, e, k, k_lo, list, ptw));
     for (uint32_t half = 128; half >= 1; half >>= 1) {
       __syncthreads();
       if (threadIdx.x >= half && threadIdx.x < 2 * half) pt_store(&sh[0][0], 128, threadIdx.x - half, r);
@@ -1295,7 +1227,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     return S2K_OK;
   };
   if (wsplit == 0) {
-    k_msm_accumulate<0><<<blocks_for(nlanes_a), 256, 0, st>>>(P, 0u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+    k_msm_accumulate<0><<<blocks_for(nlanes_a), 256, 0, st>>>(P, 0u, (uint32_t)m.nkeys, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
     HIP_TRY(ctx, hipGetLastError());
     msm_prof_mark(ctx, st, 3);
     int rc = tail(st, 0, g.nslot, 0, g.nw, m.big);
@@ -1312,7 +1244,7 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
     hipStream_t s2 = nullptr;                         // the upper part's tail: a stream of its own, served first when a slot frees up
     rc = msm_second_stream(ctx, &s2);
     if (rc) return rc;
-    k_msm_accumulate<0><<<blocks_for(nlanes_a), 256, 0, st>>>(P, 0u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+    k_msm_accumulate<0><<<blocks_for(nlanes_a), 256, 0, st>>>(P, 0u, (uint32_t)m.nkeys, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
@@ -1326,11 +1258,11 @@ int msm_core(s2k_ctx* ctx, hipStream_t st, size_t n, msm_ws& m, uint8_t* d_out65
       // (a block of LDS per workgroup keeps the others out of the CU: 48 KiB - three fit 160 KiB -, 72 KiB - two)
       const unsigned nb_ = blocks_for(P.nlanesB);
       if (b_wgs_per_cu >= 4)
-        k_msm_accumulate<0><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+        k_msm_accumulate<0><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
       else if (b_wgs_per_cu == 3)
-        k_msm_accumulate<48><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+        k_msm_accumulate<48><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
       else
-        k_msm_accumulate<72><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.sum_stride, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
+        k_msm_accumulate<72><<<nb_, 256, 0, st>>>(P, 1u, (uint32_t)m.nkeys, m.offset, m.lanekey, m.list, m.ptw, m.xsum);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, S2K_ERR_HIP, "k_msm_accumulate launch failed");
     }
     msm_prof_mark(ctx, st, 3);
