@@ -906,7 +906,13 @@ k_msm_fold(const uint32_t* __restrict__ sums, size_t stride, uint32_t* __restric
     // one level a lane per addition (128 additions), then 128 partials in LDS (slot 4 hg + lc) and five levels by quads.
     // (Eight columns and four rows per thread had two more additions on every lane's chain: the column blocks ended 15 us
     // after the row blocks.)
-    const uint32_t cb = blockIdx.x - 64 * ns, blk = s_lo + (cb >> 6), lb = cb & 63u, hg = t >> 2, lc = t & 3u;
+    // Which column block a workgroup takes is XCD-aware: a wave reads 16 rows x 16 bytes per word, eight neighbouring column
+    // blocks share every 128-byte line, and consecutive workgroups go to different XCDs (blockIdx % 8), each with an L2 of its
+    // own - taken in blockIdx order every line was fetched by up to eight L2s (283 MB per launch, 2.2 M L2 misses; now 62 MB,
+    // 0.5 M; the kernel 69.5 -> 63.4 us, profiles/r06_msm_attempts.txt section 10).  So
+    // XCD x takes the 8 ns column blocks [8 ns x, 8 ns (x + 1)), neighbours at the same time.
+    const uint32_t ci = blockIdx.x - 64 * ns, cb = (ci & 7u) * (8u * ns) + (ci >> 3);
+    const uint32_t blk = s_lo + (cb >> 6), lb = cb & 63u, hg = t >> 2, lc = t & 3u;
     const size_t k0 = ((size_t)blk * 128 + 2 * hg) * 256 + 4 * lb + lc;
     pt29 acc = pt29_add(pt_load(sums, stride, k0), pt_load(sums, stride, k0 + 256));
     if (hg >= 32) pt_store(sh, 128, (hg - 32) * 4 + lc, acc);
